@@ -1,0 +1,60 @@
+/*
+ * mi_host.h — C-ABI of the host-side scene front end (libmi_host.so): the callers of the path-trace hot path.
+ * It produces exactly the tables mi_pt_create() / mi_pt_set_environment() / mi_pt_set_frame_info() consume, from the
+ * same inputs the reference's application layer uses (a .gltf/.glb file, a Radiance .hdr file, a camera).
+ * Reference counterparts: nvvkgltf::Scene::load (src/gltf_scene.cpp:298), GltfRenderer::createHDR
+ * (src/renderer.cpp:1982), the SceneFrameInfo fill (src/renderer.cpp:675-705) and PathTracer::setupPushConstant
+ * (src/renderer_pathtracer.cpp:1496-1574).
+ */
+#ifndef MI_HOST_H
+#define MI_HOST_H
+
+#include "mi_pt.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct MiScene MiScene;
+typedef struct MiHdr   MiHdr;
+
+/* reference: nvutils::CameraManipulator::Camera as filled by toManipulatorCamera (src/gltf_camera_utils.hpp:35-55) */
+typedef struct MiCamera
+{
+  float eye[3], center[3], up[3];
+  float fovDegrees; /* vertical */
+  float znear, zfar;
+  int   orthographic;
+  float xmag, ymag;
+} MiCamera;
+
+MI_PT_API int                  mi_scene_load(const char* path, MiScene** out);
+MI_PT_API void                 mi_scene_destroy(MiScene* scene);
+MI_PT_API const MiPtSceneDesc* mi_scene_desc(const MiScene* scene);
+MI_PT_API int                  mi_scene_num_cameras(const MiScene* scene);
+MI_PT_API int                  mi_scene_camera(const MiScene* scene, int index, MiCamera* out);
+MI_PT_API void                 mi_scene_bounds(const MiScene* scene, float bmin[3], float bmax[3]);
+MI_PT_API uint64_t             mi_scene_num_triangles(const MiScene* scene);
+
+MI_PT_API int                    mi_hdr_load(const char* path, MiHdr** out);
+MI_PT_API int                    mi_hdr_from_pixels(int width, int height, const float* rgb, MiHdr** out);
+MI_PT_API void                   mi_hdr_destroy(MiHdr* hdr);
+MI_PT_API const MiPtEnvironment* mi_hdr_env(const MiHdr* hdr);
+
+/* Defaults of `SkyPhysicalParameters{}` (reference: src/renderer.cpp:1328). */
+MI_PT_API void mi_default_sky(MiSkyPhysicalParameters* sky);
+/* Defaults of PathtracePushConstant + PathTracer members (reference: shaders/shaderio.h:179-196,
+ * src/renderer_pathtracer.cpp:60-67). */
+MI_PT_API void mi_default_params(MiPathtraceParams* params);
+/* Fills view/proj matrices, imageSize, flags (orthographic bit) and zeroes/defaults the rest exactly as
+ * GltfRenderer::onRender does with default Settings; also returns pixelAngle and the auto-focus focal distance
+ * (reference: src/renderer.cpp:675-705, src/renderer_pathtracer.cpp:1508-1512,1570-1571). */
+MI_PT_API void mi_camera_frame_info(const MiCamera* camera, int width, int height, MiSceneFrameInfo* info, float* pixelAngle,
+                                    float* focalDistance);
+
+MI_PT_API const char* mi_host_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,207 @@
+/*
+ * mi_pt.h — C-ABI of the MI355X-native wavefront path tracer (libmi_pt.so).
+ *
+ * This is the drop-in boundary for ONE path of nvpro-samples/vk_gltf_renderer: the `PathTracer : BaseRenderer`
+ * plugin (reference: src/renderer_base.hpp:33-55, src/renderer_pathtracer.cpp:500-614) and the Slang megakernel it
+ * dispatches (reference: shaders/gltf_pathtrace.slang:546-699).  Every entry point below names the reference
+ * interface it replaces.  Plain pointers and sizes only; no Vulkan, torch or C++ types cross this line.
+ *
+ * Conventions: every function returns 0 on success, a negative MiPtStatus on failure, never throws; the caller owns
+ * all memory it passes in (it may be freed as soon as the call returns), the library owns all device memory.
+ * Not thread-safe per instance (like BaseRenderer::onRender, which runs on the app thread only).
+ */
+#ifndef MI_PT_H
+#define MI_PT_H
+
+#include "mi_pt_shaderio.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define MI_PT_API __attribute__((visibility("default")))
+#else
+#define MI_PT_API
+#endif
+
+typedef enum MiPtStatus
+{
+  MI_PT_OK            = 0,
+  MI_PT_ERR_ARGUMENT  = -1,
+  MI_PT_ERR_NO_DEVICE = -2, /* no HIP device: the product path never falls back to the CPU */
+  MI_PT_ERR_HIP       = -3,
+  MI_PT_ERR_STATE     = -4,
+  MI_PT_ERR_IO        = -5
+} MiPtStatus;
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Scene tables handed to the renderer.  They are what `SceneVk` uploads and what `GltfScene` points at in the
+ * reference (src/gltf_scene_vk.cpp:330-349 scene-desc, :365 materials, :531 render nodes, :741-870 vertex buffers,
+ * :951-1098 textures, :1354-1392 lights), restated with host pointers.
+ * ---------------------------------------------------------------------------------------------------------------- */
+
+/* One RenderPrimitive: SoA attribute streams, NULL = attribute absent (reference: VertexBuffers,
+ * shaders/gltf_scene_io.h.slang:50-64; indices are always u32 triplets, src/gltf_scene_vk.cpp:816-836; COLOR_0 is
+ * packed unorm4x8, :766-798). */
+typedef struct MiPtRenderPrimitive
+{
+  const uint32_t* indices; /* 3 * triangleCount */
+  uint32_t        triangleCount;
+  uint32_t        vertexCount;
+  const float*    positions;  /* 3 floats / vertex */
+  const float*    normals;    /* 3 floats / vertex or NULL */
+  const uint32_t* colors;     /* unorm4x8 / vertex or NULL */
+  const float*    tangents;   /* 4 floats / vertex or NULL */
+  const float*    texCoords0; /* 2 floats / vertex or NULL */
+  const float*    texCoords1; /* 2 floats / vertex or NULL */
+} MiPtRenderPrimitive;
+
+enum MiPtFilter { MI_FILTER_NEAREST = 0, MI_FILTER_LINEAR = 1 };
+enum MiPtWrap { MI_WRAP_REPEAT = 0, MI_WRAP_CLAMP_TO_EDGE = 1, MI_WRAP_MIRRORED_REPEAT = 2 };
+
+/* One glTF *texture* (image + sampler), indexed by GltfTextureInfo.index (reference: src/renderer.cpp:1883-1912
+ * bindless array; sampler mapping src/gltf_scene_vk.cpp:909-947; sRGB detection :1102-1154). RGBA8, full mip chain
+ * supplied by the caller (the reference blits it at upload, src/gltf_scene_vk.cpp:1247-1347). */
+typedef struct MiPtTexture
+{
+  const uint8_t* const* levels; /* numLevels pointers, level i is max(1,width>>i) x max(1,height>>i) RGBA8 */
+  int                   width, height, numLevels;
+  int                   srgb; /* 1: texels are sRGB-encoded colour (alpha linear) */
+  int                   magFilter, minFilter, mipmapMode; /* MiPtFilter */
+  int                   wrapS, wrapT;                     /* MiPtWrap */
+} MiPtTexture;
+
+typedef struct MiPtSceneDesc
+{
+  const MiGltfShadeMaterial* materials;
+  int                        numMaterials;
+  const MiGltfTextureInfo*   textureInfos; /* [0] is the reserved "no texture" slot */
+  int                        numTextureInfos;
+  const MiGltfRenderNode*    renderNodes;
+  int                        numRenderNodes;
+  const uint8_t*             renderNodeVisible; /* numRenderNodes flags or NULL (= all visible); invisible nodes get
+                                                   no geometry, reference src/gltf_scene_rtx.cpp:319-323 */
+  const MiPtRenderPrimitive* renderPrimitives;
+  int                        numRenderPrimitives;
+  const MiGltfLight*         lights;
+  int                        numLights;
+  const MiPtTexture*         textures;
+  int                        numTextures;
+} MiPtSceneDesc;
+
+/* HDR environment as `nvvk::HdrIbl` prepares it (reference: src/renderer.cpp:1982-2017; consumed at
+ * shaders/pathtrace_functions.h.slang:436-447,474-479): lat-long RGBA32F whose alpha holds the sampling pdf, plus the
+ * alias table with one entry per texel. */
+typedef struct MiPtEnvironment
+{
+  const float*      rgba; /* width*height*4 */
+  const MiEnvAccel* accel; /* width*height */
+  int               width, height;
+  float             integral; /* luminance integral (HdrIbl::getIntegral) */
+} MiPtEnvironment;
+
+typedef struct MiPtCreateOptions
+{
+  int device;          /* HIP device ordinal */
+  int collectCounters; /* 1: kernels export traversal/shading counters (slower) */
+  int bvhBuilder;      /* 0 = default (device LBVH + wide collapse) */
+  int reserved[5];
+} MiPtCreateOptions;
+
+/* Work counters behind SURVEY §8(d)'s algorithmic-bytes model; totals since the last mi_pt_reset_stats. */
+typedef struct MiPtStats
+{
+  uint64_t cameraPaths;     /* samples started */
+  uint64_t segments;        /* closest-hit rays traced */
+  uint64_t shadowRays;      /* shadow rays traced */
+  uint64_t nodesClosest;    /* BVH nodes visited by closest-hit rays (needs collectCounters) */
+  uint64_t trisClosest;     /* triangles tested by closest-hit rays */
+  uint64_t nodesShadow;
+  uint64_t trisShadow;
+  uint64_t textureTaps;     /* getTexture() calls */
+  uint64_t bvhNodeCount;    /* static: nodes in the traversal structure */
+  uint64_t bvhTriangleCount;
+  uint64_t bvhNodeBytes;    /* S_node */
+  uint64_t bvhTriangleBytes;/* S_tri */
+} MiPtStats;
+
+/* Per-kernel device time of the last mi_pt_render_frame, measured with HIP events on the frame's stream. */
+typedef struct MiPtFrameTiming
+{
+  float totalMs;
+  float generateMs;
+  float traceClosestMs;
+  float sortMs;
+  float shadeMs;
+  float traceShadowMs;
+  float accumulateMs;
+  int   traceClosestLaunches;
+  int   shadeLaunches;
+  int   traceShadowLaunches;
+  int   bounceIterations;
+} MiPtFrameTiming;
+
+typedef struct MiPt MiPt;
+
+/* replaces PathTracer::onAttach + SceneVk::create + SceneRtx BLAS/TLAS build
+ * (reference: src/renderer_pathtracer.cpp:150-260, src/gltf_scene_vk.cpp:218, src/gltf_scene_rtx.cpp:173-385).
+ * Uploads the tables, builds the BVH on the device. */
+MI_PT_API int mi_pt_create(const MiPtSceneDesc* scene, const MiPtCreateOptions* options, MiPt** out);
+
+/* replaces PathTracer::onDetach (reference: src/renderer_base.hpp:40) */
+MI_PT_API int mi_pt_destroy(MiPt* pt);
+
+/* replaces GltfRenderer::createHDR (reference: src/renderer.cpp:1982-2017). NULL env = no HDR loaded. */
+MI_PT_API int mi_pt_set_environment(MiPt* pt, const MiPtEnvironment* env);
+
+/* replaces PathTracer::onResize (reference: src/renderer_base.hpp:41): (re)allocates eImgRendered / eImgSelection /
+ * depth and the path-state queues; resets accumulation. */
+MI_PT_API int mi_pt_resize(MiPt* pt, int width, int height);
+
+/* replaces the vkCmdUpdateBuffer of bFrameInfo / bSkyParams (reference: src/renderer.cpp:675-708) */
+MI_PT_API int mi_pt_set_frame_info(MiPt* pt, const MiSceneFrameInfo* info);
+MI_PT_API int mi_pt_set_sky(MiPt* pt, const MiSkyPhysicalParameters* sky);
+
+/* Image-tile partition for multi-GPU runs (no counterpart in the reference, which is single-GPU): this instance
+ * renders only tiles whose index satisfies (tileY * tilesX + tileX) % world == rank; other pixels of the accumulator
+ * are left untouched (zero after resize) so a sum-reduce over ranks yields the full frame. world = 1 disables. */
+MI_PT_API int mi_pt_set_tile_partition(MiPt* pt, int rank, int world, int tileSize);
+
+/* Render into caller-owned device memory (width*height float4, e.g. a torch tensor) instead of the internal image. */
+MI_PT_API int mi_pt_bind_accum(MiPt* pt, void* deviceRGBA32F);
+
+/* replaces PathTracer::onRender = setupPushConstant + renderRayQuery (reference: src/renderer_pathtracer.cpp:500-614,
+ * :1496-1574, :1404-1431): enqueues ONE frame (params->numSamples spp for every owned pixel, running-mean
+ * accumulation, selection id + NDC depth when MI_PT_FIRST_FRAME is set) on `hipStream` (a hipStream_t, NULL = default
+ * stream).  Asynchronous unless counters/timing are being collected. */
+MI_PT_API int mi_pt_render_frame(MiPt* pt, const MiPathtraceParams* params, void* hipStream);
+
+/* Block until everything enqueued by this instance has finished. */
+MI_PT_API int mi_pt_synchronize(MiPt* pt);
+
+/* Read-backs (the reference reads gBuffers images back for screenshots: src/renderer.cpp:557-573). */
+MI_PT_API int mi_pt_read_accum(MiPt* pt, float* hostRGBA32F);          /* eImgRendered   */
+MI_PT_API int mi_pt_read_selection(MiPt* pt, uint32_t* hostObjectIds); /* eImgSelection: renderNode+1, 0 = none */
+MI_PT_API int mi_pt_read_depth(MiPt* pt, float* hostDepth);            /* NDC depth of frame 0 */
+MI_PT_API void* mi_pt_accum_device_ptr(MiPt* pt);
+
+/* a-trous edge-avoiding wavelet denoise of the accumulator using the first-hit albedo/normal guides captured when
+ * MI_PT_USE_OPTIX_DENOISER is set (replaces OptiXDenoiser::denoiseImageBuffer I/O contract, reference:
+ * src/optix_denoiser.hpp:128-153). Result in hostRGBA32F (may be NULL) and in the internal denoised image. */
+MI_PT_API int mi_pt_denoise(MiPt* pt, int iterations, float sigmaColor, float sigmaNormal, float sigmaAlbedo,
+                            float* hostRGBA32F, void* hipStream);
+
+MI_PT_API int mi_pt_get_stats(MiPt* pt, MiPtStats* stats);
+MI_PT_API int mi_pt_reset_stats(MiPt* pt);
+MI_PT_API int mi_pt_enable_timing(MiPt* pt, int enable);
+MI_PT_API int mi_pt_get_frame_timing(MiPt* pt, MiPtFrameTiming* timing);
+
+/* Human-readable description of the last failure on this thread ("" if none). */
+MI_PT_API const char* mi_pt_last_error(void);
+MI_PT_API const char* mi_pt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_PT_H */
