@@ -906,10 +906,13 @@ struct LightContrib
   float3 intensity{0, 0, 0};
   float  pdf = DIRAC;
 };
-float3 sampleCone(float2 xi, float cosMax, float3 axis)
+// Uniform direction inside a cone given 1 - cos(halfAngle); written so that tiny cones (the sun: 1 - cos ~ 1e-5) keep
+// full relative precision: sin^2 = (1 - cos)(1 + cos) = s (2 - s).
+float3 sampleCone(float2 xi, float oneMinusCosMax, float3 axis)
 {
-  float  cosTheta = 1.0f - xi.x * (1.0f - cosMax);
-  float  sinTheta = std::sqrt(std::fmax(0.0f, 1.0f - cosTheta * cosTheta));
+  float  s        = xi.x * oneMinusCosMax;
+  float  cosTheta = 1.0f - s;
+  float  sinTheta = std::sqrt(std::fmax(0.0f, s * (2.0f - s)));
   float  phi      = K_TWO_PI * xi.y;
   float4 t        = makeFastTangent(axis);
   float3 T = t.xyz(), B = cross(axis, T);
@@ -925,9 +928,9 @@ LightContrib singleLightContribution(const MiGltfLight& light, float3 pos, float
     float  halfAng = 0.5f * light.angularSizeOrInvRange;
     if(halfAng > 0.0f)
     {
-      float cosMax = std::cos(halfAng);
-      toLight      = sampleCone(xi, cosMax, toLight);
-      c.pdf        = 1.0f / (K_TWO_PI * (1.0f - cosMax));
+      float omc = 2.0f * sqr(std::sin(0.5f * halfAng));  // 1 - cos(halfAng)
+      toLight   = sampleCone(xi, omc, toLight);
+      c.pdf     = 1.0f / (K_TWO_PI * omc);
     }
     c.incidentVector = -toLight;
     c.distance       = INFINITE_F;
@@ -946,9 +949,9 @@ LightContrib singleLightContribution(const MiGltfLight& light, float3 pos, float
     {
       float sinMax = std::fmin(light.radius / d, 1.0f);
       float cosMax = std::sqrt(std::fmax(0.0f, 1.0f - sinMax * sinMax));
-      cosMax       = std::fmin(cosMax, 0.9999999f);
-      L            = sampleCone(xi, cosMax, axisL);
-      c.pdf        = 1.0f / (K_TWO_PI * (1.0f - cosMax));
+      float omc    = std::fmax(sinMax * sinMax / (1.0f + cosMax), 1e-12f);  // 1 - cosMax
+      L            = sampleCone(xi, omc, axisL);
+      c.pdf        = 1.0f / (K_TWO_PI * omc);
       // distance to the sphere surface along L
       float b    = dot(L, toLight);
       float disc = b * b - (d * d - light.radius * light.radius);
@@ -993,7 +996,10 @@ float perez(float cosTheta, float gamma, float cosGamma, const float c[5])
 }
 float3 skyUp(const MiSkyPhysicalParameters& s) { return s.yIsUp ? float3(0, 1, 0) : float3(0, 0, 1); }
 float  skySunAngularRadius(const MiSkyPhysicalParameters& s) { return 0.00465f * std::fmax(s.sunDiskScale, 0.0f) + 1e-6f; }
-float  skySunConeCos(const MiSkyPhysicalParameters& s) { return std::cos(std::fmin(skySunAngularRadius(s) * 4.0f, 1.5f)); }
+float  skySunConeAngle(const MiSkyPhysicalParameters& s) { return std::fmin(skySunAngularRadius(s) * 4.0f, 1.5f); }
+float  skySunConeOneMinusCos(const MiSkyPhysicalParameters& s) { return 2.0f * sqr(std::sin(0.5f * skySunConeAngle(s))); }
+// angle between two unit vectors, well conditioned near 0 (acos is not)
+float  angleBetween(float3 a, float3 b) { return std::atan2(length(cross(a, b)), dot(a, b)); }
 float3 evalPhysicalSky(const MiSkyPhysicalParameters& s, float3 dir)
 {
   if(s.multiplier <= 0.0f)
@@ -1026,7 +1032,7 @@ float3 evalPhysicalSky(const MiSkyPhysicalParameters& s, float3 dir)
   else
   {
     float cosGamma = clampf(dot(dir, sunDir), -1.0f, 1.0f);
-    float gamma    = std::acos(cosGamma);
+    float gamma    = angleBetween(dir, sunDir);
     const float cY[5] = {0.1787f * T - 1.4630f, -0.3554f * T + 0.4275f, -0.0227f * T + 5.3251f, 0.1206f * T - 2.5771f, -0.0670f * T + 0.3703f};
     const float cx[5] = {-0.0193f * T - 0.2592f, -0.0665f * T + 0.0008f, -0.0004f * T + 0.2125f, -0.0641f * T - 0.8989f, -0.0033f * T + 0.0452f};
     const float cy[5] = {-0.0167f * T - 0.2608f, -0.0950f * T + 0.0092f, -0.0079f * T + 0.2102f, -0.0441f * T - 1.6537f, -0.0109f * T + 0.0529f};
@@ -1050,7 +1056,7 @@ float3 evalPhysicalSky(const MiSkyPhysicalParameters& s, float3 dir)
     float r = skySunAngularRadius(s);
     if(s.sunDiskIntensity > 0.0f && gamma < r * 4.0f)
     {
-      float  omega = K_TWO_PI * (1.0f - std::cos(r));
+      float  omega = K_TWO_PI * 2.0f * sqr(std::sin(0.5f * r));
       float3 Lsun  = sunE / omega * s.sunDiskIntensity;
       if(gamma < r)
       {
@@ -1073,9 +1079,8 @@ float samplePhysicalSkyPDF(const MiSkyPhysicalParameters& s, float3 dir)
 {
   float wSun   = skySunWeight(s);
   float pdf    = (1.0f - wSun) * (0.25f * K_1_OVER_PI);
-  float cosMax = skySunConeCos(s);
-  if(wSun > 0.0f && dot(dir, normalize(float3(s.sunDirection))) >= cosMax)
-    pdf += wSun / (K_TWO_PI * (1.0f - cosMax));
+  if(wSun > 0.0f && angleBetween(dir, normalize(float3(s.sunDirection))) <= skySunConeAngle(s))
+    pdf += wSun / (K_TWO_PI * skySunConeOneMinusCos(s));
   return pdf;
 }
 SkySamplingResult samplePhysicalSky(const MiSkyPhysicalParameters& s, float2 xi)
@@ -1084,7 +1089,7 @@ SkySamplingResult samplePhysicalSky(const MiSkyPhysicalParameters& s, float2 xi)
   float             wSun = skySunWeight(s);
   float             u    = xi.x;
   if(splitRandom(u, wSun))
-    r.direction = sampleCone(float2(u, xi.y), skySunConeCos(s), normalize(float3(s.sunDirection)));
+    r.direction = sampleCone(float2(u, xi.y), skySunConeOneMinusCos(s), normalize(float3(s.sunDirection)));
   else
   {
     float z   = 1.0f - 2.0f * u;

@@ -1,0 +1,164 @@
+"""Host front end (glTF -> tables) against the reference's own expectations and the in-tree assets."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from vk_gltf_renderer_amd import _capi as capi
+from vk_gltf_renderer_amd import pathtracer as ptmod
+from vk_gltf_renderer_amd import scenegen
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _scene_with_materials(tmp_path, materials, with_texture=False):
+    b = scenegen.GlbBuilder()
+    if with_texture:
+        b.texture(b.image(np.full((2, 2, 4), 255, np.uint8)))
+    for m in materials:
+        b.material(m)
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    b.node(mesh=b.mesh([b.primitive(pos, np.array([0, 1, 2]), material=0 if materials else None)]))
+    return ptmod.Scene(b.save(str(tmp_path / "m.glb")))
+
+
+def test_material_cache_reference_expectations(built, tmp_path):
+    """Vectors from the reference's tests/test_material_cache.cpp (see golden file header)."""
+    cases = json.load(open(os.path.join(GOLDEN, "material_cache_cases.json")))["cases"]
+    for case in cases:
+        sc = _scene_with_materials(tmp_path, case["gltf"], with_texture="Texture" in case["name"])
+        d = sc.desc.contents
+        assert d.numMaterials == len(case["gltf"]), case["name"]
+        for i, exp in enumerate(case["expect"]):
+            mat = d.materials[i]
+            for key, val in exp.items():
+                if key == "pbrBaseColorTexture>0":
+                    assert mat.pbrBaseColorTexture > 0
+                elif key == "numTextureInfos>=":
+                    assert d.numTextureInfos >= val
+                elif "[" in key:
+                    name, idx = key[:-1].split("[")
+                    assert getattr(mat, name)[int(idx)] == pytest.approx(val, rel=1e-6)
+                else:
+                    assert getattr(mat, key) == pytest.approx(val, rel=1e-6), (case["name"], key)
+
+
+def test_empty_materials_get_default_and_sentinel(built, tmp_path):
+    """reference: MaterialCache.BuildFromEmptyMaterials keeps the sentinel texture-info; Scene::parseScene adds one
+    default material when the file has none (src/gltf_scene.cpp:1391-1395)."""
+    sc = _scene_with_materials(tmp_path, [])
+    d = sc.desc.contents
+    assert d.numTextureInfos == 1 and d.textureInfos[0].index == -1
+    assert d.numMaterials == 1
+    m = d.materials[0]
+    assert list(m.pbrBaseColorFactor) == [1, 1, 1, 1] and m.pbrRoughnessFactor == 1 and m.pbrMetallicFactor == 1
+    assert m.ior == pytest.approx(1.5) and m.specularFactor == pytest.approx(1.0) and m.alphaCutoff == pytest.approx(0.5)
+    assert m.attenuationDistance > 1e38 and m.iridescenceIor == pytest.approx(1.3)
+
+
+def test_box_glb(built, assets):
+    """reference: tests/test_basic.cpp:34-51 pins 'Box.glb loads and has > 0 render nodes'."""
+    sc = ptmod.Scene(os.path.join(assets, "Box.glb"))
+    d = sc.desc.contents
+    assert d.numRenderNodes == 1 and d.numRenderPrimitives == 1 and sc.num_triangles == 12
+    rp = d.renderPrimitives[0]
+    assert rp.triangleCount == 12 and rp.vertexCount == 24 and bool(rp.normals) and not bool(rp.texCoords0)
+    assert max(rp.indices[i] for i in range(36)) == 23
+    assert d.materials[0].pbrBaseColorFactor[0] == pytest.approx(0.8) and d.materials[0].pbrMetallicFactor == 0.0
+    cam = sc.camera(0)
+    assert list(cam.eye) == pytest.approx([0, 0, 2.0905852]) and cam.fovDegrees == pytest.approx(45.0, abs=1e-3)
+    lo, hi = sc.bounds()
+    assert np.allclose(lo, -0.5) and np.allclose(hi, 0.5)
+
+
+def test_shader_ball(built, assets):
+    sc = ptmod.Scene(os.path.join(assets, "shader_ball.gltf"))
+    d = sc.desc.contents
+    assert sc.num_triangles == 9450 and d.renderPrimitives[0].vertexCount == 8093
+    assert d.materials[0].doubleSided == 1 and d.materials[0].pbrRoughnessFactor == pytest.approx(0.6)
+
+
+def test_render_node_flattening_and_instancing(built, tmp_path):
+    """One RenderPrimitive per distinct (attributes, indices) key, one RenderNode per node x primitive, world matrices are
+    parent * local, EXT_mesh_gpu_instancing expands (reference: src/gltf_scene.cpp:2139-2165, :2338-2429)."""
+    b = scenegen.GlbBuilder()
+    m0, m1 = b.material({}), b.material({"doubleSided": True})
+    pos, nrm, uv, idx = scenegen.box()
+    prim_a = b.primitive(pos, idx, nrm, uv, material=m0)
+    prim_b = dict(prim_a)
+    prim_b["material"] = m1  # same accessors -> same RenderPrimitive
+    mesh = b.mesh([prim_a, prim_b])
+    child = b.node(root=False, mesh=mesh, translation=[0, 2, 0])
+    b.node(children=[child], translation=[1, 0, 0], scale=[2, 2, 2])
+    tr = b.accessor(np.array([[0, 0, 0], [5, 0, 0], [0, 0, 5]], np.float32))
+    b.ext_used.add("EXT_mesh_gpu_instancing")
+    b.node(mesh=mesh, extensions={"EXT_mesh_gpu_instancing": {"attributes": {"TRANSLATION": tr}}})
+    sc = ptmod.Scene(b.save(str(tmp_path / "f.glb")))
+    d = sc.desc.contents
+    assert d.numRenderPrimitives == 1
+    assert d.numRenderNodes == 2 + 2 * 3
+    n0 = d.renderNodes[0]
+    o2w = np.array(n0.objectToWorld[:]).reshape(4, 4).T
+    assert np.allclose(o2w @ np.array([0, 0, 0, 1.0]), [1, 4, 0, 1])  # parent T*S then child T
+    assert np.allclose(np.array(n0.worldToObject[:]).reshape(4, 4).T @ o2w, np.eye(4), atol=1e-6)
+    assert [d.renderNodes[i].materialID for i in range(2)] == [0, 1]
+    inst = [np.array(d.renderNodes[i].objectToWorld[:])[12:15] for i in range(2, 8)]
+    assert sorted(tuple(v) for v in inst) == sorted([(0, 0, 0), (0, 0, 0), (5, 0, 0), (5, 0, 0), (0, 0, 5), (0, 0, 5)])
+
+
+def test_texture_decode_mips_and_srgb(built, tmp_path):
+    b = scenegen.GlbBuilder()
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (8, 16, 4), dtype=np.uint8)
+    t_col = b.texture(b.image(img), b.sampler(mag=9728, min_=9986, wrap_s=33071, wrap_t=33648))
+    t_lin = b.texture(b.image(img))
+    b.material({"pbrMetallicRoughness": {"baseColorTexture": {"index": t_col}, "metallicRoughnessTexture": {"index": t_lin}}})
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    b.node(mesh=b.mesh([b.primitive(pos, np.array([0, 1, 2]), material=0)]))
+    sc = ptmod.Scene(b.save(str(tmp_path / "t.glb")))
+    d = sc.desc.contents
+    t0, t1 = d.textures[0], d.textures[1]
+    assert (t0.width, t0.height, t0.numLevels, t0.srgb) == (16, 8, 5, 1) and t1.srgb == 0
+    assert (t0.magFilter, t0.minFilter, t0.mipmapMode, t0.wrapS, t0.wrapT) == (0, 0, 0, 1, 2)  # mipmapMode follows magFilter
+    assert (t1.magFilter, t1.minFilter, t1.mipmapMode, t1.wrapS, t1.wrapT) == (1, 1, 1, 0, 0)
+    lvl0 = np.ctypeslib.as_array(t1.levels[0], shape=(8, 16, 4))
+    assert (lvl0 == img).all()  # PNG round trip is lossless
+    lvl1 = np.ctypeslib.as_array(t1.levels[1], shape=(4, 8, 4)).astype(np.int32)
+    box = img.reshape(4, 2, 8, 2, 4).astype(np.float64).mean(axis=(1, 3))
+    assert np.abs(lvl1 - box).max() <= 0.5 + 1e-6  # linear image: 2x2 box filter, rounded to nearest
+
+
+def test_hdr_importance_table(built, assets):
+    hdr = ptmod.HdrEnvironment(path=os.path.join(assets, "std_env.hdr"))
+    e = hdr.env.contents
+    assert (e.width, e.height) == (1500, 750)
+    n = e.width * e.height
+    rgba = np.ctypeslib.as_array(e.rgba, shape=(e.height, e.width, 4))
+    q = np.array([e.accel[i].q for i in range(0, n, 997)])
+    assert (q >= 0).all() and (q <= 1.0 + 1e-6).all()
+    # pdf (alpha) integrates to 1 over the sphere
+    theta0 = np.arange(e.height) * np.pi / e.height
+    area = (np.cos(theta0) - np.cos(theta0 + np.pi / e.height)) * (2 * np.pi / e.width)
+    assert (rgba[..., 3] * area[:, None]).sum() == pytest.approx(1.0, rel=1e-3)
+    # alias table reproduces the importance distribution
+    alias = np.array([e.accel[i].alias for i in range(n)], dtype=np.int64)
+    qq = np.array([e.accel[i].q for i in range(n)])
+    prob = qq / n
+    np.add.at(prob, alias, (1.0 - qq) / n)
+    target = (rgba[..., :3].max(axis=-1) * area[:, None]).reshape(-1)
+    target = target / target.sum()
+    assert np.abs(prob - target).max() < 5e-7
+
+
+def test_camera_frame_info(built, assets):
+    sc = ptmod.Scene(os.path.join(assets, "Box.glb"))
+    fi, pixel_angle, focal = ptmod.camera_frame_info(sc.camera(0), 256, 256)
+    assert focal == pytest.approx(2.0905852)
+    assert pixel_angle == pytest.approx(2 * np.tan(np.radians(45) / 2) / 256, rel=1e-5)  # src/renderer_pathtracer.cpp:1570-1571
+    view_inv = np.array(fi.viewInv[:]).reshape(4, 4).T
+    assert np.allclose(view_inv[:3, 3], [0, 0, 2.0905852])
+    proj_inv = np.array(fi.projInv[:]).reshape(4, 4).T
+    v = proj_inv @ np.array([0.0, -1.0, -1.0, 1.0])  # top edge of the screen (pixel y = 0) looks up: Vulkan y-flip
+    assert (v[:3] / v[3])[1] > 0

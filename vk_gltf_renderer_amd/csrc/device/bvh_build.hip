@@ -1,0 +1,384 @@
+// On-device BVH construction (replaces the BLAS/TLAS builds of the reference: src/gltf_scene_rtx.cpp:173-227, :299-385).
+//
+// All render-node instances are flattened to world-space triangles (288 GB of HBM make instancing-by-reference
+// unnecessary for the target scenes and it removes the per-instance ray transform from the traversal loop), then
+//   1. k_tri_setup   : world-space vertices (fixed fmaf order, shared with the oracle), AABB, centroid bounds
+//   2. k_morton      : 63-bit Morton code of the AABB centre
+//   3. rocPRIM radix sort of (code, triangle)
+//   4. k_hierarchy   : Karras 2012, "Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d Trees"
+//   5. k_fit         : bottom-up AABB refit, second arrival at a node continues upward (agent-scope fences)
+//   6. k_emit        : 64-byte traversal nodes holding both children's boxes; triangles re-ordered in Morton order
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "pt_build.h"
+#include "pt_bvh.h"
+
+namespace pt {
+
+namespace {
+
+struct BuildTables
+{
+  const MiGltfRenderNode* nodes;
+  const DevPrim*          prims;
+  const uint8_t*          instFlags;      // per render node
+  const uint32_t*         nodeTriOffset;  // exclusive scan of triangle counts over *visible* render nodes, size numEntries+1
+  const int32_t*          entryNode;      // render-node index of each entry
+  int                     numEntries;
+};
+
+__device__ __forceinline__ uint32_t floatToOrdered(float f)
+{
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float orderedToFloat(uint32_t u)
+{
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+__global__ void k_tri_setup(BuildTables T, uint32_t numTris, DevTri* tris, float4* boxLo, float4* boxHi, uint32_t* sceneBounds)
+{
+  uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  float    lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  if(g < numTris)
+  {
+    // binary search the owning entry
+    int a = 0, b = T.numEntries;
+    while(b - a > 1)
+    {
+      int m = (a + b) >> 1;
+      if(T.nodeTriOffset[m] <= g)
+        a = m;
+      else
+        b = m;
+    }
+    const int               rnode = T.entryNode[a];
+    const uint32_t          t     = g - T.nodeTriOffset[a];
+    const MiGltfRenderNode& rn    = T.nodes[rnode];
+    const DevPrim&          rp    = T.prims[rn.renderPrimID];
+    const uint32_t          i0 = rp.indices[3 * t], i1 = rp.indices[3 * t + 1], i2 = rp.indices[3 * t + 2];
+    f3 p0 = mulPoint(rn.objectToWorld, mk3(rp.positions + 3 * size_t(i0)));
+    f3 p1 = mulPoint(rn.objectToWorld, mk3(rp.positions + 3 * size_t(i1)));
+    f3 p2 = mulPoint(rn.objectToWorld, mk3(rp.positions + 3 * size_t(i2)));
+    f3 e1 = p1 - p0, e2 = p2 - p0;
+    DevTri tri;
+    tri.a   = make_float4(p0.x, p0.y, p0.z, __int_as_float(rnode));
+    tri.b   = make_float4(e1.x, e1.y, e1.z, __int_as_float(int(t)));
+    tri.c   = make_float4(e2.x, e2.y, e2.z, __uint_as_float(uint32_t(T.instFlags[rnode])));
+    tris[g] = tri;
+    // bounds from the same p0 + e arithmetic the intersector sees
+    f3 q1 = p0 + e1, q2 = p0 + e2;
+    lo[0] = fminf(p0.x, fminf(q1.x, q2.x)); hi[0] = fmaxf(p0.x, fmaxf(q1.x, q2.x));
+    lo[1] = fminf(p0.y, fminf(q1.y, q2.y)); hi[1] = fmaxf(p0.y, fmaxf(q1.y, q2.y));
+    lo[2] = fminf(p0.z, fminf(q1.z, q2.z)); hi[2] = fmaxf(p0.z, fmaxf(q1.z, q2.z));
+    // include the true vertices too (p0+e may round inward)
+    lo[0] = fminf(lo[0], fminf(p1.x, p2.x)); hi[0] = fmaxf(hi[0], fmaxf(p1.x, p2.x));
+    lo[1] = fminf(lo[1], fminf(p1.y, p2.y)); hi[1] = fmaxf(hi[1], fmaxf(p1.y, p2.y));
+    lo[2] = fminf(lo[2], fminf(p1.z, p2.z)); hi[2] = fmaxf(hi[2], fmaxf(p1.z, p2.z));
+    boxLo[g] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+    boxHi[g] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+  }
+  // block reduction of centroid bounds -> 6 atomics per block
+  __shared__ float s_lo[3][256], s_hi[3][256];
+  for(int c = 0; c < 3; ++c)
+  {
+    float cen            = (g < numTris) ? 0.5f * (lo[c] + hi[c]) : 0.0f;
+    s_lo[c][threadIdx.x] = (g < numTris) ? cen : 3.0e38f;
+    s_hi[c][threadIdx.x] = (g < numTris) ? cen : -3.0e38f;
+  }
+  __syncthreads();
+  for(int s = 128; s > 0; s >>= 1)
+  {
+    if(threadIdx.x < s)
+      for(int c = 0; c < 3; ++c)
+      {
+        s_lo[c][threadIdx.x] = fminf(s_lo[c][threadIdx.x], s_lo[c][threadIdx.x + s]);
+        s_hi[c][threadIdx.x] = fmaxf(s_hi[c][threadIdx.x], s_hi[c][threadIdx.x + s]);
+      }
+    __syncthreads();
+  }
+  if(threadIdx.x < 3)
+  {
+    atomicMin(&sceneBounds[threadIdx.x], floatToOrdered(s_lo[threadIdx.x][0]));
+    atomicMax(&sceneBounds[3 + threadIdx.x], floatToOrdered(s_hi[threadIdx.x][0]));
+  }
+}
+
+__device__ __forceinline__ uint64_t expandBits21(uint32_t v)
+{
+  uint64_t x = v & 0x1fffffu;
+  x          = (x | x << 32) & 0x1f00000000ffffull;
+  x          = (x | x << 16) & 0x1f0000ff0000ffull;
+  x          = (x | x << 8) & 0x100f00f00f00f00full;
+  x          = (x | x << 4) & 0x10c30c30c30c30c3ull;
+  x          = (x | x << 2) & 0x1249249249249249ull;
+  return x;
+}
+
+__global__ void k_morton(uint32_t numTris, const float4* boxLo, const float4* boxHi, const uint32_t* sceneBounds, uint64_t* keys, uint32_t* vals)
+{
+  uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if(g >= numTris)
+    return;
+  float blo[3], bhi[3];
+  for(int c = 0; c < 3; ++c)
+  {
+    blo[c] = orderedToFloat(sceneBounds[c]);
+    bhi[c] = orderedToFloat(sceneBounds[3 + c]);
+  }
+  float4   lo = boxLo[g], hi = boxHi[g];
+  float    cen[3] = {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
+  uint32_t q[3];
+  for(int c = 0; c < 3; ++c)
+  {
+    float ext = bhi[c] - blo[c];
+    float n   = ext > 0.0f ? (cen[c] - blo[c]) / ext : 0.0f;
+    q[c]      = uint32_t(fminf(fmaxf(n * 2097152.0f, 0.0f), 2097151.0f));
+  }
+  keys[g] = (expandBits21(q[0]) << 2) | (expandBits21(q[1]) << 1) | expandBits21(q[2]);
+  vals[g] = g;
+}
+
+// common-prefix length of sorted keys i and j, index-augmented so that duplicate codes still form a balanced tree
+__device__ __forceinline__ int delta(const uint64_t* keys, int n, int i, int j)
+{
+  if(j < 0 || j >= n)
+    return -1;
+  uint64_t a = keys[i], b = keys[j];
+  if(a == b)
+    return 64 + __clz(uint32_t(i) ^ uint32_t(j));
+  return __clzll((long long)(a ^ b));
+}
+
+// internal node i in [0, n-2]; child refs: >= 0 internal, < 0 leaf (~sorted position)
+__global__ void k_hierarchy(int n, const uint64_t* keys, int2* children, int* parentInternal, int* parentLeaf)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n - 1)
+    return;
+  int d      = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+  int dmin   = delta(keys, n, i, i - d);
+  int lmax   = 2;
+  while(delta(keys, n, i, i + lmax * d) > dmin)
+    lmax <<= 1;
+  int l = 0;
+  for(int t = lmax >> 1; t >= 1; t >>= 1)
+    if(delta(keys, n, i, i + (l + t) * d) > dmin)
+      l += t;
+  int j     = i + l * d;
+  int dnode = delta(keys, n, i, j);
+  int s     = 0;
+  for(int t = (l + 1) >> 1;; t = (t + 1) >> 1)
+  {
+    if(delta(keys, n, i, i + (s + t) * d) > dnode)
+      s += t;
+    if(t == 1)
+      break;
+  }
+  int gamma = i + s * d + min(d, 0);
+  int left  = (min(i, j) == gamma) ? ~gamma : gamma;
+  int right = (max(i, j) == gamma + 1) ? ~(gamma + 1) : (gamma + 1);
+  children[i] = make_int2(left, right);
+  if(left >= 0)
+    parentInternal[left] = i;
+  else
+    parentLeaf[~left] = i;
+  if(right >= 0)
+    parentInternal[right] = i;
+  else
+    parentLeaf[~right] = i;
+  if(i == 0)
+    parentInternal[0] = -1;
+}
+
+__global__ void k_fit(int n, const uint32_t* vals, const float4* boxLo, const float4* boxHi, const int2* children, const int* parentInternal,
+                      const int* parentLeaf, float4* nodeLo, float4* nodeHi, unsigned int* arrive)
+{
+  int leaf = blockIdx.x * blockDim.x + threadIdx.x;
+  if(leaf >= n)
+    return;
+  int cur = parentLeaf[leaf];
+  while(cur >= 0)
+  {
+    __threadfence();  // release: boxes written below this point of the tree are visible before the ticket
+    unsigned int ticket = atomicAdd(&arrive[cur], 1u);
+    if(ticket == 0)
+      return;         // first arrival: the sibling subtree finishes this node
+    __threadfence();  // acquire: drop stale L1 lines before reading the sibling's box
+    int2   ch = children[cur];
+    float4 lo0, hi0, lo1, hi1;
+    if(ch.x >= 0)
+    {
+      lo0 = nodeLo[ch.x];
+      hi0 = nodeHi[ch.x];
+    }
+    else
+    {
+      uint32_t t = vals[~ch.x];
+      lo0 = boxLo[t];
+      hi0 = boxHi[t];
+    }
+    if(ch.y >= 0)
+    {
+      lo1 = nodeLo[ch.y];
+      hi1 = nodeHi[ch.y];
+    }
+    else
+    {
+      uint32_t t = vals[~ch.y];
+      lo1 = boxLo[t];
+      hi1 = boxHi[t];
+    }
+    nodeLo[cur] = make_float4(fminf(lo0.x, lo1.x), fminf(lo0.y, lo1.y), fminf(lo0.z, lo1.z), 0.0f);
+    nodeHi[cur] = make_float4(fmaxf(hi0.x, hi1.x), fmaxf(hi0.y, hi1.y), fmaxf(hi0.z, hi1.z), 0.0f);
+    cur         = parentInternal[cur];
+  }
+}
+
+__global__ void k_emit_nodes(int n, const uint32_t* vals, const float4* boxLo, const float4* boxHi, const int2* children, const float4* nodeLo,
+                             const float4* nodeHi, float4* outNodes)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n - 1)
+    return;
+  int2   ch = children[i];
+  float4 lo0, hi0, lo1, hi1;
+  if(ch.x >= 0) { lo0 = nodeLo[ch.x]; hi0 = nodeHi[ch.x]; } else { uint32_t t = vals[~ch.x]; lo0 = boxLo[t]; hi0 = boxHi[t]; }
+  if(ch.y >= 0) { lo1 = nodeLo[ch.y]; hi1 = nodeHi[ch.y]; } else { uint32_t t = vals[~ch.y]; lo1 = boxLo[t]; hi1 = boxHi[t]; }
+  float4* o = outNodes + size_t(i) * 4;
+  o[0]      = make_float4(lo0.x, hi0.x, lo0.y, hi0.y);
+  o[1]      = make_float4(lo1.x, hi1.x, lo1.y, hi1.y);
+  o[2]      = make_float4(lo0.z, hi0.z, lo1.z, hi1.z);
+  o[3]      = make_float4(__int_as_float(ch.x), __int_as_float(ch.y), 0.0f, 0.0f);
+}
+
+__global__ void k_emit_tris(int n, const uint32_t* vals, const DevTri* tris, DevTri* outTris)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < n)
+    outTris[i] = tris[vals[i]];
+}
+
+#define BUILD_CHECK(x)                                                                                                  \
+  do                                                                                                                    \
+  {                                                                                                                     \
+    hipError_t e_ = (x);                                                                                                \
+    if(e_ != hipSuccess)                                                                                                \
+    {                                                                                                                   \
+      err = std::string(#x) + ": " + hipGetErrorString(e_);                                                             \
+      ok  = false;                                                                                                      \
+      break;                                                                                                            \
+    }                                                                                                                   \
+  } while(0)
+// NB: BUILD_CHECK `break`s out of the single do { } while(0) that wraps buildBvh's body.
+
+}  // namespace
+
+bool buildBvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream, std::string& err)
+{
+  out               = BvhBuildOutput();
+  const uint32_t n  = in.numTris;
+  out.numTris       = n;
+  out.root          = BVH_EMPTY;
+  if(n == 0)
+    return true;
+  DevTri*   trisTmp = nullptr;
+  float4 *  boxLo = nullptr, *boxHi = nullptr, *nodeLo = nullptr, *nodeHi = nullptr;
+  uint32_t *bounds = nullptr, *valsA = nullptr, *valsB = nullptr;
+  uint64_t *keysA = nullptr, *keysB = nullptr;
+  int2*     children = nullptr;
+  int *     parentInternal = nullptr, *parentLeaf = nullptr;
+  unsigned* arrive         = nullptr;
+  void*     sortTemp       = nullptr;
+  size_t    sortBytes      = 0;
+  const int B              = 256;
+  const unsigned gridT     = (n + B - 1) / B;
+  BuildTables T{in.nodes, in.prims, in.instFlags, in.nodeTriOffset, in.entryNode, in.numEntries};
+  const uint32_t initBounds[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+  bool           ok            = true;
+  uint32_t       hb[6]         = {0, 0, 0, 0, 0, 0};
+
+  do
+  {
+  BUILD_CHECK(hipMalloc(&trisTmp, sizeof(DevTri) * n));
+  BUILD_CHECK(hipMalloc(&boxLo, sizeof(float4) * n));
+  BUILD_CHECK(hipMalloc(&boxHi, sizeof(float4) * n));
+  BUILD_CHECK(hipMalloc(&bounds, sizeof(initBounds)));
+  BUILD_CHECK(hipMemcpyAsync(bounds, initBounds, sizeof(initBounds), hipMemcpyHostToDevice, stream));
+  hipLaunchKernelGGL(k_tri_setup, dim3(gridT), dim3(B), 0, stream, T, n, trisTmp, boxLo, boxHi, bounds);
+  BUILD_CHECK(hipGetLastError());
+
+  BUILD_CHECK(hipMalloc(&out.tris, sizeof(DevTri) * n));
+  if(n == 1)
+  {
+    BUILD_CHECK(hipMemcpyAsync(out.tris, trisTmp, sizeof(DevTri), hipMemcpyDeviceToDevice, stream));
+    BUILD_CHECK(hipStreamSynchronize(stream));
+    out.root     = ~0;  // leaf 0
+    out.numNodes = 0;
+  }
+  else
+  {
+    BUILD_CHECK(hipMalloc(&keysA, sizeof(uint64_t) * n));
+    BUILD_CHECK(hipMalloc(&keysB, sizeof(uint64_t) * n));
+    BUILD_CHECK(hipMalloc(&valsA, sizeof(uint32_t) * n));
+    BUILD_CHECK(hipMalloc(&valsB, sizeof(uint32_t) * n));
+    hipLaunchKernelGGL(k_morton, dim3(gridT), dim3(B), 0, stream, n, boxLo, boxHi, bounds, keysA, valsA);
+    BUILD_CHECK(hipGetLastError());
+    BUILD_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, sortBytes, keysA, keysB, valsA, valsB, int(n), 0, 63, stream));
+    BUILD_CHECK(hipMalloc(&sortTemp, sortBytes));
+    BUILD_CHECK(hipcub::DeviceRadixSort::SortPairs(sortTemp, sortBytes, keysA, keysB, valsA, valsB, int(n), 0, 63, stream));
+
+    BUILD_CHECK(hipMalloc(&children, sizeof(int2) * (n - 1)));
+    BUILD_CHECK(hipMalloc(&parentInternal, sizeof(int) * (n - 1)));
+    BUILD_CHECK(hipMalloc(&parentLeaf, sizeof(int) * n));
+    BUILD_CHECK(hipMalloc(&nodeLo, sizeof(float4) * (n - 1)));
+    BUILD_CHECK(hipMalloc(&nodeHi, sizeof(float4) * (n - 1)));
+    BUILD_CHECK(hipMalloc(&arrive, sizeof(unsigned) * (n - 1)));
+    BUILD_CHECK(hipMemsetAsync(arrive, 0, sizeof(unsigned) * (n - 1), stream));
+    hipLaunchKernelGGL(k_hierarchy, dim3((n - 1 + B - 1) / B), dim3(B), 0, stream, int(n), keysB, children, parentInternal, parentLeaf);
+    BUILD_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_fit, dim3(gridT), dim3(B), 0, stream, int(n), valsB, boxLo, boxHi, children, parentInternal, parentLeaf, nodeLo, nodeHi, arrive);
+    BUILD_CHECK(hipGetLastError());
+    BUILD_CHECK(hipMalloc(&out.nodes, sizeof(float4) * 4 * (n - 1)));
+    hipLaunchKernelGGL(k_emit_nodes, dim3((n - 1 + B - 1) / B), dim3(B), 0, stream, int(n), valsB, boxLo, boxHi, children, nodeLo, nodeHi, out.nodes);
+    BUILD_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_emit_tris, dim3(gridT), dim3(B), 0, stream, int(n), valsB, trisTmp, out.tris);
+    BUILD_CHECK(hipGetLastError());
+    BUILD_CHECK(hipStreamSynchronize(stream));
+    out.root     = 0;
+    out.numNodes = n - 1;
+  }
+  BUILD_CHECK(hipMemcpy(hb, bounds, sizeof(hb), hipMemcpyDeviceToHost));
+  } while(0);
+  if(ok)
+  {
+    for(int c = 0; c < 3; ++c)
+    {
+      auto toF = [](uint32_t u) {
+        uint32_t v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+        float    f;
+        memcpy(&f, &v, 4);
+        return f;
+      };
+      out.centroidLo[c] = toF(hb[c]);
+      out.centroidHi[c] = toF(hb[3 + c]);
+    }
+  }
+  if(!ok)
+  {
+    if(out.nodes) (void)hipFree(out.nodes);
+    if(out.tris) (void)hipFree(out.tris);
+    out.nodes = nullptr;
+    out.tris  = nullptr;
+  }
+  {
+    (void)hipFree(trisTmp); (void)hipFree(boxLo); (void)hipFree(boxHi); (void)hipFree(nodeLo); (void)hipFree(nodeHi);
+    (void)hipFree(bounds); (void)hipFree(valsA); (void)hipFree(valsB); (void)hipFree(keysA); (void)hipFree(keysB);
+    (void)hipFree(children); (void)hipFree(parentInternal); (void)hipFree(parentLeaf); (void)hipFree(arrive); (void)hipFree(sortTemp);
+    return ok;
+  }
+}
+
+}  // namespace pt

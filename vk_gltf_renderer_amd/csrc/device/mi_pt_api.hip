@@ -1,0 +1,728 @@
+// C-ABI of libmi_pt.so (include/mi_pt.h): device resource management and the per-frame wavefront schedule.
+// Host counterpart in the reference: PathTracer::{onAttach,onResize,onRender,setupPushConstant,renderRayQuery}
+// (src/renderer_pathtracer.cpp:150-260, :500-614, :1404-1431, :1496-1574) plus the uploads of SceneVk / SceneRtx.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "mi_pt.h"
+#include "pt_build.h"
+#include "pt_bvh.h"
+#include "pt_kernels.h"
+
+namespace {
+
+thread_local std::string g_lastError;
+
+int fail(int code, const std::string& msg)
+{
+  g_lastError = msg;
+  return code;
+}
+
+#define HIP_TRY(x)                                                                                                       \
+  do                                                                                                                    \
+  {                                                                                                                     \
+    hipError_t e_ = (x);                                                                                                \
+    if(e_ != hipSuccess)                                                                                                \
+      return fail(MI_PT_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));                                       \
+  } while(0)
+
+template <typename T>
+struct DevBuf
+{
+  T*     ptr   = nullptr;
+  size_t count = 0;
+  hipError_t alloc(size_t n)
+  {
+    release();
+    count = n;
+    if(n == 0)
+      return hipSuccess;
+    return hipMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T));
+  }
+  hipError_t upload(const T* src, size_t n)
+  {
+    hipError_t e = alloc(n);
+    if(e != hipSuccess || n == 0)
+      return e;
+    return hipMemcpy(ptr, src, n * sizeof(T), hipMemcpyHostToDevice);
+  }
+  void release()
+  {
+    if(ptr)
+      (void)hipFree(ptr);
+    ptr   = nullptr;
+    count = 0;
+  }
+  ~DevBuf() { release(); }
+};
+
+enum TimedKernel { TK_GENERATE, TK_TRACE, TK_SORT, TK_SHADE, TK_SHADOW, TK_ACCUM, TK_COUNT };
+
+}  // namespace
+
+struct MiPt
+{
+  int device = 0;
+  int numCUs = 256;
+  // scene
+  DevBuf<MiGltfShadeMaterial> materials;
+  DevBuf<MiGltfTextureInfo>   texInfos;
+  DevBuf<MiGltfRenderNode>    nodes;
+  DevBuf<pt::DevPrim>         prims;
+  DevBuf<MiGltfLight>         lights;
+  DevBuf<pt::DevTexture>      textures;
+  DevBuf<uchar4>              texels;
+  DevBuf<uint8_t>             geometry;  // all index / attribute streams, 16-byte aligned sub-allocations
+  DevBuf<uint8_t>             instFlags;
+  DevBuf<float>               srgbLut;
+  DevBuf<float4>              envPixels;
+  DevBuf<MiEnvAccel>          envAccel;
+  float4*                     bvhNodes = nullptr;
+  pt::DevTri*                 bvhTris  = nullptr;
+  pt::DevScene                scene{};
+  bool                        hasAlpha = false, hasVolumeScatter = false;
+  MiPtStats                   staticStats{};
+  // frame state
+  int                     width = 0, height = 0;
+  int                     tileRank = 0, tileWorld = 1, tileSize = 64;
+  MiSceneFrameInfo        frameInfo{};
+  MiSkyPhysicalParameters sky{};
+  bool                    haveFrameInfo = false;
+  DevBuf<uint32_t>        ownedTiles;
+  int                     numSlots = 0, tilesX = 0, tilesY = 0;
+  DevBuf<float4>          pathArrays;  // one allocation, sliced into PathSoA
+  pt::PathSoA             paths{};
+  DevBuf<uint32_t>        queueMem;
+  pt::Queues              queues{};
+  DevBuf<float4>          accumOwn, albedo, normal, denoiseA, denoiseB;
+  float4*                 accum = nullptr;  // accumOwn.ptr or caller-bound memory
+  DevBuf<float>           depth;
+  DevBuf<uint32_t>        selection;
+  DevBuf<pt::StatCounters> stats;
+  bool                    collectCounters = false;
+  bool                    timingEnabled   = false;
+  MiPtFrameTiming         lastTiming{};
+  std::vector<hipEvent_t> eventPool;
+  hipStream_t             lastStream = nullptr;
+
+  ~MiPt()
+  {
+    if(bvhNodes)
+      (void)hipFree(bvhNodes);
+    if(bvhTris)
+      (void)hipFree(bvhTris);
+    for(hipEvent_t e : eventPool)
+      (void)hipEventDestroy(e);
+  }
+};
+
+namespace {
+
+size_t align16(size_t v) { return (v + 15u) & ~size_t(15); }
+
+int allocFrameResources(MiPt* pt)
+{
+  const int W = pt->width, H = pt->height, T = pt->tileSize;
+  pt->tilesX = (W + T - 1) / T;
+  pt->tilesY = (H + T - 1) / T;
+  std::vector<uint32_t> owned;
+  for(int t = 0; t < pt->tilesX * pt->tilesY; ++t)
+    if(pt->tileWorld <= 1 || (t % pt->tileWorld) == pt->tileRank)
+      owned.push_back(uint32_t(t));
+  pt->numSlots = int(owned.size()) * T * T;
+  HIP_TRY(pt->ownedTiles.upload(owned.data(), owned.size()));
+  const size_t n        = size_t(std::max(pt->numSlots, 1));
+  const int    numArrays = 14;
+  HIP_TRY(pt->pathArrays.alloc(n * numArrays));
+  float4* base = pt->pathArrays.ptr;
+  pt::PathSoA& P = pt->paths;
+  P.rayOrg = base + n * 0; P.rayDir = base + n * 1; P.hit = base + n * 2; P.throughput = base + n * 3; P.radiance = base + n * 4;
+  P.misc = base + n * 5; P.medium = reinterpret_cast<uint4*>(base + n * 6); P.firstHit = base + n * 7; P.shadowOrg = base + n * 8;
+  P.shadowDir = base + n * 9; P.shadowContrib = base + n * 10; P.pixelSum = base + n * 11; P.guideAlbedo = base + n * 12; P.guideNormal = base + n * 13;
+  HIP_TRY(pt->queueMem.alloc(n * 5 + pt::QC_COUNT));
+  pt->queues.active[0] = pt->queueMem.ptr;
+  pt->queues.active[1] = pt->queueMem.ptr + n;
+  pt->queues.shadow    = pt->queueMem.ptr + 2 * n;
+  pt->queues.sortKeys  = pt->queueMem.ptr + 3 * n;
+  pt->queues.sortTmp   = pt->queueMem.ptr + 4 * n;
+  pt->queues.counters  = pt->queueMem.ptr + 5 * n;
+  HIP_TRY(hipMemset(pt->queues.counters, 0, sizeof(uint32_t) * pt::QC_COUNT));
+  const size_t px = size_t(W) * size_t(H);
+  HIP_TRY(pt->accumOwn.alloc(px));
+  HIP_TRY(hipMemset(pt->accumOwn.ptr, 0, px * sizeof(float4)));
+  pt->accum = pt->accumOwn.ptr;
+  HIP_TRY(pt->albedo.alloc(px));
+  HIP_TRY(pt->normal.alloc(px));
+  HIP_TRY(hipMemset(pt->albedo.ptr, 0, px * sizeof(float4)));
+  HIP_TRY(hipMemset(pt->normal.ptr, 0, px * sizeof(float4)));
+  HIP_TRY(pt->depth.alloc(px));
+  HIP_TRY(pt->selection.alloc(px));
+  HIP_TRY(hipMemset(pt->selection.ptr, 0, px * sizeof(uint32_t)));
+  {
+    std::vector<float> ones(px, 1.0f);
+    HIP_TRY(hipMemcpy(pt->depth.ptr, ones.data(), px * sizeof(float), hipMemcpyHostToDevice));
+  }
+  pt->denoiseA.release();
+  pt->denoiseB.release();
+  return MI_PT_OK;
+}
+
+hipEvent_t getEvent(MiPt* pt, size_t& cursor)
+{
+  if(cursor >= pt->eventPool.size())
+  {
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    pt->eventPool.push_back(e);
+  }
+  return pt->eventPool[cursor++];
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mi_pt_last_error(void)
+{
+  return g_lastError.c_str();
+}
+const char* mi_pt_version(void)
+{
+  return "mi_pt 0.1 (gfx950 wavefront path tracer)";
+}
+
+int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt** out)
+{
+  if(!sd || !out)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_create: null argument");
+  int deviceCount = 0;
+  if(hipGetDeviceCount(&deviceCount) != hipSuccess || deviceCount <= 0)
+    return fail(MI_PT_ERR_NO_DEVICE, "mi_pt_create: no HIP device visible (this library has no CPU path)");
+  const int device = options ? options->device : 0;
+  if(device < 0 || device >= deviceCount)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_create: bad device ordinal");
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if(sd->numMaterials <= 0 || sd->numTextureInfos <= 0)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_create: scene needs at least one material and the reserved texture-info slot 0");
+
+  std::unique_ptr<MiPt> pt(new MiPt());
+  pt->device          = device;
+  pt->numCUs          = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  pt->collectCounters = options && options->collectCounters;
+
+  HIP_TRY(pt->materials.upload(sd->materials, size_t(sd->numMaterials)));
+  HIP_TRY(pt->texInfos.upload(sd->textureInfos, size_t(sd->numTextureInfos)));
+  HIP_TRY(pt->nodes.upload(sd->renderNodes, size_t(sd->numRenderNodes)));
+  HIP_TRY(pt->lights.upload(sd->lights, size_t(sd->numLights)));
+
+  // ---- geometry pool ------------------------------------------------------------------------------------------------
+  size_t geomBytes = 0;
+  for(int i = 0; i < sd->numRenderPrimitives; ++i)
+  {
+    const MiPtRenderPrimitive& p = sd->renderPrimitives[i];
+    geomBytes += align16(size_t(p.triangleCount) * 12);
+    geomBytes += align16(size_t(p.vertexCount) * 12);
+    if(p.normals) geomBytes += align16(size_t(p.vertexCount) * 12);
+    if(p.colors) geomBytes += align16(size_t(p.vertexCount) * 4);
+    if(p.tangents) geomBytes += align16(size_t(p.vertexCount) * 16);
+    if(p.texCoords0) geomBytes += align16(size_t(p.vertexCount) * 8);
+    if(p.texCoords1) geomBytes += align16(size_t(p.vertexCount) * 8);
+  }
+  HIP_TRY(pt->geometry.alloc(std::max<size_t>(geomBytes, 16)));
+  std::vector<uint8_t>     staging(std::max<size_t>(geomBytes, 16));
+  std::vector<pt::DevPrim> devPrims(size_t(sd->numRenderPrimitives));
+  {
+    size_t off = 0;
+    auto   put = [&](const void* src, size_t bytes) -> const uint8_t* {
+      if(!src || bytes == 0)
+        return nullptr;
+      memcpy(staging.data() + off, src, bytes);
+      const uint8_t* d = pt->geometry.ptr + off;
+      off += align16(bytes);
+      return d;
+    };
+    for(int i = 0; i < sd->numRenderPrimitives; ++i)
+    {
+      const MiPtRenderPrimitive& p = sd->renderPrimitives[i];
+      pt::DevPrim&               d = devPrims[size_t(i)];
+      d.indices    = reinterpret_cast<const uint32_t*>(put(p.indices, size_t(p.triangleCount) * 12));
+      d.positions  = reinterpret_cast<const float*>(put(p.positions, size_t(p.vertexCount) * 12));
+      d.normals    = reinterpret_cast<const float*>(put(p.normals, size_t(p.vertexCount) * 12));
+      d.colors     = reinterpret_cast<const uint32_t*>(put(p.colors, size_t(p.vertexCount) * 4));
+      d.tangents   = reinterpret_cast<const float*>(put(p.tangents, size_t(p.vertexCount) * 16));
+      d.texCoords0 = reinterpret_cast<const float*>(put(p.texCoords0, size_t(p.vertexCount) * 8));
+      d.texCoords1 = reinterpret_cast<const float*>(put(p.texCoords1, size_t(p.vertexCount) * 8));
+    }
+    HIP_TRY(hipMemcpy(pt->geometry.ptr, staging.data(), staging.size(), hipMemcpyHostToDevice));
+  }
+  HIP_TRY(pt->prims.upload(devPrims.data(), devPrims.size()));
+
+  // ---- per-instance flags (reference: getInstanceFlag, src/gltf_scene_rtx.cpp:271-295) + triangle offsets -------------
+  std::vector<uint8_t>  flags(size_t(std::max(sd->numRenderNodes, 1)), 0);
+  std::vector<uint32_t> triOffset;
+  std::vector<int32_t>  entryNode;
+  uint64_t              totalTris = 0;
+  triOffset.push_back(0);
+  for(int n = 0; n < sd->numRenderNodes; ++n)
+  {
+    const MiGltfRenderNode&    rn  = sd->renderNodes[n];
+    const MiGltfShadeMaterial& mat = sd->materials[std::max(0, std::min(rn.materialID, sd->numMaterials - 1))];
+    uint32_t                   f   = 0;
+    if(mat.transmissionFactor == 0.0f && mat.alphaMode == MI_ALPHA_OPAQUE && mat.diffuseTransmissionFactor == 0.0f)
+      f |= pt::INST_FORCE_OPAQUE;
+    else
+      pt->hasAlpha = true;
+    if(mat.doubleSided == 1 || mat.thicknessFactor > 0.0f || mat.transmissionFactor > 0.0f)
+      f |= pt::INST_CULL_DISABLE;
+    const float* M   = rn.objectToWorld;
+    float        det = M[0] * (M[5] * M[10] - M[9] * M[6]) - M[4] * (M[1] * M[10] - M[9] * M[2]) + M[8] * (M[1] * M[6] - M[5] * M[2]);
+    if(det < 0.0f)
+      f |= pt::INST_FLIP_FACING;
+    flags[size_t(n)] = uint8_t(f);
+    if(mat.multiscatterColorFactor[0] > 0.0f || mat.multiscatterColorFactor[1] > 0.0f || mat.multiscatterColorFactor[2] > 0.0f)
+      pt->hasVolumeScatter = true;
+    if(sd->renderNodeVisible && !sd->renderNodeVisible[n])
+      continue;  // invisible nodes get no geometry (reference: src/gltf_scene_rtx.cpp:319-323)
+    if(rn.renderPrimID < 0 || rn.renderPrimID >= sd->numRenderPrimitives)
+      continue;
+    const MiPtRenderPrimitive& rp = sd->renderPrimitives[rn.renderPrimID];
+    if(!rp.positions || !rp.indices || rp.triangleCount == 0)
+      continue;
+    totalTris += rp.triangleCount;
+    if(totalTris > 0x7fffffffull)
+      return fail(MI_PT_ERR_ARGUMENT, "mi_pt_create: more than 2^31 flattened triangles");
+    entryNode.push_back(n);
+    triOffset.push_back(uint32_t(totalTris));
+  }
+  HIP_TRY(pt->instFlags.upload(flags.data(), flags.size()));
+
+  // ---- textures: one RGBA8 pool with all mip chains -----------------------------------------------------------------------
+  {
+    std::vector<pt::DevTexture> dt(size_t(sd->numTextures));
+    size_t                      totalTexels = 0;
+    for(int i = 0; i < sd->numTextures; ++i)
+    {
+      const MiPtTexture& t = sd->textures[i];
+      if(t.numLevels < 1 || t.numLevels > 16 || t.width < 1 || t.height < 1 || t.width > 65535 || t.height > 65535)
+        return fail(MI_PT_ERR_ARGUMENT, "mi_pt_create: texture dimensions / level count out of range");
+      for(int l = 0; l < t.numLevels; ++l)
+        totalTexels += size_t(std::max(1, t.width >> l)) * size_t(std::max(1, t.height >> l));
+    }
+    if(totalTexels > 0xffffffffull)
+      return fail(MI_PT_ERR_ARGUMENT, "mi_pt_create: texture pool exceeds 2^32 texels");
+    std::vector<uchar4> pool(std::max<size_t>(totalTexels, 1));
+    size_t              off = 0;
+    for(int i = 0; i < sd->numTextures; ++i)
+    {
+      const MiPtTexture& t = sd->textures[i];
+      pt::DevTexture&    d = dt[size_t(i)];
+      memset(&d, 0, sizeof(d));
+      d.width = uint16_t(t.width); d.height = uint16_t(t.height); d.numLevels = uint8_t(t.numLevels); d.srgb = uint8_t(t.srgb ? 1 : 0);
+      d.magFilter = uint8_t(t.magFilter); d.minFilter = uint8_t(t.minFilter); d.mipmapMode = uint8_t(t.mipmapMode);
+      d.wrapS = uint8_t(t.wrapS); d.wrapT = uint8_t(t.wrapT);
+      for(int l = 0; l < t.numLevels; ++l)
+      {
+        size_t n         = size_t(std::max(1, t.width >> l)) * size_t(std::max(1, t.height >> l));
+        d.levelOffset[l] = uint32_t(off);
+        memcpy(&pool[off], t.levels[l], n * 4);
+        off += n;
+      }
+    }
+    HIP_TRY(pt->textures.upload(dt.data(), dt.size()));
+    HIP_TRY(pt->texels.upload(pool.data(), pool.size()));
+  }
+  {
+    float lut[256];
+    for(int i = 0; i < 256; ++i)
+    {
+      float c = float(i) / 255.0f;
+      lut[i]  = c <= 0.04045f ? c / 12.92f : std::pow((c + 0.055f) / 1.055f, 2.4f);
+    }
+    HIP_TRY(pt->srgbLut.upload(lut, 256));
+  }
+
+  // ---- BVH ----------------------------------------------------------------------------------------------------------
+  {
+    DevBuf<uint32_t> dOffset;
+    DevBuf<int32_t>  dEntry;
+    HIP_TRY(dOffset.upload(triOffset.data(), triOffset.size()));
+    HIP_TRY(dEntry.upload(entryNode.data(), entryNode.size()));
+    pt::BvhBuildInput in{pt->nodes.ptr, pt->prims.ptr, pt->instFlags.ptr, dOffset.ptr, dEntry.ptr, int(entryNode.size()), uint32_t(totalTris)};
+    pt::BvhBuildOutput bo;
+    std::string        err;
+    if(!pt::buildBvh(in, bo, nullptr, err))
+      return fail(MI_PT_ERR_HIP, "BVH build failed: " + err);
+    pt->bvhNodes = bo.nodes;
+    pt->bvhTris  = bo.tris;
+    pt->scene.bvhRoot = bo.root;
+    pt->scene.numTris = int(bo.numTris);
+    pt->staticStats.bvhNodeCount     = bo.numNodes;
+    pt->staticStats.bvhTriangleCount = bo.numTris;
+    pt->staticStats.bvhNodeBytes     = 64;
+    pt->staticStats.bvhTriangleBytes = sizeof(pt::DevTri);
+  }
+
+  pt::DevScene& S = pt->scene;
+  S.materials = pt->materials.ptr; S.texInfos = pt->texInfos.ptr; S.nodes = pt->nodes.ptr; S.prims = pt->prims.ptr; S.lights = pt->lights.ptr;
+  S.textures = pt->textures.ptr; S.texels = pt->texels.ptr; S.envPixels = nullptr; S.envAccel = nullptr; S.bvhNodes = pt->bvhNodes; S.tris = pt->bvhTris;
+  S.srgbLut = pt->srgbLut.ptr; S.numMaterials = sd->numMaterials; S.numTextures = sd->numTextures; S.numLights = sd->numLights; S.numNodes = sd->numRenderNodes;
+  S.envWidth = 0; S.envHeight = 0;
+
+  HIP_TRY(pt->stats.alloc(1));
+  HIP_TRY(hipMemset(pt->stats.ptr, 0, sizeof(pt::StatCounters)));
+  // SkyPhysicalParameters{} defaults, so a caller that never calls mi_pt_set_sky still renders the default sky
+  MiSkyPhysicalParameters s{};
+  s.rgbUnitConversion[0] = s.rgbUnitConversion[1] = s.rgbUnitConversion[2] = 1.0f / 80000.0f;
+  s.multiplier = 0.1f; s.haze = 0.1f; s.redblueshift = 0.1f; s.saturation = 1.0f; s.groundColor[0] = s.groundColor[1] = s.groundColor[2] = 0.4f;
+  s.horizonBlur = 0.3f; s.sunDiskIntensity = 1.0f; s.sunDirection[0] = s.sunDirection[1] = s.sunDirection[2] = 0.5773502691896258f;
+  s.sunDiskScale = 1.0f; s.sunGlowIntensity = 1.0f; s.yIsUp = 1;
+  pt->sky = s;
+  *out    = pt.release();
+  return MI_PT_OK;
+}
+
+int mi_pt_destroy(MiPt* pt)
+{
+  if(!pt)
+    return MI_PT_OK;
+  (void)hipSetDevice(pt->device);
+  (void)hipDeviceSynchronize();
+  delete pt;
+  return MI_PT_OK;
+}
+
+int mi_pt_set_environment(MiPt* pt, const MiPtEnvironment* env)
+{
+  if(!pt)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_set_environment: null instance");
+  HIP_TRY(hipSetDevice(pt->device));
+  HIP_TRY(hipDeviceSynchronize());
+  if(!env || !env->rgba || !env->accel || env->width <= 0 || env->height <= 0)
+  {
+    pt->envPixels.release();
+    pt->envAccel.release();
+    pt->scene.envPixels = nullptr;
+    pt->scene.envAccel  = nullptr;
+    pt->scene.envWidth = pt->scene.envHeight = 0;
+    return MI_PT_OK;
+  }
+  const size_t n = size_t(env->width) * size_t(env->height);
+  HIP_TRY(pt->envPixels.upload(reinterpret_cast<const float4*>(env->rgba), n));
+  HIP_TRY(pt->envAccel.upload(env->accel, n));
+  pt->scene.envPixels = pt->envPixels.ptr;
+  pt->scene.envAccel  = pt->envAccel.ptr;
+  pt->scene.envWidth  = env->width;
+  pt->scene.envHeight = env->height;
+  return MI_PT_OK;
+}
+
+int mi_pt_resize(MiPt* pt, int width, int height)
+{
+  if(!pt || width <= 0 || height <= 0)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_resize: bad arguments");
+  HIP_TRY(hipSetDevice(pt->device));
+  HIP_TRY(hipDeviceSynchronize());
+  pt->width  = width;
+  pt->height = height;
+  return allocFrameResources(pt);
+}
+
+int mi_pt_set_frame_info(MiPt* pt, const MiSceneFrameInfo* info)
+{
+  if(!pt || !info)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_set_frame_info: null argument");
+  pt->frameInfo     = *info;
+  pt->haveFrameInfo = true;
+  return MI_PT_OK;
+}
+int mi_pt_set_sky(MiPt* pt, const MiSkyPhysicalParameters* sky)
+{
+  if(!pt || !sky)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_set_sky: null argument");
+  pt->sky = *sky;
+  return MI_PT_OK;
+}
+
+int mi_pt_set_tile_partition(MiPt* pt, int rank, int world, int tileSize)
+{
+  if(!pt || world < 1 || rank < 0 || rank >= world || tileSize < 8 || (tileSize & 7) != 0)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_set_tile_partition: need 0 <= rank < world and tileSize a positive multiple of 8");
+  pt->tileRank  = rank;
+  pt->tileWorld = world;
+  pt->tileSize  = tileSize;
+  if(pt->width > 0)
+  {
+    HIP_TRY(hipSetDevice(pt->device));
+    HIP_TRY(hipDeviceSynchronize());
+    void* bound = (pt->accum != pt->accumOwn.ptr) ? pt->accum : nullptr;
+    int   rc    = allocFrameResources(pt);
+    if(rc == MI_PT_OK && bound)
+      pt->accum = reinterpret_cast<float4*>(bound);
+    return rc;
+  }
+  return MI_PT_OK;
+}
+
+int mi_pt_bind_accum(MiPt* pt, void* deviceRGBA32F)
+{
+  if(!pt)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_bind_accum: null instance");
+  pt->accum = deviceRGBA32F ? reinterpret_cast<float4*>(deviceRGBA32F) : pt->accumOwn.ptr;
+  return MI_PT_OK;
+}
+
+int mi_pt_render_frame(MiPt* pt, const MiPathtraceParams* params, void* hipStream)
+{
+  if(!pt || !params)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_render_frame: null argument");
+  if(pt->width <= 0 || !pt->haveFrameInfo)
+    return fail(MI_PT_ERR_STATE, "mi_pt_render_frame: call mi_pt_resize and mi_pt_set_frame_info first");
+  if(params->numSamples < 1 || params->maxDepth < 0 || params->maxDepth > 255)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_render_frame: numSamples >= 1 and 0 <= maxDepth <= 255 required");
+  if((pt->frameInfo.flags & MI_SCENE_USE_HDR_ENVIRONMENT) && !pt->scene.envPixels)
+    return fail(MI_PT_ERR_STATE, "mi_pt_render_frame: HDR environment requested but none was set");
+  if((pt->frameInfo.flags & MI_SCENE_USE_INFINITE_PLANE) && (pt->frameInfo.flags & MI_SCENE_INFINITE_PLANE_SHADOW_CATCHER))
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_render_frame: the shadow-catcher plane is not implemented in the wavefront split yet");
+  HIP_TRY(hipSetDevice(pt->device));
+  hipStream_t stream = reinterpret_cast<hipStream_t>(hipStream);
+  pt->lastStream     = stream;
+  if(pt->numSlots == 0)
+    return MI_PT_OK;
+
+  pt::LaunchCtx c;
+  c.scene = pt->scene;
+  memset(&c.fc, 0, sizeof(c.fc));
+  c.fc.frameInfo = pt->frameInfo;
+  c.fc.sky       = pt->sky;
+  c.fc.pc        = *params;
+  c.fc.width     = pt->width;
+  c.fc.height    = pt->height;
+  c.fc.tileSize  = pt->tileSize;
+  c.fc.tilesX    = pt->tilesX;
+  c.fc.tilesY    = pt->tilesY;
+  c.fc.numSlots  = pt->numSlots;
+  c.paths        = pt->paths;
+  const bool guides = (params->flags & MI_PT_USE_OPTIX_DENOISER) != 0;
+  if(!guides)
+  {
+    c.paths.guideAlbedo = nullptr;
+    c.paths.guideNormal = nullptr;
+  }
+  c.queues           = pt->queues;
+  c.ownedTiles       = pt->ownedTiles.ptr;
+  c.stats            = pt->stats.ptr;
+  c.stream           = stream;
+  c.persistentBlocks = unsigned(pt->numCUs) * 8u;
+  c.hasAlpha         = pt->hasAlpha;
+  c.collectCounters  = pt->collectCounters;
+
+  struct Span
+  {
+    int        kind;
+    hipEvent_t a, b;
+  };
+  std::vector<Span> spans;
+  size_t            evCursor = 0;
+  auto timed = [&](int kind, auto&& launch) {
+    if(pt->timingEnabled)
+    {
+      hipEvent_t a = getEvent(pt, evCursor), b = getEvent(pt, evCursor);
+      (void)hipEventRecord(a, stream);
+      launch();
+      (void)hipEventRecord(b, stream);
+      spans.push_back({kind, a, b});
+    }
+    else
+      launch();
+  };
+  hipEvent_t frameA = nullptr, frameB = nullptr;
+  if(pt->timingEnabled)
+  {
+    frameA = getEvent(pt, evCursor);
+    frameB = getEvent(pt, evCursor);
+    (void)hipEventRecord(frameA, stream);
+  }
+  int iterations = 0, traceLaunches = 0, shadeLaunches = 0, shadowLaunches = 0;
+  for(int s = 0; s < params->numSamples; ++s)
+  {
+    pt::launchResetCounters(c.queues, stream);
+    timed(TK_GENERATE, [&] { pt::launchGenerate(c, s); });
+    int cur = 0;
+    // Every iteration either ends a path or consumes one unit of surfaceDepth, except volume scatter events
+    // (pathtrace_functions.h.slang:925-931), which are free for VOLUME_FREE_BUDGET bounces and then Russian-rouletted.
+    int maxIters = params->maxDepth;
+    if(pt->hasVolumeScatter)
+      maxIters = params->maxDepth * 66 + 512;
+    for(int it = 0; it < maxIters; ++it)
+    {
+      if(pt->hasVolumeScatter && it >= params->maxDepth && (it % 8) == 0)
+      {
+        uint32_t remaining = 0;
+        HIP_TRY(hipMemcpyAsync(&remaining, &c.queues.counters[cur], sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if(remaining == 0)
+          break;
+      }
+      timed(TK_TRACE, [&] { pt::launchTraceClosest(c, cur); });
+      timed(TK_SHADE, [&] { pt::launchShade(c, cur); });
+      timed(TK_SHADOW, [&] { pt::launchTraceShadow(c); });
+      ++iterations; ++traceLaunches; ++shadeLaunches; ++shadowLaunches;
+      cur ^= 1;
+    }
+    timed(TK_ACCUM, [&] {
+      pt::launchFinishSample(c, s, pt->accum, pt->depth.ptr, guides ? pt->albedo.ptr : nullptr, guides ? pt->normal.ptr : nullptr);
+    });
+  }
+  if(params->flags & MI_PT_FIRST_FRAME)
+    pt::launchSelection(c, pt->selection.ptr);
+  HIP_TRY(hipGetLastError());
+  if(pt->timingEnabled)
+  {
+    (void)hipEventRecord(frameB, stream);
+    HIP_TRY(hipStreamSynchronize(stream));
+    MiPtFrameTiming t{};
+    (void)hipEventElapsedTime(&t.totalMs, frameA, frameB);
+    for(const Span& sp : spans)
+    {
+      float ms = 0.0f;
+      (void)hipEventElapsedTime(&ms, sp.a, sp.b);
+      switch(sp.kind)
+      {
+        case TK_GENERATE: t.generateMs += ms; break;
+        case TK_TRACE: t.traceClosestMs += ms; break;
+        case TK_SORT: t.sortMs += ms; break;
+        case TK_SHADE: t.shadeMs += ms; break;
+        case TK_SHADOW: t.traceShadowMs += ms; break;
+        case TK_ACCUM: t.accumulateMs += ms; break;
+      }
+    }
+    t.traceClosestLaunches = traceLaunches;
+    t.shadeLaunches        = shadeLaunches;
+    t.traceShadowLaunches  = shadowLaunches;
+    t.bounceIterations     = iterations;
+    pt->lastTiming         = t;
+  }
+  return MI_PT_OK;
+}
+
+int mi_pt_synchronize(MiPt* pt)
+{
+  if(!pt)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_synchronize: null instance");
+  HIP_TRY(hipSetDevice(pt->device));
+  HIP_TRY(hipDeviceSynchronize());
+  return MI_PT_OK;
+}
+
+int mi_pt_read_accum(MiPt* pt, float* host)
+{
+  if(!pt || !host || pt->width <= 0)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_read_accum: bad arguments");
+  HIP_TRY(hipSetDevice(pt->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(host, pt->accum, size_t(pt->width) * size_t(pt->height) * sizeof(float4), hipMemcpyDeviceToHost));
+  return MI_PT_OK;
+}
+int mi_pt_read_selection(MiPt* pt, uint32_t* host)
+{
+  if(!pt || !host || pt->width <= 0)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_read_selection: bad arguments");
+  HIP_TRY(hipSetDevice(pt->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(host, pt->selection.ptr, size_t(pt->width) * size_t(pt->height) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return MI_PT_OK;
+}
+int mi_pt_read_depth(MiPt* pt, float* host)
+{
+  if(!pt || !host || pt->width <= 0)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_read_depth: bad arguments");
+  HIP_TRY(hipSetDevice(pt->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(host, pt->depth.ptr, size_t(pt->width) * size_t(pt->height) * sizeof(float), hipMemcpyDeviceToHost));
+  return MI_PT_OK;
+}
+void* mi_pt_accum_device_ptr(MiPt* pt)
+{
+  return pt ? pt->accum : nullptr;
+}
+
+int mi_pt_denoise(MiPt* pt, int iterations, float sigmaColor, float sigmaNormal, float sigmaAlbedo, float* host, void* hipStream)
+{
+  if(!pt || pt->width <= 0 || iterations < 1 || iterations > 8)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_denoise: bad arguments");
+  HIP_TRY(hipSetDevice(pt->device));
+  hipStream_t  stream = reinterpret_cast<hipStream_t>(hipStream);
+  const size_t px     = size_t(pt->width) * size_t(pt->height);
+  if(pt->denoiseA.count != px)
+  {
+    HIP_TRY(pt->denoiseA.alloc(px));
+    HIP_TRY(pt->denoiseB.alloc(px));
+  }
+  const float4* in  = pt->accum;
+  float4*       out = pt->denoiseA.ptr;
+  for(int i = 0; i < iterations; ++i)
+  {
+    pt::launchAtrous(in, out, pt->albedo.ptr, pt->normal.ptr, pt->width, pt->height, 1 << i, sigmaColor, sigmaNormal, sigmaAlbedo, stream);
+    in  = out;
+    out = (out == pt->denoiseA.ptr) ? pt->denoiseB.ptr : pt->denoiseA.ptr;
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(stream));
+  if(host)
+    HIP_TRY(hipMemcpy(host, in, px * sizeof(float4), hipMemcpyDeviceToHost));
+  return MI_PT_OK;
+}
+
+int mi_pt_get_stats(MiPt* pt, MiPtStats* out)
+{
+  if(!pt || !out)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_get_stats: null argument");
+  HIP_TRY(hipSetDevice(pt->device));
+  HIP_TRY(hipDeviceSynchronize());
+  pt::StatCounters h{};
+  HIP_TRY(hipMemcpy(&h, pt->stats.ptr, sizeof(h), hipMemcpyDeviceToHost));
+  *out              = pt->staticStats;
+  out->cameraPaths  = h.cameraPaths;
+  out->segments     = h.segments;
+  out->shadowRays   = h.shadowRays;
+  out->nodesClosest = h.nodesClosest;
+  out->trisClosest  = h.trisClosest;
+  out->nodesShadow  = h.nodesShadow;
+  out->trisShadow   = h.trisShadow;
+  out->textureTaps  = h.textureTaps;
+  return MI_PT_OK;
+}
+int mi_pt_reset_stats(MiPt* pt)
+{
+  if(!pt)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_reset_stats: null instance");
+  HIP_TRY(hipSetDevice(pt->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemset(pt->stats.ptr, 0, sizeof(pt::StatCounters)));
+  return MI_PT_OK;
+}
+int mi_pt_enable_timing(MiPt* pt, int enable)
+{
+  if(!pt)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_enable_timing: null instance");
+  pt->timingEnabled = enable != 0;
+  return MI_PT_OK;
+}
+int mi_pt_get_frame_timing(MiPt* pt, MiPtFrameTiming* out)
+{
+  if(!pt || !out)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_get_frame_timing: null argument");
+  *out = pt->lastTiming;
+  return MI_PT_OK;
+}
+}

@@ -1,0 +1,31 @@
+// Host-side interface of the on-device BVH builder (bvh_build.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "pt_scene.h"
+
+namespace pt {
+
+struct BvhBuildInput
+{
+  const MiGltfRenderNode* nodes;          // device
+  const DevPrim*          prims;          // device
+  const uint8_t*          instFlags;      // device, per render node
+  const uint32_t*         nodeTriOffset;  // device, numEntries + 1
+  const int32_t*          entryNode;      // device, numEntries
+  int                     numEntries;
+  uint32_t                numTris;
+};
+struct BvhBuildOutput
+{
+  float4*  nodes    = nullptr;  // device, 4 float4 per node
+  DevTri*  tris     = nullptr;  // device, Morton order
+  uint32_t numNodes = 0, numTris = 0;
+  int      root     = 0;
+  float    centroidLo[3] = {0, 0, 0}, centroidHi[3] = {0, 0, 0};
+};
+bool buildBvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream, std::string& err);
+
+}  // namespace pt

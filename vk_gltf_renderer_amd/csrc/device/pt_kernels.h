@@ -1,0 +1,35 @@
+// Host-visible launch interface of the wavefront kernels (pt_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pt_scene.h"
+
+namespace pt {
+
+struct LaunchCtx
+{
+  DevScene        scene;
+  FrameConsts     fc;
+  PathSoA         paths;
+  Queues          queues;
+  const uint32_t* ownedTiles;
+  StatCounters*   stats;
+  hipStream_t     stream;
+  unsigned        persistentBlocks;
+  bool            hasAlpha;
+  bool            collectCounters;
+};
+
+void launchResetCounters(const Queues& Q, hipStream_t s);
+void launchGenerate(const LaunchCtx& c, int sampleIndex);
+void launchTraceClosest(const LaunchCtx& c, int cur);
+void launchShade(const LaunchCtx& c, int cur);
+void launchTraceShadow(const LaunchCtx& c);
+void launchFinishSample(const LaunchCtx& c, int sampleIndex, float4* accum, float* depth, float4* albedo, float4* normal);
+void launchSelection(const LaunchCtx& c, uint32_t* selection);
+
+// a-trous edge-avoiding wavelet filter (denoise.hip)
+void launchAtrous(const float4* in, float4* out, const float4* albedo, const float4* normal, int width, int height, int step, float sigmaColor,
+                  float sigmaNormal, float sigmaAlbedo, hipStream_t s);
+
+}  // namespace pt

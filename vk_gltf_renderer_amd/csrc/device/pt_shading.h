@@ -1,0 +1,564 @@
+// Hit attribute fetch, glTF material evaluation, alpha / shadow-transmission tests and next-event estimation: the device
+// restatement of shaders/get_hit.h.slang, shaders/gltf_material_eval.h.slang, shaders/gltf_vertex_access.h.slang and the
+// non-tracing parts of shaders/pathtrace_functions.h.slang.  Each function cites the lines it follows.
+#pragma once
+#include "pt_light.h"
+
+namespace pt {
+
+constexpr float MIN_TRANSMISSION                = 0.01f;       // pathtrace_functions.h.slang:36
+constexpr float ANTIALIASING_STANDARD_DEVIATION = 0.4246609f;  // :37
+constexpr int   RR_MIN_DEPTH                    = 3;           // :38
+constexpr float VOLUME_MIN_SCATTER              = 0.001f;      // :39
+constexpr float VOLUME_RAND_FLOOR               = 1.0e-10f;    // :40
+constexpr int   VOLUME_FREE_BUDGET              = 64;          // :41
+constexpr float RR_PCONT_FLOOR                  = 0.001f;      // :42
+constexpr float RR_PCONT_CAP                    = 0.95f;       // :43
+constexpr float MICROFACET_MIN_ROUGHNESS        = 0.0014142f;  // gltf_material_eval.h.slang:51
+
+PT_DEV bool hasFlag(int flags, int f) { return (flags & f) != 0; }
+
+// ---- gltf_vertex_access.h.slang:30-150 ---------------------------------------------------------------------------------
+struct u3
+{
+  uint32_t x, y, z;
+};
+PT_DEV u3 getTriangleIndices(const DevPrim& rp, int prim)
+{
+  const uint32_t* p = rp.indices + 3 * size_t(prim);
+  return u3{p[0], p[1], p[2]};
+}
+PT_DEV f3 getVertexPosition(const DevPrim& rp, uint32_t i) { return mk3(rp.positions + 3 * size_t(i)); }
+PT_DEV f4 unpackUnorm4x8(uint32_t p)
+{
+  return mk4(float((p >> 0) & 0xFF) / 255.0f, float((p >> 8) & 0xFF) / 255.0f, float((p >> 16) & 0xFF) / 255.0f, float((p >> 24) & 0xFF) / 255.0f);
+}
+PT_DEV f2 getInterpolatedVertexTexCoord(const DevPrim& rp, int channel, u3 idx, f3 b)
+{
+  const float* tc = channel == 0 ? rp.texCoords0 : rp.texCoords1;
+  if(!tc)
+    return mk2(0.0f, 0.0f);
+  const float2* t2 = reinterpret_cast<const float2*>(tc);
+  float2        a = t2[idx.x], bb = t2[idx.y], c = t2[idx.z];
+  return mk2(a.x, a.y) * b.x + mk2(bb.x, bb.y) * b.y + mk2(c.x, c.y) * b.z;
+}
+PT_DEV f4 getInterpolatedVertexColor(const DevPrim& rp, u3 idx, f3 b)
+{
+  if(!rp.colors)
+    return mk4(1.0f);
+  return unpackUnorm4x8(rp.colors[idx.x]) * b.x + unpackUnorm4x8(rp.colors[idx.y]) * b.y + unpackUnorm4x8(rp.colors[idx.z]) * b.z;
+}
+
+// ---- get_hit.h.slang:26-173 -----------------------------------------------------------------------------------------------
+struct HitState
+{
+  f3    pos, nrm;
+  f4    color;
+  f3    geonrm, shadowPos;
+  f2    uv0, uv1;
+  f3    tangent, bitangent;
+  float texelDensity;
+};
+PT_DEV f3 pointOffset(f3 p, f3 p0, f3 p1, f3 p2, f3 n0, f3 n1, f3 n2, f3 bary)  // Hanika 2021 (nvshaders/ray_utils, external)
+{
+  f3    tmpu = p - p0, tmpv = p - p1, tmpw = p - p2;
+  float dotu = fminf(0.0f, dot(tmpu, n0)), dotv = fminf(0.0f, dot(tmpv, n1)), dotw = fminf(0.0f, dot(tmpw, n2));
+  tmpu -= n0 * dotu;
+  tmpv -= n1 * dotv;
+  tmpw -= n2 * dotw;
+  return p + tmpu * bary.x + tmpv * bary.y + tmpw * bary.z;
+}
+PT_DEV HitState getHitState(const DevPrim& rp, f3 bary, const float* w2o, const float* o2w, int triangleID, f3 worldRayDir)
+{
+  HitState hit;
+  u3 ti   = getTriangleIndices(rp, triangleID);
+  f3 pos0 = getVertexPosition(rp, ti.x), pos1 = getVertexPosition(rp, ti.y), pos2 = getVertexPosition(rp, ti.z);
+  f3 position  = pos0 * bary.x + pos1 * bary.y + pos2 * bary.z;
+  hit.pos      = mulPoint(o2w, position);
+  f3 geoNormal = normalize(cross(pos1 - pos0, pos2 - pos0));
+  hit.geonrm   = normalize(mulTransposed(w2o, geoNormal));
+  f3 nrm0 = geoNormal, nrm1 = geoNormal, nrm2 = geoNormal, normal = geoNormal;
+  if(rp.normals)
+  {
+    nrm0   = mk3(rp.normals + 3 * size_t(ti.x));
+    nrm1   = mk3(rp.normals + 3 * size_t(ti.y));
+    nrm2   = mk3(rp.normals + 3 * size_t(ti.z));
+    normal = nrm0 * bary.x + nrm1 * bary.y + nrm2 * bary.z;
+  }
+  hit.nrm         = normalize(mulTransposed(w2o, normal));
+  bool  frontFace = dot(hit.geonrm, worldRayDir) < 0.0f;
+  float sideFlip  = frontFace ? 1.0f : -1.0f;
+  f3    shadowPos = pointOffset(position, pos0, pos1, pos2, nrm0 * sideFlip, nrm1 * sideFlip, nrm2 * sideFlip, bary);
+  hit.shadowPos   = mulPoint(o2w, shadowPos);
+  hit.uv0         = getInterpolatedVertexTexCoord(rp, 0, ti, bary);
+  hit.uv1         = getInterpolatedVertexTexCoord(rp, 1, ti, bary);
+  if(rp.texCoords0)
+  {
+    const float2* t2 = reinterpret_cast<const float2*>(rp.texCoords0);
+    float2        a = t2[ti.x], b = t2[ti.y], c = t2[ti.z];
+    // computeTexelDensity, get_hit.h.slang:44-56
+    f3    we1 = mulVector(o2w, pos1 - pos0), we2 = mulVector(o2w, pos2 - pos0);
+    float wArea = length(cross(we1, we2));
+    f2    duv1 = mk2(b.x - a.x, b.y - a.y), duv2 = mk2(c.x - a.x, c.y - a.y);
+    float uvArea     = fabsf(duv1.x * duv2.y - duv1.y * duv2.x);
+    hit.texelDensity = sqrtf(fmaxf(uvArea, 1e-20f) / fmaxf(wArea, 1e-20f));
+  }
+  else
+    hit.texelDensity = 0.0f;
+  hit.color = getInterpolatedVertexColor(rp, ti, bary);
+  f4 tng0, tng1, tng2;
+  if(rp.tangents)
+  {
+    const float4* t4 = reinterpret_cast<const float4*>(rp.tangents);
+    tng0 = mk4(t4[ti.x]);
+    tng1 = mk4(t4[ti.y]);
+    tng2 = mk4(t4[ti.z]);
+  }
+  else
+  {
+    tng0 = tng1 = tng2 = makeFastTangent(normal);
+  }
+  hit.tangent   = normalize(xyz(tng0) * bary.x + xyz(tng1) * bary.y + xyz(tng2) * bary.z);
+  hit.tangent   = mulVector(o2w, hit.tangent);
+  hit.tangent   = normalize(hit.tangent - hit.nrm * dot(hit.nrm, hit.tangent));
+  hit.bitangent = cross(hit.nrm, hit.tangent) * tng0.w;
+  if(!frontFace)
+    hit.geonrm = -hit.geonrm;
+  if(dot(hit.geonrm, hit.nrm) < 0.0f)
+  {
+    hit.nrm       = -hit.nrm;
+    hit.tangent   = -hit.tangent;
+    hit.bitangent = -hit.bitangent;
+  }
+  f3 r = reflect(normalize(worldRayDir), hit.nrm);
+  if(dot(r, hit.geonrm) < 0.0f)
+    hit.nrm = hit.geonrm;
+  return hit;
+}
+
+// ---- gltf_material_eval.h.slang -------------------------------------------------------------------------------------------
+struct MeshState
+{
+  f3    N, T, B, Ng;
+  f2    tc0, tc1;
+  bool  isInside;
+  float texGrad;
+  f4    baseColorVertexMul;
+};
+PT_DEV bool isTexturePresent(uint16_t t) { return t > 0; }
+__device__ __noinline__ f4 getTexture(const DevScene& sc, uint16_t slot, f2 tc0, f2 tc1, float texGrad, unsigned& taps)  // :76-110
+{
+  ++taps;
+  const MiGltfTextureInfo ti = sc.texInfos[slot];
+  f2                      t  = ti.texCoord == 0 ? tc0 : tc1;
+  const float*            U  = ti.uvTransform;
+  f2                      tt = mk2(t.x * U[0] + t.y * U[2] + U[4], t.x * U[1] + t.y * U[3] + U[5]);
+  if(texGrad > 0.0f)
+    return sampleTexture(sc, ti.index, tt, true, mk2(U[0] * texGrad, U[1] * texGrad), mk2(U[2] * texGrad, U[3] * texGrad));
+  return sampleTexture(sc, ti.index, tt, false, mk2(0, 0), mk2(0, 0));
+}
+PT_DEV f3 multiToSingleScatterAlbedo(f3 rho)  // :125-129
+{
+  f3 t = mk3(4.09712f) + rho * 4.20863f - sqrt3(mk3(9.59217f) + rho * 41.6808f + rho * rho * 17.7126f);
+  return mk3(1.0f) - t * t;
+}
+PT_DEV f3 convertSGToMR(f3 diffuseColor, f3 specularColor, float glossiness, float& metallic, f2& roughness)  // :136-161
+{
+  const float dielectricSpecular = 0.04f;
+  float       specularIntensity  = fmaxf(specularColor.x, fmaxf(specularColor.y, specularColor.z));
+  metallic                       = smoothstepf(dielectricSpecular + 0.01f, dielectricSpecular + 0.05f, specularIntensity);
+  f3 baseColor;
+  if(metallic > 0.0f)
+    baseColor = specularColor;
+  else
+  {
+    baseColor = diffuseColor / (1.0f - dielectricSpecular * (1.0f - metallic));
+    baseColor = clamp3(baseColor, 0.0f, 1.0f);
+  }
+  float r   = 1.0f - glossiness;
+  roughness = mk2(r * r, r * r);
+  return baseColor;
+}
+PT_DEV PbrMaterial evaluateMaterial(const DevScene& sc, const MiGltfShadeMaterial& m, const MeshState& st, unsigned& taps)  // :168-457
+{
+#define TEX(slot) getTexture(sc, slot, st.tc0, st.tc1, st.texGrad, taps)
+  PbrMaterial p = defaultPbrMaterial();
+  if(m.pbrModel == MI_PBR_SPECULAR_GLOSSINESS)
+  {
+    f4    diffuse    = mk4(m.pbrDiffuseFactor[0], m.pbrDiffuseFactor[1], m.pbrDiffuseFactor[2], m.pbrDiffuseFactor[3]) * st.baseColorVertexMul;
+    float glossiness = m.pbrGlossinessFactor;
+    f3    specular   = mk3(m.pbrSpecularFactor);
+    if(isTexturePresent(m.pbrDiffuseTexture))
+      diffuse *= TEX(m.pbrDiffuseTexture);
+    if(isTexturePresent(m.pbrSpecularGlossinessTexture))
+    {
+      f4 s = TEX(m.pbrSpecularGlossinessTexture);
+      specular *= xyz(s);
+      glossiness *= s.w;
+    }
+    p.baseColor = convertSGToMR(xyz(diffuse), specular, glossiness, p.metallic, p.roughness);
+    p.opacity   = diffuse.w;
+  }
+  else
+  {
+    f4 baseColor = mk4(m.pbrBaseColorFactor[0], m.pbrBaseColorFactor[1], m.pbrBaseColorFactor[2], m.pbrBaseColorFactor[3]) * st.baseColorVertexMul;
+    if(isTexturePresent(m.pbrBaseColorTexture))
+      baseColor *= TEX(m.pbrBaseColorTexture);
+    p.baseColor     = xyz(baseColor);
+    p.opacity       = baseColor.w;
+    float roughness = m.pbrRoughnessFactor, metallic = m.pbrMetallicFactor;
+    if(isTexturePresent(m.pbrMetallicRoughnessTexture))
+    {
+      f4 s = TEX(m.pbrMetallicRoughnessTexture);
+      roughness *= s.y;
+      metallic *= s.z;
+    }
+    roughness   = fmaxf(roughness, MICROFACET_MIN_ROUGHNESS);
+    p.roughness = mk2(roughness * roughness, roughness * roughness);
+    p.metallic  = clampf(metallic, 0.0f, 1.0f);
+  }
+  p.occlusion = m.occlusionStrength;
+  if(isTexturePresent(m.occlusionTexture))
+  {
+    float occ   = TEX(m.occlusionTexture).x;
+    p.occlusion = 1.0f + p.occlusion * (occ - 1.0f);
+  }
+  p.N  = st.N;
+  p.T  = st.T;
+  p.B  = st.B;
+  p.Ng = st.Ng;
+  bool needsTangentUpdate = false;
+  if(isTexturePresent(m.normalTexture))
+  {
+    f3 nv = xyz(TEX(m.normalTexture));
+    nv    = nv * 2.0f - mk3(1.0f);
+    nv *= mk3(m.normalTextureScale, m.normalTextureScale, 1.0f);
+    p.N                = normalize(st.T * nv.x + st.B * nv.y + st.N * nv.z);
+    needsTangentUpdate = true;
+  }
+  p.emissive = mk3(m.emissiveFactor);
+  if(isTexturePresent(m.emissiveTexture))
+    p.emissive *= xyz(TEX(m.emissiveTexture));
+  p.emissive            = max3(mk3(0.0f), p.emissive);
+  p.attenuationColor    = mk3(m.attenuationColor);
+  p.attenuationDistance = m.attenuationDistance;
+  p.thickness           = m.thicknessFactor;
+  if(isTexturePresent(m.thicknessTexture))
+    p.thickness *= TEX(m.thicknessTexture).y;
+  p.specularColor = mk3(m.specularColorFactor);
+  if(isTexturePresent(m.specularColorTexture))
+    p.specularColor *= xyz(TEX(m.specularColorTexture));
+  p.specular = m.specularFactor;
+  if(isTexturePresent(m.specularTexture))
+    p.specular *= TEX(m.specularTexture).w;
+  float ior1 = 1.0f, ior2 = m.ior;
+  if(st.isInside && (p.thickness > 0.0f))
+  {
+    ior1 = ior2;
+    ior2 = 1.0f;
+  }
+  p.ior1         = ior1;
+  p.ior2         = ior2;
+  p.transmission = m.transmissionFactor;
+  if(isTexturePresent(m.transmissionTexture))
+    p.transmission *= TEX(m.transmissionTexture).x;
+  f3 ms = mk3(m.multiscatterColorFactor);
+  if(ms.x > 0.0f || ms.y > 0.0f || ms.z > 0.0f)
+  {
+    f3 ssa               = multiToSingleScatterAlbedo(ms);
+    f3 attC              = -log3(max3(p.attenuationColor, mk3(0.001f))) / fmaxf(p.attenuationDistance, 0.001f);
+    p.scatterCoefficient = attC * ssa;
+  }
+  p.scatterAnisotropy  = m.scatterAnisotropy;
+  p.clearcoat          = m.clearcoatFactor;
+  p.clearcoatRoughness = m.clearcoatRoughness;
+  p.Nc                 = p.N;
+  if(isTexturePresent(m.clearcoatTexture))
+    p.clearcoat *= TEX(m.clearcoatTexture).x;
+  if(isTexturePresent(m.clearcoatRoughnessTexture))
+    p.clearcoatRoughness *= TEX(m.clearcoatRoughnessTexture).y;
+  if(isTexturePresent(m.clearcoatNormalTexture))
+  {
+    f3 nv = xyz(TEX(m.clearcoatNormalTexture));
+    nv    = nv * 2.0f - mk3(1.0f);
+    p.Nc  = normalize(p.T * nv.x + p.B * nv.y + p.Nc * nv.z);
+  }
+  p.clearcoatRoughness = fmaxf(p.clearcoatRoughness, 0.001f);
+  float iridescence = m.iridescenceFactor, iridescenceThickness = m.iridescenceThicknessMaximum;
+  p.iridescenceIor = m.iridescenceIor;
+  if(isTexturePresent(m.iridescenceTexture))
+    iridescence *= TEX(m.iridescenceTexture).x;
+  if(isTexturePresent(m.iridescenceThicknessTexture))
+  {
+    float t              = TEX(m.iridescenceThicknessTexture).y;
+    iridescenceThickness = lerpf(m.iridescenceThicknessMinimum, m.iridescenceThicknessMaximum, t);
+  }
+  p.iridescence          = (iridescenceThickness > 0.0f) ? iridescence : 0.0f;
+  p.iridescenceThickness = iridescenceThickness;
+  float anisotropyStrength = m.anisotropyStrength;
+  if(anisotropyStrength > 0.0f)
+  {
+    f2 dir = mk2(1.0f, 0.0f);
+    if(isTexturePresent(m.anisotropyTexture))
+    {
+      f4 a = TEX(m.anisotropyTexture);
+      dir  = normalize(mk2(a.x, a.y) * 2.0f - mk2(1.0f, 1.0f));
+      anisotropyStrength *= a.z;
+    }
+    p.roughness.x = lerpf(p.roughness.y, 1.0f, anisotropyStrength * anisotropyStrength);
+    float s = m.anisotropyRotation[0], c = m.anisotropyRotation[1];
+    dir                = mk2(c * dir.x + s * dir.y, c * dir.y - s * dir.x);
+    p.T                = p.T * dir.x + p.B * dir.y;
+    needsTangentUpdate = true;
+  }
+  if(needsTangentUpdate)
+  {
+    p.B         = normalize(cross(p.N, p.T));
+    float bsign = signfz(dot(st.B, p.B));
+    p.B         = p.B * bsign;
+    p.T         = normalize(cross(p.B, p.N) * bsign);
+  }
+  p.sheenColor = mk3(m.sheenColorFactor);
+  if(isTexturePresent(m.sheenColorTexture))
+    p.sheenColor *= xyz(TEX(m.sheenColorTexture));
+  p.sheenRoughness = m.sheenRoughnessFactor;
+  if(isTexturePresent(m.sheenRoughnessTexture))
+    p.sheenRoughness *= TEX(m.sheenRoughnessTexture).w;
+  p.sheenRoughness            = fmaxf(MICROFACET_MIN_ROUGHNESS, p.sheenRoughness);
+  p.dispersion                = m.dispersion;
+  p.diffuseTransmissionFactor = m.diffuseTransmissionFactor;
+  if(isTexturePresent(m.diffuseTransmissionTexture))
+    p.diffuseTransmissionFactor *= TEX(m.diffuseTransmissionTexture).w;
+  p.diffuseTransmissionColor = mk3(m.diffuseTransmissionColor);
+  if(isTexturePresent(m.diffuseTransmissionColorTexture))
+    p.diffuseTransmissionColor *= xyz(TEX(m.diffuseTransmissionColorTexture));
+  p.retroreflection = m.retroreflectionFactor;
+  if(isTexturePresent(m.retroreflectionTexture))
+    p.retroreflection *= TEX(m.retroreflectionTexture).x;
+#undef TEX
+  return p;
+}
+
+// ---- pathtrace_functions.h.slang helpers ------------------------------------------------------------------------------------
+PT_DEV f3 safeOffsetRay(f3 p, f3 dir)  // :151-167
+{
+  const float scaleValue = 256.0f;
+  int         ix = int(scaleValue * dir.x), iy = int(scaleValue * dir.y), iz = int(scaleValue * dir.z);
+  f3 op = mk3(__int_as_float(__float_as_int(p.x) + ((p.x < 0) ? -ix : ix)), __int_as_float(__float_as_int(p.y) + ((p.y < 0) ? -iy : iy)),
+              __int_as_float(__float_as_int(p.z) + ((p.z < 0) ? -iz : iz)));
+  const float origin = 1.0f / 32.0f, floatScale = 1.0f / 65536.0f;
+  return mk3(fabsf(p.x) < origin ? p.x + floatScale * dir.x : op.x, fabsf(p.y) < origin ? p.y + floatScale * dir.y : op.y,
+             fabsf(p.z) < origin ? p.z + floatScale * dir.z : op.z);
+}
+
+// getOpacity, :189-234.  Returns 1 for opaque materials.
+__device__ __noinline__ float getOpacity(const DevScene& sc, int rnode, int triangleID, f3 bary)
+{
+  const MiGltfRenderNode& rn  = sc.nodes[rnode];
+  const int               mi  = max(0, rn.materialID);
+  const int               alphaMode = sc.materials[mi].alphaMode;
+  if(alphaMode == MI_ALPHA_OPAQUE)
+    return 1.0f;
+  const MiGltfShadeMaterial& mat = sc.materials[mi];
+  const DevPrim              rp  = sc.prims[rn.renderPrimID];
+  u3                         ti  = getTriangleIndices(rp, triangleID);
+  float                      alpha;
+  uint16_t                   slot;
+  if(mat.pbrModel == MI_PBR_SPECULAR_GLOSSINESS)
+  {
+    alpha = mat.pbrDiffuseFactor[3];
+    slot  = mat.pbrDiffuseTexture;
+  }
+  else
+  {
+    alpha = mat.pbrBaseColorFactor[3];
+    slot  = mat.pbrBaseColorTexture;
+  }
+  if(isTexturePresent(slot))
+  {
+    const MiGltfTextureInfo info = sc.texInfos[slot];
+    f2                      uv   = getInterpolatedVertexTexCoord(rp, info.texCoord, ti, bary);
+    alpha *= sampleTexture(sc, info.index, uv, false, mk2(0, 0), mk2(0, 0)).w;
+  }
+  alpha *= getInterpolatedVertexColor(rp, ti, bary).w;
+  if(alphaMode == MI_ALPHA_MASK)
+    return alpha >= mat.alphaCutoff ? 1.0f : 0.0f;
+  return alpha;
+}
+
+// getShadowTransmission, :244-343
+__device__ __noinline__ f3 getShadowTransmission(const DevScene& sc, int rnode, int triangleID, f3 bary, float hitT, f3 rayDir, bool& isInside)
+{
+  const MiGltfRenderNode&    rn  = sc.nodes[rnode];
+  const MiGltfShadeMaterial& mat = sc.materials[max(0, rn.materialID)];
+  float                      tFactor = mat.transmissionFactor;
+  if(tFactor <= MIN_TRANSMISSION)
+    return mk3(0.0f);
+  const DevPrim rp = sc.prims[rn.renderPrimID];
+  u3            ti = getTriangleIndices(rp, triangleID);
+  f3 v0 = getVertexPosition(rp, ti.x), v1 = getVertexPosition(rp, ti.y), v2 = getVertexPosition(rp, ti.z);
+  f3 normal = normalize(cross(v1 - v0, v2 - v0));
+  normal    = normalize(mulTransposed(rn.worldToObject, normal));
+  float cosTheta = fabsf(dot(rayDir, normal));
+  float fresnel  = schlickFresnelIor(mat.ior, cosTheta);
+  f3    T        = mk3(mat.pbrBaseColorFactor[0], mat.pbrBaseColorFactor[1], mat.pbrBaseColorFactor[2]) * tFactor;
+  T *= (1.0f - fresnel);
+  if(mat.thicknessFactor > 0.0f)
+  {
+    if(isInside)
+    {
+      f3 absCoeff     = -log3(max3(mk3(mat.attenuationColor), mk3(0.001f))) / fmaxf(mat.attenuationDistance, 0.001f);
+      f3 scatterCoeff = absCoeff * multiToSingleScatterAlbedo(mk3(mat.multiscatterColorFactor));
+      f3 extinction   = absCoeff + scatterCoeff;
+      T *= exp3(extinction * (-hitT));
+      float maxScatter = maxComp(scatterCoeff);
+      if(maxScatter > 0.001f)
+        T *= expf(-(hitT * maxComp(extinction)));
+    }
+    isInside = !isInside;
+  }
+  float roughness = mat.pbrRoughnessFactor, metallic = mat.pbrMetallicFactor;
+  if(isTexturePresent(mat.pbrMetallicRoughnessTexture))
+  {
+    const MiGltfTextureInfo info = sc.texInfos[mat.pbrMetallicRoughnessTexture];
+    f2                      uv   = getInterpolatedVertexTexCoord(rp, info.texCoord, ti, bary);
+    f4                      mr   = sampleTexture(sc, info.index, uv, false, mk2(0, 0), mk2(0, 0));
+    roughness *= mr.y;
+    metallic *= mr.z;
+  }
+  float att = (1.0f - metallic);
+  att *= lerpf(0.65f, 1.0f, 1.0f - roughness * roughness);
+  return T * att;
+}
+
+// ---- direct lighting (pathtrace_functions.h.slang:357-492) ------------------------------------------------------------------
+struct DirectLight
+{
+  f3    direction, radianceOverPdf;
+  float distance, pdf;
+};
+PT_DEV void getDirectLightingTechniqueProbabilities(const DevScene& sc, const FrameConsts& fc, float& lightWeight, float& envWeight)
+{
+  lightWeight = (sc.numLights > 0) ? 0.5f : 0.0f;
+  envWeight   = (!hasFlag(fc.frameInfo.flags, MI_SCENE_USE_HDR_ENVIRONMENT) || fc.frameInfo.envIntensity > 0.0f) ? 0.5f : 0.0f;
+  float total = lightWeight + envWeight;
+  if(total > 0.0f)
+  {
+    lightWeight /= total;
+    envWeight /= total;
+  }
+}
+__device__ __noinline__ void sampleLights(const DevScene& sc, const FrameConsts& fc, f3 pos, uint32_t& seed, DirectLight& dl)  // :379-464
+{
+  f3 radiance        = mk3(0.0f);
+  dl.pdf             = 0.0f;
+  dl.distance        = INFINITE_F;
+  dl.radianceOverPdf = mk3(0.0f);
+  dl.direction       = mk3(0.0f);
+  float envPdf       = 0.0f;
+  float lightWeight, envWeight;
+  getDirectLightingTechniqueProbabilities(sc, fc, lightWeight, envWeight);
+  if(lightWeight == 0.0f && envWeight == 0.0f)
+    return;
+  bool       sampleLight = (rnd(seed) < lightWeight);
+  const bool useHdr      = hasFlag(fc.frameInfo.flags, MI_SCENE_USE_HDR_ENVIRONMENT);
+  if(sampleLight)
+  {
+    int         numLights    = sc.numLights;
+    float       selectionPdf = 1.0f / float(numLights);
+    int         lightIndex   = min(int(rnd(seed) * float(numLights)), numLights - 1);
+    MiGltfLight light        = sc.lights[lightIndex];
+    float       r1 = rnd(seed), r2 = rnd(seed);
+    LightContrib contrib = singleLightContribution(light, pos, mk2(r1, r2));
+    dl.direction         = -contrib.incidentVector;
+    dl.distance          = contrib.distance;
+    radiance             = contrib.intensity / (selectionPdf * lightWeight);
+    dl.pdf               = (contrib.pdf == DIRAC) ? DIRAC : selectionPdf * contrib.pdf;
+  }
+  if(envWeight > 0.0f && dl.pdf != DIRAC)
+  {
+    if(!useHdr)
+    {
+      if(!sampleLight)
+      {
+        float r1 = rnd(seed), r2 = rnd(seed);
+        f3    skyRadiance;
+        samplePhysicalSky(fc.sky, mk2(r1, r2), dl.direction, envPdf, skyRadiance);
+        radiance = skyRadiance / (envPdf * envWeight);
+      }
+      else
+        envPdf = samplePhysicalSkyPDF(fc.sky, dl.direction);
+    }
+    else
+    {
+      if(!sampleLight)
+      {
+        float r1 = rnd(seed), r2 = rnd(seed), r3 = rnd(seed);
+        f4    rp = environmentSample(sc, mk3(r1, r2, r3), dl.direction);
+        envPdf   = rp.w;
+        radiance = xyz(rp) * fc.frameInfo.envIntensity / (envPdf * envWeight);
+        dl.direction = rotateAxis(dl.direction, mk3(0, 1, 0), fc.frameInfo.envRotation);
+      }
+      else
+      {
+        f3 dir = rotateAxis(dl.direction, mk3(0, 1, 0), -fc.frameInfo.envRotation);
+        envPdf = sampleHdr(sc, getSphericalUv(dir)).w;
+      }
+    }
+  }
+  float misWeight = 1.0f;
+  if(dl.pdf != DIRAC)
+  {
+    float pdfSum = lightWeight * dl.pdf + envWeight * envPdf;
+    if(pdfSum > 0.0f)
+      misWeight = (sampleLight ? lightWeight * dl.pdf : envWeight * envPdf) / pdfSum;
+    dl.pdf = pdfSum;
+  }
+  radiance *= misWeight;
+  if(!isFinite3(radiance))  // zero-pdf environment texel: treat as "no light"
+  {
+    radiance = mk3(0.0f);
+    dl.pdf   = 0.0f;
+  }
+  dl.radianceOverPdf = radiance;
+}
+PT_DEV void sampleEnvironment(const DevScene& sc, const FrameConsts& fc, f3 direction, f3& envColor, float& envPdf)  // :466-481
+{
+  if(!hasFlag(fc.frameInfo.flags, MI_SCENE_USE_HDR_ENVIRONMENT))
+  {
+    envColor = evalPhysicalSky(fc.sky, direction);
+    envPdf   = samplePhysicalSkyPDF(fc.sky, direction);
+  }
+  else
+  {
+    f3 dir   = rotateAxis(direction, mk3(0, 1, 0), -fc.frameInfo.envRotation);
+    f4 env   = sampleHdr(sc, getSphericalUv(dir));
+    envColor = xyz(env) * fc.frameInfo.envIntensity;
+    envPdf   = env.w;
+  }
+}
+PT_DEV float computeEnvHitMisWeight(const DevScene& sc, const FrameConsts& fc, float lastSamplePdf, float envPdf)  // :483-492
+{
+  if(lastSamplePdf == DIRAC)
+    return 1.0f;
+  float lw, ew;
+  getDirectLightingTechniqueProbabilities(sc, fc, lw, ew);
+  return lastSamplePdf / (lastSamplePdf + ew * envPdf);
+}
+// smoothHDRBlur (backplate only; nvshaders/sample_blur.h.slang is external): 3x3 tent of level-0 taps
+PT_DEV f3 smoothHDRBlur(const DevScene& sc, f2 uv, float blur)
+{
+  f3    sum  = mk3(0.0f);
+  float wsum = 0.0f;
+  float r    = blur * 0.02f;
+  for(int j = -1; j <= 1; ++j)
+    for(int i = -1; i <= 1; ++i)
+    {
+      float w = (2.0f - fabsf(float(i))) * (2.0f - fabsf(float(j)));
+      sum += xyz(sampleHdr(sc, mk2(uv.x + float(i) * r, uv.y + float(j) * r * 0.5f))) * w;
+      wsum += w;
+    }
+  return sum / wsum;
+}
+
+}  // namespace pt

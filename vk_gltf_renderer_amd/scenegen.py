@@ -1,0 +1,482 @@
+"""Seeded procedural glTF (.glb) scenes.
+
+The benchmark assets BASELINE.json names (DamagedHelmet, Sponza, BistroExterior, TransmissionTest, DragonDispersion)
+are not available offline, so every config other than Box.glb uses a *synthetic stand-in of the same class* written by
+this module as a real .glb file: the CPU oracle and the HIP tracer then load identical bytes through the same front end.
+All generators take an explicit integer seed; numpy's PCG64 stream makes the bytes reproducible.
+
+Also used by the tests to build small analytic scenes (planes, spheres, material sweeps).
+"""
+import json
+import struct
+import zlib
+
+import numpy as np
+
+_COMPONENT = {np.dtype(np.float32): 5126, np.dtype(np.uint32): 5125, np.dtype(np.uint16): 5123, np.dtype(np.uint8): 5121,
+              np.dtype(np.int16): 5122, np.dtype(np.int8): 5120}
+_TYPE = {1: "SCALAR", 2: "VEC2", 3: "VEC3", 4: "VEC4", 16: "MAT4"}
+
+
+def png_bytes(rgba):
+    """Encode an (H, W, 4) uint8 array as a PNG (filter 0, zlib level 6)."""
+    rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+    h, w, c = rgba.shape
+    assert c == 4
+    raw = np.concatenate([np.zeros((h, 1), np.uint8), rgba.reshape(h, w * 4)], axis=1).tobytes()
+
+    def chunk(tag, data):
+        body = tag + data
+        return struct.pack(">I", len(data)) + body + struct.pack(">I", zlib.crc32(body) & 0xFFFFFFFF)
+
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, 6))
+            + chunk(b"IEND", b""))
+
+
+class GlbBuilder:
+    def __init__(self, generator="vk_gltf_renderer_amd.scenegen"):
+        self.doc = {"asset": {"version": "2.0", "generator": generator}, "scene": 0, "scenes": [{"nodes": []}], "nodes": [], "meshes": [],
+                    "materials": [], "accessors": [], "bufferViews": [], "buffers": [{"byteLength": 0}]}
+        self.bin = bytearray()
+        self.ext_used = set()
+
+    # ---- raw data ------------------------------------------------------------------------------------------------------
+    def _view(self, data, target=None):
+        while len(self.bin) % 4:
+            self.bin.append(0)
+        off = len(self.bin)
+        self.bin += data
+        bv = {"buffer": 0, "byteOffset": off, "byteLength": len(data)}
+        if target:
+            bv["target"] = target
+        self.doc["bufferViews"].append(bv)
+        return len(self.doc["bufferViews"]) - 1
+
+    def accessor(self, arr, target=None, normalized=False, minmax=False):
+        arr = np.ascontiguousarray(arr)
+        ncomp = 1 if arr.ndim == 1 else arr.shape[1]
+        acc = {"bufferView": self._view(arr.tobytes(), target), "componentType": _COMPONENT[arr.dtype], "count": int(arr.shape[0]),
+               "type": _TYPE[ncomp]}
+        if normalized:
+            acc["normalized"] = True
+        if minmax:
+            acc["min"] = [float(v) for v in np.atleast_1d(arr.min(axis=0))]
+            acc["max"] = [float(v) for v in np.atleast_1d(arr.max(axis=0))]
+        self.doc["accessors"].append(acc)
+        return len(self.doc["accessors"]) - 1
+
+    # ---- images / textures -----------------------------------------------------------------------------------------------
+    def image(self, rgba):
+        self.doc.setdefault("images", []).append({"bufferView": self._view(png_bytes(rgba)), "mimeType": "image/png"})
+        return len(self.doc["images"]) - 1
+
+    def sampler(self, mag=9729, min_=9987, wrap_s=10497, wrap_t=10497):
+        self.doc.setdefault("samplers", []).append({"magFilter": mag, "minFilter": min_, "wrapS": wrap_s, "wrapT": wrap_t})
+        return len(self.doc["samplers"]) - 1
+
+    def texture(self, image, sampler=None):
+        t = {"source": image}
+        if sampler is not None:
+            t["sampler"] = sampler
+        self.doc.setdefault("textures", []).append(t)
+        return len(self.doc["textures"]) - 1
+
+    # ---- materials / meshes / nodes ----------------------------------------------------------------------------------------
+    def material(self, mat):
+        for k in mat.get("extensions", {}):
+            self.ext_used.add(k)
+        self.doc["materials"].append(mat)
+        return len(self.doc["materials"]) - 1
+
+    def primitive(self, positions, indices=None, normals=None, uv0=None, uv1=None, colors=None, tangents=None, material=None):
+        attrs = {"POSITION": self.accessor(np.asarray(positions, np.float32), 34962, minmax=True)}
+        if normals is not None:
+            attrs["NORMAL"] = self.accessor(np.asarray(normals, np.float32), 34962)
+        if uv0 is not None:
+            attrs["TEXCOORD_0"] = self.accessor(np.asarray(uv0, np.float32), 34962)
+        if uv1 is not None:
+            attrs["TEXCOORD_1"] = self.accessor(np.asarray(uv1, np.float32), 34962)
+        if tangents is not None:
+            attrs["TANGENT"] = self.accessor(np.asarray(tangents, np.float32), 34962)
+        if colors is not None:
+            colors = np.asarray(colors)
+            attrs["COLOR_0"] = self.accessor(colors, 34962, normalized=colors.dtype != np.float32)
+        prim = {"attributes": attrs, "mode": 4}
+        if indices is not None:
+            idx = np.asarray(indices).reshape(-1)
+            idx = idx.astype(np.uint16) if idx.max(initial=0) < 65535 else idx.astype(np.uint32)
+            prim["indices"] = self.accessor(idx, 34963)
+        if material is not None:
+            prim["material"] = material
+        return prim
+
+    def mesh(self, primitives):
+        self.doc["meshes"].append({"primitives": primitives})
+        return len(self.doc["meshes"]) - 1
+
+    def node(self, root=True, **kw):
+        for k in kw.get("extensions", {}):
+            self.ext_used.add(k)
+        self.doc["nodes"].append(kw)
+        idx = len(self.doc["nodes"]) - 1
+        if root:
+            self.doc["scenes"][0]["nodes"].append(idx)
+        return idx
+
+    def camera(self, yfov, znear, zfar, aspect=16 / 9):
+        self.doc.setdefault("cameras", []).append({"type": "perspective", "perspective": {"yfov": yfov, "znear": znear, "zfar": zfar, "aspectRatio": aspect}})
+        return len(self.doc["cameras"]) - 1
+
+    def camera_node(self, eye, center, up=(0, 1, 0), yfov=0.7854, znear=0.05, zfar=1000.0):
+        cam = self.camera(yfov, znear, zfar)
+        eye, center, up = (np.asarray(v, np.float64) for v in (eye, center, up))
+        f = center - eye
+        f /= np.linalg.norm(f)
+        s = np.cross(f, up)
+        s /= np.linalg.norm(s)
+        u = np.cross(s, f)
+        m = np.eye(4)
+        m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = s, u, -f, eye
+        return self.node(camera=cam, matrix=[float(v) for v in m.T.reshape(-1)],
+                         extras={"camera::eye": eye.tolist(), "camera::center": center.tolist(), "camera::up": up.tolist()})
+
+    def light(self, light):
+        self.ext_used.add("KHR_lights_punctual")
+        ext = self.doc.setdefault("extensions", {}).setdefault("KHR_lights_punctual", {"lights": []})
+        ext["lights"].append(light)
+        return len(ext["lights"]) - 1
+
+    def save(self, path):
+        doc = dict(self.doc)
+        if self.ext_used:
+            doc["extensionsUsed"] = sorted(self.ext_used)
+        while len(self.bin) % 4:
+            self.bin.append(0)
+        doc["buffers"] = [{"byteLength": len(self.bin)}]
+        js = json.dumps(doc, separators=(",", ":")).encode()
+        js += b" " * ((4 - len(js) % 4) % 4)
+        total = 12 + 8 + len(js) + 8 + len(self.bin)
+        with open(path, "wb") as f:
+            f.write(struct.pack("<4sII", b"glTF", 2, total))
+            f.write(struct.pack("<I4s", len(js), b"JSON") + js)
+            f.write(struct.pack("<I4s", len(self.bin), b"BIN\0") + bytes(self.bin))
+        return path
+
+
+# ---- geometry helpers -------------------------------------------------------------------------------------------------------
+def grid(nx, ny, size=(1.0, 1.0), axis="y"):
+    """A (nx x ny)-quad plane centred at the origin, normal +axis, uv in [0,1]^2."""
+    u, v = np.meshgrid(np.linspace(0, 1, nx + 1), np.linspace(0, 1, ny + 1), indexing="xy")
+    u, v = u.reshape(-1), v.reshape(-1)
+    a, b = (u - 0.5) * size[0], (v - 0.5) * size[1]
+    z = np.zeros_like(a)
+    if axis == "y":
+        pos, nrm = np.stack([a, z, -b], 1), np.array([0, 1, 0], np.float32)
+    elif axis == "z":
+        pos, nrm = np.stack([a, b, z], 1), np.array([0, 0, 1], np.float32)
+    else:
+        pos, nrm = np.stack([z, b, -a], 1), np.array([1, 0, 0], np.float32)
+    i = (np.arange(ny)[:, None] * (nx + 1) + np.arange(nx)[None, :]).reshape(-1)
+    idx = np.stack([i, i + 1, i + nx + 2, i, i + nx + 2, i + nx + 1], 1).reshape(-1, 3)
+    return pos.astype(np.float32), np.tile(nrm, (pos.shape[0], 1)).astype(np.float32), np.stack([u, 1 - v], 1).astype(np.float32), idx.astype(np.uint32)
+
+
+def uv_sphere(nu, nv, radius=1.0, displace=None):
+    """Lat-long sphere with nu x nv quads; optional radial displacement callback f(dir)->scale."""
+    th = np.linspace(0, np.pi, nv + 1)
+    ph = np.linspace(0, 2 * np.pi, nu + 1)
+    T, Pm = np.meshgrid(th, ph, indexing="ij")
+    d = np.stack([np.sin(T) * np.cos(Pm), np.cos(T), np.sin(T) * np.sin(Pm)], -1).reshape(-1, 3)
+    r = radius * (displace(d) if displace is not None else 1.0)
+    pos = d * np.reshape(r, (-1, 1)) if np.ndim(r) else d * r
+    uv = np.stack([Pm / (2 * np.pi), T / np.pi], -1).reshape(-1, 2)
+    i = (np.arange(nv)[:, None] * (nu + 1) + np.arange(nu)[None, :]).reshape(-1)
+    idx = np.stack([i, i + nu + 1, i + nu + 2, i, i + nu + 2, i + 1], 1).reshape(-1, 3)
+    # outward-facing counter-clockwise winding
+    idx = idx[:, [0, 2, 1]]
+    nrm = d.copy()
+    if displace is not None:
+        nrm = _vertex_normals(pos, idx)
+    return pos.astype(np.float32), nrm.astype(np.float32), uv.astype(np.float32), idx.astype(np.uint32)
+
+
+def _vertex_normals(pos, idx):
+    n = np.zeros_like(pos, dtype=np.float64)
+    fn = np.cross(pos[idx[:, 1]] - pos[idx[:, 0]], pos[idx[:, 2]] - pos[idx[:, 0]])
+    for k in range(3):
+        np.add.at(n, idx[:, k], fn)
+    ln = np.linalg.norm(n, axis=1, keepdims=True)
+    return n / np.maximum(ln, 1e-20)
+
+
+def box(size=(1, 1, 1), inward=False):
+    """Axis-aligned box made of 6 quads (24 vertices)."""
+    sx, sy, sz = (0.5 * s for s in size)
+    faces = [((1, 0, 0), (0, 1, 0), (0, 0, 1)), ((-1, 0, 0), (0, 1, 0), (0, 0, -1)), ((0, 1, 0), (0, 0, 1), (1, 0, 0)),
+             ((0, -1, 0), (0, 0, -1), (1, 0, 0)), ((0, 0, 1), (1, 0, 0), (0, 1, 0)), ((0, 0, -1), (-1, 0, 0), (0, 1, 0))]
+    pos, nrm, uv, idx = [], [], [], []
+    for n, a, b in faces:
+        n, a, b = (np.array(v, np.float64) for v in (n, a, b))
+        ext = np.array([sx, sy, sz])
+        c = n * ext
+        a, b = a * ext, b * ext
+        base = len(pos)
+        for (u, v) in ((-1, -1), (1, -1), (1, 1), (-1, 1)):
+            pos.append(c + u * a + v * b)
+            nrm.append(-n if inward else n)
+            uv.append(((u + 1) / 2, (1 - v) / 2))
+        quad = [[0, 1, 2], [0, 2, 3]]
+        for t in quad:
+            t = [base + k for k in t]
+            # a x b == n for every face above, so (0,1,2) is CCW seen from outside
+            idx.append(t[::-1] if inward else t)
+    return np.array(pos, np.float32), np.array(nrm, np.float32), np.array(uv, np.float32), np.array(idx, np.uint32)
+
+
+def value_noise(rng, size, octaves=5, channels=1):
+    """Tileable value noise in [0,1], (size, size, channels)."""
+    out = np.zeros((size, size, channels), np.float64)
+    amp, total = 1.0, 0.0
+    for o in range(octaves):
+        n = min(4 << o, size)
+        g = rng.random((n, n, channels))
+        rep = size // n
+        # bilinear upsample with wrap
+        xs = (np.arange(size) + 0.5) / rep - 0.5
+        x0 = np.floor(xs).astype(int)
+        t = xs - x0
+        t = t * t * (3 - 2 * t)
+        x0m, x1m = x0 % n, (x0 + 1) % n
+        rows = g[x0m] * (1 - t)[:, None, None] + g[x1m] * t[:, None, None]
+        up = rows[:, x0m] * (1 - t)[None, :, None] + rows[:, x1m] * t[None, :, None]
+        out += amp * up
+        total += amp
+        amp *= 0.5
+    return out / total
+
+
+# ---- analytic test scenes -------------------------------------------------------------------------------------------------
+def lambert_material(color=(1, 1, 1), **extra):
+    """Pure Lambertian: KHR_materials_specular.specularFactor = 0 removes the dielectric specular lobe."""
+    m = {"pbrMetallicRoughness": {"baseColorFactor": [*color, 1.0], "metallicFactor": 0.0, "roughnessFactor": 1.0},
+         "extensions": {"KHR_materials_specular": {"specularFactor": 0.0}}}
+    m.update(extra)
+    return m
+
+
+def scene_sphere(path, material, nu=64, nv=32, eye=(0, 0, 3.0), radius=1.0):
+    b = GlbBuilder()
+    m = b.material(material)
+    pos, nrm, uv, idx = uv_sphere(nu, nv, radius)
+    b.node(mesh=b.mesh([b.primitive(pos, idx, nrm, uv, material=m)]))
+    b.camera_node(eye, (0, 0, 0), yfov=0.8)
+    return b.save(path)
+
+
+def scene_plane_with_light(path, albedo=0.5, light=None, size=20.0):
+    """Large Lambert quad in the xz plane, camera above looking down, one punctual light."""
+    b = GlbBuilder()
+    m = b.material(lambert_material((albedo, albedo, albedo)))
+    pos, nrm, uv, idx = grid(1, 1, (size, size), "y")
+    b.node(mesh=b.mesh([b.primitive(pos, idx, nrm, uv, material=m)]))
+    b.camera_node((0, 4.0, 0.0), (0, 0, 0), up=(0, 0, -1), yfov=0.5)
+    if light is not None:
+        li = b.light(light["def"])
+        b.node(extensions={"KHR_lights_punctual": {"light": li}}, **light.get("node", {}))
+    return b.save(path)
+
+
+# ---- benchmark-class stand-ins ----------------------------------------------------------------------------------------------
+def scene_helmet_class(path, seed=1234, tess=192, tex_size=1024):
+    """DamagedHelmet-class: ONE mesh (~2*tess*tess/2 triangles), ONE material with five textures (baseColor sRGB,
+    metallicRoughness, normal, occlusion, emissive), procedural value noise.  tess=192 -> 73 728 triangles."""
+    rng = np.random.default_rng(seed)
+    bumps = rng.normal(size=(24, 3))
+    bumps /= np.linalg.norm(bumps, axis=1, keepdims=True)
+    amp = rng.uniform(0.03, 0.12, 24)
+
+    def displace(d):
+        s = np.ones(d.shape[0])
+        for k in range(24):
+            s += amp[k] * np.exp(-((1 - d @ bumps[k]) * 14.0))
+        return s
+
+    pos, nrm, uv, idx = uv_sphere(tess, tess // 2, 1.0, displace)
+    b = GlbBuilder()
+    smp = b.sampler()
+    n1 = value_noise(rng, tex_size, 6, 3)
+    n2 = value_noise(rng, tex_size, 5, 1)[..., 0]
+    base = np.clip(0.25 + 0.7 * n1 * np.array([0.9, 0.75, 0.6]), 0, 1)
+    rough = np.clip(0.15 + 0.8 * n2, 0, 1)
+    metal = (value_noise(rng, tex_size, 3, 1)[..., 0] > 0.5).astype(np.float64)
+    occl = np.clip(0.6 + 0.4 * value_noise(rng, tex_size, 4, 1)[..., 0], 0, 1)
+    hgt = value_noise(rng, tex_size, 6, 1)[..., 0]
+    gx = np.roll(hgt, -1, 1) - np.roll(hgt, 1, 1)
+    gy = np.roll(hgt, -1, 0) - np.roll(hgt, 1, 0)
+    nmap = np.stack([-gx * 8.0, -gy * 8.0, np.ones_like(gx)], -1)
+    nmap /= np.linalg.norm(nmap, axis=-1, keepdims=True)
+    emis = np.clip((value_noise(rng, tex_size, 3, 1)[..., 0] - 0.72) * 6.0, 0, 1)[..., None] * np.array([0.2, 0.6, 1.0])
+
+    def tex(rgb, alpha=None):
+        a = np.ones(rgb.shape[:2]) if alpha is None else alpha
+        img = np.concatenate([rgb, a[..., None]], -1)
+        return b.texture(b.image((np.clip(img, 0, 1) * 255 + 0.5).astype(np.uint8)), smp)
+
+    t_base, t_mr = tex(base), tex(np.stack([occl, rough, metal], -1))
+    t_nrm, t_emis = tex(nmap * 0.5 + 0.5), tex(emis)
+    mat = b.material({"pbrMetallicRoughness": {"baseColorTexture": {"index": t_base}, "metallicRoughnessTexture": {"index": t_mr}},
+                      "normalTexture": {"index": t_nrm, "scale": 1.0}, "occlusionTexture": {"index": t_mr, "strength": 1.0},
+                      "emissiveTexture": {"index": t_emis}, "emissiveFactor": [1.0, 1.0, 1.0]})
+    # tangents along +u
+    d = pos / np.linalg.norm(pos, axis=1, keepdims=True)
+    tan = np.stack([-d[:, 2], np.zeros(len(d)), d[:, 0]], 1)
+    ln = np.linalg.norm(tan, axis=1, keepdims=True)
+    tan = np.where(ln > 1e-6, tan / np.maximum(ln, 1e-6), np.array([1.0, 0, 0]))
+    tan = np.concatenate([tan, np.ones((len(tan), 1))], 1).astype(np.float32)
+    b.node(mesh=b.mesh([b.primitive(pos, idx, nrm, uv, tangents=tan, material=mat)]))
+    b.camera_node((0.0, 0.3, 3.2), (0, 0, 0), yfov=0.7)
+    return b.save(path)
+
+
+def scene_atrium_class(path, seed=4321, detail=1.0, tex_size=512):
+    """Sponza-class interior: a long two-storey hall with columns, arches, drapes and alpha-MASK foliage, ~25 materials in
+    ~100 primitives, one directional light + sky.  detail=1.0 gives ~262k triangles."""
+    rng = np.random.default_rng(seed)
+    b = GlbBuilder()
+    smp = b.sampler()
+
+    def tex(rgb, alpha=None):
+        a = np.ones(rgb.shape[:2]) if alpha is None else alpha
+        img = np.concatenate([rgb, a[..., None]], -1)
+        return b.texture(b.image((np.clip(img, 0, 1) * 255 + 0.5).astype(np.uint8)), smp)
+
+    mats = []
+    for k in range(22):
+        hue = rng.uniform(0.35, 0.95, 3) * rng.uniform(0.5, 1.0)
+        n = value_noise(rng, tex_size, 5, 3)
+        t = tex(np.clip(hue * (0.55 + 0.45 * n), 0, 1))
+        m = {"pbrMetallicRoughness": {"baseColorTexture": {"index": t}, "metallicFactor": float(rng.random() < 0.15),
+                                      "roughnessFactor": float(rng.uniform(0.25, 0.95))}}
+        if k % 5 == 0:
+            m["doubleSided"] = True
+        mats.append(b.material(m))
+    # foliage: alpha-masked, double sided
+    leaf_n = value_noise(rng, tex_size, 4, 1)[..., 0]
+    yy, xx = np.mgrid[0:tex_size, 0:tex_size] / tex_size - 0.5
+    leaf_a = ((np.sqrt(xx * xx * 3 + yy * yy) + 0.15 * (leaf_n - 0.5)) < 0.42).astype(np.float64)
+    leaf_rgb = np.clip(np.stack([0.15 + 0.2 * leaf_n, 0.45 + 0.4 * leaf_n, 0.1 + 0.1 * leaf_n], -1), 0, 1)
+    t_leaf = tex(leaf_rgb, leaf_a)
+    m_leaf = b.material({"pbrMetallicRoughness": {"baseColorTexture": {"index": t_leaf}, "metallicFactor": 0.0, "roughnessFactor": 0.7},
+                         "alphaMode": "MASK", "alphaCutoff": 0.5, "doubleSided": True})
+    m_drape = b.material({"pbrMetallicRoughness": {"baseColorFactor": [0.6, 0.08, 0.08, 1], "metallicFactor": 0.0, "roughnessFactor": 0.9},
+                          "doubleSided": True})
+
+    L, Wd, Hh = 36.0, 14.0, 12.0
+    g = max(2, int(24 * detail))
+
+    def add(prim_args, material, **node):
+        b.node(mesh=b.mesh([b.primitive(*prim_args, material=material)]), **node)
+
+    def quad_grid(nx, ny, size, axis, flip=False):
+        pos, nrm, uv, idx = grid(nx, ny, size, axis)
+        if flip:
+            idx, nrm = idx[:, [0, 2, 1]], -nrm
+        return pos, idx, nrm, uv * np.array([size[0] / 4, size[1] / 4], np.float32)
+
+    # shell: floor, ceiling (with a skylight slot), walls
+    add(quad_grid(g * 3, g, (L, Wd), "y"), mats[0])
+    for s in (-1, 1):
+        add(quad_grid(g * 3, g // 2, (L, Wd * 0.32), "y", flip=True), mats[1], translation=[0, Hh, s * Wd * 0.34])
+        add(quad_grid(g * 3, g, (L, Hh), "z", flip=(s > 0)), mats[2], translation=[0, Hh / 2, s * Wd / 2])
+        add(quad_grid(g, g, (Wd, Hh), "x", flip=(s > 0)), mats[3], translation=[s * L / 2, Hh / 2, 0])
+        # gallery floor of the upper storey
+        add(quad_grid(g * 3, 4, (L, 2.6), "y"), mats[4], translation=[0, Hh * 0.5, s * (Wd / 2 - 1.3)])
+    # columns (tessellated cylinders = stretched spheres) and arches (tori segments)
+    ncol = 10
+    cu, cv = max(8, int(40 * detail)), max(8, int(56 * detail))
+    for i in range(ncol):
+        x = -L / 2 + (i + 0.5) * L / ncol
+        for s in (-1, 1):
+            for storey in range(2):
+                pos, nrm, uv, idx = uv_sphere(cu, cv, 1.0)
+                pos = pos * np.array([0.42, Hh * 0.25, 0.42], np.float32)
+                nn = nrm / np.array([0.42, Hh * 0.25, 0.42], np.float32)
+                nn /= np.linalg.norm(nn, axis=1, keepdims=True)
+                add((pos, idx, nn.astype(np.float32), uv * np.array([2, 6], np.float32)), mats[5 + (i + storey) % 6],
+                    translation=[x, Hh * (0.25 + 0.5 * storey), s * (Wd / 2 - 2.6)])
+    # drapes: wavy vertical sheets
+    for i in range(6):
+        x = -L / 2 + (i + 0.75) * L / 6
+        nx, ny = max(6, int(48 * detail)), max(6, int(64 * detail))
+        pos, nrm, uv, idx = grid(nx, ny, (3.0, 5.0), "z")
+        phase = rng.uniform(0, 6.28)
+        pos[:, 2] += (0.18 * np.sin(pos[:, 0] * 7.0 + phase) * (0.3 + (2.5 - pos[:, 1]) / 5.0)).astype(np.float32)
+        nrm = _vertex_normals(pos.astype(np.float64), idx).astype(np.float32)
+        add((pos, idx, nrm, uv), m_drape, translation=[x, Hh * 0.72, (-1) ** i * (Wd / 2 - 2.2)])
+    # foliage: clusters of alpha-masked quads (~10 % of the triangles)
+    nleaf = int(13000 * detail)
+    for cl in range(8):
+        c = np.array([-L / 2 + 6.0 + cl * (L - 9.0) / 8.0, 0.0, (-1) ** cl * (Wd / 2 - 4.2) + rng.uniform(-0.4, 0.4)])
+        n = nleaf // 8
+        centers = c + rng.normal(size=(n, 3)) * np.array([0.9, 0.7, 0.9]) + np.array([0, 1.6, 0])
+        ax = rng.normal(size=(n, 3))
+        ax /= np.linalg.norm(ax, axis=1, keepdims=True)
+        bx = np.cross(ax, rng.normal(size=(n, 3)))
+        bx /= np.linalg.norm(bx, axis=1, keepdims=True)
+        sz = np.exp(rng.uniform(np.log(0.08), np.log(0.35), (n, 1)))
+        quad = np.stack([centers - ax * sz - bx * sz, centers + ax * sz - bx * sz, centers + ax * sz + bx * sz, centers - ax * sz + bx * sz], 1)
+        pos = quad.reshape(-1, 3)
+        nrm = np.repeat(np.cross(ax, bx), 4, 0)
+        uv = np.tile(np.array([[0, 1], [1, 1], [1, 0], [0, 0]], np.float32), (n, 1))
+        base = np.arange(n)[:, None] * 4
+        idx = np.concatenate([base + np.array([0, 1, 2]), base + np.array([0, 2, 3])], 1).reshape(-1, 3)
+        add((pos.astype(np.float32), idx.astype(np.uint32), nrm.astype(np.float32), uv), m_leaf)
+    # clutter: displaced blobs standing in for statues/vases, varied materials
+    for k in range(16):
+        amp = rng.uniform(0.05, 0.25)
+        fr = rng.normal(size=(6, 3)) * 3.0
+
+        def displace(d, amp=amp, fr=fr):
+            return 1.0 + amp * np.sin(d @ fr.T).sum(1) / 3.0
+
+        pos, nrm, uv, idx = uv_sphere(max(8, int(96 * detail)), max(6, int(48 * detail)), rng.uniform(0.5, 1.1), displace)
+        add((pos, idx, nrm, uv), mats[11 + k % 11], translation=[float(rng.uniform(-L / 2 + 2, L / 2 - 2)), float(rng.uniform(0.6, 1.2)),
+                                                                float(rng.uniform(-Wd / 2 + 3.4, Wd / 2 - 3.4))])
+    li = b.light({"type": "directional", "intensity": 12.0, "color": [1.0, 0.96, 0.9]})
+    # light direction = -Z of the node: tilt so it shines through the skylight slot
+    ang = 0.35
+    b.node(extensions={"KHR_lights_punctual": {"light": li}}, rotation=[-float(np.sin((np.pi / 2 - ang) / 2)), 0.0, 0.0, float(np.cos((np.pi / 2 - ang) / 2))])
+    b.camera_node((-L / 2 + 2.5, 2.2, 0.6), (L / 2, 3.8, -0.4), yfov=1.0, znear=0.05, zfar=200.0)
+    return b.save(path)
+
+
+def scene_glass_class(path, seed=99, tess=48):
+    """TransmissionTest-class: a grid of spheres sweeping transmission / roughness / IOR / attenuation / dispersion /
+    volume scatter, plus opaque reference spheres, on a diffuse floor with one point light."""
+    rng = np.random.default_rng(seed)
+    b = GlbBuilder()
+    floor = b.material(lambert_material((0.55, 0.55, 0.55)))
+    pos, nrm, uv, idx = grid(8, 8, (16, 16), "y")
+    b.node(mesh=b.mesh([b.primitive(pos, idx, nrm, uv, material=floor)]))
+    sp = uv_sphere(tess, tess // 2, 0.45)
+    k = 0
+    for iy in range(3):
+        for ix in range(6):
+            ext = {"KHR_materials_transmission": {"transmissionFactor": float([1.0, 0.9, 0.6][iy])}, "KHR_materials_ior": {"ior": float(1.1 + 0.15 * ix)}}
+            if ix % 2 == 0:
+                ext["KHR_materials_volume"] = {"thicknessFactor": 0.9, "attenuationDistance": float(0.4 + 0.4 * ix),
+                                               "attenuationColor": [float(v) for v in rng.uniform(0.2, 1.0, 3)]}
+            if ix == 3:
+                ext["KHR_materials_dispersion"] = {"dispersion": 8.0}
+                ext.setdefault("KHR_materials_volume", {"thicknessFactor": 0.9})
+            if ix == 5 and iy == 2:
+                ext["KHR_materials_volume"] = {"thicknessFactor": 0.9, "attenuationDistance": 0.6, "attenuationColor": [0.9, 0.5, 0.3]}
+                ext["KHR_materials_volume_scatter"] = {"multiscatterColor": [0.8, 0.6, 0.4], "scatterAnisotropy": 0.3}
+            m = b.material({"pbrMetallicRoughness": {"baseColorFactor": [*[float(v) for v in rng.uniform(0.7, 1.0, 3)], 1.0], "metallicFactor": 0.0,
+                                                     "roughnessFactor": float([0.0, 0.15, 0.4][iy])}, "extensions": ext})
+            b.node(mesh=b.mesh([b.primitive(sp[0], sp[3], sp[1], sp[2], material=m)]), translation=[-3.0 + 1.2 * ix, 0.46, -1.2 + 1.2 * iy])
+            k += 1
+    li = b.light({"type": "point", "intensity": 300.0, "color": [1, 1, 1], "extras": {"radius": 0.25}})
+    b.node(extensions={"KHR_lights_punctual": {"light": li}}, translation=[0.0, 5.0, 2.0])
+    b.camera_node((0.0, 3.2, 5.2), (0, 0.3, 0), yfov=0.75)
+    return b.save(path)
