@@ -126,7 +126,8 @@ typedef struct MiPtStats
   uint64_t bvhTriangleBytes;/* S_tri */
 } MiPtStats;
 
-/* Per-kernel device time of the last mi_pt_render_frame, measured with HIP events on the frame's stream. */
+/* Per-kernel device time summed over every mi_pt_render_frame since mi_pt_enable_timing(pt, 1), measured with HIP events
+ * recorded on the frame's stream around each launch; resolved (one device sync) by mi_pt_get_frame_timing. */
 typedef struct MiPtFrameTiming
 {
   float totalMs;

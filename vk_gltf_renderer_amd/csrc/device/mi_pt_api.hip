@@ -109,7 +109,15 @@ struct MiPt
   DevBuf<pt::StatCounters> stats;
   bool                    collectCounters = false;
   bool                    timingEnabled   = false;
-  MiPtFrameTiming         lastTiming{};
+  // deferred timing: events are recorded per launch and only resolved in mi_pt_get_frame_timing (no per-frame sync)
+  struct Span
+  {
+    int        kind;
+    hipEvent_t a, b;
+  };
+  std::vector<Span>       pendingSpans;
+  size_t                  evCursor = 0;
+  MiPtFrameTiming         accTiming{};
   std::vector<hipEvent_t> eventPool;
   hipStream_t             lastStream = nullptr;
 
@@ -526,21 +534,14 @@ int mi_pt_render_frame(MiPt* pt, const MiPathtraceParams* params, void* hipStrea
   c.hasAlpha         = pt->hasAlpha;
   c.collectCounters  = pt->collectCounters;
 
-  struct Span
-  {
-    int        kind;
-    hipEvent_t a, b;
-  };
-  std::vector<Span> spans;
-  size_t            evCursor = 0;
   auto timed = [&](int kind, auto&& launch) {
     if(pt->timingEnabled)
     {
-      hipEvent_t a = getEvent(pt, evCursor), b = getEvent(pt, evCursor);
+      hipEvent_t a = getEvent(pt, pt->evCursor), b = getEvent(pt, pt->evCursor);
       (void)hipEventRecord(a, stream);
       launch();
       (void)hipEventRecord(b, stream);
-      spans.push_back({kind, a, b});
+      pt->pendingSpans.push_back({kind, a, b});
     }
     else
       launch();
@@ -548,8 +549,8 @@ int mi_pt_render_frame(MiPt* pt, const MiPathtraceParams* params, void* hipStrea
   hipEvent_t frameA = nullptr, frameB = nullptr;
   if(pt->timingEnabled)
   {
-    frameA = getEvent(pt, evCursor);
-    frameB = getEvent(pt, evCursor);
+    frameA = getEvent(pt, pt->evCursor);
+    frameB = getEvent(pt, pt->evCursor);
     (void)hipEventRecord(frameA, stream);
   }
   int iterations = 0, traceLaunches = 0, shadeLaunches = 0, shadowLaunches = 0;
@@ -589,28 +590,11 @@ int mi_pt_render_frame(MiPt* pt, const MiPathtraceParams* params, void* hipStrea
   if(pt->timingEnabled)
   {
     (void)hipEventRecord(frameB, stream);
-    HIP_TRY(hipStreamSynchronize(stream));
-    MiPtFrameTiming t{};
-    (void)hipEventElapsedTime(&t.totalMs, frameA, frameB);
-    for(const Span& sp : spans)
-    {
-      float ms = 0.0f;
-      (void)hipEventElapsedTime(&ms, sp.a, sp.b);
-      switch(sp.kind)
-      {
-        case TK_GENERATE: t.generateMs += ms; break;
-        case TK_TRACE: t.traceClosestMs += ms; break;
-        case TK_SORT: t.sortMs += ms; break;
-        case TK_SHADE: t.shadeMs += ms; break;
-        case TK_SHADOW: t.traceShadowMs += ms; break;
-        case TK_ACCUM: t.accumulateMs += ms; break;
-      }
-    }
-    t.traceClosestLaunches = traceLaunches;
-    t.shadeLaunches        = shadeLaunches;
-    t.traceShadowLaunches  = shadowLaunches;
-    t.bounceIterations     = iterations;
-    pt->lastTiming         = t;
+    pt->pendingSpans.push_back({TK_COUNT, frameA, frameB});
+    pt->accTiming.traceClosestLaunches += traceLaunches;
+    pt->accTiming.shadeLaunches += shadeLaunches;
+    pt->accTiming.traceShadowLaunches += shadowLaunches;
+    pt->accTiming.bounceIterations += iterations;
   }
   return MI_PT_OK;
 }
@@ -716,13 +700,40 @@ int mi_pt_enable_timing(MiPt* pt, int enable)
   if(!pt)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_enable_timing: null instance");
   pt->timingEnabled = enable != 0;
+  if(enable)
+  {
+    pt->pendingSpans.clear();
+    pt->evCursor  = 0;
+    pt->accTiming = MiPtFrameTiming{};
+  }
   return MI_PT_OK;
 }
 int mi_pt_get_frame_timing(MiPt* pt, MiPtFrameTiming* out)
 {
   if(!pt || !out)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_get_frame_timing: null argument");
-  *out = pt->lastTiming;
+  // Totals since mi_pt_enable_timing(1): resolves the recorded events (one device synchronisation, here, not per frame).
+  HIP_TRY(hipSetDevice(pt->device));
+  HIP_TRY(hipDeviceSynchronize());
+  MiPtFrameTiming& t = pt->accTiming;
+  for(const MiPt::Span& sp : pt->pendingSpans)
+  {
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, sp.a, sp.b);
+    switch(sp.kind)
+    {
+      case TK_GENERATE: t.generateMs += ms; break;
+      case TK_TRACE: t.traceClosestMs += ms; break;
+      case TK_SORT: t.sortMs += ms; break;
+      case TK_SHADE: t.shadeMs += ms; break;
+      case TK_SHADOW: t.traceShadowMs += ms; break;
+      case TK_ACCUM: t.accumulateMs += ms; break;
+      default: t.totalMs += ms; break;
+    }
+  }
+  pt->pendingSpans.clear();
+  pt->evCursor = 0;
+  *out         = t;
   return MI_PT_OK;
 }
 }

@@ -287,9 +287,9 @@ def scene_plane_with_light(path, albedo=0.5, light=None, size=20.0):
 
 
 # ---- benchmark-class stand-ins ----------------------------------------------------------------------------------------------
-def scene_helmet_class(path, seed=1234, tess=192, tex_size=1024):
+def scene_helmet_class(path, seed=1234, tess=272, tex_size=1024):
     """DamagedHelmet-class: ONE mesh (~2*tess*tess/2 triangles), ONE material with five textures (baseColor sRGB,
-    metallicRoughness, normal, occlusion, emissive), procedural value noise.  tess=192 -> 73 728 triangles."""
+    metallicRoughness, normal, occlusion, emissive), procedural value noise.  tess=272 -> 73 984 triangles."""
     rng = np.random.default_rng(seed)
     bumps = rng.normal(size=(24, 3))
     bumps /= np.linalg.norm(bumps, axis=1, keepdims=True)
