@@ -101,6 +101,7 @@ struct MiPt
   DevBuf<float4>          pathArrays;  // one allocation, sliced into PathSoA
   pt::PathSoA             paths{};
   DevBuf<uint32_t>        queueMem;
+  DevBuf<float4>          queuePayload;
   pt::Queues              queues{};
   DevBuf<float4>          accumOwn, albedo, normal, denoiseA, denoiseB;
   float4*                 accum = nullptr;  // accumOwn.ptr or caller-bound memory
@@ -141,27 +142,35 @@ int allocFrameResources(MiPt* pt)
   const int W = pt->width, H = pt->height, T = pt->tileSize;
   pt->tilesX = (W + T - 1) / T;
   pt->tilesY = (H + T - 1) / T;
-  std::vector<uint32_t> owned;
+  std::vector<uint32_t> owned;  // pixel origin x0 | y0 << 16 of every tile this rank renders
   for(int t = 0; t < pt->tilesX * pt->tilesY; ++t)
     if(pt->tileWorld <= 1 || (t % pt->tileWorld) == pt->tileRank)
-      owned.push_back(uint32_t(t));
+      owned.push_back(uint32_t((t % pt->tilesX) * T) | (uint32_t((t / pt->tilesX) * T) << 16));
   pt->numSlots = int(owned.size()) * T * T;
   HIP_TRY(pt->ownedTiles.upload(owned.data(), owned.size()));
-  const size_t n        = size_t(std::max(pt->numSlots, 1));
-  const int    numArrays = 14;
+  const size_t n         = size_t(std::max(pt->numSlots, 1));
+  const int    numArrays = 8;
   HIP_TRY(pt->pathArrays.alloc(n * numArrays));
-  float4* base = pt->pathArrays.ptr;
-  pt::PathSoA& P = pt->paths;
-  P.rayOrg = base + n * 0; P.rayDir = base + n * 1; P.hit = base + n * 2; P.throughput = base + n * 3; P.radiance = base + n * 4;
-  P.misc = base + n * 5; P.medium = reinterpret_cast<uint4*>(base + n * 6); P.firstHit = base + n * 7; P.shadowOrg = base + n * 8;
-  P.shadowDir = base + n * 9; P.shadowContrib = base + n * 10; P.pixelSum = base + n * 11; P.guideAlbedo = base + n * 12; P.guideNormal = base + n * 13;
-  HIP_TRY(pt->queueMem.alloc(n * 5 + pt::QC_COUNT));
-  pt->queues.active[0] = pt->queueMem.ptr;
-  pt->queues.active[1] = pt->queueMem.ptr + n;
-  pt->queues.shadow    = pt->queueMem.ptr + 2 * n;
-  pt->queues.sortKeys  = pt->queueMem.ptr + 3 * n;
-  pt->queues.sortTmp   = pt->queueMem.ptr + 4 * n;
-  pt->queues.counters  = pt->queueMem.ptr + 5 * n;
+  float4*      base = pt->pathArrays.ptr;
+  pt::PathSoA& P    = pt->paths;
+  P.throughput = base + n * 0; P.radiance = base + n * 1; P.misc = base + n * 2; P.medium = reinterpret_cast<uint4*>(base + n * 3);
+  P.firstHit = base + n * 4; P.pixelSum = base + n * 5; P.guideAlbedo = base + n * 6; P.guideNormal = base + n * 7;
+  // sub-queue capacity: ceil(numChunks / NSUB) chunks (+1 of slack), see pt_scene.h
+  const size_t numChunks = (n + pt::QCHUNK - 1) / pt::QCHUNK;
+  const size_t subCap    = ((numChunks + pt::NSUB - 1) / pt::NSUB + 1) * pt::QCHUNK;
+  const size_t qsize     = subCap * pt::NSUB;
+  HIP_TRY(pt->queueMem.alloc(qsize * 3 + pt::QC_COUNT));
+  HIP_TRY(pt->queuePayload.alloc(qsize * 9));
+  pt::RayQueue* qs[3] = {&pt->queues.active[0], &pt->queues.active[1], &pt->queues.shadow};
+  for(int i = 0; i < 3; ++i)
+  {
+    qs[i]->slot = pt->queueMem.ptr + qsize * size_t(i);
+    qs[i]->org  = pt->queuePayload.ptr + qsize * size_t(3 * i + 0);
+    qs[i]->dir  = pt->queuePayload.ptr + qsize * size_t(3 * i + 1);
+    qs[i]->aux  = pt->queuePayload.ptr + qsize * size_t(3 * i + 2);
+  }
+  pt->queues.counters = pt->queueMem.ptr + 3 * qsize;
+  pt->queues.subCap   = uint32_t(subCap);
   HIP_TRY(hipMemset(pt->queues.counters, 0, sizeof(uint32_t) * pt::QC_COUNT));
   const size_t px = size_t(W) * size_t(H);
   HIP_TRY(pt->accumOwn.alloc(px));
@@ -292,6 +301,8 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
       pt->hasAlpha = true;
     if(mat.doubleSided == 1 || mat.thicknessFactor > 0.0f || mat.transmissionFactor > 0.0f)
       f |= pt::INST_CULL_DISABLE;
+    if(mat.transmissionFactor > 0.01f)  // MIN_TRANSMISSION, shaders/pathtrace_functions.h.slang:36,256
+      f |= pt::INST_TRANSMISSIVE;
     const float* M   = rn.objectToWorld;
     float        det = M[0] * (M[5] * M[10] - M[9] * M[6]) - M[4] * (M[1] * M[10] - M[9] * M[2]) + M[8] * (M[1] * M[6] - M[5] * M[2]);
     if(det < 0.0f)
@@ -436,8 +447,8 @@ int mi_pt_set_environment(MiPt* pt, const MiPtEnvironment* env)
 
 int mi_pt_resize(MiPt* pt, int width, int height)
 {
-  if(!pt || width <= 0 || height <= 0)
-    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_resize: bad arguments");
+  if(!pt || width <= 0 || height <= 0 || width > 32768 || height > 32768)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_resize: need 0 < width, height <= 32768");
   HIP_TRY(hipSetDevice(pt->device));
   HIP_TRY(hipDeviceSynchronize());
   pt->width  = width;
@@ -463,8 +474,8 @@ int mi_pt_set_sky(MiPt* pt, const MiSkyPhysicalParameters* sky)
 
 int mi_pt_set_tile_partition(MiPt* pt, int rank, int world, int tileSize)
 {
-  if(!pt || world < 1 || rank < 0 || rank >= world || tileSize < 8 || (tileSize & 7) != 0)
-    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_set_tile_partition: need 0 <= rank < world and tileSize a positive multiple of 8");
+  if(!pt || world < 1 || rank < 0 || rank >= world || tileSize < 16 || tileSize > 4096 || (tileSize & (tileSize - 1)) != 0)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_set_tile_partition: need 0 <= rank < world and tileSize a power of two in [16, 4096]");
   pt->tileRank  = rank;
   pt->tileWorld = world;
   pt->tileSize  = tileSize;
@@ -516,9 +527,10 @@ int mi_pt_render_frame(MiPt* pt, const MiPathtraceParams* params, void* hipStrea
   c.fc.width     = pt->width;
   c.fc.height    = pt->height;
   c.fc.tileSize  = pt->tileSize;
-  c.fc.tilesX    = pt->tilesX;
-  c.fc.tilesY    = pt->tilesY;
-  c.fc.numSlots  = pt->numSlots;
+  c.fc.tileShift = 0;
+  while((1 << c.fc.tileShift) < pt->tileSize)
+    ++c.fc.tileShift;
+  c.fc.numSlots = pt->numSlots;
   c.paths        = pt->paths;
   const bool guides = (params->flags & MI_PT_USE_OPTIX_DENOISER) != 0;
   if(!guides)
@@ -568,9 +580,12 @@ int mi_pt_render_frame(MiPt* pt, const MiPathtraceParams* params, void* hipStrea
     {
       if(pt->hasVolumeScatter && it >= params->maxDepth && (it % 8) == 0)
       {
-        uint32_t remaining = 0;
-        HIP_TRY(hipMemcpyAsync(&remaining, &c.queues.counters[cur], sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        uint32_t counts[pt::NSUB];
+        HIP_TRY(hipMemcpyAsync(counts, &c.queues.counters[cur ? pt::QC_ACTIVE1 : pt::QC_ACTIVE0], sizeof(counts), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        uint32_t remaining = 0;
+        for(uint32_t v : counts)
+          remaining += v;
         if(remaining == 0)
           break;
       }

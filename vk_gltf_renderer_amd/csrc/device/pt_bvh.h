@@ -6,6 +6,9 @@
 //   n2 = (c0.lo.z, c0.hi.z, c1.lo.z, c1.hi.z)   n3 = (child0, child1, -, -) as int bits
 //   child >= 0: inner node index; child < 0: leaf, ~child = index of the (single) triangle.
 // Triangle (48 B): see DevTri in pt_scene.h.
+//
+// The walk is exposed as a single-step function so that the trace kernels can run it as a per-lane state machine and
+// hand a finished lane a new ray while its neighbours keep walking (wave-level dynamic refill, pt_kernels.hip).
 #pragma once
 #include "pt_scene.h"
 
@@ -88,65 +91,56 @@ struct LaneStack
   }
 };
 
-// Generic walk. `visit(triIndex, tmax) -> tmax'` is called for every leaf whose box the ray enters (conservative:
-// boxes are widened by a few ulps so no triangle accepted by intersectTri can be missed). Returning a smaller tmax
-// shrinks the search interval; returning a negative value terminates the walk.
+// One inner-node step: tests both children's boxes (conservatively widened by a few ulps so that no triangle accepted by
+// intersectTri is ever culled) and returns the next node to visit (BVH_EMPTY when the stack ran dry).
+PT_DEV int bvhInnerStep(const DevScene& sc, const RaySetup& r, float tmax, int cur, LaneStack& st)
+{
+  const float4* n  = sc.bvhNodes + size_t(cur) * 4;
+  const float4  n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+  float c0x0 = __fmaf_rn(n0.x, r.idir.x, -r.ood.x), c0x1 = __fmaf_rn(n0.y, r.idir.x, -r.ood.x);
+  float c0y0 = __fmaf_rn(n0.z, r.idir.y, -r.ood.y), c0y1 = __fmaf_rn(n0.w, r.idir.y, -r.ood.y);
+  float c0z0 = __fmaf_rn(n2.x, r.idir.z, -r.ood.z), c0z1 = __fmaf_rn(n2.y, r.idir.z, -r.ood.z);
+  float c1x0 = __fmaf_rn(n1.x, r.idir.x, -r.ood.x), c1x1 = __fmaf_rn(n1.y, r.idir.x, -r.ood.x);
+  float c1y0 = __fmaf_rn(n1.z, r.idir.y, -r.ood.y), c1y1 = __fmaf_rn(n1.w, r.idir.y, -r.ood.y);
+  float c1z0 = __fmaf_rn(n2.z, r.idir.z, -r.ood.z), c1z1 = __fmaf_rn(n2.w, r.idir.z, -r.ood.z);
+  float t0n  = fmaxf(fmaxf(fminf(c0x0, c0x1), fminf(c0y0, c0y1)), fmaxf(fminf(c0z0, c0z1), 0.0f));
+  float t0f  = fminf(fminf(fmaxf(c0x0, c0x1), fmaxf(c0y0, c0y1)), fminf(fmaxf(c0z0, c0z1), tmax));
+  float t1n  = fmaxf(fmaxf(fminf(c1x0, c1x1), fminf(c1y0, c1y1)), fmaxf(fminf(c1z0, c1z1), 0.0f));
+  float t1f  = fminf(fminf(fmaxf(c1x0, c1x1), fmaxf(c1y0, c1y1)), fminf(fmaxf(c1z0, c1z1), tmax));
+  bool  hit0 = t0n <= t0f * 1.0000012f + 1e-30f;
+  bool  hit1 = t1n <= t1f * 1.0000012f + 1e-30f;
+  int   ch0 = __float_as_int(n3.x), ch1 = __float_as_int(n3.y);
+  if(hit0 && hit1)
+  {
+    bool swap = t1n < t0n;
+    st.push(swap ? ch0 : ch1);
+    return swap ? ch1 : ch0;
+  }
+  if(hit0)
+    return ch0;
+  if(hit1)
+    return ch1;
+  return st.sp > 0 ? st.pop() : BVH_EMPTY;
+}
+PT_DEV int bvhPop(LaneStack& st) { return st.sp > 0 ? st.pop() : BVH_EMPTY; }
+
+// Whole walk in one call (used by the one-off selection pass). `visit(triIndex, tmax) -> tmax'`; negative terminates.
 template <typename Visit>
-PT_DEV void bvhWalk(const DevScene& sc, const RaySetup& r, float tmax, LaneStack& st, Visit&& visit, unsigned& nodeCount)
+PT_DEV void bvhWalk(const DevScene& sc, const RaySetup& r, float tmax, LaneStack& st, Visit&& visit)
 {
   int cur = sc.bvhRoot;
-  if(cur == BVH_EMPTY)
-    return;
-  st.sp = 0;
-  for(;;)
+  st.sp   = 0;
+  while(cur != BVH_EMPTY)
   {
     if(cur >= 0)
-    {
-      ++nodeCount;
-      const float4* n  = sc.bvhNodes + size_t(cur) * 4;
-      const float4  n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-      // slab tests of both children
-      float c0x0 = __fmaf_rn(n0.x, r.idir.x, -r.ood.x), c0x1 = __fmaf_rn(n0.y, r.idir.x, -r.ood.x);
-      float c0y0 = __fmaf_rn(n0.z, r.idir.y, -r.ood.y), c0y1 = __fmaf_rn(n0.w, r.idir.y, -r.ood.y);
-      float c0z0 = __fmaf_rn(n2.x, r.idir.z, -r.ood.z), c0z1 = __fmaf_rn(n2.y, r.idir.z, -r.ood.z);
-      float c1x0 = __fmaf_rn(n1.x, r.idir.x, -r.ood.x), c1x1 = __fmaf_rn(n1.y, r.idir.x, -r.ood.x);
-      float c1y0 = __fmaf_rn(n1.z, r.idir.y, -r.ood.y), c1y1 = __fmaf_rn(n1.w, r.idir.y, -r.ood.y);
-      float c1z0 = __fmaf_rn(n2.z, r.idir.z, -r.ood.z), c1z1 = __fmaf_rn(n2.w, r.idir.z, -r.ood.z);
-      float t0n  = fmaxf(fmaxf(fminf(c0x0, c0x1), fminf(c0y0, c0y1)), fmaxf(fminf(c0z0, c0z1), 0.0f));
-      float t0f  = fminf(fminf(fmaxf(c0x0, c0x1), fmaxf(c0y0, c0y1)), fminf(fmaxf(c0z0, c0z1), tmax));
-      float t1n  = fmaxf(fmaxf(fminf(c1x0, c1x1), fminf(c1y0, c1y1)), fmaxf(fminf(c1z0, c1z1), 0.0f));
-      float t1f  = fminf(fminf(fmaxf(c1x0, c1x1), fmaxf(c1y0, c1y1)), fminf(fmaxf(c1z0, c1z1), tmax));
-      bool  hit0 = t0n <= t0f * 1.0000012f + 1e-30f;
-      bool  hit1 = t1n <= t1f * 1.0000012f + 1e-30f;
-      int   ch0 = __float_as_int(n3.x), ch1 = __float_as_int(n3.y);
-      if(hit0 && hit1)
-      {
-        bool swap = t1n < t0n;
-        int  nearC = swap ? ch1 : ch0, farC = swap ? ch0 : ch1;
-        st.push(farC);
-        cur = nearC;
-        continue;
-      }
-      if(hit0)
-      {
-        cur = ch0;
-        continue;
-      }
-      if(hit1)
-      {
-        cur = ch1;
-        continue;
-      }
-    }
+      cur = bvhInnerStep(sc, r, tmax, cur, st);
     else
     {
       tmax = visit(~cur, tmax);
       if(tmax < 0.0f)
         return;
+      cur = bvhPop(st);
     }
-    if(st.sp == 0)
-      return;
-    cur = st.pop();
   }
 }
 

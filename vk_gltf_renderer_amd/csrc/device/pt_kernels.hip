@@ -17,37 +17,125 @@ namespace {
 constexpr int TRACE_BLOCK = 256;
 constexpr int SHADE_BLOCK = 256;
 
-// ---- wave-aggregated queue append ------------------------------------------------------------------------------------------
+// ---- queues ------------------------------------------------------------------------------------------------------------------
 PT_DEV uint32_t laneId() { return __lane_id(); }
-PT_DEV void queuePush(bool pred, uint32_t* queue, uint32_t* counter, uint32_t value)
+
+// Exclusive prefix of the NSUB sub-queue counts into LDS (s_prefix[NSUB] = total).  Call from every thread of the block.
+PT_DEV void queuePrefix(const uint32_t* counts, uint32_t* s_prefix)
 {
-  unsigned long long mask = __ballot(pred);
-  if(mask == 0ull)
-    return;
-  uint32_t lane   = laneId();
-  uint32_t leader = uint32_t(__ffsll((long long)mask) - 1);
-  uint32_t base   = 0;
-  if(lane == leader)
-    base = atomicAdd(counter, uint32_t(__popcll(mask)));
-  base = uint32_t(__shfl(int(base), int(leader)));
-  if(pred)
+  if(threadIdx.x <= NSUB)
   {
-    uint32_t rank = uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
-    queue[base + rank] = value;
+    uint32_t sum = 0;
+    for(uint32_t q = 0; q < threadIdx.x; ++q)
+      sum += counts[q];
+    s_prefix[threadIdx.x] = sum;
   }
+  __syncthreads();
+}
+// Array position of entry `flat` of the concatenated sub-queues.
+PT_DEV uint32_t queuePos(uint32_t subCap, const uint32_t* s_prefix, uint32_t flat)
+{
+  uint32_t q = 0;
+#pragma unroll
+  for(uint32_t step = NSUB / 2; step > 0; step >>= 1)
+    if(s_prefix[q + step] <= flat)
+      q += step;
+  return q * subCap + (flat - s_prefix[q]);
+}
+// Block-aggregated append of the survivors of one chunk: one LDS atomic per wave, ONE global atomic per block and queue.
+// Must be called by every thread of the block (contains __syncthreads).  s_tmp: 2 words of LDS per call site.
+// Returns the array position reserved for this thread's entry (meaningless when !pred).
+PT_DEV uint32_t queuePushBlock(bool pred, uint32_t subCap, uint32_t* counts, uint32_t sub, uint32_t* s_tmp)
+{
+  if(threadIdx.x == 0)
+    s_tmp[0] = 0;
+  __syncthreads();
+  unsigned long long mask = __ballot(pred);
+  uint32_t           lane = laneId();
+  uint32_t           wbase = 0;
+  if(mask != 0ull)
+  {
+    uint32_t leader = uint32_t(__ffsll((long long)mask) - 1);
+    if(lane == leader)
+      wbase = atomicAdd(&s_tmp[0], uint32_t(__popcll(mask)));
+    wbase = uint32_t(__shfl(int(wbase), int(leader)));
+  }
+  __syncthreads();
+  if(threadIdx.x == 0)
+    s_tmp[1] = s_tmp[0] ? atomicAdd(&counts[sub], s_tmp[0]) : 0u;
+  __syncthreads();
+  return sub * subCap + s_tmp[1] + wbase + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
+}
+
+// Wave-level dynamic work fetch (persistent waves): a wave owns a private range [cur, end) of flat queue indices and takes
+// the next chunk of QCHUNK indices from one of 8 head counters (own XCD's first) when the range runs dry.
+struct WaveFeed
+{
+  uint32_t cur, end, total, numChunks;
+  bool     exhausted;
+};
+PT_DEV bool feedNextChunk(WaveFeed& f, uint32_t* heads)
+{
+  uint32_t chunk = 0xffffffffu;
+  if(laneId() == 0)
+  {
+    const uint32_t h0 = blockIdx.x & 7u;
+    for(uint32_t k = 0; k < 8u; ++k)
+    {
+      uint32_t h = (h0 + k) & 7u;
+      // peek first: a head that already ran past the end must not be hammered by every idle wave of the grid
+      if(__hip_atomic_load(&heads[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 8u + h >= f.numChunks)
+        continue;
+      uint32_t fc = atomicAdd(&heads[h], 1u) * 8u + h;
+      if(fc < f.numChunks)
+      {
+        chunk = fc;
+        break;
+      }
+    }
+  }
+  chunk = uint32_t(__shfl(int(chunk), 0));
+  if(chunk == 0xffffffffu)
+  {
+    f.exhausted = true;
+    return false;
+  }
+  f.cur = chunk * QCHUNK;
+  f.end = min(f.cur + uint32_t(QCHUNK), f.total);
+  return true;
+}
+// Hands flat indices to the lanes whose `idle` predicate is set; returns the index or 0xffffffff (none left for this lane).
+PT_DEV uint32_t feedTake(WaveFeed& f, bool idle, uint32_t* heads)
+{
+  unsigned long long mask = __ballot(idle);
+  uint32_t           need = uint32_t(__popcll(mask));
+  uint32_t           rank = uint32_t(__popcll(mask & ((1ull << laneId()) - 1ull)));
+  uint32_t           mine = 0xffffffffu, assigned = 0;
+  while(need > 0 && !f.exhausted)
+  {
+    if(f.cur == f.end && !feedNextChunk(f, heads))
+      break;
+    uint32_t take = min(need, f.end - f.cur);
+    if(idle && rank >= assigned && rank < assigned + take)
+      mine = f.cur + (rank - assigned);
+    assigned += take;
+    f.cur += take;
+    need -= take;
+  }
+  return mine;
 }
 
 // ---- slot <-> pixel -----------------------------------------------------------------------------------------------------------
 // Slots are tile-major; inside a tile 8x8 micro-tiles, so one 64-lane wave owns one 8x8 pixel block (coherent camera rays).
+// ownedTiles[i] = x0 | y0 << 16 (pixel origin of the i-th tile this rank renders).
 PT_DEV bool slotToPixel(const FrameConsts& fc, const uint32_t* ownedTiles, uint32_t slot, int& px, int& py)
 {
-  const uint32_t T2    = uint32_t(fc.tileSize * fc.tileSize);
-  uint32_t       tile  = ownedTiles[slot / T2];
-  uint32_t       w     = slot % T2;
-  uint32_t       micro = w >> 6, lane = w & 63u;
-  uint32_t       mpr   = uint32_t(fc.tileSize) >> 3;
-  px                   = int((tile % uint32_t(fc.tilesX)) * uint32_t(fc.tileSize) + (micro % mpr) * 8u + (lane & 7u));
-  py                   = int((tile / uint32_t(fc.tilesX)) * uint32_t(fc.tileSize) + (micro / mpr) * 8u + (lane >> 3));
+  const uint32_t tile  = ownedTiles[slot >> (2 * fc.tileShift)];
+  const uint32_t w     = slot & ((1u << (2 * fc.tileShift)) - 1u);
+  const uint32_t micro = w >> 6, lane = w & 63u;
+  const uint32_t mshift = uint32_t(fc.tileShift) - 3u;
+  px                   = int((tile & 0xffffu) + (micro & ((1u << mshift) - 1u)) * 8u + (lane & 7u));
+  py                   = int((tile >> 16) + (micro >> mshift) * 8u + (lane >> 3));
   return px < fc.width && py < fc.height;
 }
 
@@ -98,6 +186,7 @@ __global__ void __launch_bounds__(256) k_generate(DevScene sc, FrameConsts fc, P
   uint32_t slot  = blockIdx.x * blockDim.x + threadIdx.x;
   bool     valid = slot < uint32_t(fc.numSlots);
   int      px = 0, py = 0;
+  float4   genOrg = make_float4(0, 0, 0, 0), genDir = make_float4(0, 0, 0, 0);
   if(valid)
     valid = slotToPixel(fc, ownedTiles, slot, px, py);
   if(valid)
@@ -141,84 +230,184 @@ __global__ void __launch_bounds__(256) k_generate(DevScene sc, FrameConsts fc, P
       direction = finalDir;
     }
     direction          = normalize(direction);  // pathTrace loop head, gltf_pathtrace.slang:447
-    P.rayOrg[slot]     = make_float4(origin.x, origin.y, origin.z, INFINITE_F);
-    P.rayDir[slot]     = make_float4(direction.x, direction.y, direction.z, 0.0f);  // cone.width = 0
+    genOrg = make_float4(origin.x, origin.y, origin.z, 0.0f);
+    genDir = make_float4(direction.x, direction.y, direction.z, 0.0f);
     P.throughput[slot] = make_float4(1.0f, 1.0f, 1.0f, DIRAC);
     P.radiance[slot]   = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    P.misc[slot]       = make_float4(0.0f, __uint_as_float(PF_ALIVE), __uint_as_float(seed), 0.0f);
+    P.misc[slot]       = make_float4(0.0f, __uint_as_float(PF_ALIVE), __uint_as_float(seed), 0.0f);  // cone.width = 0
     P.medium[slot]     = make_uint4(0, 0, 0, 0);
     P.firstHit[slot]   = make_float4(1e34f, 1e34f, 1e34f, 0.0f);
     if(stats)
       atomicAdd(&stats->cameraPaths, 1ull);
   }
-  queuePush(valid, Q.active[0], &Q.counters[QC_ACTIVE0], slot);
+  // Queue placement is a pure function of the slot (chunk = slot / QCHUNK goes to sub-queue chunk % NSUB): no atomics.
+  if(slot < uint32_t(fc.numSlots))
+  {
+    const uint32_t chunk = slot / QCHUNK;
+    const uint32_t pos   = (chunk % NSUB) * Q.subCap + (chunk / NSUB) * QCHUNK + (slot % QCHUNK);
+    Q.active[0].slot[pos] = valid ? slot : QUEUE_DEAD;
+    if(valid)
+    {
+      Q.active[0].org[pos] = genOrg;
+      Q.active[0].dir[pos] = genDir;
+    }
+  }
+  if(blockIdx.x == 0 && threadIdx.x < NSUB)
+  {
+    const uint32_t numChunks = uint32_t(fc.numSlots) / QCHUNK;
+    Q.counters[QC_ACTIVE0 + threadIdx.x] = QCHUNK * (numChunks / NSUB + (threadIdx.x < numChunks % NSUB ? 1u : 0u));
+  }
+  if(blockIdx.x == 0 && threadIdx.x < 8)
+    Q.counters[QC_HEADS_TRACE + threadIdx.x] = 0;
 }
 
 //================================================================================================================================
 // k_trace_closest: RayQueryRaytracer::Trace (raytracer_interface.h.slang:69-122) on the software BVH
 //================================================================================================================================
+// Refill policy of the persistent trace waves: go back for new rays once this many lanes of the wave are idle.
+constexpr int REFILL_IDLE_LANES = 16;
+
 template <bool HAS_ALPHA, bool COUNT>
 __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_closest(DevScene sc, PathSoA P, Queues Q, int cur, StatCounters* stats)
 {
-  __shared__ int s_stack[BVH_STACK_LDS * TRACE_BLOCK];
-  if(blockIdx.x == 0 && threadIdx.x == 0)
+  __shared__ int      s_stack[BVH_STACK_LDS * TRACE_BLOCK];
+  __shared__ uint32_t s_prefix[NSUB + 1];
+  if(blockIdx.x == 0 && threadIdx.x < NSUB)
   {
-    // the shade kernel of this iteration appends to these; zero them here (kernel boundary orders the write)
-    Q.counters[cur ^ 1]    = 0;
-    Q.counters[QC_SHADOW]  = 0;
+    // the shade kernel of this iteration appends to these; zero them here (the kernel boundary orders the writes)
+    Q.counters[(cur ? QC_ACTIVE0 : QC_ACTIVE1) + threadIdx.x] = 0;
+    Q.counters[QC_SHADOW + threadIdx.x]                        = 0;
+    if(threadIdx.x < 8)
+      Q.counters[QC_HEADS_SHADOW + threadIdx.x] = 0;
   }
-  const uint32_t count = Q.counters[cur];
-  LaneStack      st;
+  const RayQueue in = Q.active[cur];
+  queuePrefix(&Q.counters[cur ? QC_ACTIVE1 : QC_ACTIVE0], s_prefix);
+  WaveFeed feed;
+  feed.cur = feed.end = 0;
+  feed.total          = s_prefix[NSUB];
+  feed.numChunks      = (feed.total + QCHUNK - 1) / QCHUNK;
+  feed.exhausted      = feed.total == 0;
+  if(blockIdx.x * 2u >= feed.numChunks + 1u)  // a short queue needs few blocks: one per two chunks, the rest leave at once
+    return;
+  LaneStack st;
   st.lds    = s_stack;
   st.tid    = int(threadIdx.x);
   st.stride = TRACE_BLOCK;
-  for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
+  st.sp     = 0;
+  // per-lane walk state
+  bool     active = false;
+  uint32_t slot = 0, pos = 0;
+  RaySetup r{};
+  int      node = BVH_EMPTY;
+  float    bestT = INFINITE_F, bestU = 0.0f, bestV = 0.0f;
+  int      bestTri   = -1;
+  uint32_t bestRnode = 0xffffffffu, bestPrim = 0xffffffffu, seed0 = 0;
+  bool     seedLoaded = false;
+  unsigned nodes = 0, tris = 0, rays = 0;
+  // every lane keeps its NEXT ray prefetched in registers: the loads are issued one ray ahead and land while the lane walks
+  bool     pValid = false;
+  uint32_t pPos = 0, pSlot = QUEUE_DEAD;
+  float4   pO = make_float4(0, 0, 0, 0), pD = make_float4(0, 0, 0, 0);
+  for(;;)
   {
-    const uint32_t slot = Q.active[cur][i];
-    const float4   o4 = P.rayOrg[slot], d4 = P.rayDir[slot];
-    const RaySetup r     = makeRaySetup(xyz(o4), xyz(d4));
-    float          bestT = INFINITE_F;  // ray.TMax
-    int            bestTri = -1;
-    float          bestU = 0.0f, bestV = 0.0f;
-    uint32_t       bestRnode = 0xffffffffu, bestPrim = 0xffffffffu;
-    uint32_t       seed0 = 0;
-    bool           seedLoaded = false;
-    unsigned       nodes = 0, tris = 0;
-    bvhWalk(sc, r, bestT, st, [&](int triIndex, float tmax) -> float {
-      if(COUNT) ++tris;
-      const DevTri T = sc.tris[triIndex];
-      TriHit       h;
-      if(!intersectTri(xyz(T.a), xyz(T.b), xyz(T.c), r.org, r.dir, h) || !(h.t > 0.0f))
-        return tmax;
-      const uint32_t rnode = __float_as_uint(T.a.w), prim = __float_as_uint(T.b.w), flags = __float_as_uint(T.c.w);
-      // deterministic closest hit: smaller t wins, exact ties by (renderNode, primitive)
-      if(!(h.t < bestT || (h.t == bestT && (rnode < bestRnode || (rnode == bestRnode && prim < bestPrim)))))
-        return tmax;
-      // RAY_FLAG_CULL_BACK_FACING_TRIANGLES unless TRIANGLE_FACING_CULL_DISABLE; facing is decided in object space
-      const bool front = h.front != ((flags & INST_FLIP_FACING) != 0u);
-      if(!front && !(flags & INST_CULL_DISABLE))
-        return tmax;
-      if(HAS_ALPHA && !(flags & INST_FORCE_OPAQUE))
-      {
-        if(!seedLoaded)
-        {
-          seed0      = __float_as_uint(P.misc[slot].z);
-          seedLoaded = true;
-        }
-        float opacity = getOpacity(sc, int(rnode), int(prim), mk3(1.0f - h.u - h.v, h.u, h.v));
-        if(!(candidateRand(seed0, int(rnode), int(prim)) <= opacity))
-          return tmax;
-      }
-      bestT = h.t; bestTri = triIndex; bestU = h.u; bestV = h.v; bestRnode = rnode; bestPrim = prim;
-      return bestT;
-    }, nodes);
-    P.hit[slot] = make_float4(bestT, __int_as_float(bestTri), bestU, bestV);
-    if(COUNT)
+    // ---- idle lanes start their prefetched ray; every lane without a prefetched ray takes the next queue index
+    if(!active && pValid)
     {
-      atomicAdd(&stats->segments, 1ull);
-      atomicAdd(&stats->nodesClosest, (unsigned long long)nodes);
-      atomicAdd(&stats->trisClosest, (unsigned long long)tris);
+      pValid = false;
+      if(pSlot != QUEUE_DEAD)
+      {
+        slot    = pSlot;
+        pos     = pPos;
+        r       = makeRaySetup(xyz(pO), xyz(pD));
+        bestT   = INFINITE_F;  // ray.TMax
+        bestTri = -1;
+        bestU = bestV = 0.0f;
+        bestRnode = bestPrim = 0xffffffffu;
+        seedLoaded           = false;
+        st.sp                = 0;
+        node                 = sc.bvhRoot;
+        active               = true;
+        if(COUNT) ++rays;
+      }
     }
+    if(!feed.exhausted)
+    {
+      uint32_t flat = feedTake(feed, !pValid, &Q.counters[QC_HEADS_TRACE]);
+      if(flat != 0xffffffffu)
+      {
+        pPos   = queuePos(Q.subCap, s_prefix, flat);
+        pSlot  = in.slot[pPos];
+        pO     = in.org[pPos];
+        pD     = in.dir[pPos];
+        pValid = true;
+      }
+    }
+    const bool moreWork = !feed.exhausted || __ballot(pValid) != 0ull;
+    if(__ballot(active) == 0ull)
+    {
+      if(!moreWork)
+        break;
+      continue;
+    }
+    // ---- walk until enough lanes have finished to make a refill worthwhile
+    for(;;)
+    {
+      if(active)
+      {
+        // inner nodes first (bounded), so that most lanes arrive at a leaf together
+#pragma unroll 1
+        for(int k = 0; k < 4 && node >= 0; ++k)
+        {
+          node = bvhInnerStep(sc, r, bestT, node, st);
+          if(COUNT) ++nodes;
+        }
+        if(node < 0 && node != BVH_EMPTY)
+        {
+          const int    triIndex = ~node;
+          const DevTri T        = sc.tris[triIndex];
+          if(COUNT) ++tris;
+          TriHit h;
+          if(intersectTri(xyz(T.a), xyz(T.b), xyz(T.c), r.org, r.dir, h) && h.t > 0.0f)
+          {
+            const uint32_t rnode = __float_as_uint(T.a.w), prim = __float_as_uint(T.b.w), flags = __float_as_uint(T.c.w);
+            // deterministic closest hit: smaller t wins, exact ties by (renderNode, primitive)
+            bool better = h.t < bestT || (h.t == bestT && (rnode < bestRnode || (rnode == bestRnode && prim < bestPrim)));
+            // RAY_FLAG_CULL_BACK_FACING_TRIANGLES unless TRIANGLE_FACING_CULL_DISABLE; facing is decided in object space
+            const bool front = h.front != ((flags & INST_FLIP_FACING) != 0u);
+            better           = better && (front || (flags & INST_CULL_DISABLE));
+            if(HAS_ALPHA && better && !(flags & INST_FORCE_OPAQUE))
+            {
+              if(!seedLoaded)
+              {
+                seed0      = __float_as_uint(P.misc[slot].z);
+                seedLoaded = true;
+              }
+              float opacity = getOpacity(sc, int(rnode), int(prim), mk3(1.0f - h.u - h.v, h.u, h.v));
+              better        = candidateRand(seed0, int(rnode), int(prim)) <= opacity;
+            }
+            if(better)
+            {
+              bestT = h.t; bestTri = triIndex; bestU = h.u; bestV = h.v; bestRnode = rnode; bestPrim = prim;
+            }
+          }
+          node = bvhPop(st);
+        }
+        if(node == BVH_EMPTY)
+        {
+          in.aux[pos] = make_float4(bestT, __int_as_float(bestTri), bestU, bestV);
+          active      = false;
+        }
+      }
+      const unsigned long long act = __ballot(active);
+      if(act == 0ull || (moreWork && __popcll(act) <= 64 - REFILL_IDLE_LANES))
+        break;
+    }
+  }
+  if(COUNT)
+  {
+    atomicAdd(&stats->segments, (unsigned long long)rays);
+    atomicAdd(&stats->nodesClosest, (unsigned long long)nodes);
+    atomicAdd(&stats->trisClosest, (unsigned long long)tris);
   }
 }
 
@@ -241,7 +430,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_selection(DevScene sc, FrameCon
   const RaySetup r     = makeRaySetup(origin, direction);
   float          bestT = INFINITE_F;
   uint32_t       bestRnode = 0xffffffffu, bestPrim = 0xffffffffu;
-  unsigned       nodes = 0;
   bvhWalk(sc, r, bestT, st, [&](int triIndex, float tmax) -> float {
     const DevTri T = sc.tris[triIndex];
     TriHit       h;
@@ -252,7 +440,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_selection(DevScene sc, FrameCon
       return tmax;
     bestT = h.t; bestRnode = rnode; bestPrim = prim;
     return bestT;
-  }, nodes);
+  });
   selection[size_t(py) * size_t(fc.width) + size_t(px)] = (bestRnode != 0xffffffffu) ? bestRnode + 1u : 0u;
 }
 
@@ -262,22 +450,30 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_selection(DevScene sc, FrameCon
 template <bool COUNT>
 __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, FrameConsts fc, PathSoA P, Queues Q, int cur, StatCounters* stats)
 {
-  const uint32_t count = Q.counters[cur];
-  const int      nxt   = cur ^ 1;
-  const uint32_t iters = (count + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
-  for(uint32_t it = 0; it < iters; ++it)
+  __shared__ uint32_t s_prefix[NSUB + 1];
+  __shared__ uint32_t s_push[4];
+  if(blockIdx.x == 0 && threadIdx.x < 8)
+    Q.counters[QC_HEADS_TRACE + threadIdx.x] = 0;  // for the next iteration's k_trace_closest
+  queuePrefix(&Q.counters[cur ? QC_ACTIVE1 : QC_ACTIVE0], s_prefix);
+  const uint32_t count     = s_prefix[NSUB];
+  const int      nxt       = cur ^ 1;
+  const uint32_t numChunks = (count + SHADE_BLOCK - 1) / SHADE_BLOCK;  // SHADE_BLOCK == QCHUNK
+  for(uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x)
   {
-    const uint32_t i      = it * gridDim.x * blockDim.x + blockIdx.x * blockDim.x + threadIdx.x;
-    const bool     inRange = i < count;
-    uint32_t       slot = 0;
+    const uint32_t i    = chunk * SHADE_BLOCK + threadIdx.x;
+    const uint32_t inPos = (i < count) ? queuePos(Q.subCap, s_prefix, i) : 0u;
+    uint32_t       slot  = (i < count) ? Q.active[cur].slot[inPos] : QUEUE_DEAD;
+    const bool     inRange = slot != QUEUE_DEAD;
     bool           alive = false, pushShadow = false;
     unsigned       taps = 0;
+    float4         nextOrg = make_float4(0, 0, 0, 0), nextDir = make_float4(0, 0, 0, 0);
+    float4         shOrg = make_float4(0, 0, 0, 0), shDir = make_float4(0, 0, 0, 0), shCon = make_float4(0, 0, 0, 0);
     if(inRange)
     {
-      slot = Q.active[cur][i];
-      const float4 hit4 = P.hit[slot], o4 = P.rayOrg[slot], d4 = P.rayDir[slot], tp4 = P.throughput[slot], rad4 = P.radiance[slot], misc4 = P.misc[slot];
+      const float4 hit4 = Q.active[cur].aux[inPos], o4 = Q.active[cur].org[inPos], d4 = Q.active[cur].dir[inPos];
+      const float4 tp4 = P.throughput[slot], rad4 = P.radiance[slot], misc4 = P.misc[slot];
       f3       rayOrigin = xyz(o4), rayDir = xyz(d4);
-      float    coneWidth = d4.w;
+      float    coneWidth = misc4.w;
       f3       throughput = xyz(tp4), radiance = xyz(rad4);
       float    lastSamplePdf = tp4.w;
       f2       maxRoughness  = mk2(rad4.w, misc4.x);
@@ -453,9 +649,9 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, FrameConsts 
                 float phasePdf = henyeyGreensteinPdf(dot(wiBefore, dl.direction), aniso);
                 float mis      = dl.pdf / (dl.pdf + phasePdf);
                 f3    contrib  = throughput * dl.radianceOverPdf * mis * phasePdf;
-                P.shadowOrg[slot]     = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, dl.distance);
-                P.shadowDir[slot]     = make_float4(dl.direction.x, dl.direction.y, dl.direction.z, __uint_as_float(1u));
-                P.shadowContrib[slot] = make_float4(contrib.x, contrib.y, contrib.z, __uint_as_float(seed));
+                shOrg = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, dl.distance);
+                shDir = make_float4(dl.direction.x, dl.direction.y, dl.direction.z, __uint_as_float(1u));
+                shCon = make_float4(contrib.x, contrib.y, contrib.z, __uint_as_float(seed));
                 pushShadow            = true;
               }
               if(scatterBounces >= VOLUME_FREE_BUDGET)
@@ -513,9 +709,9 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, FrameConsts 
           {
             bool forward = dot(dl.direction, hit.nrm) > 0.0f;
             f3   sOrg    = safeOffsetRay(forward ? hit.shadowPos : hit.pos, forward ? hit.geonrm : -hit.geonrm);
-            P.shadowOrg[slot]     = make_float4(sOrg.x, sOrg.y, sOrg.z, dl.distance);
-            P.shadowDir[slot]     = make_float4(dl.direction.x, dl.direction.y, dl.direction.z, __uint_as_float(0u));
-            P.shadowContrib[slot] = make_float4(contribution.x, contribution.y, contribution.z, __uint_as_float(seed));
+            shOrg = make_float4(sOrg.x, sOrg.y, sOrg.z, dl.distance);
+            shDir = make_float4(dl.direction.x, dl.direction.y, dl.direction.z, __uint_as_float(0u));
+            shCon = make_float4(contribution.x, contribution.y, contribution.z, __uint_as_float(seed));
             pushShadow            = true;
           }
           // Russian roulette, :476-482
@@ -540,18 +736,31 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, FrameConsts 
       flags = (isInside ? PF_INSIDE : 0u) | (solid ? 0u : PF_NOT_SOLID) | (alive ? PF_ALIVE : 0u) | (uint32_t(min(surfaceDepth, 255)) << PF_DEPTH_SHIFT)
               | (uint32_t(scatterBounces) << PF_SCATTER_SHIFT);
       P.radiance[slot] = make_float4(radiance.x, radiance.y, radiance.z, maxRoughness.x);
-      P.misc[slot]     = make_float4(maxRoughness.y, __uint_as_float(flags), __uint_as_float(seed), 0.0f);
+      P.misc[slot]     = make_float4(maxRoughness.y, __uint_as_float(flags), __uint_as_float(seed), coneWidth);
       if(alive)
       {
-        P.rayOrg[slot]     = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, INFINITE_F);
-        P.rayDir[slot]     = make_float4(rayDir.x, rayDir.y, rayDir.z, coneWidth);
+        nextOrg            = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, 0.0f);
+        nextDir            = make_float4(rayDir.x, rayDir.y, rayDir.z, 0.0f);
         P.throughput[slot] = make_float4(throughput.x, throughput.y, throughput.z, lastSamplePdf);
       }
       if(COUNT && taps)
         atomicAdd(&stats->textureTaps, (unsigned long long)taps);
     }
-    queuePush(alive, Q.active[nxt], &Q.counters[nxt], slot);
-    queuePush(pushShadow, Q.shadow, &Q.counters[QC_SHADOW], slot);
+    const uint32_t posNext = queuePushBlock(alive, Q.subCap, &Q.counters[nxt ? QC_ACTIVE1 : QC_ACTIVE0], chunk % NSUB, s_push);
+    if(alive)
+    {
+      Q.active[nxt].slot[posNext] = slot;
+      Q.active[nxt].org[posNext]  = nextOrg;
+      Q.active[nxt].dir[posNext]  = nextDir;
+    }
+    const uint32_t posShadow = queuePushBlock(pushShadow, Q.subCap, &Q.counters[QC_SHADOW], chunk % NSUB, s_push + 2);
+    if(pushShadow)
+    {
+      Q.shadow.slot[posShadow] = slot;
+      Q.shadow.org[posShadow]  = shOrg;
+      Q.shadow.dir[posShadow]  = shDir;
+      Q.shadow.aux[posShadow]  = shCon;
+    }
   }
 }
 
@@ -561,101 +770,192 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, FrameConsts 
 template <bool HAS_ALPHA, bool COUNT>
 __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_shadow(DevScene sc, PathSoA P, Queues Q, StatCounters* stats)
 {
-  __shared__ int s_stack[BVH_STACK_LDS * TRACE_BLOCK];
-  const uint32_t count = Q.counters[QC_SHADOW];
-  LaneStack      st;
+  __shared__ int      s_stack[BVH_STACK_LDS * TRACE_BLOCK];
+  __shared__ uint32_t s_prefix[NSUB + 1];
+  queuePrefix(&Q.counters[QC_SHADOW], s_prefix);
+  const RayQueue in = Q.shadow;
+  WaveFeed feed;
+  feed.cur = feed.end = 0;
+  feed.total          = s_prefix[NSUB];
+  feed.numChunks      = (feed.total + QCHUNK - 1) / QCHUNK;
+  feed.exhausted      = feed.total == 0;
+  if(blockIdx.x * 2u >= feed.numChunks + 1u)
+    return;
+  LaneStack st;
   st.lds    = s_stack;
   st.tid    = int(threadIdx.x);
   st.stride = TRACE_BLOCK;
-  for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
+  st.sp     = 0;
+  // per-lane state.  phase 0: any-hit walk (opaque geometry and non-transmissive alpha resolve here, order independent);
+  // phase 1: one walk per transmissive candidate, in increasing (t, renderNode, primitive) order.
+  bool     active = false;
+  uint32_t slot   = 0;
+  RaySetup r{};
+  int      node  = BVH_EMPTY;
+  float    tMax  = 0.0f;
+  int      phase = 0;
+  unsigned nTrans = 0;
+  bool     occluded = false;
+  uint32_t seed0 = 0;
+  f3       contrib = mk3(0.0f);
+  // phase-1 search state
+  float    bT = 0.0f, bU = 0.0f, bV = 0.0f, lastT = -1.0f, prevHitT = 0.0f;
+  uint32_t bRnode = 0, bPrim = 0, lastRnode = 0, lastPrim = 0;
+  bool     found = false, haveLast = false, isInside = false;
+  f3       total = mk3(1.0f);
+  unsigned nodes = 0, tris = 0, rays = 0;
+  // prefetched next shadow ray
+  bool     pValid = false;
+  uint32_t pSlot = QUEUE_DEAD;
+  float4   pO = make_float4(0, 0, 0, 0), pD = make_float4(0, 0, 0, 0), pC = make_float4(0, 0, 0, 0);
+  for(;;)
   {
-    const uint32_t slot = Q.shadow[i];
-    const float4   o4 = P.shadowOrg[slot], d4 = P.shadowDir[slot], c4 = P.shadowContrib[slot];
-    const RaySetup r    = makeRaySetup(xyz(o4), xyz(d4));
-    const float    tMax = o4.w;
-    unsigned       nodes = 0, tris = 0;
-    bool           occluded = false;
-    unsigned       nonOpaque = 0;
-    // pass 1: any opaque-instance triangle in (0, tMax) terminates (RAY_FLAG_NONE: no culling)
-    bvhWalk(sc, r, tMax, st, [&](int triIndex, float tmax) -> float {
-      if(COUNT) ++tris;
-      const DevTri T = sc.tris[triIndex];
-      TriHit       h;
-      if(!intersectTri(xyz(T.a), xyz(T.b), xyz(T.c), r.org, r.dir, h) || !(h.t > 0.0f) || !(h.t < tMax))
-        return tmax;
-      if(!HAS_ALPHA || (__float_as_uint(T.c.w) & INST_FORCE_OPAQUE))
-      {
-        occluded = true;
-        return -1.0f;
-      }
-      ++nonOpaque;
-      return tmax;
-    }, nodes);
-    f3 total = occluded ? mk3(0.0f) : mk3(1.0f);
-    if(HAS_ALPHA && !occluded && nonOpaque > 0)
+    if(!active && pValid)
     {
-      // pass 2: non-opaque candidates in increasing (t, renderNode, primitive) order, one walk per candidate
-      const uint32_t seed0    = __float_as_uint(c4.w);
-      bool           isInside = (__float_as_uint(d4.w) & 1u) != 0u;
-      float          prevHitT = 0.0f;
-      float          lastT = -1.0f;
-      uint32_t       lastRnode = 0, lastPrim = 0;
-      bool           haveLast = false;
-      for(unsigned n = 0; n < nonOpaque; ++n)
+      pValid = false;
+      if(pSlot != QUEUE_DEAD)
       {
-        float    bT = tMax;
-        uint32_t bRnode = 0xffffffffu, bPrim = 0xffffffffu;
-        float    bU = 0.0f, bV = 0.0f;
-        bool     found = false;
-        bvhWalk(sc, r, tMax, st, [&](int triIndex, float tmax) -> float {
-          if(COUNT) ++tris;
-          const DevTri T = sc.tris[triIndex];
-          if(__float_as_uint(T.c.w) & INST_FORCE_OPAQUE)
-            return tmax;
-          TriHit h;
-          if(!intersectTri(xyz(T.a), xyz(T.b), xyz(T.c), r.org, r.dir, h) || !(h.t > 0.0f) || !(h.t < tMax))
-            return tmax;
-          const uint32_t rnode = __float_as_uint(T.a.w), prim = __float_as_uint(T.b.w);
-          if(haveLast && !(h.t > lastT || (h.t == lastT && (rnode > lastRnode || (rnode == lastRnode && prim > lastPrim)))))
-            return tmax;  // already processed
-          if(found && !(h.t < bT || (h.t == bT && (rnode < bRnode || (rnode == bRnode && prim < bPrim)))))
-            return tmax;
-          found = true; bT = h.t; bRnode = rnode; bPrim = prim; bU = h.u; bV = h.v;
-          return bT;
-        }, nodes);
-        if(!found)
-          break;
-        haveLast = true; lastT = bT; lastRnode = bRnode; lastPrim = bPrim;
-        f3    bary    = mk3(1.0f - bU - bV, bU, bV);
-        float opacity = getOpacity(sc, int(bRnode), int(bPrim), bary);
-        if(candidateRand(seed0, int(bRnode), int(bPrim)) < opacity)
+        slot     = pSlot;
+        r        = makeRaySetup(xyz(pO), xyz(pD));
+        tMax     = pO.w;
+        isInside = (__float_as_uint(pD.w) & 1u) != 0u;
+        contrib  = xyz(pC);
+        seed0    = __float_as_uint(pC.w);
+        phase    = 0;
+        nTrans   = 0;
+        occluded = false;
+        total    = mk3(1.0f);
+        haveLast = false;
+        prevHitT = 0.0f;
+        st.sp    = 0;
+        node     = sc.bvhRoot;
+        active   = true;
+        if(COUNT) ++rays;
+      }
+    }
+    if(!feed.exhausted)
+    {
+      uint32_t flat = feedTake(feed, !pValid, &Q.counters[QC_HEADS_SHADOW]);
+      if(flat != 0xffffffffu)
+      {
+        const uint32_t pPos = queuePos(Q.subCap, s_prefix, flat);
+        pSlot  = in.slot[pPos];
+        pO     = in.org[pPos];
+        pD     = in.dir[pPos];
+        pC     = in.aux[pPos];
+        pValid = true;
+      }
+    }
+    const bool moreWork = !feed.exhausted || __ballot(pValid) != 0ull;
+    if(__ballot(active) == 0ull)
+    {
+      if(!moreWork)
+        break;
+      continue;
+    }
+    for(;;)
+    {
+      if(active)
+      {
+#pragma unroll 1
+        for(int k = 0; k < 4 && node >= 0; ++k)
         {
-          float segment = fmaxf(0.0f, bT - prevHitT);
-          f3    cur     = getShadowTransmission(sc, int(bRnode), int(bPrim), bary, segment, r.dir, isInside);
-          prevHitT      = bT;
-          total *= cur;
-          if(maxComp(total) <= MIN_TRANSMISSION)
+          node = bvhInnerStep(sc, r, (HAS_ALPHA && phase == 1 && found) ? bT : tMax, node, st);
+          if(COUNT) ++nodes;
+        }
+        if(node < 0 && node != BVH_EMPTY)
+        {
+          const DevTri T = sc.tris[~node];
+          if(COUNT) ++tris;
+          const uint32_t flags = __float_as_uint(T.c.w);
+          TriHit         h;
+          const bool consider = !HAS_ALPHA || phase == 0 || ((flags & INST_TRANSMISSIVE) && !(flags & INST_FORCE_OPAQUE));
+          if(consider && intersectTri(xyz(T.a), xyz(T.b), xyz(T.c), r.org, r.dir, h) && h.t > 0.0f && h.t < tMax)
           {
-            total = mk3(0.0f);
-            break;
+            const uint32_t rnode = __float_as_uint(T.a.w), prim = __float_as_uint(T.b.w);
+            if(!HAS_ALPHA || phase == 0)
+            {
+              if(!HAS_ALPHA || (flags & INST_FORCE_OPAQUE))
+                occluded = true;  // RAY_FLAG_NONE: no culling; opaque geometry commits
+              else if(flags & INST_TRANSMISSIVE)
+                ++nTrans;
+              else
+              {
+                // non-transmissive alpha material: an accepted candidate multiplies the transmission by
+                // getShadowTransmission() == 0 (pathtrace_functions.h.slang:256-261) whatever its position in the order
+                float opacity = getOpacity(sc, int(rnode), int(prim), mk3(1.0f - h.u - h.v, h.u, h.v));
+                if(candidateRand(seed0, int(rnode), int(prim)) < opacity)
+                  occluded = true;
+              }
+            }
+            else
+            {
+              const bool afterLast = !haveLast || h.t > lastT || (h.t == lastT && (rnode > lastRnode || (rnode == lastRnode && prim > lastPrim)));
+              const bool beforeBest = !found || h.t < bT || (h.t == bT && (rnode < bRnode || (rnode == bRnode && prim < bPrim)));
+              if(afterLast && beforeBest)
+              {
+                found = true; bT = h.t; bRnode = rnode; bPrim = prim; bU = h.u; bV = h.v;
+              }
+            }
+          }
+          node = occluded ? BVH_EMPTY : bvhPop(st);
+        }
+        if(node == BVH_EMPTY)
+        {
+          bool finished = true;
+          if(HAS_ALPHA && !occluded && !(phase == 1 && !found))
+          {
+            if(phase == 1)
+            {
+              // process the candidate (raytracer_interface.h.slang:160-178)
+              haveLast = true; lastT = bT; lastRnode = bRnode; lastPrim = bPrim;
+              f3    bary    = mk3(1.0f - bU - bV, bU, bV);
+              float opacity = getOpacity(sc, int(bRnode), int(bPrim), bary);
+              if(candidateRand(seed0, int(bRnode), int(bPrim)) < opacity)
+              {
+                float segment = fmaxf(0.0f, bT - prevHitT);
+                f3    curT    = getShadowTransmission(sc, int(bRnode), int(bPrim), bary, segment, r.dir, isInside);
+                prevHitT      = bT;
+                total *= curT;
+                if(maxComp(total) <= MIN_TRANSMISSION)
+                  occluded = true;
+              }
+              --nTrans;
+            }
+            if(!occluded && nTrans > 0)
+            {
+              // (re)start a search walk for the next transmissive candidate
+              phase    = 1;
+              found    = false;
+              st.sp    = 0;
+              node     = sc.bvhRoot;
+              finished = false;
+            }
+          }
+          if(finished)
+          {
+            if(!occluded)
+            {
+              float4 rad = P.radiance[slot];
+              rad.x += contrib.x * total.x;
+              rad.y += contrib.y * total.y;
+              rad.z += contrib.z * total.z;
+              P.radiance[slot] = rad;
+            }
+            active = false;
           }
         }
       }
+      const unsigned long long act = __ballot(active);
+      if(act == 0ull || (moreWork && __popcll(act) <= 64 - REFILL_IDLE_LANES))
+        break;
     }
-    if(total.x != 0.0f || total.y != 0.0f || total.z != 0.0f)
-    {
-      float4 rad = P.radiance[slot];
-      rad.x += c4.x * total.x;
-      rad.y += c4.y * total.y;
-      rad.z += c4.z * total.z;
-      P.radiance[slot] = rad;
-    }
-    if(COUNT)
-    {
-      atomicAdd(&stats->shadowRays, 1ull);
-      atomicAdd(&stats->nodesShadow, (unsigned long long)nodes);
-      atomicAdd(&stats->trisShadow, (unsigned long long)tris);
-    }
+  }
+  if(COUNT)
+  {
+    atomicAdd(&stats->shadowRays, (unsigned long long)rays);
+    atomicAdd(&stats->nodesShadow, (unsigned long long)nodes);
+    atomicAdd(&stats->trisShadow, (unsigned long long)tris);
   }
 }
 
@@ -731,8 +1031,8 @@ __global__ void __launch_bounds__(256) k_finish_sample(FrameConsts fc, PathSoA P
 
 __global__ void k_reset_counters(uint32_t* counters)
 {
-  if(threadIdx.x < QC_COUNT)
-    counters[threadIdx.x] = 0;
+  for(int i = threadIdx.x; i < QC_COUNT; i += blockDim.x)
+    counters[i] = 0;
 }
 
 }  // namespace

@@ -36,6 +36,7 @@ enum : uint32_t
   INST_FORCE_OPAQUE = 1u,  // reference: src/gltf_scene_rtx.cpp:271-295
   INST_CULL_DISABLE = 2u,
   INST_FLIP_FACING  = 4u,  // det(objectToWorld) < 0: world-space winding is the mirror of object-space winding
+  INST_TRANSMISSIVE = 8u,  // material.transmissionFactor > MIN_TRANSMISSION: shadow rays attenuate instead of stopping
 };
 
 // World-space triangle, 48 B: {v0, rnode} {e1, prim} {e2, instFlags}
@@ -71,9 +72,9 @@ struct FrameConsts
   MiSkyPhysicalParameters sky;
   MiPathtraceParams       pc;
   int                     width, height;
-  int                     tileSize, tilesX, tilesY;
-  int                     numSlots;  // owned tiles * tileSize^2
-  int                     lightWeightValid;
+  int                     tileSize, tileShift;  // tileSize = 1 << tileShift, >= 16
+  int                     numSlots;             // owned tiles * tileSize^2 (a multiple of QCHUNK)
+  int                     _pad;
 };
 
 // ---- per-path state, structure of arrays indexed by slot -----------------------------------------------------------------
@@ -90,40 +91,49 @@ enum : uint32_t
 
 struct PathSoA
 {
-  float4*   rayOrg;       // origin.xyz, tmax
-  float4*   rayDir;       // direction.xyz, cone.width
-  float4*   hit;          // t, triIndex (int bits; -1 = miss), u, v
   float4*   throughput;   // rgb, lastSamplePdf
   float4*   radiance;     // rgb, maxRoughness.x
-  float4*   misc;         // maxRoughness.y, flags (uint bits), seed (uint bits), unused
+  float4*   misc;         // maxRoughness.y, flags (uint bits), seed (uint bits), cone.width
   uint4*    medium;       // VolumeMedium as 7 halves packed
   float4*   firstHit;     // firstHitPos.xyz, unused
-  float4*   shadowOrg;    // origin.xyz, dist
-  float4*   shadowDir;    // direction.xyz, flags (bit0 = initialInside)
-  float4*   shadowContrib;// rgb, unused
   float4*   pixelSum;     // sum over the frame's samples of the clamped radiance rgba
   float4*   guideAlbedo;  // optional (denoiser guides): sum over samples
   float4*   guideNormal;
 };
 
+// Work queues.  Every logical queue is split into NSUB sub-queues so that appends hit 16 different counter words instead
+// of one (a single device-scope atomic word saturates at ~88 M ops/s on gfx950: MI355X_MICROARCH.md "dequeue" row).
+// A consumer sees the concatenation of the sub-queues ("flat" index space, prefix sums of the 16 counts); work is cut
+// into chunks of QCHUNK flat indices and chunk c appends its survivors to sub-queue c % NSUB, which bounds every sub-queue
+// by ceil(numChunks / NSUB) * QCHUNK entries whatever the scheduling.  An entry of QUEUE_DEAD is skipped by consumers.
+constexpr int      NSUB       = 16;
+constexpr int      QCHUNK     = 256;
+constexpr uint32_t QUEUE_DEAD = 0xffffffffu;
+// Rays and hit records live IN the queues (queue-ordered arrays of NSUB x subCap entries), not in the slot-indexed path
+// state: the trace kernels then read their rays with unit-stride, single-level loads and never touch the path state.
+struct RayQueue
+{
+  uint32_t* slot;  // path slot of the entry, or QUEUE_DEAD
+  float4*   org;   // origin.xyz, (closest: unused | shadow: distance to the light)
+  float4*   dir;   // direction.xyz, (closest: unused | shadow: uint bits, bit0 = initialInside)
+  float4*   aux;   // closest: hit record written by k_trace_closest (t, triangle index bits or -1, u, v)
+                   // shadow : contribution.rgb, seed bits (input of k_trace_shadow)
+};
 struct Queues
 {
-  uint32_t* active[2];   // path slots to trace/shade this iteration, ping-pong
-  uint32_t* shadow;      // path slots with a pending shadow ray
-  uint32_t* sortKeys;    // scratch for the per-bounce sort
-  uint32_t* sortTmp;
-  // counters live in one small device array: see QC_* indices
-  uint32_t* counters;
+  RayQueue  active[2];  // paths to trace/shade this iteration, ping-pong
+  RayQueue  shadow;     // pending shadow rays
+  uint32_t* counters;   // see QC_* indices
+  uint32_t  subCap;
 };
 enum : int
 {
-  QC_ACTIVE0 = 0,
-  QC_ACTIVE1 = 1,
-  QC_SHADOW  = 2,
-  QC_HEAD_TRACE  = 3,  // dynamic-fetch heads (persistent kernels)
-  QC_HEAD_SHADE  = 4,
-  QC_HEAD_SHADOW = 5,
-  QC_COUNT       = 16
+  QC_ACTIVE0      = 0,            // NSUB counts
+  QC_ACTIVE1      = NSUB,         // NSUB counts
+  QC_SHADOW       = 2 * NSUB,     // NSUB counts
+  QC_HEADS_TRACE  = 3 * NSUB,     // 8 dynamic-fetch heads (one per XCD by convention) of k_trace_closest
+  QC_HEADS_SHADOW = 3 * NSUB + 8, // 8 heads of k_trace_shadow
+  QC_COUNT        = 3 * NSUB + 16
 };
 
 struct StatCounters  // device mirror of MiPtStats' dynamic part
