@@ -1,0 +1,79 @@
+// Headless entry of the path-trace mode — the CLI subset of the reference's src/main.cpp:70-462 that a benchmark run uses:
+//   mi_gltf_renderer --headless --size 1920 1080 --scenefile scene.glb --hdrfile std_env.hdr --frames N --maxFrames N
+//                    --ptSamples S --ptAdaptiveSampling 0 --renderSystem 0 --envSystem 1 [--output out.png]
+// (docs/benchmarking.md:16-23).  Positional arguments ending in .gltf/.glb/.hdr are accepted like in the reference.
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "renderer.hpp"
+
+int main(int argc, char** argv)
+{
+  GltfRenderer      app;
+  ParameterRegistry registry;
+  std::string       sceneFile, hdrFile = "std_env.hdr", outputFile;
+  int               size[2] = {1280, 720};
+  int               frames = 1, renderSystem = 0;
+  bool              headless = false, vvl = false, selftest = false;
+  registry.add("scenefile", "Input scene filename (.gltf / .glb)", &sceneFile);
+  registry.add("hdrfile", "Input HDR filename", &hdrFile);
+  registry.add("output", "Headless output image (.png or .hdr)", &outputFile);
+  registry.addVec2("size", "Render size: width height", size);
+  registry.add("frames", "Number of frames to render in headless mode", &frames);
+  registry.add("headless", "Run without a window", &headless, true);
+  registry.add("renderSystem", "Renderer [Pathtracer:0]; only 0 exists here", &renderSystem);
+  registry.add("vvl", "accepted and ignored (Vulkan validation layers)", &vvl, true);
+  registry.add("benchmarkSelftest", "Print a fabricated headless log (format check, no GPU needed)", &selftest, true);
+  app.registerParameters(&registry);
+  std::vector<std::string> positional;
+  try
+  {
+    positional = registry.parse(argc, argv);
+  }
+  catch(const std::exception& e)
+  {
+    fprintf(stderr, "%s\nusage:\n%s", e.what(), registry.usage().c_str());
+    return 2;
+  }
+  for(const std::string& p : positional)
+  {
+    if(p.size() > 4 && p.substr(p.size() - 4) == ".hdr")
+      hdrFile = p;
+    else
+      sceneFile = p;
+  }
+  if(selftest)
+  {
+    BenchmarkController::HeadlessFrameInfo info;
+    info.totalFrames = 3; info.maxFrames = 3; info.ptSamples = 2; info.imageSize = {64, 32};
+    app.benchmark().beginHeadlessTimingIfNeeded(true, info);
+    for(int i = 0; i < 3; ++i)
+      app.benchmark().updateHeadlessProgressIfNeeded(info);
+    app.benchmark().logHeadlessSummary(info);
+    return 0;
+  }
+  if(!headless || renderSystem != 0)
+  {
+    fprintf(stderr, "only `--headless --renderSystem 0` (path tracer) is implemented\n");
+    return 2;
+  }
+  if(sceneFile.empty())
+  {
+    fprintf(stderr, "no --scenefile given\n");
+    return 2;
+  }
+  // alignMaxFramesForHeadless (reference: src/main.cpp:133-136)
+  BenchmarkController::alignMaxFramesForHeadless(app.resources().settings.maxFrames, uint32_t(frames));
+  app.resources().headlessOutputPath = outputFile;
+  app.onAttach(Extent2D{uint32_t(size[0]), uint32_t(size[1])});
+  if(!app.createScene(sceneFile))
+    return 1;
+  if(!app.createHDR(hdrFile) && app.resources().settings.envSystem == EnvSystem::eHdr)
+    return 1;
+  for(int f = 0; f < frames; ++f)
+    app.onRender(nullptr, true, uint32_t(frames));
+  app.onLastHeadlessFrame(uint32_t(frames));
+  return 0;
+}

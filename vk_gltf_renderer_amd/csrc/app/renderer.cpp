@@ -1,0 +1,265 @@
+#include "renderer.hpp"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+GltfRenderer::GltfRenderer()
+{
+  mi_default_sky(&m_resources.skyParams);  // reference: skyParams = {} at src/renderer.cpp:1328
+}
+
+GltfRenderer::~GltfRenderer()
+{
+  m_pathTracer.onDetach(m_resources);
+  if(m_resources.scene)
+    mi_scene_destroy(m_resources.scene);
+  if(m_resources.hdrIbl)
+    mi_hdr_destroy(m_resources.hdrIbl);
+}
+
+void GltfRenderer::registerParameters(ParameterRegistry* r)
+{
+  Settings& s = m_resources.settings;
+  r->add("envSystem", "Environment: [Sky:0, HDR:1]", &m_envSystem);
+  r->add("maxFrames", "Maximum number of iterations", &s.maxFrames);
+  r->add("hdrEnvIntensity", "HDR environment intensity", &s.hdrEnvIntensity);
+  r->add("hdrEnvRotation", "HDR environment rotation", &s.hdrEnvRotation);
+  r->add("hdrBlur", "HDR environment blur", &s.hdrBlur);
+  r->add("useSolidBackground", "Use a solid background color", &s.useSolidBackground);
+  r->add("useInfinitePlane", "Ground plane", &s.useInfinitePlane);
+  r->add("isShadowCatcher", "Ground plane only catches shadows", &s.isShadowCatcher);
+  r->add("infinitePlaneDistance", "Ground plane height", &s.infinitePlaneDistance);
+  r->add("device", "HIP device ordinal", &m_resources.device);
+  m_pathTracer.registerParameters(r);
+}
+
+bool GltfRenderer::createScene(const std::string& sceneFile)
+{
+  if(m_resources.scene)
+    mi_scene_destroy(m_resources.scene);
+  m_resources.scene = nullptr;
+  if(mi_scene_load(sceneFile.c_str(), &m_resources.scene) != MI_PT_OK)
+  {
+    fprintf(stderr, "createScene: %s\n", mi_host_last_error());
+    return false;
+  }
+  // addSceneCamerasToWidget: first glTF camera -> manipulator (reference: src/gltf_camera_utils.hpp:62-90)
+  mi_scene_camera(m_resources.scene, 0, &m_resources.camera);
+  resetFrame();
+  m_pathTracer.onSceneInvalidated(m_resources);
+  return m_pathTracer.handle() != nullptr;
+}
+
+bool GltfRenderer::createHDR(const std::string& hdrFile)
+{
+  if(m_resources.hdrIbl)
+    mi_hdr_destroy(m_resources.hdrIbl);
+  m_resources.hdrIbl = nullptr;
+  if(hdrFile.empty())
+    return true;
+  if(mi_hdr_load(hdrFile.c_str(), &m_resources.hdrIbl) != MI_PT_OK)
+  {
+    fprintf(stderr, "createHDR: %s\n", mi_host_last_error());
+    return false;
+  }
+  if(m_pathTracer.handle())
+    mi_pt_set_environment(m_pathTracer.handle(), mi_hdr_env(m_resources.hdrIbl));
+  return true;
+}
+
+void GltfRenderer::onAttach(const Extent2D& size)
+{
+  m_resources.renderSize = size;
+  m_resources.settings.envSystem = m_envSystem == 1 ? EnvSystem::eHdr : EnvSystem::eSky;
+  m_pathTracer.onAttach(m_resources, nullptr);
+}
+
+bool GltfRenderer::updateFrameCounter()
+{
+  const MiCamera& cur = m_resources.camera;
+  if(!m_haveRefCamera || memcmp(&m_refCamera, &cur, sizeof(MiCamera)) != 0)
+  {
+    resetFrame();
+    m_refCamera     = cur;
+    m_haveRefCamera = true;
+  }
+  if(m_resources.frameCount >= m_resources.settings.maxFrames)
+    return false;
+  m_resources.frameCount++;
+  return true;
+}
+
+BenchmarkController::HeadlessFrameInfo GltfRenderer::benchmarkFrameInfo(uint32_t frames) const
+{
+  BenchmarkController::HeadlessFrameInfo info;
+  info.totalFrames = frames;
+  info.maxFrames   = m_resources.settings.maxFrames;
+  info.ptSamples   = m_pathTracer.m_pushConst.numSamples;
+  info.imageSize   = m_resources.renderSize;
+  return info;
+}
+
+void GltfRenderer::onRender(StreamHandle cmd, bool headless, uint32_t headlessFrames)
+{
+  m_benchmark.beginHeadlessTimingIfNeeded(headless, benchmarkFrameInfo(headlessFrames));
+  if(updateFrameCounter())
+  {
+    // fill SceneFrameInfo (reference: src/renderer.cpp:675-705)
+    const Settings& s = m_resources.settings;
+    float           pixelAngle = 0, focal = 0;
+    mi_camera_frame_info(&m_resources.camera, int(m_resources.renderSize.width), int(m_resources.renderSize.height), &m_resources.frameInfo, &pixelAngle,
+                         &focal);
+    MiSceneFrameInfo& f = m_resources.frameInfo;
+    f.flags |= (s.useSolidBackground ? MI_SCENE_USE_SOLID_BACKGROUND : 0) | (s.envSystem == EnvSystem::eHdr ? MI_SCENE_USE_HDR_ENVIRONMENT : 0)
+               | (s.useInfinitePlane ? MI_SCENE_USE_INFINITE_PLANE : 0)
+               | ((s.useInfinitePlane && s.isShadowCatcher) ? MI_SCENE_INFINITE_PLANE_SHADOW_CATCHER : 0);
+    f.envRotation  = s.hdrEnvRotation;
+    f.envBlur      = s.hdrBlur;
+    f.envIntensity = s.hdrEnvIntensity;
+    memcpy(f.backgroundColor, s.solidBackgroundColor, sizeof(f.backgroundColor));
+    f.infinitePlaneDistance = s.infinitePlaneDistance;
+    memcpy(f.infinitePlaneBaseColor, s.infinitePlaneBaseColor, sizeof(f.infinitePlaneBaseColor));
+    f.infinitePlaneMetallic     = s.infinitePlaneMetallic;
+    f.infinitePlaneRoughness    = s.infinitePlaneRoughness;
+    f.shadowCatcherDarkenAmount = std::max(s.shadowCatcherDarkness, 0.0f);
+    m_resources.skyParams.yIsUp = m_resources.camera.up[1] > 0.5f;  // reference: src/renderer.cpp:707
+    m_pathTracer.onRender(cmd, m_resources);
+    if(headless)
+      mi_pt_synchronize(m_pathTracer.handle());  // the reference's headless loop waits for each frame's submission
+  }
+  if(headless)
+    m_benchmark.updateHeadlessProgressIfNeeded(benchmarkFrameInfo(headlessFrames));
+}
+
+void GltfRenderer::onLastHeadlessFrame(uint32_t headlessFrames)
+{
+  m_benchmark.logHeadlessSummary(benchmarkFrameInfo(headlessFrames));
+  m_benchmark.finishHeadlessTiming();
+  saveHeadlessOutputImage();
+}
+
+// Filmic tone curve (Hejl / Burgess-Dawson) with a fixed exposure, then the curve's built-in ~sRGB response.
+// nvshaders::Tonemapper (external to the reference) offers Filmic as its method 0; exact parameter parity is a "next" row.
+void GltfRenderer::tonemap(const float* rgba, int w, int h, float exposure, std::vector<unsigned char>& ldr)
+{
+  ldr.resize(size_t(w) * size_t(h) * 4);
+  for(size_t i = 0; i < size_t(w) * size_t(h); ++i)
+  {
+    for(int c = 0; c < 3; ++c)
+    {
+      float x = std::max(0.0f, rgba[4 * i + size_t(c)] * exposure - 0.004f);
+      float y = (x * (6.2f * x + 0.5f)) / (x * (6.2f * x + 1.7f) + 0.06f);
+      ldr[4 * i + size_t(c)] = (unsigned char)(std::min(std::max(y, 0.0f), 1.0f) * 255.0f + 0.5f);
+    }
+    ldr[4 * i + 3] = 255;
+  }
+}
+
+bool GltfRenderer::savePng(const std::string& path, const unsigned char* rgba8, int w, int h)
+{
+  std::vector<unsigned char> raw(size_t(h) * (size_t(w) * 4 + 1));
+  for(int y = 0; y < h; ++y)
+  {
+    raw[size_t(y) * (size_t(w) * 4 + 1)] = 0;
+    memcpy(&raw[size_t(y) * (size_t(w) * 4 + 1) + 1], rgba8 + size_t(y) * size_t(w) * 4, size_t(w) * 4);
+  }
+  uLongf                     clen = compressBound(uLong(raw.size()));
+  std::vector<unsigned char> comp(clen);
+  if(compress2(comp.data(), &clen, raw.data(), uLong(raw.size()), 6) != Z_OK)
+    return false;
+  FILE* f = fopen(path.c_str(), "wb");
+  if(!f)
+    return false;
+  auto be32 = [](unsigned v, unsigned char* p) { p[0] = (unsigned char)(v >> 24); p[1] = (unsigned char)(v >> 16); p[2] = (unsigned char)(v >> 8); p[3] = (unsigned char)v; };
+  auto chunk = [&](const char* tag, const unsigned char* data, unsigned len) {
+    unsigned char hdr[8];
+    be32(len, hdr);
+    memcpy(hdr + 4, tag, 4);
+    fwrite(hdr, 1, 8, f);
+    if(len)
+      fwrite(data, 1, len, f);
+    uLong crc = crc32(0, reinterpret_cast<const Bytef*>(tag), 4);
+    if(len)
+      crc = crc32(crc, data, len);
+    unsigned char c[4];
+    be32(unsigned(crc), c);
+    fwrite(c, 1, 4, f);
+  };
+  const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+  fwrite(sig, 1, 8, f);
+  unsigned char ihdr[13];
+  be32(unsigned(w), ihdr);
+  be32(unsigned(h), ihdr + 4);
+  ihdr[8] = 8; ihdr[9] = 6; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
+  chunk("IHDR", ihdr, 13);
+  chunk("IDAT", comp.data(), unsigned(clen));
+  chunk("IEND", nullptr, 0);
+  fclose(f);
+  return true;
+}
+
+bool GltfRenderer::saveHdr(const std::string& path, const float* rgba, int w, int h)
+{
+  FILE* f = fopen(path.c_str(), "wb");
+  if(!f)
+    return false;
+  fprintf(f, "#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n", h, w);
+  std::vector<unsigned char> row(size_t(w) * 4);
+  for(int y = 0; y < h; ++y)
+  {
+    for(int x = 0; x < w; ++x)
+    {
+      const float* p = rgba + (size_t(y) * size_t(w) + size_t(x)) * 4;
+      float        m = std::max(p[0], std::max(p[1], p[2]));
+      unsigned char* o = &row[size_t(x) * 4];
+      if(m < 1e-32f)
+        o[0] = o[1] = o[2] = o[3] = 0;
+      else
+      {
+        int   e;
+        float s = std::frexp(m, &e) * 256.0f / m;
+        o[0] = (unsigned char)(p[0] * s); o[1] = (unsigned char)(p[1] * s); o[2] = (unsigned char)(p[2] * s); o[3] = (unsigned char)(e + 128);
+      }
+    }
+    fwrite(row.data(), 1, row.size(), f);
+  }
+  fclose(f);
+  return true;
+}
+
+void GltfRenderer::saveHeadlessOutputImage()
+{
+  const int w = int(m_resources.renderSize.width), h = int(m_resources.renderSize.height);
+  if(w <= 0 || !m_pathTracer.handle())
+    return;
+  std::vector<float> rgba(size_t(w) * size_t(h) * 4);
+  if(!m_pathTracer.readRendered(rgba.data()))
+    return;
+  std::string out = m_resources.headlessOutputPath.empty() ? std::string("mi_gltf_renderer.png") : m_resources.headlessOutputPath;
+  // auto exposure (the reference enables tonemapper auto-exposure: src/resources.hpp:206): key 0.18 over the log-average luminance
+  double logSum = 0.0;
+  size_t n      = 0;
+  for(size_t i = 0; i < size_t(w) * size_t(h); ++i)
+  {
+    float lum = 0.2126f * rgba[4 * i] + 0.7152f * rgba[4 * i + 1] + 0.0722f * rgba[4 * i + 2];
+    if(lum > 0.0f && std::isfinite(lum))
+    {
+      logSum += std::log(double(lum) + 1e-6);
+      ++n;
+    }
+  }
+  float exposure = n ? float(0.18 / std::exp(logSum / double(n))) : 1.0f;
+  if(out.size() > 4 && out.substr(out.size() - 4) == ".hdr")
+    saveHdr(out, rgba.data(), w, h);
+  else
+  {
+    std::vector<unsigned char> ldr;
+    tonemap(rgba.data(), w, h, exposure, ldr);
+    savePng(out, ldr.data(), w, h);
+  }
+  printf("Saved headless output image: %s\n", out.c_str());
+}

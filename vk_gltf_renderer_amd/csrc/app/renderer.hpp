@@ -1,0 +1,45 @@
+// GltfRenderer — the slice of the reference's application element (src/renderer.{hpp,cpp}) that feeds the path tracer in
+// headless runs: scene/HDR creation, per-frame SceneFrameInfo, frame counter, accumulation reset, tonemap + image save.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "benchmarking.hpp"
+#include "parameter_registry.hpp"
+#include "renderer_pathtracer.hpp"
+#include "resources.hpp"
+
+class GltfRenderer
+{
+public:
+  GltfRenderer();
+  ~GltfRenderer();
+  void registerParameters(ParameterRegistry* registry);
+  bool createScene(const std::string& sceneFile);  // reference: src/renderer.cpp:1238
+  bool createHDR(const std::string& hdrFile);      // reference: src/renderer.cpp:1982
+  void onAttach(const Extent2D& size);
+  void onRender(StreamHandle cmd, bool headless, uint32_t headlessFrames);  // reference: src/renderer.cpp:588-742
+  void onLastHeadlessFrame(uint32_t headlessFrames);                        // reference: src/renderer.cpp:762-767
+  void resetFrame() { m_resources.frameCount = -1; }                        // reference: :1939-1942
+  Resources&   resources() { return m_resources; }
+  PathTracer&  pathTracer() { return m_pathTracer; }
+  BenchmarkController& benchmark() { return m_benchmark; }
+
+  // tonemap + save helpers (also used by tests): Filmic curve + sRGB, PNG via zlib, Radiance .hdr dump
+  static void tonemap(const float* rgba, int w, int h, float exposure, std::vector<unsigned char>& ldr);
+  static bool savePng(const std::string& path, const unsigned char* rgba8, int w, int h);
+  static bool saveHdr(const std::string& path, const float* rgba, int w, int h);
+
+private:
+  bool updateFrameCounter();  // reference: src/renderer.cpp:1959-1977
+  BenchmarkController::HeadlessFrameInfo benchmarkFrameInfo(uint32_t frames) const;
+  void saveHeadlessOutputImage();
+
+  Resources           m_resources;
+  PathTracer          m_pathTracer;
+  BenchmarkOptions    m_benchmarkOptions;
+  BenchmarkController m_benchmark{m_benchmarkOptions};
+  MiCamera            m_refCamera{};
+  bool                m_haveRefCamera{false};
+  int                 m_envSystem{0};
+};
