@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bvh", type=int, default=0, help="0: 8-wide compressed BVH (default), 1: plain BVH2")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -114,7 +115,7 @@ def main():
     params.maxDepth, params.numSamples, params.pixelAngle, params.focalDistance = w["depth"], 1, pixel_angle, focal
 
     def make_tracer(counters):
-        t = ptmod.PathTracer(scene, device=local_rank, collect_counters=counters)
+        t = ptmod.PathTracer(scene, device=local_rank, collect_counters=counters, bvh=args.bvh)
         if hdr is not None:
             t.set_environment(hdr)
         t.set_tile_partition(rank, world, 64)

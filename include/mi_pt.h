@@ -105,7 +105,7 @@ typedef struct MiPtCreateOptions
 {
   int device;          /* HIP device ordinal */
   int collectCounters; /* 1: kernels export traversal/shading counters (slower) */
-  int bvhBuilder;      /* 0 = default (device LBVH + wide collapse) */
+  int bvhBuilder;      /* 0 = default: device LBVH collapsed to the 8-wide compressed BVH; 1 = plain BVH2 (A/B, tests) */
   int reserved[5];
 } MiPtCreateOptions;
 

@@ -79,8 +79,8 @@ def render_oracle(setup, frames, threads=None, tile=None):
         O.oracle_pt_destroy(o)
 
 
-def render_gpu(setup, frames, collect_counters=True, tile=None):
-    tracer = ptmod.PathTracer(setup.scene, collect_counters=collect_counters)
+def render_gpu(setup, frames, collect_counters=True, tile=None, bvh=0):
+    tracer = ptmod.PathTracer(setup.scene, collect_counters=collect_counters, bvh=bvh)
     try:
         if setup.hdr is not None:
             tracer.set_environment(setup.hdr)

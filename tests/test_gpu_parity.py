@@ -92,6 +92,23 @@ def test_glass_class_transmission_volume(built, tmp_path):
     _check(pu.render_oracle(s, 3), pu.render_gpu(s, 3), rel_l2=1e-2, within_1e4=0.95)
 
 
+def test_image_independent_of_acceleration_structure(built, tmp_path):
+    """The 8-wide compressed BVH and the plain BVH2 are both conservative and hits are tie-broken deterministically, so the
+    two structures must give bit-identical images (and the oracle's own SAH tree a tolerance-identical one)."""
+    path = scenegen.scene_atrium_class(str(tmp_path / "atrium.glb"), seed=5, detail=0.12, tex_size=64)
+    s = pu.Setup(path, 160, 96, max_depth=8)
+    wide = pu.render_gpu(s, 2, bvh=0)
+    bvh2 = pu.render_gpu(s, 2, bvh=1)
+    assert (wide["accum"] == bvh2["accum"]).all()
+    assert (wide["selection"] == bvh2["selection"]).all() and (wide["depth"] == bvh2["depth"]).all()
+    for k in ("segments", "shadowRays", "textureTaps"):
+        assert wide["stats"][k] == bvh2["stats"][k]
+    assert wide["stats"]["nodesClosest"] < 0.6 * bvh2["stats"]["nodesClosest"]  # the point of the wide structure
+    path = scenegen.scene_glass_class(str(tmp_path / "glass.glb"), seed=3, tess=24)
+    s = pu.Setup(path, 128, 80, max_depth=12, hdr_path=os.path.join(os.path.dirname(os.path.dirname(__file__)), "assets", "std_env.hdr"))
+    assert (pu.render_gpu(s, 2, bvh=0)["accum"] == pu.render_gpu(s, 2, bvh=1)["accum"]).all()
+
+
 def test_furnace_on_gpu(built, tmp_path):
     """The analytic furnace KAT on the device itself: white Lambert sphere in a uniform environment is invisible."""
     path = scenegen.scene_sphere(str(tmp_path / "s.glb"), scenegen.lambert_material((1, 1, 1)), 48, 24)

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -85,8 +87,10 @@ struct MiPt
   DevBuf<float>               srgbLut;
   DevBuf<float4>              envPixels;
   DevBuf<MiEnvAccel>          envAccel;
-  float4*                     bvhNodes = nullptr;
-  pt::DevTri*                 bvhTris  = nullptr;
+  float4*                     bvhNodes  = nullptr;
+  uint4*                      bvh8Nodes = nullptr;
+  pt::DevTri*                 bvhTris   = nullptr;
+  bool                        wide      = true;
   pt::DevScene                scene{};
   bool                        hasAlpha = false, hasVolumeScatter = false;
   MiPtStats                   staticStats{};
@@ -128,6 +132,8 @@ struct MiPt
       (void)hipFree(bvhNodes);
     if(bvhTris)
       (void)hipFree(bvhTris);
+    if(bvh8Nodes)
+      (void)hipFree(bvh8Nodes);
     for(hipEvent_t e : eventPool)
       (void)hipEventDestroy(e);
   }
@@ -389,11 +395,27 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
     pt->staticStats.bvhTriangleCount = bo.numTris;
     pt->staticStats.bvhNodeBytes     = 64;
     pt->staticStats.bvhTriangleBytes = sizeof(pt::DevTri);
+    pt->wide = !(options && options->bvhBuilder == 1);
+    if(pt->wide && bo.numTris > 0)
+    {
+      pt::Bvh8Output b8;
+      if(!pt::buildBvh8(bo, b8, nullptr, err))
+        return fail(MI_PT_ERR_HIP, "BVH8 collapse failed: " + err);
+      // the wide structure owns its own triangle order; the BVH2 arrays are no longer needed
+      (void)hipFree(pt->bvhNodes);
+      (void)hipFree(pt->bvhTris);
+      pt->bvhNodes  = nullptr;
+      pt->bvhTris   = b8.tris;
+      pt->bvh8Nodes = b8.nodes;
+      pt->scene.bvhRoot = 0;
+      pt->staticStats.bvhNodeCount = b8.numNodes;
+      pt->staticStats.bvhNodeBytes = 80;
+    }
   }
 
   pt::DevScene& S = pt->scene;
   S.materials = pt->materials.ptr; S.texInfos = pt->texInfos.ptr; S.nodes = pt->nodes.ptr; S.prims = pt->prims.ptr; S.lights = pt->lights.ptr;
-  S.textures = pt->textures.ptr; S.texels = pt->texels.ptr; S.envPixels = nullptr; S.envAccel = nullptr; S.bvhNodes = pt->bvhNodes; S.tris = pt->bvhTris;
+  S.textures = pt->textures.ptr; S.texels = pt->texels.ptr; S.envPixels = nullptr; S.envAccel = nullptr; S.bvhNodes = pt->bvhNodes; S.bvh8Nodes = pt->bvh8Nodes; S.tris = pt->bvhTris;
   S.srgbLut = pt->srgbLut.ptr; S.numMaterials = sd->numMaterials; S.numTextures = sd->numTextures; S.numLights = sd->numLights; S.numNodes = sd->numRenderNodes;
   S.envWidth = 0; S.envHeight = 0;
 
@@ -544,6 +566,7 @@ int mi_pt_render_frame(MiPt* pt, const MiPathtraceParams* params, void* hipStrea
   c.stream           = stream;
   c.persistentBlocks = unsigned(pt->numCUs) * 8u;
   c.hasAlpha         = pt->hasAlpha;
+  c.wide             = pt->wide;
   c.collectCounters  = pt->collectCounters;
 
   auto timed = [&](int kind, auto&& launch) {
@@ -566,6 +589,7 @@ int mi_pt_render_frame(MiPt* pt, const MiPathtraceParams* params, void* hipStrea
     (void)hipEventRecord(frameA, stream);
   }
   int iterations = 0, traceLaunches = 0, shadeLaunches = 0, shadowLaunches = 0;
+  static const bool debugSpans = getenv("MI_PT_TRACE_SPANS") != nullptr;
   for(int s = 0; s < params->numSamples; ++s)
   {
     pt::launchResetCounters(c.queues, stream);
@@ -589,9 +613,36 @@ int mi_pt_render_frame(MiPt* pt, const MiPathtraceParams* params, void* hipStrea
         if(remaining == 0)
           break;
       }
-      timed(TK_TRACE, [&] { pt::launchTraceClosest(c, cur); });
-      timed(TK_SHADE, [&] { pt::launchShade(c, cur); });
-      timed(TK_SHADOW, [&] { pt::launchTraceShadow(c); });
+      if(debugSpans)  // MI_PT_TRACE_SPANS=1: per-launch wall time and queue lengths (synchronising; diagnostics only)
+      {
+        auto count = [&](int base) {
+          uint32_t v[pt::NSUB];
+          (void)hipMemcpy(v, &c.queues.counters[base], sizeof(v), hipMemcpyDeviceToHost);
+          uint32_t t = 0;
+          for(uint32_t x : v) t += x;
+          return t;
+        };
+        auto span = [&](auto&& launch) {
+          (void)hipStreamSynchronize(stream);
+          auto t0 = std::chrono::steady_clock::now();
+          launch();
+          (void)hipStreamSynchronize(stream);
+          return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        };
+        uint32_t nIn = count(cur ? pt::QC_ACTIVE1 : pt::QC_ACTIVE0);
+        double   tTrace = span([&] { pt::launchTraceClosest(c, cur); });
+        double   tShade = span([&] { pt::launchShade(c, cur); });
+        uint32_t nSh    = count(pt::QC_SHADOW);
+        double   tShadow = span([&] { pt::launchTraceShadow(c); });
+        fprintf(stderr, "[mi_pt span] frame %d it %2d rays %8u trace %8.3f ms shade %8.3f ms | shadow rays %8u %8.3f ms\n", params->frameCount, it, nIn, tTrace,
+                tShade, nSh, tShadow);
+      }
+      else
+      {
+        timed(TK_TRACE, [&] { pt::launchTraceClosest(c, cur); });
+        timed(TK_SHADE, [&] { pt::launchShade(c, cur); });
+        timed(TK_SHADOW, [&] { pt::launchTraceShadow(c); });
+      }
       ++iterations; ++traceLaunches; ++shadeLaunches; ++shadowLaunches;
       cur ^= 1;
     }

@@ -28,4 +28,13 @@ struct BvhBuildOutput
 };
 bool buildBvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream, std::string& err);
 
+// 8-wide compressed BVH collapsed from the BVH2 above (bvh8.hip)
+struct Bvh8Output
+{
+  uint4*   nodes    = nullptr;  // device, 5 uint4 per node
+  DevTri*  tris     = nullptr;  // device, node order (triangles of a node's leaf children are contiguous)
+  uint32_t numNodes = 0, numTris = 0;
+};
+bool buildBvh8(const BvhBuildOutput& b2, Bvh8Output& out, hipStream_t stream, std::string& err);
+
 }  // namespace pt

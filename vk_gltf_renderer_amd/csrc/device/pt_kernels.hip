@@ -9,6 +9,7 @@
 #include "pt_kernels.h"
 #include "pt_shading.h"
 #include "pt_bvh.h"
+#include "pt_bvh8.h"
 
 namespace pt {
 
@@ -71,9 +72,21 @@ PT_DEV uint32_t queuePushBlock(bool pred, uint32_t subCap, uint32_t* counts, uin
 // the next chunk of QCHUNK indices from one of 8 head counters (own XCD's first) when the range runs dry.
 struct WaveFeed
 {
-  uint32_t cur, end, total, numChunks;
+  uint32_t cur, end, total, numChunks, chunk;  // chunk = indices fetched per head atomic
   bool     exhausted;
 };
+// Long queues are fetched QCHUNK indices at a time (few atomics); queues shorter than the machine (fewer rays than resident
+// lanes) are fetched one wave-load at a time so that they spread over every CU instead of serialising in a few waves.
+PT_DEV void feedInit(WaveFeed& f, uint32_t total)
+{
+  f.cur = f.end = 0;
+  f.total       = total;
+  f.chunk       = total >= 512u * 1024u ? uint32_t(QCHUNK) : 64u;
+  f.numChunks   = (total + f.chunk - 1) / f.chunk;
+  f.exhausted   = total == 0;
+}
+// blocks beyond the ones the queue can feed (one wave per fetch chunk) leave at once
+PT_DEV bool feedBlockHasWork(const WaveFeed& f) { return blockIdx.x * uint32_t(TRACE_BLOCK / 64) < f.numChunks; }
 PT_DEV bool feedNextChunk(WaveFeed& f, uint32_t* heads)
 {
   uint32_t chunk = 0xffffffffu;
@@ -100,8 +113,8 @@ PT_DEV bool feedNextChunk(WaveFeed& f, uint32_t* heads)
     f.exhausted = true;
     return false;
   }
-  f.cur = chunk * QCHUNK;
-  f.end = min(f.cur + uint32_t(QCHUNK), f.total);
+  f.cur = chunk * f.chunk;
+  f.end = min(f.cur + f.chunk, f.total);
   return true;
 }
 // Hands flat indices to the lanes whose `idle` predicate is set; returns the index or 0xffffffff (none left for this lane).
@@ -267,11 +280,50 @@ __global__ void __launch_bounds__(256) k_generate(DevScene sc, FrameConsts fc, P
 // Refill policy of the persistent trace waves: go back for new rays once this many lanes of the wave are idle.
 constexpr int REFILL_IDLE_LANES = 16;
 
-template <bool HAS_ALPHA, bool COUNT>
+// Closest-hit candidate test shared by both BVH flavours: deterministic tie-break, object-space back-face culling,
+// stochastic alpha (raytracer_interface.h.slang:76-111).
+struct ClosestBest
+{
+  float    t, u, v;
+  int      tri;
+  uint32_t rnode, prim;
+};
+template <bool HAS_ALPHA>
+PT_DEV void closestTestTriangle(const DevScene& sc, const RaySetup& r, int triIndex, ClosestBest& best, uint32_t& seed0, bool& seedLoaded,
+                                const float4* misc, uint32_t slot)
+{
+  const DevTri T = sc.tris[triIndex];
+  TriHit       h;
+  if(!intersectTri(xyz(T.a), xyz(T.b), xyz(T.c), r.org, r.dir, h) || !(h.t > 0.0f))
+    return;
+  const uint32_t rnode = __float_as_uint(T.a.w), prim = __float_as_uint(T.b.w), flags = __float_as_uint(T.c.w);
+  // deterministic closest hit: smaller t wins, exact ties by (renderNode, primitive)
+  bool better = h.t < best.t || (h.t == best.t && (rnode < best.rnode || (rnode == best.rnode && prim < best.prim)));
+  // RAY_FLAG_CULL_BACK_FACING_TRIANGLES unless TRIANGLE_FACING_CULL_DISABLE; facing is decided in object space
+  const bool front = h.front != ((flags & INST_FLIP_FACING) != 0u);
+  better           = better && (front || (flags & INST_CULL_DISABLE));
+  if(HAS_ALPHA && better && !(flags & INST_FORCE_OPAQUE))
+  {
+    if(!seedLoaded)
+    {
+      seed0      = __float_as_uint(misc[slot].z);
+      seedLoaded = true;
+    }
+    float opacity = getOpacity(sc, int(rnode), int(prim), mk3(1.0f - h.u - h.v, h.u, h.v));
+    better        = candidateRand(seed0, int(rnode), int(prim)) <= opacity;
+  }
+  if(better)
+  {
+    best.t = h.t; best.tri = triIndex; best.u = h.u; best.v = h.v; best.rnode = rnode; best.prim = prim;
+  }
+}
+
+template <bool WIDE, bool HAS_ALPHA, bool COUNT>
 __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_closest(DevScene sc, PathSoA P, Queues Q, int cur, StatCounters* stats)
 {
-  __shared__ int      s_stack[BVH_STACK_LDS * TRACE_BLOCK];
+  __shared__ int      s_stack[BVH_STACK_LDS * TRACE_BLOCK];  // BVH2: 24 ints/lane; BVH8: 12 node groups x 2 ints/lane
   __shared__ uint32_t s_prefix[NSUB + 1];
+  static_assert(2 * BVH8_STACK_LDS == BVH_STACK_LDS, "both stack flavours share one LDS allocation");
   if(blockIdx.x == 0 && threadIdx.x < NSUB)
   {
     // the shade kernel of this iteration appends to these; zero them here (the kernel boundary orders the writes)
@@ -283,27 +335,23 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_closest(DevScene sc, Path
   const RayQueue in = Q.active[cur];
   queuePrefix(&Q.counters[cur ? QC_ACTIVE1 : QC_ACTIVE0], s_prefix);
   WaveFeed feed;
-  feed.cur = feed.end = 0;
-  feed.total          = s_prefix[NSUB];
-  feed.numChunks      = (feed.total + QCHUNK - 1) / QCHUNK;
-  feed.exhausted      = feed.total == 0;
-  if(blockIdx.x * 2u >= feed.numChunks + 1u)  // a short queue needs few blocks: one per two chunks, the rest leave at once
+  feedInit(feed, s_prefix[NSUB]);
+  if(!feedBlockHasWork(feed))
     return;
-  LaneStack st;
-  st.lds    = s_stack;
-  st.tid    = int(threadIdx.x);
-  st.stride = TRACE_BLOCK;
-  st.sp     = 0;
-  // per-lane walk state
-  bool     active = false;
-  uint32_t slot = 0, pos = 0;
-  RaySetup r{};
-  int      node = BVH_EMPTY;
-  float    bestT = INFINITE_F, bestU = 0.0f, bestV = 0.0f;
-  int      bestTri   = -1;
-  uint32_t bestRnode = 0xffffffffu, bestPrim = 0xffffffffu, seed0 = 0;
-  bool     seedLoaded = false;
-  unsigned nodes = 0, tris = 0, rays = 0;
+  LaneStack  st;   // BVH2 walk state
+  LaneStack2 st2;  // BVH8 walk state
+  st.lds = s_stack;  st.tid = int(threadIdx.x);  st.stride = TRACE_BLOCK;  st.sp = 0;
+  st2.lds = s_stack; st2.tid = int(threadIdx.x); st2.stride = TRACE_BLOCK; st2.sp = 0;
+  bool        active = false;
+  uint32_t    slot = 0, pos = 0;
+  RaySetup    r{};
+  int         node = BVH_EMPTY;
+  NodeGroup   G{0, 0};
+  uint32_t    octinv = 0;
+  ClosestBest best{INFINITE_F, 0.0f, 0.0f, -1, 0xffffffffu, 0xffffffffu};
+  uint32_t    seed0 = 0;
+  bool        seedLoaded = false;
+  unsigned    nodes = 0, tris = 0, rays = 0;
   // every lane keeps its NEXT ray prefetched in registers: the loads are issued one ray ahead and land while the lane walks
   bool     pValid = false;
   uint32_t pPos = 0, pSlot = QUEUE_DEAD;
@@ -316,17 +364,25 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_closest(DevScene sc, Path
       pValid = false;
       if(pSlot != QUEUE_DEAD)
       {
-        slot    = pSlot;
-        pos     = pPos;
-        r       = makeRaySetup(xyz(pO), xyz(pD));
-        bestT   = INFINITE_F;  // ray.TMax
-        bestTri = -1;
-        bestU = bestV = 0.0f;
-        bestRnode = bestPrim = 0xffffffffu;
-        seedLoaded           = false;
-        st.sp                = 0;
-        node                 = sc.bvhRoot;
-        active               = true;
+        slot       = pSlot;
+        pos        = pPos;
+        r          = makeRaySetup(xyz(pO), xyz(pD));
+        best       = ClosestBest{INFINITE_F, 0.0f, 0.0f, -1, 0xffffffffu, 0xffffffffu};  // t = ray.TMax
+        seedLoaded = false;
+        if(WIDE)
+        {
+          octinv = rayOctInv(r.dir);
+          G      = rootGroup(octinv);
+          st2.sp = 0;
+        }
+        else
+        {
+          st.sp = 0;
+          node  = sc.bvhRoot;
+        }
+        active = sc.bvhRoot != BVH_EMPTY;
+        if(!active)
+          in.aux[pos] = make_float4(INFINITE_F, __int_as_float(-1), 0.0f, 0.0f);
         if(COUNT) ++rays;
       }
     }
@@ -354,47 +410,49 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_closest(DevScene sc, Path
     {
       if(active)
       {
-        // inner nodes first (bounded), so that most lanes arrive at a leaf together
-#pragma unroll 1
-        for(int k = 0; k < 4 && node >= 0; ++k)
+        bool finished = false;
+        if(WIDE)
         {
-          node = bvhInnerStep(sc, r, bestT, node, st);
-          if(COUNT) ++nodes;
-        }
-        if(node < 0 && node != BVH_EMPTY)
-        {
-          const int    triIndex = ~node;
-          const DevTri T        = sc.tris[triIndex];
-          if(COUNT) ++tris;
-          TriHit h;
-          if(intersectTri(xyz(T.a), xyz(T.b), xyz(T.c), r.org, r.dir, h) && h.t > 0.0f)
+          if((G.bits >> 8) == 0u && st2.sp > 0)
+            G = st2.pop();
+          if(G.bits >> 8)
           {
-            const uint32_t rnode = __float_as_uint(T.a.w), prim = __float_as_uint(T.b.w), flags = __float_as_uint(T.c.w);
-            // deterministic closest hit: smaller t wins, exact ties by (renderNode, primitive)
-            bool better = h.t < bestT || (h.t == bestT && (rnode < bestRnode || (rnode == bestRnode && prim < bestPrim)));
-            // RAY_FLAG_CULL_BACK_FACING_TRIANGLES unless TRIANGLE_FACING_CULL_DISABLE; facing is decided in object space
-            const bool front = h.front != ((flags & INST_FLIP_FACING) != 0u);
-            better           = better && (front || (flags & INST_CULL_DISABLE));
-            if(HAS_ALPHA && better && !(flags & INST_FORCE_OPAQUE))
+            const uint32_t child = groupPopChild(G, octinv);
+            if(G.bits >> 8)
+              st2.push(G);
+            uint32_t tBase, tMask;
+            bvh8Visit(sc, r, best.t, octinv, child, G, tBase, tMask);
+            if(COUNT) ++nodes;
+            while(tMask)
             {
-              if(!seedLoaded)
-              {
-                seed0      = __float_as_uint(P.misc[slot].z);
-                seedLoaded = true;
-              }
-              float opacity = getOpacity(sc, int(rnode), int(prim), mk3(1.0f - h.u - h.v, h.u, h.v));
-              better        = candidateRand(seed0, int(rnode), int(prim)) <= opacity;
-            }
-            if(better)
-            {
-              bestT = h.t; bestTri = triIndex; bestU = h.u; bestV = h.v; bestRnode = rnode; bestPrim = prim;
+              const int k = __ffs(int(tMask)) - 1;
+              tMask &= tMask - 1u;
+              if(COUNT) ++tris;
+              closestTestTriangle<HAS_ALPHA>(sc, r, int(tBase) + k, best, seed0, seedLoaded, P.misc, slot);
             }
           }
-          node = bvhPop(st);
+          finished = (G.bits >> 8) == 0u && st2.sp == 0;
         }
-        if(node == BVH_EMPTY)
+        else
         {
-          in.aux[pos] = make_float4(bestT, __int_as_float(bestTri), bestU, bestV);
+          // inner nodes first (bounded), so that most lanes arrive at a leaf together
+#pragma unroll 1
+          for(int k = 0; k < 4 && node >= 0; ++k)
+          {
+            node = bvhInnerStep(sc, r, best.t, node, st);
+            if(COUNT) ++nodes;
+          }
+          if(node < 0 && node != BVH_EMPTY)
+          {
+            if(COUNT) ++tris;
+            closestTestTriangle<HAS_ALPHA>(sc, r, ~node, best, seed0, seedLoaded, P.misc, slot);
+            node = bvhPop(st);
+          }
+          finished = node == BVH_EMPTY;
+        }
+        if(finished)
+        {
+          in.aux[pos] = make_float4(best.t, __int_as_float(best.tri), best.u, best.v);
           active      = false;
         }
       }
@@ -414,6 +472,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_closest(DevScene sc, Path
 //================================================================================================================================
 // k_selection: traceSelectionRay / TraceLow (pathtrace_functions.h.slang:813-820, raytracer_interface.h.slang:124-137)
 //================================================================================================================================
+template <bool WIDE>
 __global__ void __launch_bounds__(TRACE_BLOCK) k_selection(DevScene sc, FrameConsts fc, const uint32_t* ownedTiles, uint32_t* selection)
 {
   __shared__ int s_stack[BVH_STACK_LDS * TRACE_BLOCK];
@@ -421,26 +480,62 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_selection(DevScene sc, FrameCon
   int            px, py;
   if(slot >= uint32_t(fc.numSlots) || !slotToPixel(fc, ownedTiles, slot, px, py))
     return;
-  LaneStack st;
-  st.lds    = s_stack;
-  st.tid    = int(threadIdx.x);
-  st.stride = TRACE_BLOCK;
   f3 origin, direction;
   getRay(fc, mk2(float(px), float(py)), mk2(0.5f, 0.5f), origin, direction);
   const RaySetup r     = makeRaySetup(origin, direction);
   float          bestT = INFINITE_F;
   uint32_t       bestRnode = 0xffffffffu, bestPrim = 0xffffffffu;
-  bvhWalk(sc, r, bestT, st, [&](int triIndex, float tmax) -> float {
+  // RAY_FLAG_FORCE_OPAQUE, no culling: plain closest hit over every triangle
+  auto testTri = [&](int triIndex) {
     const DevTri T = sc.tris[triIndex];
     TriHit       h;
     if(!intersectTri(xyz(T.a), xyz(T.b), xyz(T.c), r.org, r.dir, h) || !(h.t > 0.0f))
-      return tmax;
+      return;
     const uint32_t rnode = __float_as_uint(T.a.w), prim = __float_as_uint(T.b.w);
-    if(!(h.t < bestT || (h.t == bestT && (rnode < bestRnode || (rnode == bestRnode && prim < bestPrim)))))
-      return tmax;
-    bestT = h.t; bestRnode = rnode; bestPrim = prim;
-    return bestT;
-  });
+    if(h.t < bestT || (h.t == bestT && (rnode < bestRnode || (rnode == bestRnode && prim < bestPrim))))
+    {
+      bestT = h.t; bestRnode = rnode; bestPrim = prim;
+    }
+  };
+  if(sc.bvhRoot != BVH_EMPTY)
+  {
+    if(WIDE)
+    {
+      LaneStack2 st2;
+      st2.lds = s_stack; st2.tid = int(threadIdx.x); st2.stride = TRACE_BLOCK; st2.sp = 0;
+      const uint32_t octinv = rayOctInv(r.dir);
+      NodeGroup      G      = rootGroup(octinv);
+      for(;;)
+      {
+        if((G.bits >> 8) == 0u)
+        {
+          if(st2.sp == 0)
+            break;
+          G = st2.pop();
+        }
+        const uint32_t child = groupPopChild(G, octinv);
+        if(G.bits >> 8)
+          st2.push(G);
+        uint32_t tBase, tMask;
+        bvh8Visit(sc, r, bestT, octinv, child, G, tBase, tMask);
+        while(tMask)
+        {
+          const int k = __ffs(int(tMask)) - 1;
+          tMask &= tMask - 1u;
+          testTri(int(tBase) + k);
+        }
+      }
+    }
+    else
+    {
+      LaneStack st;
+      st.lds = s_stack; st.tid = int(threadIdx.x); st.stride = TRACE_BLOCK; st.sp = 0;
+      bvhWalk(sc, r, bestT, st, [&](int triIndex, float) -> float {
+        testTri(triIndex);
+        return bestT;
+      });
+    }
+  }
   selection[size_t(py) * size_t(fc.width) + size_t(px)] = (bestRnode != 0xffffffffu) ? bestRnode + 1u : 0u;
 }
 
@@ -767,7 +862,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, FrameConsts 
 //================================================================================================================================
 // k_trace_shadow: RayQueryRaytracer::TraceShadow (raytracer_interface.h.slang:139-187) + `pt.radiance += contribution * T`
 //================================================================================================================================
-template <bool HAS_ALPHA, bool COUNT>
+template <bool WIDE, bool HAS_ALPHA, bool COUNT>
 __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_shadow(DevScene sc, PathSoA P, Queues Q, StatCounters* stats)
 {
   __shared__ int      s_stack[BVH_STACK_LDS * TRACE_BLOCK];
@@ -775,29 +870,27 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_shadow(DevScene sc, PathS
   queuePrefix(&Q.counters[QC_SHADOW], s_prefix);
   const RayQueue in = Q.shadow;
   WaveFeed feed;
-  feed.cur = feed.end = 0;
-  feed.total          = s_prefix[NSUB];
-  feed.numChunks      = (feed.total + QCHUNK - 1) / QCHUNK;
-  feed.exhausted      = feed.total == 0;
-  if(blockIdx.x * 2u >= feed.numChunks + 1u)
+  feedInit(feed, s_prefix[NSUB]);
+  if(!feedBlockHasWork(feed))
     return;
-  LaneStack st;
-  st.lds    = s_stack;
-  st.tid    = int(threadIdx.x);
-  st.stride = TRACE_BLOCK;
-  st.sp     = 0;
+  LaneStack  st;
+  LaneStack2 st2;
+  st.lds = s_stack;  st.tid = int(threadIdx.x);  st.stride = TRACE_BLOCK;  st.sp = 0;
+  st2.lds = s_stack; st2.tid = int(threadIdx.x); st2.stride = TRACE_BLOCK; st2.sp = 0;
   // per-lane state.  phase 0: any-hit walk (opaque geometry and non-transmissive alpha resolve here, order independent);
   // phase 1: one walk per transmissive candidate, in increasing (t, renderNode, primitive) order.
-  bool     active = false;
-  uint32_t slot   = 0;
-  RaySetup r{};
-  int      node  = BVH_EMPTY;
-  float    tMax  = 0.0f;
-  int      phase = 0;
-  unsigned nTrans = 0;
-  bool     occluded = false;
-  uint32_t seed0 = 0;
-  f3       contrib = mk3(0.0f);
+  bool      active = false;
+  uint32_t  slot   = 0;
+  RaySetup  r{};
+  int       node = BVH_EMPTY;
+  NodeGroup G{0, 0};
+  uint32_t  octinv = 0;
+  float     tMax  = 0.0f;
+  int       phase = 0;
+  unsigned  nTrans = 0;
+  bool      occluded = false;
+  uint32_t  seed0 = 0;
+  f3        contrib = mk3(0.0f);
   // phase-1 search state
   float    bT = 0.0f, bU = 0.0f, bV = 0.0f, lastT = -1.0f, prevHitT = 0.0f;
   uint32_t bRnode = 0, bPrim = 0, lastRnode = 0, lastPrim = 0;
@@ -808,6 +901,55 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_shadow(DevScene sc, PathS
   bool     pValid = false;
   uint32_t pSlot = QUEUE_DEAD;
   float4   pO = make_float4(0, 0, 0, 0), pD = make_float4(0, 0, 0, 0), pC = make_float4(0, 0, 0, 0);
+
+  auto restartWalk = [&]() {
+    if(WIDE)
+    {
+      G      = rootGroup(octinv);
+      st2.sp = 0;
+    }
+    else
+    {
+      st.sp = 0;
+      node  = sc.bvhRoot;
+    }
+  };
+  // one shadow candidate (raytracer_interface.h.slang:149-179); returns true when the ray is decided (occluded)
+  auto testTri = [&](int triIndex) {
+    const DevTri T = sc.tris[triIndex];
+    if(COUNT) ++tris;
+    const uint32_t flags = __float_as_uint(T.c.w);
+    TriHit         h;
+    const bool consider = !HAS_ALPHA || phase == 0 || ((flags & INST_TRANSMISSIVE) && !(flags & INST_FORCE_OPAQUE));
+    if(!(consider && intersectTri(xyz(T.a), xyz(T.b), xyz(T.c), r.org, r.dir, h) && h.t > 0.0f && h.t < tMax))
+      return;
+    const uint32_t rnode = __float_as_uint(T.a.w), prim = __float_as_uint(T.b.w);
+    if(!HAS_ALPHA || phase == 0)
+    {
+      if(!HAS_ALPHA || (flags & INST_FORCE_OPAQUE))
+        occluded = true;  // RAY_FLAG_NONE: no culling; opaque geometry commits
+      else if(flags & INST_TRANSMISSIVE)
+        ++nTrans;
+      else
+      {
+        // non-transmissive alpha material: an accepted candidate multiplies the transmission by
+        // getShadowTransmission() == 0 (pathtrace_functions.h.slang:256-261) whatever its position in the order
+        float opacity = getOpacity(sc, int(rnode), int(prim), mk3(1.0f - h.u - h.v, h.u, h.v));
+        if(candidateRand(seed0, int(rnode), int(prim)) < opacity)
+          occluded = true;
+      }
+    }
+    else
+    {
+      const bool afterLast  = !haveLast || h.t > lastT || (h.t == lastT && (rnode > lastRnode || (rnode == lastRnode && prim > lastPrim)));
+      const bool beforeBest = !found || h.t < bT || (h.t == bT && (rnode < bRnode || (rnode == bRnode && prim < bPrim)));
+      if(afterLast && beforeBest)
+      {
+        found = true; bT = h.t; bRnode = rnode; bPrim = prim; bU = h.u; bV = h.v;
+      }
+    }
+  };
+
   for(;;)
   {
     if(!active && pValid)
@@ -826,11 +968,19 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_shadow(DevScene sc, PathS
         occluded = false;
         total    = mk3(1.0f);
         haveLast = false;
+        found    = false;
         prevHitT = 0.0f;
-        st.sp    = 0;
-        node     = sc.bvhRoot;
-        active   = true;
+        octinv   = rayOctInv(r.dir);
+        restartWalk();
+        active = true;
         if(COUNT) ++rays;
+        if(sc.bvhRoot == BVH_EMPTY)  // nothing to hit: unoccluded
+        {
+          float4 rad = P.radiance[slot];
+          rad.x += contrib.x; rad.y += contrib.y; rad.z += contrib.z;
+          P.radiance[slot] = rad;
+          active           = false;
+        }
       }
     }
     if(!feed.exhausted)
@@ -857,50 +1007,45 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_shadow(DevScene sc, PathS
     {
       if(active)
       {
-#pragma unroll 1
-        for(int k = 0; k < 4 && node >= 0; ++k)
+        const float walkTmax = (HAS_ALPHA && phase == 1 && found) ? bT : tMax;
+        bool        walkDone = false;
+        if(WIDE)
         {
-          node = bvhInnerStep(sc, r, (HAS_ALPHA && phase == 1 && found) ? bT : tMax, node, st);
-          if(COUNT) ++nodes;
-        }
-        if(node < 0 && node != BVH_EMPTY)
-        {
-          const DevTri T = sc.tris[~node];
-          if(COUNT) ++tris;
-          const uint32_t flags = __float_as_uint(T.c.w);
-          TriHit         h;
-          const bool consider = !HAS_ALPHA || phase == 0 || ((flags & INST_TRANSMISSIVE) && !(flags & INST_FORCE_OPAQUE));
-          if(consider && intersectTri(xyz(T.a), xyz(T.b), xyz(T.c), r.org, r.dir, h) && h.t > 0.0f && h.t < tMax)
+          if((G.bits >> 8) == 0u && st2.sp > 0)
+            G = st2.pop();
+          if(G.bits >> 8)
           {
-            const uint32_t rnode = __float_as_uint(T.a.w), prim = __float_as_uint(T.b.w);
-            if(!HAS_ALPHA || phase == 0)
+            const uint32_t child = groupPopChild(G, octinv);
+            if(G.bits >> 8)
+              st2.push(G);
+            uint32_t tBase, tMask;
+            bvh8Visit(sc, r, walkTmax, octinv, child, G, tBase, tMask);
+            if(COUNT) ++nodes;
+            while(tMask && !occluded)
             {
-              if(!HAS_ALPHA || (flags & INST_FORCE_OPAQUE))
-                occluded = true;  // RAY_FLAG_NONE: no culling; opaque geometry commits
-              else if(flags & INST_TRANSMISSIVE)
-                ++nTrans;
-              else
-              {
-                // non-transmissive alpha material: an accepted candidate multiplies the transmission by
-                // getShadowTransmission() == 0 (pathtrace_functions.h.slang:256-261) whatever its position in the order
-                float opacity = getOpacity(sc, int(rnode), int(prim), mk3(1.0f - h.u - h.v, h.u, h.v));
-                if(candidateRand(seed0, int(rnode), int(prim)) < opacity)
-                  occluded = true;
-              }
-            }
-            else
-            {
-              const bool afterLast = !haveLast || h.t > lastT || (h.t == lastT && (rnode > lastRnode || (rnode == lastRnode && prim > lastPrim)));
-              const bool beforeBest = !found || h.t < bT || (h.t == bT && (rnode < bRnode || (rnode == bRnode && prim < bPrim)));
-              if(afterLast && beforeBest)
-              {
-                found = true; bT = h.t; bRnode = rnode; bPrim = prim; bU = h.u; bV = h.v;
-              }
+              const int k = __ffs(int(tMask)) - 1;
+              tMask &= tMask - 1u;
+              testTri(int(tBase) + k);
             }
           }
-          node = occluded ? BVH_EMPTY : bvhPop(st);
+          walkDone = occluded || ((G.bits >> 8) == 0u && st2.sp == 0);
         }
-        if(node == BVH_EMPTY)
+        else
+        {
+#pragma unroll 1
+          for(int k = 0; k < 4 && node >= 0; ++k)
+          {
+            node = bvhInnerStep(sc, r, walkTmax, node, st);
+            if(COUNT) ++nodes;
+          }
+          if(node < 0 && node != BVH_EMPTY)
+          {
+            testTri(~node);
+            node = bvhPop(st);
+          }
+          walkDone = occluded || node == BVH_EMPTY;
+        }
+        if(walkDone)
         {
           bool finished = true;
           if(HAS_ALPHA && !occluded && !(phase == 1 && !found))
@@ -925,10 +1070,9 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_shadow(DevScene sc, PathS
             if(!occluded && nTrans > 0)
             {
               // (re)start a search walk for the next transmissive candidate
-              phase    = 1;
-              found    = false;
-              st.sp    = 0;
-              node     = sc.bvhRoot;
+              phase = 1;
+              found = false;
+              restartWalk();
               finished = false;
             }
           }
@@ -1050,23 +1194,52 @@ void launchGenerate(const LaunchCtx& c, int sampleIndex)
   hipLaunchKernelGGL(k_generate, dim3(grid), dim3(256), 0, c.stream, c.scene, c.fc, c.paths, c.queues, c.ownedTiles, sampleIndex,
                      c.collectCounters ? c.stats : nullptr);
 }
-void launchTraceClosest(const LaunchCtx& c, int cur)
+namespace {
+template <bool WIDE>
+void launchTraceClosestT(const LaunchCtx& c, int cur)
 {
   dim3 grid(c.persistentBlocks), block(TRACE_BLOCK);
   if(c.hasAlpha)
   {
     if(c.collectCounters)
-      hipLaunchKernelGGL((k_trace_closest<true, true>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, cur, c.stats);
+      hipLaunchKernelGGL((k_trace_closest<WIDE, true, true>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, cur, c.stats);
     else
-      hipLaunchKernelGGL((k_trace_closest<true, false>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, cur, c.stats);
+      hipLaunchKernelGGL((k_trace_closest<WIDE, true, false>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, cur, c.stats);
   }
   else
   {
     if(c.collectCounters)
-      hipLaunchKernelGGL((k_trace_closest<false, true>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, cur, c.stats);
+      hipLaunchKernelGGL((k_trace_closest<WIDE, false, true>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, cur, c.stats);
     else
-      hipLaunchKernelGGL((k_trace_closest<false, false>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, cur, c.stats);
+      hipLaunchKernelGGL((k_trace_closest<WIDE, false, false>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, cur, c.stats);
   }
+}
+template <bool WIDE>
+void launchTraceShadowT(const LaunchCtx& c)
+{
+  dim3 grid(c.persistentBlocks), block(TRACE_BLOCK);
+  if(c.hasAlpha)
+  {
+    if(c.collectCounters)
+      hipLaunchKernelGGL((k_trace_shadow<WIDE, true, true>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, c.stats);
+    else
+      hipLaunchKernelGGL((k_trace_shadow<WIDE, true, false>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, c.stats);
+  }
+  else
+  {
+    if(c.collectCounters)
+      hipLaunchKernelGGL((k_trace_shadow<WIDE, false, true>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, c.stats);
+    else
+      hipLaunchKernelGGL((k_trace_shadow<WIDE, false, false>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, c.stats);
+  }
+}
+}  // namespace
+void launchTraceClosest(const LaunchCtx& c, int cur)
+{
+  if(c.wide)
+    launchTraceClosestT<true>(c, cur);
+  else
+    launchTraceClosestT<false>(c, cur);
 }
 void launchShade(const LaunchCtx& c, int cur)
 {
@@ -1078,21 +1251,10 @@ void launchShade(const LaunchCtx& c, int cur)
 }
 void launchTraceShadow(const LaunchCtx& c)
 {
-  dim3 grid(c.persistentBlocks), block(TRACE_BLOCK);
-  if(c.hasAlpha)
-  {
-    if(c.collectCounters)
-      hipLaunchKernelGGL((k_trace_shadow<true, true>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, c.stats);
-    else
-      hipLaunchKernelGGL((k_trace_shadow<true, false>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, c.stats);
-  }
+  if(c.wide)
+    launchTraceShadowT<true>(c);
   else
-  {
-    if(c.collectCounters)
-      hipLaunchKernelGGL((k_trace_shadow<false, true>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, c.stats);
-    else
-      hipLaunchKernelGGL((k_trace_shadow<false, false>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, c.stats);
-  }
+    launchTraceShadowT<false>(c);
 }
 void launchFinishSample(const LaunchCtx& c, int sampleIndex, float4* accum, float* depth, float4* albedo, float4* normal)
 {
@@ -1102,7 +1264,10 @@ void launchFinishSample(const LaunchCtx& c, int sampleIndex, float4* accum, floa
 void launchSelection(const LaunchCtx& c, uint32_t* selection)
 {
   unsigned grid = (unsigned(c.fc.numSlots) + TRACE_BLOCK - 1) / TRACE_BLOCK;
-  hipLaunchKernelGGL(k_selection, dim3(grid), dim3(TRACE_BLOCK), 0, c.stream, c.scene, c.fc, c.ownedTiles, selection);
+  if(c.wide)
+    hipLaunchKernelGGL(k_selection<true>, dim3(grid), dim3(TRACE_BLOCK), 0, c.stream, c.scene, c.fc, c.ownedTiles, selection);
+  else
+    hipLaunchKernelGGL(k_selection<false>, dim3(grid), dim3(TRACE_BLOCK), 0, c.stream, c.scene, c.fc, c.ownedTiles, selection);
 }
 
 }  // namespace pt

@@ -56,8 +56,9 @@ struct DevScene
   const uchar4*              texels;
   const float4*              envPixels;  // rgb + pdf
   const MiEnvAccel*          envAccel;
-  const float4*              bvhNodes;  // 4 x float4 per node (see pt_bvh.h)
-  const DevTri*              tris;
+  const float4*              bvhNodes;  // BVH2: 4 x float4 per node (see pt_bvh.h); null when the wide BVH is active
+  const uint4*               bvh8Nodes; // BVH8: 5 x uint4 per node (see pt_bvh8.h)
+  const DevTri*              tris;      // triangles in the order of the ACTIVE structure (hit records index this array)
   const float*               srgbLut;  // 256 floats
   int                        numMaterials, numTextures, numLights, numNodes;
   int                        envWidth, envHeight;

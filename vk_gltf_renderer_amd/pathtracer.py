@@ -118,13 +118,14 @@ def camera_frame_info(cam, width, height):
 class PathTracer:
     """The HIP path tracer instance (libmi_pt.so)."""
 
-    def __init__(self, scene, device=0, collect_counters=False):
+    def __init__(self, scene, device=0, collect_counters=False, bvh=0):
         self._l = capi.pt_lib()
         self._p = C.c_void_p()
         self._scene = scene  # keep host tables alive for the duration of mi_pt_create only (they are copied)
         opts = capi.MiPtCreateOptions()
         opts.device = device
         opts.collectCounters = 1 if collect_counters else 0
+        opts.bvhBuilder = bvh  # 0: 8-wide compressed BVH (default), 1: plain BVH2
         _check_pt(self._l.mi_pt_create(scene.desc, C.byref(opts), C.byref(self._p)))
         self.width = self.height = 0
 
