@@ -87,6 +87,7 @@ struct MiPt
   DevBuf<float>               srgbLut;
   DevBuf<float4>              envPixels;
   DevBuf<MiEnvAccel>          envAccel;
+  DevBuf<pt::DevAlphaTri>     alphaTris;
   float4*                     bvhNodes  = nullptr;
   uint4*                      bvh8Nodes = nullptr;
   pt::DevTri*                 bvhTris   = nullptr;
@@ -416,9 +417,17 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
   pt::DevScene& S = pt->scene;
   S.materials = pt->materials.ptr; S.texInfos = pt->texInfos.ptr; S.nodes = pt->nodes.ptr; S.prims = pt->prims.ptr; S.lights = pt->lights.ptr;
   S.textures = pt->textures.ptr; S.texels = pt->texels.ptr; S.envPixels = nullptr; S.envAccel = nullptr; S.bvhNodes = pt->bvhNodes; S.bvh8Nodes = pt->bvh8Nodes; S.tris = pt->bvhTris;
-  S.srgbLut = pt->srgbLut.ptr; S.numMaterials = sd->numMaterials; S.numTextures = sd->numTextures; S.numLights = sd->numLights; S.numNodes = sd->numRenderNodes;
+  S.alphaTris = nullptr; S.srgbLut = pt->srgbLut.ptr; S.numMaterials = sd->numMaterials; S.numTextures = sd->numTextures; S.numLights = sd->numLights; S.numNodes = sd->numRenderNodes;
   S.envWidth = 0; S.envHeight = 0;
 
+  if(pt->hasAlpha && S.numTris > 0)
+  {
+    HIP_TRY(pt->alphaTris.alloc(size_t(S.numTris)));
+    pt::launchBuildAlphaRecords(S, uint32_t(S.numTris), pt->alphaTris.ptr, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    S.alphaTris = pt->alphaTris.ptr;
+  }
   HIP_TRY(pt->stats.alloc(1));
   HIP_TRY(hipMemset(pt->stats.ptr, 0, sizeof(pt::StatCounters)));
   // SkyPhysicalParameters{} defaults, so a caller that never calls mi_pt_set_sky still renders the default sky

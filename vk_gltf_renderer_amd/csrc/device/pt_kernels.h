@@ -21,6 +21,7 @@ struct LaunchCtx
   bool            collectCounters;
 };
 
+void launchBuildAlphaRecords(const DevScene& scene, uint32_t numTris, DevAlphaTri* out, hipStream_t s);
 void launchResetCounters(const Queues& Q, hipStream_t s);
 void launchGenerate(const LaunchCtx& c, int sampleIndex);
 void launchTraceClosest(const LaunchCtx& c, int cur);

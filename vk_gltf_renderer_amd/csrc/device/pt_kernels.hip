@@ -309,7 +309,7 @@ PT_DEV void closestTestTriangle(const DevScene& sc, const RaySetup& r, int triIn
       seed0      = __float_as_uint(misc[slot].z);
       seedLoaded = true;
     }
-    float opacity = getOpacity(sc, int(rnode), int(prim), mk3(1.0f - h.u - h.v, h.u, h.v));
+    float opacity = getOpacityFast(sc, triIndex, mk3(1.0f - h.u - h.v, h.u, h.v));
     better        = candidateRand(seed0, int(rnode), int(prim)) <= opacity;
   }
   if(better)
@@ -934,7 +934,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_shadow(DevScene sc, PathS
       {
         // non-transmissive alpha material: an accepted candidate multiplies the transmission by
         // getShadowTransmission() == 0 (pathtrace_functions.h.slang:256-261) whatever its position in the order
-        float opacity = getOpacity(sc, int(rnode), int(prim), mk3(1.0f - h.u - h.v, h.u, h.v));
+        float opacity = getOpacityFast(sc, triIndex, mk3(1.0f - h.u - h.v, h.u, h.v));
         if(candidateRand(seed0, int(rnode), int(prim)) < opacity)
           occluded = true;
       }
@@ -1173,6 +1173,13 @@ __global__ void __launch_bounds__(256) k_finish_sample(FrameConsts fc, PathSoA P
   }
 }
 
+__global__ void k_alpha_records(DevScene sc, uint32_t n, DevAlphaTri* out)
+{
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < n)
+    out[i] = makeAlphaRecord(sc, sc.tris[i]);
+}
+
 __global__ void k_reset_counters(uint32_t* counters)
 {
   for(int i = threadIdx.x; i < QC_COUNT; i += blockDim.x)
@@ -1184,6 +1191,11 @@ __global__ void k_reset_counters(uint32_t* counters)
 //================================================================================================================================
 // host-side launch helpers
 //================================================================================================================================
+void launchBuildAlphaRecords(const DevScene& scene, uint32_t numTris, DevAlphaTri* out, hipStream_t s)
+{
+  if(numTris)
+    hipLaunchKernelGGL(k_alpha_records, dim3((numTris + 255) / 256), dim3(256), 0, s, scene, numTris, out);
+}
 void launchResetCounters(const Queues& Q, hipStream_t s)
 {
   hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(64), 0, s, Q.counters);

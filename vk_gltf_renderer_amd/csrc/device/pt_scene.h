@@ -45,6 +45,26 @@ struct DevTri
   float4 a, b, c;
 };
 
+// Everything the stochastic-alpha test of one triangle needs, in ONE 48-byte record next to the triangle (same index):
+// getOpacity (shaders/pathtrace_functions.h.slang:189-234) walks instance -> material -> primitive -> indices -> uvs ->
+// texture-info -> texture -> texels, eight dependent loads per candidate; on the software walk that chain, not the
+// arithmetic, dominated foliage rays.  Here it is record -> texels.
+struct DevAlphaTri
+{
+  float4 a;  // uv0.x, uv0.y, uv1.x, uv1.y            (of the TEXCOORD set the alpha texture uses)
+  float4 b;  // uv2.x, uv2.y, alpha factor, alpha cutoff
+  uint4  c;  // level-0 texel offset | width | height << 16 | flags | vertex alpha bytes a0 | a1 << 8 | a2 << 16
+};
+enum : uint32_t
+{
+  AT_MODE_MASK   = 3u,       // MiAlphaMode
+  AT_HAS_TEXTURE = 1u << 2,
+  AT_LINEAR      = 1u << 3,  // magFilter (SampleLevel(uv, 0) is a magnification)
+  AT_WRAPS_SHIFT = 4,        // 2 bits
+  AT_WRAPT_SHIFT = 6,        // 2 bits
+  AT_HAS_COLORS  = 1u << 8,
+};
+
 struct DevScene
 {
   const MiGltfShadeMaterial* materials;
@@ -59,6 +79,7 @@ struct DevScene
   const float4*              bvhNodes;  // BVH2: 4 x float4 per node (see pt_bvh.h); null when the wide BVH is active
   const uint4*               bvh8Nodes; // BVH8: 5 x uint4 per node (see pt_bvh8.h)
   const DevTri*              tris;      // triangles in the order of the ACTIVE structure (hit records index this array)
+  const DevAlphaTri*         alphaTris; // same indexing as tris; valid for triangles of non-FORCE_OPAQUE instances
   const float*               srgbLut;  // 256 floats
   int                        numMaterials, numTextures, numLights, numNodes;
   int                        envWidth, envHeight;

@@ -386,6 +386,94 @@ __device__ __noinline__ float getOpacity(const DevScene& sc, int rnode, int tria
   return alpha;
 }
 
+// getOpacity through the per-triangle alpha record (same arithmetic, two dependent loads instead of eight)
+PT_DEV float getOpacityFast(const DevScene& sc, int triIndex, f3 bary)
+{
+  const DevAlphaTri rec  = sc.alphaTris[triIndex];
+  const uint32_t    flg  = rec.c.z;
+  const uint32_t    mode = flg & AT_MODE_MASK;
+  if(mode == MI_ALPHA_OPAQUE)
+    return 1.0f;
+  float alpha = rec.b.z;
+  if(flg & AT_HAS_TEXTURE)
+  {
+    f2          uv = mk2(rec.a.x, rec.a.y) * bary.x + mk2(rec.a.z, rec.a.w) * bary.y + mk2(rec.b.x, rec.b.y) * bary.z;
+    const int   w = int(rec.c.y & 0xffffu), h = int(rec.c.y >> 16);
+    const int   wrapS = int((flg >> AT_WRAPS_SHIFT) & 3u), wrapT = int((flg >> AT_WRAPT_SHIFT) & 3u);
+    const uchar4* texels = sc.texels + rec.c.x;
+    float       fx = uv.x * float(w), fy = uv.y * float(h);
+    float       ta;
+    if(!(flg & AT_LINEAR))
+      ta = float(texels[size_t(wrapCoord(int(floorf(fy)), h, wrapT)) * size_t(w) + size_t(wrapCoord(int(floorf(fx)), w, wrapS))].w) * (1.0f / 255.0f);
+    else
+    {
+      fx -= 0.5f;
+      fy -= 0.5f;
+      float flx = floorf(fx), fly = floorf(fy);
+      float tx = fx - flx, ty = fy - fly;
+      int   x0 = wrapCoord(int(flx), w, wrapS), x1 = wrapCoord(int(flx) + 1, w, wrapS);
+      int   y0 = wrapCoord(int(fly), h, wrapT), y1 = wrapCoord(int(fly) + 1, h, wrapT);
+      float a = float(texels[size_t(y0) * size_t(w) + size_t(x0)].w) * (1.0f / 255.0f), b = float(texels[size_t(y0) * size_t(w) + size_t(x1)].w) * (1.0f / 255.0f);
+      float c = float(texels[size_t(y1) * size_t(w) + size_t(x0)].w) * (1.0f / 255.0f), d = float(texels[size_t(y1) * size_t(w) + size_t(x1)].w) * (1.0f / 255.0f);
+      ta      = (a * (1.0f - tx) + b * tx) * (1.0f - ty) + (c * (1.0f - tx) + d * tx) * ty;
+    }
+    alpha *= ta;
+  }
+  if(flg & AT_HAS_COLORS)
+  {
+    const uint32_t v = rec.c.w;
+    alpha *= (float(v & 0xffu) / 255.0f) * bary.x + (float((v >> 8) & 0xffu) / 255.0f) * bary.y + (float((v >> 16) & 0xffu) / 255.0f) * bary.z;
+  }
+  if(mode == MI_ALPHA_MASK)
+    return alpha >= rec.b.w ? 1.0f : 0.0f;
+  return alpha;
+}
+// Fills the record of one triangle (run once after the BVH build, for every triangle of the active order).
+PT_DEV DevAlphaTri makeAlphaRecord(const DevScene& sc, const DevTri& T)
+{
+  DevAlphaTri rec;
+  rec.a = make_float4(0, 0, 0, 0);
+  rec.b = make_float4(0, 0, 1.0f, 0.5f);
+  rec.c = make_uint4(0, 0, MI_ALPHA_OPAQUE, 0);
+  const int                  rnode = int(__float_as_uint(T.a.w)), prim = int(__float_as_uint(T.b.w));
+  const MiGltfRenderNode&    rn    = sc.nodes[rnode];
+  const MiGltfShadeMaterial& mat   = sc.materials[max(0, rn.materialID)];
+  if(mat.alphaMode == MI_ALPHA_OPAQUE)
+    return rec;
+  const DevPrim rp   = sc.prims[rn.renderPrimID];
+  const u3      ti   = getTriangleIndices(rp, prim);
+  uint32_t      flg  = uint32_t(mat.alphaMode) & AT_MODE_MASK;
+  const bool    sg   = mat.pbrModel == MI_PBR_SPECULAR_GLOSSINESS;
+  const uint16_t slot = sg ? mat.pbrDiffuseTexture : mat.pbrBaseColorTexture;
+  rec.b.z            = sg ? mat.pbrDiffuseFactor[3] : mat.pbrBaseColorFactor[3];
+  rec.b.w            = mat.alphaCutoff;
+  if(isTexturePresent(slot))
+  {
+    const MiGltfTextureInfo info = sc.texInfos[slot];
+    if(info.index >= 0 && info.index < sc.numTextures)
+    {
+      const DevTexture t  = sc.textures[info.index];
+      const float*     tc = info.texCoord == 0 ? rp.texCoords0 : rp.texCoords1;
+      if(tc)
+      {
+        rec.a   = make_float4(tc[2 * size_t(ti.x)], tc[2 * size_t(ti.x) + 1], tc[2 * size_t(ti.y)], tc[2 * size_t(ti.y) + 1]);
+        rec.b.x = tc[2 * size_t(ti.z)];
+        rec.b.y = tc[2 * size_t(ti.z) + 1];
+      }
+      rec.c.x = t.levelOffset[0];
+      rec.c.y = uint32_t(t.width) | (uint32_t(t.height) << 16);
+      flg |= AT_HAS_TEXTURE | (t.magFilter == MI_FILTER_LINEAR ? AT_LINEAR : 0u) | (uint32_t(t.wrapS) << AT_WRAPS_SHIFT) | (uint32_t(t.wrapT) << AT_WRAPT_SHIFT);
+    }
+  }
+  if(rp.colors)
+  {
+    flg |= AT_HAS_COLORS;
+    rec.c.w = (rp.colors[ti.x] >> 24) | ((rp.colors[ti.y] >> 24) << 8) | ((rp.colors[ti.z] >> 24) << 16);
+  }
+  rec.c.z = flg;
+  return rec;
+}
+
 // getShadowTransmission, :244-343
 __device__ __noinline__ f3 getShadowTransmission(const DevScene& sc, int rnode, int triangleID, f3 bary, float hitT, f3 rayDir, bool& isInside)
 {
