@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bvh", type=int, default=0, help="0: 8-wide compressed BVH (default), 1: plain BVH2")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--in-flight", type=int, default=1, help="frames in flight per step (mi_pt_render_frames); bit-identical to sequential frames")
     args = ap.parse_args()
 
     import torch
@@ -135,7 +136,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    runner.render(args.warmup, stream.cuda_stream)
+    F = max(1, args.in_flight)  # a step = one batch of F frames (1 spp each) sharing every wavefront launch
+    runner.render(args.warmup * F, stream.cuda_stream, in_flight=F)
     if dist is not None:  # warm the RCCL path too
         dist.reduce(accum.clone(), dst=0)
     sync_all()
@@ -143,7 +145,7 @@ def main():
     tracer.enable_timing(True)
     sync_all()
     t0 = time.perf_counter()
-    runner.render(args.steps, stream.cuda_stream)
+    runner.render(args.steps * F, stream.cuda_stream, in_flight=F)
     if dist is not None:
         dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # disjoint tiles: sum == gather
     sync_all()
@@ -154,7 +156,7 @@ def main():
         elapsed = float(t.item())
     timing = tracer.frame_timing()
     tracer.enable_timing(False)
-    samples = float(W) * float(H) * float(args.steps)
+    samples = float(W) * float(H) * float(args.steps) * F
     value = samples / elapsed / 1e6
 
     result = None
@@ -164,7 +166,7 @@ def main():
         # counter pass (deterministic: same frames -> same counts) for the algorithmic-bytes model
         ctr = make_tracer(True)
         ctr_runner = ptmod.HeadlessRenderer(ctr, params)
-        n_ctr = min(args.steps, 4)
+        n_ctr = min(args.steps * F, 4)
         ctr_runner.render(n_ctr)
         stats = ctr.stats()
         ctr.close()
@@ -176,7 +178,7 @@ def main():
         launches = max(timing[n_key], 1)
         avg_launch_ms = timing[ms_key] / launches
         # counters were taken on rank 0's tiles; bytes per launch = bytes per frame / launches per frame
-        launches_per_frame = launches / args.steps
+        launches_per_frame = launches / (args.steps * F)
         bytes_per_launch = algorithmic_bytes(per_frame, dominant) / launches_per_frame
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
         traffic = None
@@ -193,7 +195,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": w["config"] + " (seeded synthetic stand-in)" if w["gen"] else w["config"], "scene_triangles": scene.num_triangles,
-                       "resolution": [W, H], "spp_per_step": 1, "max_depth": w["depth"], "tile": 64,
+                       "resolution": [W, H], "spp_per_step": F, "frames_in_flight": F, "max_depth": w["depth"], "tile": 64,
                        "parallelism": f"tiles{world}" if world > 1 else "single"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_launch_ms": round(avg_launch_ms, 5),

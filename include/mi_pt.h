@@ -178,6 +178,15 @@ MI_PT_API int mi_pt_bind_accum(MiPt* pt, void* deviceRGBA32F);
  * stream).  Asynchronous unless counters/timing are being collected. */
 MI_PT_API int mi_pt_render_frame(MiPt* pt, const MiPathtraceParams* params, void* hipStream);
 
+/* Frames in flight: the result (accumulator, guides, depth, selection) is bit-identical to `numFrames` successive
+ * mi_pt_render_frame calls with params->frameCount + f, params->totalSamples + f * numSamples and MI_PT_FIRST_FRAME only
+ * on f = 0 -- i.e. the frames GltfRenderer::onRender / updateFrameCounter would issue one after the other
+ * (reference: src/renderer.cpp:1939-1977, src/renderer_pathtracer.cpp:1401, :1502-1505) -- but their paths share every
+ * wavefront launch, so the short late-bounce queues and the launch overheads are paid once per batch.  Frames only
+ * couple through the running mean, which the finish kernel folds in frame order.  1 <= numFrames <= 64; the path-state
+ * arrays grow (one synchronising reallocation) the first time a larger batch is requested: ~0.3 KB per pixel per frame. */
+MI_PT_API int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames, void* hipStream);
+
 /* Block until everything enqueued by this instance has finished. */
 MI_PT_API int mi_pt_synchronize(MiPt* pt);
 

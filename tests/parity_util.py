@@ -79,7 +79,7 @@ def render_oracle(setup, frames, threads=None, tile=None):
         O.oracle_pt_destroy(o)
 
 
-def render_gpu(setup, frames, collect_counters=True, tile=None, bvh=0):
+def render_gpu(setup, frames, collect_counters=True, tile=None, bvh=0, in_flight=1):
     tracer = ptmod.PathTracer(setup.scene, collect_counters=collect_counters, bvh=bvh)
     try:
         if setup.hdr is not None:
@@ -89,11 +89,16 @@ def render_gpu(setup, frames, collect_counters=True, tile=None, bvh=0):
         tracer.resize(setup.width, setup.height)
         tracer.set_frame_info(setup.frame_info)
         tracer.set_sky(setup.sky)
-        total = 0
-        for f in range(frames):
+        total, f = 0, 0
+        while f < frames:
+            batch = min(in_flight, frames - f)
             p = setup.frame_params(f, total)
-            tracer.render_frame(p)
-            total += p.numSamples
+            if batch == 1:
+                tracer.render_frame(p)
+            else:
+                tracer.render_frames(p, batch)
+            total += p.numSamples * batch
+            f += batch
         out = {"accum": tracer.read_accum(), "depth": tracer.read_depth(), "selection": tracer.read_selection(), "stats": tracer.stats()}
         return out
     finally:

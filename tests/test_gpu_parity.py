@@ -109,6 +109,25 @@ def test_image_independent_of_acceleration_structure(built, tmp_path):
     assert (pu.render_gpu(s, 2, bvh=0)["accum"] == pu.render_gpu(s, 2, bvh=1)["accum"]).all()
 
 
+def test_frames_in_flight_bit_identical(built, assets, tmp_path):
+    """mi_pt_render_frames(F) == F successive mi_pt_render_frame calls, bit for bit (accumulator, depth, selection,
+    counters): ragged batches, multi-sample frames, a tile partition, an alpha/light scene."""
+    hdr = os.path.join(assets, "std_env.hdr")
+    s = pu.Setup(os.path.join(assets, "Box.glb"), 150, 90, max_depth=5, hdr_path=hdr)
+    seq = pu.render_gpu(s, 7)
+    for f in (2, 3, 7):
+        bat = pu.render_gpu(s, 7, in_flight=f)
+        assert (seq["accum"] == bat["accum"]).all() and (seq["depth"] == bat["depth"]).all()
+        assert (seq["selection"] == bat["selection"]).all()
+        for k in ("cameraPaths", "segments", "shadowRays", "textureTaps"):
+            assert seq["stats"][k] == bat["stats"][k]
+    s2 = pu.Setup(os.path.join(assets, "shader_ball.gltf"), 200, 120, max_depth=6, spp_per_frame=3, hdr_path=hdr)
+    assert (pu.render_gpu(s2, 4, tile=(1, 2, 32))["accum"] == pu.render_gpu(s2, 4, tile=(1, 2, 32), in_flight=4)["accum"]).all()
+    path = scenegen.scene_atrium_class(str(tmp_path / "atrium.glb"), seed=5, detail=0.12, tex_size=64)
+    s3 = pu.Setup(path, 160, 96, max_depth=8)
+    assert (pu.render_gpu(s3, 6, bvh=1)["accum"] == pu.render_gpu(s3, 6, bvh=1, in_flight=4)["accum"]).all()
+
+
 def test_furnace_on_gpu(built, tmp_path):
     """The analytic furnace KAT on the device itself: white Lambert sphere in a uniform environment is invisible."""
     path = scenegen.scene_sphere(str(tmp_path / "s.glb"), scenegen.lambert_material((1, 1, 1)), 48, 24)

@@ -103,6 +103,7 @@ struct MiPt
   bool                    haveFrameInfo = false;
   DevBuf<uint32_t>        ownedTiles;
   int                     numSlots = 0, tilesX = 0, tilesY = 0;
+  int                     framesCap = 1;  // frames in flight the path/queue arrays are sized for
   DevBuf<float4>          pathArrays;  // one allocation, sliced into PathSoA
   pt::PathSoA             paths{};
   DevBuf<uint32_t>        queueMem;
@@ -144,18 +145,13 @@ namespace {
 
 size_t align16(size_t v) { return (v + 15u) & ~size_t(15); }
 
-int allocFrameResources(MiPt* pt)
+// Path state and ray queues for `frames` frames in flight (path slot = frame * numSlots + pixel slot).
+int allocPathResources(MiPt* pt, int frames)
 {
-  const int W = pt->width, H = pt->height, T = pt->tileSize;
-  pt->tilesX = (W + T - 1) / T;
-  pt->tilesY = (H + T - 1) / T;
-  std::vector<uint32_t> owned;  // pixel origin x0 | y0 << 16 of every tile this rank renders
-  for(int t = 0; t < pt->tilesX * pt->tilesY; ++t)
-    if(pt->tileWorld <= 1 || (t % pt->tileWorld) == pt->tileRank)
-      owned.push_back(uint32_t((t % pt->tilesX) * T) | (uint32_t((t / pt->tilesX) * T) << 16));
-  pt->numSlots = int(owned.size()) * T * T;
-  HIP_TRY(pt->ownedTiles.upload(owned.data(), owned.size()));
-  const size_t n         = size_t(std::max(pt->numSlots, 1));
+  if(size_t(pt->numSlots) * size_t(frames) >= 0x7fffffffull)
+    return fail(MI_PT_ERR_ARGUMENT, "too many path slots: reduce the frames in flight or the resolution");
+  pt->framesCap          = frames;
+  const size_t n         = std::max(size_t(pt->numSlots) * size_t(frames), size_t(1));
   const int    numArrays = 8;
   HIP_TRY(pt->pathArrays.alloc(n * numArrays));
   float4*      base = pt->pathArrays.ptr;
@@ -179,6 +175,22 @@ int allocFrameResources(MiPt* pt)
   pt->queues.counters = pt->queueMem.ptr + 3 * qsize;
   pt->queues.subCap   = uint32_t(subCap);
   HIP_TRY(hipMemset(pt->queues.counters, 0, sizeof(uint32_t) * pt::QC_COUNT));
+  return MI_PT_OK;
+}
+
+int allocFrameResources(MiPt* pt)
+{
+  const int W = pt->width, H = pt->height, T = pt->tileSize;
+  pt->tilesX = (W + T - 1) / T;
+  pt->tilesY = (H + T - 1) / T;
+  std::vector<uint32_t> owned;  // pixel origin x0 | y0 << 16 of every tile this rank renders
+  for(int t = 0; t < pt->tilesX * pt->tilesY; ++t)
+    if(pt->tileWorld <= 1 || (t % pt->tileWorld) == pt->tileRank)
+      owned.push_back(uint32_t((t % pt->tilesX) * T) | (uint32_t((t / pt->tilesX) * T) << 16));
+  pt->numSlots = int(owned.size()) * T * T;
+  HIP_TRY(pt->ownedTiles.upload(owned.data(), owned.size()));
+  if(int rc = allocPathResources(pt, pt->framesCap))
+    return rc;
   const size_t px = size_t(W) * size_t(H);
   HIP_TRY(pt->accumOwn.alloc(px));
   HIP_TRY(hipMemset(pt->accumOwn.ptr, 0, px * sizeof(float4)));
@@ -533,8 +545,15 @@ int mi_pt_bind_accum(MiPt* pt, void* deviceRGBA32F)
 
 int mi_pt_render_frame(MiPt* pt, const MiPathtraceParams* params, void* hipStream)
 {
+  return mi_pt_render_frames(pt, params, 1, hipStream);
+}
+
+int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames, void* hipStream)
+{
   if(!pt || !params)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_render_frame: null argument");
+  if(numFrames < 1 || numFrames > 64)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_render_frames: 1 <= numFrames <= 64 required");
   if(pt->width <= 0 || !pt->haveFrameInfo)
     return fail(MI_PT_ERR_STATE, "mi_pt_render_frame: call mi_pt_resize and mi_pt_set_frame_info first");
   if(params->numSamples < 1 || params->maxDepth < 0 || params->maxDepth > 255)
@@ -548,6 +567,12 @@ int mi_pt_render_frame(MiPt* pt, const MiPathtraceParams* params, void* hipStrea
   pt->lastStream     = stream;
   if(pt->numSlots == 0)
     return MI_PT_OK;
+  if(numFrames > pt->framesCap)  // grow the path/queue arrays once; later batches of this size reuse them
+  {
+    HIP_TRY(hipDeviceSynchronize());
+    if(int rc = allocPathResources(pt, numFrames))
+      return rc;
+  }
 
   pt::LaunchCtx c;
   c.scene = pt->scene;
@@ -561,7 +586,8 @@ int mi_pt_render_frame(MiPt* pt, const MiPathtraceParams* params, void* hipStrea
   c.fc.tileShift = 0;
   while((1 << c.fc.tileShift) < pt->tileSize)
     ++c.fc.tileShift;
-  c.fc.numSlots = pt->numSlots;
+  c.fc.numSlots  = pt->numSlots;
+  c.fc.numFrames = numFrames;
   c.paths        = pt->paths;
   const bool guides = (params->flags & MI_PT_USE_OPTIX_DENOISER) != 0;
   if(!guides)

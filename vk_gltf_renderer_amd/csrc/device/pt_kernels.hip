@@ -196,19 +196,21 @@ PT_DEV void unpackMedium(uint4 m, f3& ext, f3& sc, float& g)
 __global__ void __launch_bounds__(256) k_generate(DevScene sc, FrameConsts fc, PathSoA P, Queues Q, const uint32_t* ownedTiles, int sampleIndex,
                                                    StatCounters* stats)
 {
-  uint32_t slot  = blockIdx.x * blockDim.x + threadIdx.x;
-  bool     valid = slot < uint32_t(fc.numSlots);
-  int      px = 0, py = 0;
-  float4   genOrg = make_float4(0, 0, 0, 0), genDir = make_float4(0, 0, 0, 0);
+  const uint32_t batchSlots = uint32_t(fc.numSlots) * uint32_t(fc.numFrames);
+  uint32_t       slot       = blockIdx.x * blockDim.x + threadIdx.x;
+  bool           valid      = slot < batchSlots;
+  const uint32_t frame      = slot / uint32_t(fc.numSlots);  // uniform per block: numSlots is a multiple of the block size
+  int            px = 0, py = 0;
+  float4         genOrg = make_float4(0, 0, 0, 0), genDir = make_float4(0, 0, 0, 0);
   if(valid)
-    valid = slotToPixel(fc, ownedTiles, slot, px, py);
+    valid = slotToPixel(fc, ownedTiles, slot - frame * uint32_t(fc.numSlots), px, py);
   if(valid)
   {
     uint32_t seed;
     f2       jitter;
     if(sampleIndex == 0)
     {
-      seed     = xxhash32(uint32_t(px), uint32_t(py), uint32_t(fc.pc.frameCount));
+      seed     = xxhash32(uint32_t(px), uint32_t(py), uint32_t(fc.pc.frameCount) + frame);
       float u1 = rnd(seed), u2 = rnd(seed);
       // sampleGaussian (Box-Muller), pathtrace_functions.h.slang:784-789
       float r     = sqrtf(-2.0f * logf(fmaxf(1e-38f, u1)));
@@ -254,7 +256,7 @@ __global__ void __launch_bounds__(256) k_generate(DevScene sc, FrameConsts fc, P
       atomicAdd(&stats->cameraPaths, 1ull);
   }
   // Queue placement is a pure function of the slot (chunk = slot / QCHUNK goes to sub-queue chunk % NSUB): no atomics.
-  if(slot < uint32_t(fc.numSlots))
+  if(slot < batchSlots)
   {
     const uint32_t chunk = slot / QCHUNK;
     const uint32_t pos   = (chunk % NSUB) * Q.subCap + (chunk / NSUB) * QCHUNK + (slot % QCHUNK);
@@ -267,7 +269,7 @@ __global__ void __launch_bounds__(256) k_generate(DevScene sc, FrameConsts fc, P
   }
   if(blockIdx.x == 0 && threadIdx.x < NSUB)
   {
-    const uint32_t numChunks = uint32_t(fc.numSlots) / QCHUNK;
+    const uint32_t numChunks = batchSlots / QCHUNK;
     Q.counters[QC_ACTIVE0 + threadIdx.x] = QCHUNK * (numChunks / NSUB + (threadIdx.x < numChunks % NSUB ? 1u : 0u));
   }
   if(blockIdx.x == 0 && threadIdx.x < 8)
@@ -1110,65 +1112,89 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_shadow(DevScene sc, PathS
 __global__ void __launch_bounds__(256) k_finish_sample(FrameConsts fc, PathSoA P, const uint32_t* ownedTiles, int sampleIndex, float4* accum, float* depth,
                                                        float4* albedoOut, float4* normalOut)
 {
-  uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-  int      px, py;
-  if(slot >= uint32_t(fc.numSlots) || !slotToPixel(fc, ownedTiles, slot, px, py))
+  // One thread per PIXEL slot; the frames in flight are folded into the running mean in frame order, with exactly the
+  // arithmetic of numFrames successive single-frame dispatches.
+  const uint32_t pslot = blockIdx.x * blockDim.x + threadIdx.x;
+  int            px, py;
+  if(pslot >= uint32_t(fc.numSlots) || !slotToPixel(fc, ownedTiles, pslot, px, py))
     return;
-  const float4   rad4  = P.radiance[slot];
-  const uint32_t flags = __float_as_uint(P.misc[slot].y);
-  const bool     solid = !(flags & PF_NOT_SOLID);
-  f4             r     = mk4(rad4.x, rad4.y, rad4.z, solid ? 1.0f : 0.0f);
-  float          lum   = dot(xyz(r), mk3(1.0f / 3.0f));
-  if(lum > fc.pc.fireflyClampThreshold)
-    r *= fc.pc.fireflyClampThreshold / lum;
-  float4 sum = P.pixelSum[slot];
-  sum        = make_float4(sum.x + r.x, sum.y + r.y, sum.z + r.z, sum.w + r.w);
-  if(sampleIndex + 1 < fc.pc.numSamples)
+  const size_t idx      = size_t(py) * size_t(fc.width) + size_t(px);
+  const bool   lastSample = sampleIndex + 1 >= fc.pc.numSamples;
+  const float  n        = float(fc.pc.numSamples);
+  const bool   guides   = P.guideAlbedo && albedoOut;
+  float4       acc = make_float4(0, 0, 0, 0), accA = acc, accN = acc;
+  bool         loaded = false;
+  for(int f = 0; f < fc.numFrames; ++f)
   {
-    P.pixelSum[slot] = sum;
-    return;
-  }
-  const float  n     = float(fc.pc.numSamples);
-  const f4     pixel = mk4(sum.x, sum.y, sum.z, sum.w) / n;
-  const size_t idx   = size_t(py) * size_t(fc.width) + size_t(px);
-  const bool   firstFrame = hasFlag(fc.pc.flags, MI_PT_FIRST_FRAME);
-  if(firstFrame)
-  {
-    const bool hasSolidHit = r.w > 0.0f;
-    float      ndcDepth    = 1.0f;
-    if(hasSolidHit)
+    const uint32_t slot  = uint32_t(f) * uint32_t(fc.numSlots) + pslot;
+    const float4   rad4  = P.radiance[slot];
+    const uint32_t flags = __float_as_uint(P.misc[slot].y);
+    const bool     solid = !(flags & PF_NOT_SOLID);
+    f4             r     = mk4(rad4.x, rad4.y, rad4.z, solid ? 1.0f : 0.0f);
+    float          lum   = dot(xyz(r), mk3(1.0f / 3.0f));
+    if(lum > fc.pc.fireflyClampThreshold)
+      r *= fc.pc.fireflyClampThreshold / lum;
+    float4 sum = P.pixelSum[slot];
+    sum        = make_float4(sum.x + r.x, sum.y + r.y, sum.z + r.z, sum.w + r.w);
+    if(!lastSample)
     {
-      float4 fh   = P.firstHit[slot];
-      f4     clip = mulFull(fc.frameInfo.viewProjMatrix, mk4(fh.x, fh.y, fh.z, 1.0f));
-      ndcDepth    = clip.z / clip.w;
+      P.pixelSum[slot] = sum;
+      continue;
     }
-    depth[idx] = ndcDepth;
-    accum[idx] = make_float4(pixel.x, pixel.y, pixel.z, pixel.w);
-  }
-  else
-  {
-    const float  tot = float(fc.pc.totalSamples), after = float(fc.pc.totalSamples + fc.pc.numSamples);
-    const float4 old = accum[idx];
-    accum[idx] = make_float4((old.x * tot + pixel.x * n) / after, (old.y * tot + pixel.y * n) / after, (old.z * tot + pixel.z * n) / after,
-                             (old.w * tot + pixel.w * n) / after);
-  }
-  if(P.guideAlbedo && albedoOut)
-  {
-    const float4 ga = P.guideAlbedo[slot], gn = P.guideNormal[slot];
-    const float4 a  = make_float4(ga.x / n, ga.y / n, ga.z / n, r.w > 0.0f ? 1.0f : 0.0f);
-    const float4 nn = make_float4(gn.x / n, gn.y / n, gn.z / n, 0.0f);
+    const f4    pixel      = mk4(sum.x, sum.y, sum.z, sum.w) / n;
+    const bool  firstFrame = f == 0 && hasFlag(fc.pc.flags, MI_PT_FIRST_FRAME);
+    const float tot = float(fc.pc.totalSamples + f * fc.pc.numSamples), after = float(fc.pc.totalSamples + (f + 1) * fc.pc.numSamples);
+    if(!firstFrame && !loaded)
+    {
+      acc = accum[idx];
+      if(guides)
+      {
+        accA = albedoOut[idx];
+        accN = normalOut[idx];
+      }
+    }
+    loaded = true;
     if(firstFrame)
     {
-      albedoOut[idx] = a;
-      normalOut[idx] = nn;
+      const bool hasSolidHit = r.w > 0.0f;
+      float      ndcDepth    = 1.0f;
+      if(hasSolidHit)
+      {
+        float4 fh   = P.firstHit[slot];
+        f4     clip = mulFull(fc.frameInfo.viewProjMatrix, mk4(fh.x, fh.y, fh.z, 1.0f));
+        ndcDepth    = clip.z / clip.w;
+      }
+      depth[idx] = ndcDepth;
+      acc        = make_float4(pixel.x, pixel.y, pixel.z, pixel.w);
     }
     else
+      acc = make_float4((acc.x * tot + pixel.x * n) / after, (acc.y * tot + pixel.y * n) / after, (acc.z * tot + pixel.z * n) / after,
+                        (acc.w * tot + pixel.w * n) / after);
+    if(guides)
     {
-      const float  tot = float(fc.pc.totalSamples), after = float(fc.pc.totalSamples + fc.pc.numSamples);
-      const float  wOld = tot / after, wNew = n / after;
-      const float4 oa = albedoOut[idx], on = normalOut[idx];
-      albedoOut[idx] = make_float4(oa.x * wOld + a.x * wNew, oa.y * wOld + a.y * wNew, oa.z * wOld + a.z * wNew, oa.w * wOld + a.w * wNew);
-      normalOut[idx] = make_float4(on.x * wOld + nn.x * wNew, on.y * wOld + nn.y * wNew, on.z * wOld + nn.z * wNew, 0.0f);
+      const float4 ga = P.guideAlbedo[slot], gn = P.guideNormal[slot];
+      const float4 a  = make_float4(ga.x / n, ga.y / n, ga.z / n, r.w > 0.0f ? 1.0f : 0.0f);
+      const float4 nn = make_float4(gn.x / n, gn.y / n, gn.z / n, 0.0f);
+      if(firstFrame)
+      {
+        accA = a;
+        accN = nn;
+      }
+      else
+      {
+        const float wOld = tot / after, wNew = n / after;
+        accA = make_float4(accA.x * wOld + a.x * wNew, accA.y * wOld + a.y * wNew, accA.z * wOld + a.z * wNew, accA.w * wOld + a.w * wNew);
+        accN = make_float4(accN.x * wOld + nn.x * wNew, accN.y * wOld + nn.y * wNew, accN.z * wOld + nn.z * wNew, 0.0f);
+      }
+    }
+  }
+  if(lastSample)
+  {
+    accum[idx] = acc;
+    if(guides)
+    {
+      albedoOut[idx] = accA;
+      normalOut[idx] = accN;
     }
   }
 }
@@ -1202,7 +1228,7 @@ void launchResetCounters(const Queues& Q, hipStream_t s)
 }
 void launchGenerate(const LaunchCtx& c, int sampleIndex)
 {
-  unsigned grid = (unsigned(c.fc.numSlots) + 255u) / 256u;
+  unsigned grid = (unsigned(c.fc.numSlots) * unsigned(c.fc.numFrames) + 255u) / 256u;
   hipLaunchKernelGGL(k_generate, dim3(grid), dim3(256), 0, c.stream, c.scene, c.fc, c.paths, c.queues, c.ownedTiles, sampleIndex,
                      c.collectCounters ? c.stats : nullptr);
 }

@@ -95,8 +95,8 @@ struct FrameConsts
   MiPathtraceParams       pc;
   int                     width, height;
   int                     tileSize, tileShift;  // tileSize = 1 << tileShift, >= 16
-  int                     numSlots;             // owned tiles * tileSize^2 (a multiple of QCHUNK)
-  int                     _pad;
+  int                     numSlots;             // owned tiles * tileSize^2 (a multiple of QCHUNK): pixel slots of ONE frame
+  int                     numFrames;            // frames in flight; path slot = frame * numSlots + pixel slot
 };
 
 // ---- per-path state, structure of arrays indexed by slot -----------------------------------------------------------------

@@ -151,6 +151,10 @@ class PathTracer:
     def render_frame(self, params, stream=None):
         _check_pt(self._l.mi_pt_render_frame(self._p, C.byref(params), C.c_void_p(stream or 0)))
 
+    def render_frames(self, params, num_frames, stream=None):
+        """num_frames frames in flight; bit-identical to num_frames successive render_frame calls (include/mi_pt.h)."""
+        _check_pt(self._l.mi_pt_render_frames(self._p, C.byref(params), num_frames, C.c_void_p(stream or 0)))
+
     def synchronize(self):
         _check_pt(self._l.mi_pt_synchronize(self._p))
 
@@ -217,8 +221,11 @@ class HeadlessRenderer:
     def reset_frame(self):
         self.frame_count = -1
 
-    def render(self, frames=1, stream=None):
-        for _ in range(frames):
+    def render(self, frames=1, stream=None, in_flight=1):
+        """Advance `frames` frames; in_flight > 1 issues them in batches that share the wavefront launches."""
+        done = 0
+        while done < frames:
+            batch = min(max(1, in_flight), frames - done)
             self.frame_count += 1
             if self.frame_count == 0:
                 self.total_samples = 0
@@ -226,5 +233,10 @@ class HeadlessRenderer:
             p.frameCount = self.frame_count
             p.totalSamples = self.total_samples
             p.flags = (p.flags & ~capi.MI_PT_FIRST_FRAME) | (capi.MI_PT_FIRST_FRAME if self.frame_count == 0 else 0)
-            self.tracer.render_frame(p, stream)
-            self.total_samples += p.numSamples
+            if batch == 1:
+                self.tracer.render_frame(p, stream)
+            else:
+                self.tracer.render_frames(p, batch, stream)
+            self.frame_count += batch - 1
+            self.total_samples += p.numSamples * batch
+            done += batch

@@ -352,7 +352,7 @@ def scene_atrium_class(path, seed=4321, detail=1.0, tex_size=512):
 
     mats = []
     for k in range(22):
-        hue = rng.uniform(0.35, 0.95, 3) * rng.uniform(0.5, 1.0)
+        hue = rng.uniform(0.55, 0.95, 3) * rng.uniform(0.75, 1.0)  # sRGB; ~0.25 linear albedo like scanned stone/fabric
         n = value_noise(rng, tex_size, 5, 3)
         t = tex(np.clip(hue * (0.55 + 0.45 * n), 0, 1))
         m = {"pbrMetallicRoughness": {"baseColorTexture": {"index": t}, "metallicFactor": float(rng.random() < 0.15),
