@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--bvh", type=int, default=0, help="0: 8-wide compressed BVH (default), 1: plain BVH2")
+    ap.add_argument("--bvh", type=int, default=0, help="bit0: 0 = 8-wide compressed BVH (default), 1 = plain BVH2; bit1: 0 = PLOC topology (default), 1 = LBVH")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--in-flight", type=int, default=1, help="frames in flight per step (mi_pt_render_frames); bit-identical to sequential frames")
     args = ap.parse_args()

@@ -105,7 +105,8 @@ typedef struct MiPtCreateOptions
 {
   int device;          /* HIP device ordinal */
   int collectCounters; /* 1: kernels export traversal/shading counters (slower) */
-  int bvhBuilder;      /* 0 = default: device LBVH collapsed to the 8-wide compressed BVH; 1 = plain BVH2 (A/B, tests) */
+  int bvhBuilder;      /* bit 0: 0 = 8-wide compressed BVH (default), 1 = plain BVH2 (A/B, tests);
+                        * bit 1: 0 = PLOC clustering over the Morton order (default), 1 = Karras LBVH topology (A/B) */
   int reserved[5];
 } MiPtCreateOptions;
 

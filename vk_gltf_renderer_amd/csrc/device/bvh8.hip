@@ -22,6 +22,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 #include "pt_build.h"
@@ -110,13 +111,13 @@ bool buildBvh8(const BvhBuildOutput& b2, Bvh8Output& out, hipStream_t stream, st
       lo[0] = n1.x; hi[0] = n1.y; lo[1] = n1.z; hi[1] = n1.w; lo[2] = n2.z; hi[2] = n2.w;
     }
   };
-  // ---- subtree triangle counts / first triangle (LBVH subtrees cover contiguous ranges of the sorted triangles) ----------
-  std::vector<uint32_t> cnt(numInner, 0), first(numInner, 0);
+  // ---- subtree triangle counts ---------------------------------------------------------------------------------------------
+  std::vector<uint32_t> cnt(numInner, 0);
   if(numInner)
   {
     std::vector<int> order;  // pre-order; children have larger positions than parents
     order.reserve(numInner);
-    std::vector<int> stack{0};
+    std::vector<int> stack{b2.root};
     while(!stack.empty())
     {
       int v = stack.back();
@@ -132,27 +133,26 @@ bool buildBvh8(const BvhBuildOutput& b2, Bvh8Output& out, hipStream_t stream, st
     for(size_t k = order.size(); k-- > 0;)
     {
       int      v = order[k];
-      uint32_t c = 0, f = 0xffffffffu;
+      uint32_t c = 0;
       for(int w = 0; w < 2; ++w)
       {
         int r = childRef(v, w);
-        if(r >= 0)
-        {
-          c += cnt[size_t(r)];
-          f = std::min(f, first[size_t(r)]);
-        }
-        else
-        {
-          c += 1;
-          f = std::min(f, uint32_t(~r));
-        }
+        c += r >= 0 ? cnt[size_t(r)] : 1u;
       }
-      cnt[size_t(v)]   = c;
-      first[size_t(v)] = f;
+      cnt[size_t(v)] = c;
     }
   }
   auto triCount = [&](int ref) { return ref >= 0 ? cnt[size_t(ref)] : 1u; };
-  auto triFirst = [&](int ref) { return ref >= 0 ? first[size_t(ref)] : uint32_t(~ref); };
+  // triangles below a (small) subtree, left to right
+  std::function<void(int, std::vector<uint32_t>&)> collectTris = [&](int ref, std::vector<uint32_t>& dst) {
+    if(ref < 0)
+    {
+      dst.push_back(uint32_t(~ref));
+      return;
+    }
+    collectTris(childRef(ref, 0), dst);
+    collectTris(childRef(ref, 1), dst);
+  };
 
   // ---- breadth-first collapse ----------------------------------------------------------------------------------------
   std::vector<Node8>    nodes8;
@@ -187,8 +187,8 @@ bool buildBvh8(const BvhBuildOutput& b2, Bvh8Output& out, hipStream_t stream, st
       for(int k = 0; k < 2; ++k)
       {
         Cand c;
-        c.ref = childRef(0, k);
-        childBox(0, k, c.lo, c.hi);
+        c.ref = childRef(b2.root, k);
+        childBox(b2.root, k, c.lo, c.hi);
         w.cands.push_back(c);
       }
     queue.push_back(std::move(w));
@@ -335,11 +335,10 @@ bool buildBvh8(const BvhBuildOutput& b2, Bvh8Output& out, hipStream_t stream, st
       }
       else
       {
-        uint32_t count  = triCount(c.ref), f = triFirst(c.ref);
+        uint32_t count  = triCount(c.ref);
         uint32_t offset = uint32_t(perm.size()) - N.triBase;
         N.meta[s]       = uint8_t((count << 5) | offset);
-        for(uint32_t k = 0; k < count; ++k)
-          perm.push_back(f + k);
+        collectTris(c.ref, perm);
       }
     }
     nodes8[self] = N;

@@ -396,6 +396,7 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
     HIP_TRY(dOffset.upload(triOffset.data(), triOffset.size()));
     HIP_TRY(dEntry.upload(entryNode.data(), entryNode.size()));
     pt::BvhBuildInput in{pt->nodes.ptr, pt->prims.ptr, pt->instFlags.ptr, dOffset.ptr, dEntry.ptr, int(entryNode.size()), uint32_t(totalTris)};
+    in.karrasTopology = options && (options->bvhBuilder & 2) != 0;
     pt::BvhBuildOutput bo;
     std::string        err;
     if(!pt::buildBvh(in, bo, nullptr, err))
@@ -408,7 +409,7 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
     pt->staticStats.bvhTriangleCount = bo.numTris;
     pt->staticStats.bvhNodeBytes     = 64;
     pt->staticStats.bvhTriangleBytes = sizeof(pt::DevTri);
-    pt->wide = !(options && options->bvhBuilder == 1);
+    pt->wide = !(options && (options->bvhBuilder & 1) != 0);
     if(pt->wide && bo.numTris > 0)
     {
       pt::Bvh8Output b8;

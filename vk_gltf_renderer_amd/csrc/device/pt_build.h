@@ -17,11 +17,12 @@ struct BvhBuildInput
   const int32_t*          entryNode;      // device, numEntries
   int                     numEntries;
   uint32_t                numTris;
+  bool                    karrasTopology = false;  // true: plain LBVH (Morton-prefix hierarchy); false: PLOC clustering
 };
 struct BvhBuildOutput
 {
   float4*  nodes    = nullptr;  // device, 4 float4 per node
-  DevTri*  tris     = nullptr;  // device, Morton order
+  DevTri*  tris     = nullptr;  // device, Morton order (leaf reference ~i = triangle i of this array)
   uint32_t numNodes = 0, numTris = 0;
   int      root     = 0;
   float    centroidLo[3] = {0, 0, 0}, centroidHi[3] = {0, 0, 0};
