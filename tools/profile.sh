@@ -8,7 +8,7 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 run() { # name, rocprof args...
   local name=$1; shift
-  ( cd /tmp && timeout 300 rocprofv3 "$@" --output-format csv -d "$out/$name" -- python "$OLDPWD/bench.py" "${BENCH_ARGS[@]}" > "$out/$name.log" 2>&1 )
+  ( cd /tmp && timeout 90 rocprofv3 "$@" --output-format csv -d "$out/$name" -- python "$OLDPWD/bench.py" "${BENCH_ARGS[@]}" > "$out/$name.log" 2>&1 )
 }
 BENCH_ARGS=("$@" --no-cpu-baseline)
 run stats --kernel-trace --stats

@@ -422,6 +422,7 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
       pt->bvhTris   = b8.tris;
       pt->bvh8Nodes = b8.nodes;
       pt->scene.bvhRoot = 0;
+      pt->scene.bvh8NumNodes = int(b8.numNodes);
       pt->staticStats.bvhNodeCount = b8.numNodes;
       pt->staticStats.bvhNodeBytes = 80;
     }
@@ -460,6 +461,7 @@ int mi_pt_destroy(MiPt* pt)
     return MI_PT_OK;
   (void)hipSetDevice(pt->device);
   (void)hipDeviceSynchronize();
+  pt::dumpTraceProfile();
   delete pt;
   return MI_PT_OK;
 }

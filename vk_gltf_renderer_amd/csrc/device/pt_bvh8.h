@@ -55,9 +55,9 @@ struct LaneStack2
   }
 };
 
-PT_DEV uint32_t rayOctInv(f3 dir)
+PT_DEV uint32_t rayOctInv(f3 idir)  // pass RaySetup::idir (sign well defined for -0.0 components)
 {
-  uint32_t oct = (dir.x < 0.0f ? 1u : 0u) | (dir.y < 0.0f ? 2u : 0u) | (dir.z < 0.0f ? 4u : 0u);
+  uint32_t oct = (idir.x < 0.0f ? 1u : 0u) | (idir.y < 0.0f ? 2u : 0u) | (idir.z < 0.0f ? 4u : 0u);
   return 7u ^ oct;
 }
 // The root is "a group with one inner child in slot 0".
@@ -81,47 +81,64 @@ PT_DEV uint32_t groupPopChild(NodeGroup& g, uint32_t octinv)
 
 PT_DEV float byteF(uint32_t w, int i) { return float((w >> (8 * i)) & 0xffu); }  // v_cvt_f32_ubyteN
 
-// One node visit.  Boxes decode as fmaf(q, 2^e, p) (identical to the builder's containment check) and are slab-tested
-// exactly like the BVH2 boxes, widened by a few ulps.
+// One node visit.  The builder guarantees that the decoded boxes fmaf(q, 2^e, p) contain their triangles.  Here every slab
+// plane costs ONE fma: t = q * A + B with A = 2^e / dir and B = (p - org -/+ delta) / dir per axis and per node, the near
+// planes pulled towards the ray's origin and the far planes pushed away by delta = 2^-21 (|p - org| + 255 * 2^e), which
+// bounds the accumulated rounding of p - org, of the two products and of the fma -- so the test stays conservative
+// without a multiplicative fudge, including the cancellation case of an origin inside the node.
+// Nodes below index `cached` are read from the workgroup's LDS copy (ldsNodes), the rest from global memory.
 PT_DEV void bvh8Visit(const DevScene& sc, const RaySetup& r, float tmax, uint32_t octinv, uint32_t nodeIndex, NodeGroup& outGroup, uint32_t& triBase,
-                      uint32_t& triMask)
+                      uint32_t& triMask, const uint4* ldsNodes, uint32_t cached)
 {
-  const uint4* N  = sc.bvh8Nodes + size_t(nodeIndex) * 5;
-  const uint4  n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3], n4 = N[4];
-  const float  px = __uint_as_float(n0.x), py = __uint_as_float(n0.y), pz = __uint_as_float(n0.z);
+  uint4 n0, n1, n2, n3, n4;
+  if(nodeIndex < cached)
+  {
+    const uint4* N = ldsNodes + nodeIndex * 5u;
+    n0 = N[0]; n1 = N[1]; n2 = N[2]; n3 = N[3]; n4 = N[4];
+  }
+  else
+  {
+    const uint4* N = sc.bvh8Nodes + size_t(nodeIndex) * 5;
+    n0 = N[0]; n1 = N[1]; n2 = N[2]; n3 = N[3]; n4 = N[4];
+  }
   const float  sx = __uint_as_float((n0.w & 0xffu) << 23), sy = __uint_as_float(((n0.w >> 8) & 0xffu) << 23), sz = __uint_as_float(((n0.w >> 16) & 0xffu) << 23);
   const uint32_t imask = n0.w >> 24;
-  // near / far byte planes per axis, chosen by the ray's direction sign
-  const bool nx = r.dir.x < 0.0f, ny = r.dir.y < 0.0f, nz = r.dir.z < 0.0f;
-  const uint32_t qlx[2] = {n2.x, n2.y}, qly[2] = {n2.z, n2.w}, qlz[2] = {n3.x, n3.y}, qhx[2] = {n3.z, n3.w}, qhy[2] = {n4.x, n4.y}, qhz[2] = {n4.z, n4.w};
+  const float  Px = __uint_as_float(n0.x) - r.org.x, Py = __uint_as_float(n0.y) - r.org.y, Pz = __uint_as_float(n0.z) - r.org.z;
+  const float  k  = 4.76837158e-7f;  // 2^-21
+  const float  dx = __fmaf_rn(255.0f, sx, fabsf(Px)) * k, dy = __fmaf_rn(255.0f, sy, fabsf(Py)) * k, dz = __fmaf_rn(255.0f, sz, fabsf(Pz)) * k;
+  // a negative direction enters through the upper plane (the sign is idir's: it is well defined for -0.0 as well)
+  const bool   nx = r.idir.x < 0.0f, ny = r.idir.y < 0.0f, nz = r.idir.z < 0.0f;
+  const float  Ax = sx * r.idir.x, Ay = sy * r.idir.y, Az = sz * r.idir.z;
+  const float  Bnx = (nx ? Px + dx : Px - dx) * r.idir.x, Bfx = (nx ? Px - dx : Px + dx) * r.idir.x;
+  const float  Bny = (ny ? Py + dy : Py - dy) * r.idir.y, Bfy = (ny ? Py - dy : Py + dy) * r.idir.y;
+  const float  Bnz = (nz ? Pz + dz : Pz - dz) * r.idir.z, Bfz = (nz ? Pz - dz : Pz + dz) * r.idir.z;
+  // near / far byte planes per axis (4 children per word), chosen once per node by the direction sign
+  const uint32_t qnx[2] = {nx ? n3.z : n2.x, nx ? n3.w : n2.y}, qfx[2] = {nx ? n2.x : n3.z, nx ? n2.y : n3.w};
+  const uint32_t qny[2] = {ny ? n4.x : n2.z, ny ? n4.y : n2.w}, qfy[2] = {ny ? n2.z : n4.x, ny ? n2.w : n4.y};
+  const uint32_t qnz[2] = {nz ? n4.z : n3.x, nz ? n4.w : n3.y}, qfz[2] = {nz ? n3.x : n4.z, nz ? n3.y : n4.w};
   const uint32_t meta[2] = {n1.z, n1.w};
-  uint32_t       hits = 0, tmask = 0;
+  uint32_t       hm = 0, tmask = 0;  // hm: hit children, SLOT space
 #pragma unroll
   for(int i = 0; i < 8; ++i)
   {
     const int      w = i >> 2, b = i & 3;
     const uint32_t m = (meta[w] >> (8 * b)) & 0xffu;
-    const float lox = __fmaf_rn(byteF(qlx[w], b), sx, px), hix = __fmaf_rn(byteF(qhx[w], b), sx, px);
-    const float loy = __fmaf_rn(byteF(qly[w], b), sy, py), hiy = __fmaf_rn(byteF(qhy[w], b), sy, py);
-    const float loz = __fmaf_rn(byteF(qlz[w], b), sz, pz), hiz = __fmaf_rn(byteF(qhz[w], b), sz, pz);
-    const float tx0 = ((nx ? hix : lox) - r.org.x) * r.idir.x, tx1 = ((nx ? lox : hix) - r.org.x) * r.idir.x;
-    const float ty0 = ((ny ? hiy : loy) - r.org.y) * r.idir.y, ty1 = ((ny ? loy : hiy) - r.org.y) * r.idir.y;
-    const float tz0 = ((nz ? hiz : loz) - r.org.z) * r.idir.z, tz1 = ((nz ? loz : hiz) - r.org.z) * r.idir.z;
-    const float tn  = fmaxf(fmaxf(tx0, ty0), fmaxf(tz0, 0.0f));
-    const float tf  = fminf(fminf(tx1, ty1), fminf(tz1, tmax));
-    const bool  hit = (m != 0u) && (tn <= tf * 1.0000012f + 1e-30f);
-    if(hit)
-    {
-      if((imask >> i) & 1u)
-        hits |= 1u << (uint32_t(i) ^ octinv);
-      else
-        tmask |= ((1u << (m >> 5)) - 1u) << (m & 31u);
-    }
+    const float tn = fmaxf(fmaxf(__fmaf_rn(byteF(qnx[w], b), Ax, Bnx), __fmaf_rn(byteF(qny[w], b), Ay, Bny)), fmaxf(__fmaf_rn(byteF(qnz[w], b), Az, Bnz), 0.0f));
+    const float tf = fminf(fminf(__fmaf_rn(byteF(qfx[w], b), Ax, Bfx), __fmaf_rn(byteF(qfy[w], b), Ay, Bfy)), fminf(__fmaf_rn(byteF(qfz[w], b), Az, Bfz), tmax));
+    const bool  hit = (m != 0u) && (tn <= tf);
+    hm |= hit ? (1u << i) : 0u;
+    tmask |= hit ? (((1u << (m >> 5)) - 1u) << (m & 31u)) : 0u;  // inner children carry meta 0xff: masked out below
   }
+  // leaf children of this node own triangle bits [0, 24); inner ones produced garbage above bit 24 at most: 0xff -> 127 << 31
+  uint32_t hits = hm & imask;
+  // slot space -> priority space: bit p = slot ^ octinv, a butterfly on the three index bits
+  hits = (octinv & 1u) ? (((hits & 0x55u) << 1) | ((hits & 0xaau) >> 1)) : hits;
+  hits = (octinv & 2u) ? (((hits & 0x33u) << 2) | ((hits & 0xccu) >> 2)) : hits;
+  hits = (octinv & 4u) ? (((hits & 0x0fu) << 4) | ((hits & 0xf0u) >> 4)) : hits;
   outGroup.base = n1.x;
   outGroup.bits = (hits << 8) | imask;
   triBase       = n1.y;
-  triMask       = tmask;
+  triMask       = tmask & 0x7fffffffu;
 }
 
 }  // namespace pt

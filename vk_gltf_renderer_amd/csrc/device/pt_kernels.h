@@ -22,6 +22,7 @@ struct LaunchCtx
 };
 
 void launchBuildAlphaRecords(const DevScene& scene, uint32_t numTris, DevAlphaTri* out, hipStream_t s);
+void dumpTraceProfile();  // prints the -DTRACE_PROFILE section timers (no-op in the product build)
 void launchResetCounters(const Queues& Q, hipStream_t s);
 void launchGenerate(const LaunchCtx& c, int sampleIndex);
 void launchTraceClosest(const LaunchCtx& c, int cur);

@@ -15,7 +15,14 @@ namespace pt {
 
 namespace {
 
-constexpr int TRACE_BLOCK = 256;
+// One trace workgroup per CU: 16 waves share one LDS copy of the top of the 8-wide BVH (the first nodes of the BFS-ordered
+// node array), next to the per-lane traversal stacks.  96 KiB of stacks + 60 KiB of nodes of the CU's 160 KiB.
+constexpr int TRACE_BLOCK = 1024;
+constexpr int NODE_CACHE  = 768;  // BVH8 nodes (80 B each) resident in LDS
+constexpr int SEL_BLOCK   = 256;
+#ifndef TRACE_MIN_WAVES
+#define TRACE_MIN_WAVES 1
+#endif
 constexpr int SHADE_BLOCK = 256;
 
 // ---- queues ------------------------------------------------------------------------------------------------------------------
@@ -279,8 +286,31 @@ __global__ void __launch_bounds__(256) k_generate(DevScene sc, FrameConsts fc, P
 //================================================================================================================================
 // k_trace_closest: RayQueryRaytracer::Trace (raytracer_interface.h.slang:69-122) on the software BVH
 //================================================================================================================================
+#ifdef TRACE_PROFILE
+// Diagnostics build only (-DTRACE_PROFILE): shader-clock ticks per wave spent in the sections of k_trace_closest.
+__device__ unsigned long long g_traceProf[8];
+#define PROF_T() __builtin_amdgcn_s_memtime()
+#define PROF_ADD(i, t0) profAcc[i] += PROF_T() - (t0)
+#else
+#define PROF_T() 0ull
+#define PROF_ADD(i, t0) (void)(t0)
+#endif
+
 // Refill policy of the persistent trace waves: go back for new rays once this many lanes of the wave are idle.
 constexpr int REFILL_IDLE_LANES = 16;
+// Dense triangle phase of the 8-wide walk: start once this many lanes have parked triangles, leave below the exit count.
+constexpr int TRI_PHASE_LANES      = 24;
+constexpr int TRI_PHASE_EXIT_LANES = 10;
+
+// Copies the top of the 8-wide BVH into this workgroup's LDS (whole block; contains a barrier).
+PT_DEV uint32_t fillNodeCache(const DevScene& sc, uint4* s_nodes)
+{
+  const uint32_t n = min(uint32_t(sc.bvh8NumNodes), uint32_t(NODE_CACHE));
+  for(uint32_t i = threadIdx.x; i < n * 5u; i += blockDim.x)
+    s_nodes[i] = sc.bvh8Nodes[i];
+  __syncthreads();
+  return n;
+}
 
 // Closest-hit candidate test shared by both BVH flavours: deterministic tie-break, object-space back-face culling,
 // stochastic alpha (raytracer_interface.h.slang:76-111).
@@ -321,10 +351,12 @@ PT_DEV void closestTestTriangle(const DevScene& sc, const RaySetup& r, int triIn
 }
 
 template <bool WIDE, bool HAS_ALPHA, bool COUNT>
-__global__ void __launch_bounds__(TRACE_BLOCK) k_trace_closest(DevScene sc, PathSoA P, Queues Q, int cur, StatCounters* stats)
+__global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(DevScene sc, PathSoA P, Queues Q, int cur, StatCounters* stats)
 {
   __shared__ int      s_stack[BVH_STACK_LDS * TRACE_BLOCK];  // BVH2: 24 ints/lane; BVH8: 12 node groups x 2 ints/lane
   __shared__ uint32_t s_prefix[NSUB + 1];
+  __shared__ uint4    s_nodes[WIDE ? NODE_CACHE * 5 : 1];
+
   static_assert(2 * BVH8_STACK_LDS == BVH_STACK_LDS, "both stack flavours share one LDS allocation");
   if(blockIdx.x == 0 && threadIdx.x < NSUB)
   {
@@ -340,6 +372,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_closest(DevScene sc, Path
   feedInit(feed, s_prefix[NSUB]);
   if(!feedBlockHasWork(feed))
     return;
+  const uint32_t cachedNodes = WIDE ? fillNodeCache(sc, s_nodes) : 0u;
   LaneStack  st;   // BVH2 walk state
   LaneStack2 st2;  // BVH8 walk state
   st.lds = s_stack;  st.tid = int(threadIdx.x);  st.stride = TRACE_BLOCK;  st.sp = 0;
@@ -350,6 +383,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_closest(DevScene sc, Path
   int         node = BVH_EMPTY;
   NodeGroup   G{0, 0};
   uint32_t    octinv = 0;
+  uint32_t    pBase = 0, pMask = 0, qBase = 0, qMask = 0;  // parked leaf hits (8-wide walk): triangle base + bit mask
   ClosestBest best{INFINITE_F, 0.0f, 0.0f, -1, 0xffffffffu, 0xffffffffu};
   uint32_t    seed0 = 0;
   bool        seedLoaded = false;
@@ -358,8 +392,13 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_closest(DevScene sc, Path
   bool     pValid = false;
   uint32_t pPos = 0, pSlot = QUEUE_DEAD;
   float4   pO = make_float4(0, 0, 0, 0), pD = make_float4(0, 0, 0, 0);
+#ifdef TRACE_PROFILE
+  unsigned long long profAcc[4] = {0, 0, 0, 0};
+  const unsigned long long profStart = PROF_T();
+#endif
   for(;;)
   {
+    const unsigned long long tFeed = PROF_T();
     // ---- idle lanes start their prefetched ray; every lane without a prefetched ray takes the next queue index
     if(!active && pValid)
     {
@@ -373,7 +412,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_closest(DevScene sc, Path
         seedLoaded = false;
         if(WIDE)
         {
-          octinv = rayOctInv(r.dir);
+          octinv = rayOctInv(r.idir);
           G      = rootGroup(octinv);
           st2.sp = 0;
         }
@@ -407,13 +446,19 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_closest(DevScene sc, Path
         break;
       continue;
     }
+    PROF_ADD(0, tFeed);
     // ---- walk until enough lanes have finished to make a refill worthwhile
     for(;;)
     {
-      if(active)
+      if(WIDE)
       {
-        bool finished = false;
-        if(WIDE)
+        const unsigned long long tNode = PROF_T();
+        // Node step: lanes with room for one more leaf record visit their next node.  Triangles are NOT tested here: a
+        // memory instruction costs the CU's address unit the same 64 lane-slots whether 3 or 64 lanes are active, and
+        // straight after a node visit only a few lanes have triangles.  The hits are parked (two records per lane) and
+        // tested in a dense phase once enough lanes have some; the closest hit does not depend on the test order.
+        bool visited = false;
+        if(active && qMask == 0u)
         {
           if((G.bits >> 8) == 0u && st2.sp > 0)
             G = st2.pop();
@@ -423,35 +468,63 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_closest(DevScene sc, Path
             if(G.bits >> 8)
               st2.push(G);
             uint32_t tBase, tMask;
-            bvh8Visit(sc, r, best.t, octinv, child, G, tBase, tMask);
+            bvh8Visit(sc, r, best.t, octinv, child, G, tBase, tMask, s_nodes, cachedNodes);
             if(COUNT) ++nodes;
-            while(tMask)
+            visited = true;
+            if(tMask)
             {
-              const int k = __ffs(int(tMask)) - 1;
-              tMask &= tMask - 1u;
-              if(COUNT) ++tris;
-              closestTestTriangle<HAS_ALPHA>(sc, r, int(tBase) + k, best, seed0, seedLoaded, P.misc, slot);
+              if(pMask == 0u) { pBase = tBase; pMask = tMask; }
+              else            { qBase = tBase; qMask = tMask; }
             }
           }
-          finished = (G.bits >> 8) == 0u && st2.sp == 0;
         }
-        else
+        PROF_ADD(1, tNode);
+        const unsigned long long tTri = PROF_T();
+        unsigned long long pend = __ballot(active && pMask != 0u);
+        if(pend != 0ull)
         {
-          // inner nodes first (bounded), so that most lanes arrive at a leaf together
-#pragma unroll 1
-          for(int k = 0; k < 4 && node >= 0; ++k)
+          const int  visiting = __popcll(__ballot(visited));
+          const bool drain    = visiting < TRI_PHASE_LANES;  // few lanes left walking: nothing to wait for
+          if(drain || __popcll(pend) >= TRI_PHASE_LANES || __ballot(active && qMask != 0u) != 0ull)
           {
-            node = bvhInnerStep(sc, r, best.t, node, st);
-            if(COUNT) ++nodes;
+            do
+            {
+              if(active && pMask != 0u)
+              {
+                const int k = __ffs(int(pMask)) - 1;
+                pMask &= pMask - 1u;
+                if(COUNT) ++tris;
+                closestTestTriangle<HAS_ALPHA>(sc, r, int(pBase) + k, best, seed0, seedLoaded, P.misc, slot);
+                if(pMask == 0u) { pBase = qBase; pMask = qMask; qMask = 0u; }
+              }
+              pend = __ballot(active && pMask != 0u);
+            } while(pend != 0ull && (drain || __popcll(pend) >= TRI_PHASE_EXIT_LANES || __ballot(active && qMask != 0u) != 0ull));
           }
-          if(node < 0 && node != BVH_EMPTY)
-          {
-            if(COUNT) ++tris;
-            closestTestTriangle<HAS_ALPHA>(sc, r, ~node, best, seed0, seedLoaded, P.misc, slot);
-            node = bvhPop(st);
-          }
-          finished = node == BVH_EMPTY;
         }
+        PROF_ADD(2, tTri);
+        if(active && pMask == 0u && (G.bits >> 8) == 0u && st2.sp == 0)
+        {
+          in.aux[pos] = make_float4(best.t, __int_as_float(best.tri), best.u, best.v);
+          active      = false;
+        }
+      }
+      else if(active)
+      {
+        bool finished = false;
+        // inner nodes first (bounded), so that most lanes arrive at a leaf together
+#pragma unroll 1
+        for(int k = 0; k < 4 && node >= 0; ++k)
+        {
+          node = bvhInnerStep(sc, r, best.t, node, st);
+          if(COUNT) ++nodes;
+        }
+        if(node < 0 && node != BVH_EMPTY)
+        {
+          if(COUNT) ++tris;
+          closestTestTriangle<HAS_ALPHA>(sc, r, ~node, best, seed0, seedLoaded, P.misc, slot);
+          node = bvhPop(st);
+        }
+        finished = node == BVH_EMPTY;
         if(finished)
         {
           in.aux[pos] = make_float4(best.t, __int_as_float(best.tri), best.u, best.v);
@@ -463,6 +536,16 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_closest(DevScene sc, Path
         break;
     }
   }
+#ifdef TRACE_PROFILE
+  if(laneId() == 0)
+  {
+    atomicAdd(&g_traceProf[0], profAcc[0]);
+    atomicAdd(&g_traceProf[1], profAcc[1]);
+    atomicAdd(&g_traceProf[2], profAcc[2]);
+    atomicAdd(&g_traceProf[3], PROF_T() - profStart);
+    atomicAdd(&g_traceProf[4], 1ull);
+  }
+#endif
   if(COUNT)
   {
     atomicAdd(&stats->segments, (unsigned long long)rays);
@@ -475,9 +558,9 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_closest(DevScene sc, Path
 // k_selection: traceSelectionRay / TraceLow (pathtrace_functions.h.slang:813-820, raytracer_interface.h.slang:124-137)
 //================================================================================================================================
 template <bool WIDE>
-__global__ void __launch_bounds__(TRACE_BLOCK) k_selection(DevScene sc, FrameConsts fc, const uint32_t* ownedTiles, uint32_t* selection)
+__global__ void __launch_bounds__(SEL_BLOCK) k_selection(DevScene sc, FrameConsts fc, const uint32_t* ownedTiles, uint32_t* selection)
 {
-  __shared__ int s_stack[BVH_STACK_LDS * TRACE_BLOCK];
+  __shared__ int s_stack[BVH_STACK_LDS * SEL_BLOCK];
   uint32_t       slot = blockIdx.x * blockDim.x + threadIdx.x;
   int            px, py;
   if(slot >= uint32_t(fc.numSlots) || !slotToPixel(fc, ownedTiles, slot, px, py))
@@ -504,8 +587,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_selection(DevScene sc, FrameCon
     if(WIDE)
     {
       LaneStack2 st2;
-      st2.lds = s_stack; st2.tid = int(threadIdx.x); st2.stride = TRACE_BLOCK; st2.sp = 0;
-      const uint32_t octinv = rayOctInv(r.dir);
+      st2.lds = s_stack; st2.tid = int(threadIdx.x); st2.stride = SEL_BLOCK; st2.sp = 0;
+      const uint32_t octinv = rayOctInv(r.idir);
       NodeGroup      G      = rootGroup(octinv);
       for(;;)
       {
@@ -519,7 +602,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_selection(DevScene sc, FrameCon
         if(G.bits >> 8)
           st2.push(G);
         uint32_t tBase, tMask;
-        bvh8Visit(sc, r, bestT, octinv, child, G, tBase, tMask);
+        bvh8Visit(sc, r, bestT, octinv, child, G, tBase, tMask, nullptr, 0u);
         while(tMask)
         {
           const int k = __ffs(int(tMask)) - 1;
@@ -531,7 +614,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_selection(DevScene sc, FrameCon
     else
     {
       LaneStack st;
-      st.lds = s_stack; st.tid = int(threadIdx.x); st.stride = TRACE_BLOCK; st.sp = 0;
+      st.lds = s_stack; st.tid = int(threadIdx.x); st.stride = SEL_BLOCK; st.sp = 0;
       bvhWalk(sc, r, bestT, st, [&](int triIndex, float) -> float {
         testTri(triIndex);
         return bestT;
@@ -865,16 +948,18 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, FrameConsts 
 // k_trace_shadow: RayQueryRaytracer::TraceShadow (raytracer_interface.h.slang:139-187) + `pt.radiance += contribution * T`
 //================================================================================================================================
 template <bool WIDE, bool HAS_ALPHA, bool COUNT>
-__global__ void __launch_bounds__(TRACE_BLOCK) k_trace_shadow(DevScene sc, PathSoA P, Queues Q, StatCounters* stats)
+__global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_shadow(DevScene sc, PathSoA P, Queues Q, StatCounters* stats)
 {
   __shared__ int      s_stack[BVH_STACK_LDS * TRACE_BLOCK];
   __shared__ uint32_t s_prefix[NSUB + 1];
+  __shared__ uint4    s_nodes[WIDE ? NODE_CACHE * 5 : 1];
   queuePrefix(&Q.counters[QC_SHADOW], s_prefix);
   const RayQueue in = Q.shadow;
   WaveFeed feed;
   feedInit(feed, s_prefix[NSUB]);
   if(!feedBlockHasWork(feed))
     return;
+  const uint32_t cachedNodes = WIDE ? fillNodeCache(sc, s_nodes) : 0u;
   LaneStack  st;
   LaneStack2 st2;
   st.lds = s_stack;  st.tid = int(threadIdx.x);  st.stride = TRACE_BLOCK;  st.sp = 0;
@@ -972,7 +1057,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_shadow(DevScene sc, PathS
         haveLast = false;
         found    = false;
         prevHitT = 0.0f;
-        octinv   = rayOctInv(r.dir);
+        octinv   = rayOctInv(r.idir);
         restartWalk();
         active = true;
         if(COUNT) ++rays;
@@ -1021,7 +1106,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_shadow(DevScene sc, PathS
             if(G.bits >> 8)
               st2.push(G);
             uint32_t tBase, tMask;
-            bvh8Visit(sc, r, walkTmax, octinv, child, G, tBase, tMask);
+            bvh8Visit(sc, r, walkTmax, octinv, child, G, tBase, tMask, s_nodes, cachedNodes);
             if(COUNT) ++nodes;
             while(tMask && !occluded)
             {
@@ -1222,6 +1307,17 @@ void launchBuildAlphaRecords(const DevScene& scene, uint32_t numTris, DevAlphaTr
   if(numTris)
     hipLaunchKernelGGL(k_alpha_records, dim3((numTris + 255) / 256), dim3(256), 0, s, scene, numTris, out);
 }
+void dumpTraceProfile()
+{
+#ifdef TRACE_PROFILE
+  unsigned long long h[8] = {};
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_traceProf), sizeof(h));
+  const double tot = double(h[3]) > 0 ? double(h[3]) : 1.0;
+  fprintf(stderr, "[mi_pt trace profile] waves %llu total ticks %.4g: feed %.1f%% node %.1f%% tri %.1f%% other %.1f%%\n", h[4], tot, 100.0 * h[0] / tot,
+          100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * (tot - h[0] - h[1] - h[2]) / tot);
+#endif
+}
 void launchResetCounters(const Queues& Q, hipStream_t s)
 {
   hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(64), 0, s, Q.counters);
@@ -1236,7 +1332,7 @@ namespace {
 template <bool WIDE>
 void launchTraceClosestT(const LaunchCtx& c, int cur)
 {
-  dim3 grid(c.persistentBlocks), block(TRACE_BLOCK);
+  dim3 grid(c.persistentBlocks * 256u / TRACE_BLOCK), block(TRACE_BLOCK);
   if(c.hasAlpha)
   {
     if(c.collectCounters)
@@ -1255,7 +1351,7 @@ void launchTraceClosestT(const LaunchCtx& c, int cur)
 template <bool WIDE>
 void launchTraceShadowT(const LaunchCtx& c)
 {
-  dim3 grid(c.persistentBlocks), block(TRACE_BLOCK);
+  dim3 grid(c.persistentBlocks * 256u / TRACE_BLOCK), block(TRACE_BLOCK);
   if(c.hasAlpha)
   {
     if(c.collectCounters)
@@ -1301,11 +1397,11 @@ void launchFinishSample(const LaunchCtx& c, int sampleIndex, float4* accum, floa
 }
 void launchSelection(const LaunchCtx& c, uint32_t* selection)
 {
-  unsigned grid = (unsigned(c.fc.numSlots) + TRACE_BLOCK - 1) / TRACE_BLOCK;
+  unsigned grid = (unsigned(c.fc.numSlots) + SEL_BLOCK - 1) / SEL_BLOCK;
   if(c.wide)
-    hipLaunchKernelGGL(k_selection<true>, dim3(grid), dim3(TRACE_BLOCK), 0, c.stream, c.scene, c.fc, c.ownedTiles, selection);
+    hipLaunchKernelGGL(k_selection<true>, dim3(grid), dim3(SEL_BLOCK), 0, c.stream, c.scene, c.fc, c.ownedTiles, selection);
   else
-    hipLaunchKernelGGL(k_selection<false>, dim3(grid), dim3(TRACE_BLOCK), 0, c.stream, c.scene, c.fc, c.ownedTiles, selection);
+    hipLaunchKernelGGL(k_selection<false>, dim3(grid), dim3(SEL_BLOCK), 0, c.stream, c.scene, c.fc, c.ownedTiles, selection);
 }
 
 }  // namespace pt

@@ -84,6 +84,7 @@ struct DevScene
   int                        numMaterials, numTextures, numLights, numNodes;
   int                        envWidth, envHeight;
   int                        numTris;
+  int                        bvh8NumNodes;
   int                        bvhRoot;  // node index, or ~tri for a single-triangle scene; INT_MIN when empty
 };
 
