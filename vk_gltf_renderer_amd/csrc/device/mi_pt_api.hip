@@ -93,7 +93,7 @@ struct MiPt
   pt::DevTri*                 bvhTris   = nullptr;
   bool                        wide      = true;
   pt::DevScene                scene{};
-  bool                        hasAlpha = false, hasVolumeScatter = false;
+  bool                        hasAlpha = false, hasVolumeScatter = false, simpleMaterials = true;
   MiPtStats                   staticStats{};
   // frame state
   int                     width = 0, height = 0;
@@ -329,6 +329,11 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
     flags[size_t(n)] = uint8_t(f);
     if(mat.multiscatterColorFactor[0] > 0.0f || mat.multiscatterColorFactor[1] > 0.0f || mat.multiscatterColorFactor[2] > 0.0f)
       pt->hasVolumeScatter = true;
+    // the materials the specialised shade kernel cannot serve (see evaluateMaterial<SIMPLE>, pt_shading.h)
+    if(mat.transmissionFactor != 0.0f || mat.diffuseTransmissionFactor != 0.0f || mat.clearcoatFactor != 0.0f || mat.iridescenceFactor != 0.0f
+       || mat.anisotropyStrength > 0.0f || mat.retroreflectionFactor != 0.0f || mat.sheenColorFactor[0] != 0.0f || mat.sheenColorFactor[1] != 0.0f
+       || mat.sheenColorFactor[2] != 0.0f)
+      pt->simpleMaterials = false;
     if(sd->renderNodeVisible && !sd->renderNodeVisible[n])
       continue;  // invisible nodes get no geometry (reference: src/gltf_scene_rtx.cpp:319-323)
     if(rn.renderPrimID < 0 || rn.renderPrimID >= sd->numRenderPrimitives)
@@ -604,6 +609,7 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   c.stream           = stream;
   c.persistentBlocks = unsigned(pt->numCUs) * 8u;
   c.hasAlpha         = pt->hasAlpha;
+  c.simpleMaterials  = pt->simpleMaterials && getenv("MI_PT_GENERIC_SHADE") == nullptr;
   c.wide             = pt->wide;
   c.collectCounters  = pt->collectCounters;
 

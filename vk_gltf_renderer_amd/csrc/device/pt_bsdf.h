@@ -352,7 +352,7 @@ PT_DEV LobePick findLobe(const PbrMaterial& mat, float VdotN, float rndVal)
     {
       lo = weight;
       weight += w[l];
-      if(rndVal < weight)
+      if(w[l] > 0.0f && rndVal < weight)  // (w == 0 can never be picked: rndVal >= the running weight here)
       {
         found = true;
         lobe  = l;

@@ -17,6 +17,7 @@ struct LaunchCtx
   hipStream_t     stream;
   unsigned        persistentBlocks;
   bool            hasAlpha;
+  bool            simpleMaterials;  // no material needs the transmission / clearcoat / sheen / iridescence / anisotropy paths
   bool            wide;  // traverse the 8-wide compressed BVH (scene.bvh8Nodes) instead of the BVH2
   bool            collectCounters;
 };

@@ -627,11 +627,15 @@ __global__ void __launch_bounds__(SEL_BLOCK) k_selection(DevScene sc, FrameConst
 //================================================================================================================================
 // k_shade: everything of pathTraceOneBounce / pathTrace between the two Trace calls (gltf_pathtrace.slang:104-430, 441-494)
 //================================================================================================================================
-template <bool COUNT>
+template <bool COUNT, bool SIMPLE>
 __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, FrameConsts fc, PathSoA P, Queues Q, int cur, StatCounters* stats)
 {
   __shared__ uint32_t s_prefix[NSUB + 1];
   __shared__ uint32_t s_push[4];
+  __shared__ float    s_srgb[256];  // sRGB decode table next to the ALU: 3 lookups per texel, up to 8 texels per tap
+  s_srgb[threadIdx.x] = sc.srgbLut[threadIdx.x];
+  static_assert(SHADE_BLOCK == 256, "one table entry per thread");
+  sc.srgbLut = s_srgb;
   if(blockIdx.x == 0 && threadIdx.x < 8)
     Q.counters[QC_HEADS_TRACE + threadIdx.x] = 0;  // for the next iteration's k_trace_closest
   queuePrefix(&Q.counters[cur ? QC_ACTIVE1 : QC_ACTIVE0], s_prefix);
@@ -660,7 +664,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, FrameConsts 
       uint32_t flags = __float_as_uint(misc4.y), seed = __float_as_uint(misc4.z);
       int      surfaceDepth   = int((flags >> PF_DEPTH_SHIFT) & 0xffu);
       int      scatterBounces = int((flags >> PF_SCATTER_SHIFT) & 0xffu);
-      bool     isInside = (flags & PF_INSIDE) != 0u, solid = !(flags & PF_NOT_SOLID);
+      bool     isInside = !SIMPLE && (flags & PF_INSIDE) != 0u, solid = !(flags & PF_NOT_SOLID);
       const bool firstRay = (surfaceDepth == 0);
       const int  maxDepth = fc.pc.maxDepth;
 
@@ -764,7 +768,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, FrameConsts 
           mesh.isInside           = isInside;
           mesh.texGrad            = worldFoot * hit.texelDensity * fc.pc.texGradScale;
           mesh.baseColorVertexMul = hit.color;
-          pbrMat                  = evaluateMaterial(sc, mat, mesh, taps);
+          pbrMat                  = evaluateMaterial<SIMPLE>(sc, mat, mesh, taps);
           unlit                   = mat.unlit > 0;
         }
         if(firstRay)  // gltf_pathtrace.slang:228-264
@@ -788,7 +792,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, FrameConsts 
 
         // processVolumeSegment, pathtrace_functions.h.slang:904-939
         bool volumeContinue = false;
-        if(!done && isInside)
+        if(!SIMPLE && !done && isInside)
         {
           f3    ext, scat;
           float aniso;
@@ -875,7 +879,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, FrameConsts 
             {
               f3 offsetDir = dot(rayDir, hit.geonrm) > 0.0f ? hit.geonrm : -hit.geonrm;
               rayOrigin    = safeOffsetRay(hit.pos, offsetDir);
-              if(sd.event_type & BSDF_EVENT_TRANSMISSION)
+              if(!SIMPLE && (sd.event_type & BSDF_EVENT_TRANSMISSION))
               {
                 isInside = !isInside;
                 if(isInside)  // makeVolumeMedium, pathtrace_functions.h.slang:125-132
@@ -1378,10 +1382,20 @@ void launchTraceClosest(const LaunchCtx& c, int cur)
 void launchShade(const LaunchCtx& c, int cur)
 {
   dim3 grid(c.persistentBlocks), block(SHADE_BLOCK);
-  if(c.collectCounters)
-    hipLaunchKernelGGL((k_shade<true>), grid, block, 0, c.stream, c.scene, c.fc, c.paths, c.queues, cur, c.stats);
+  if(c.simpleMaterials)
+  {
+    if(c.collectCounters)
+      hipLaunchKernelGGL((k_shade<true, true>), grid, block, 0, c.stream, c.scene, c.fc, c.paths, c.queues, cur, c.stats);
+    else
+      hipLaunchKernelGGL((k_shade<false, true>), grid, block, 0, c.stream, c.scene, c.fc, c.paths, c.queues, cur, c.stats);
+  }
   else
-    hipLaunchKernelGGL((k_shade<false>), grid, block, 0, c.stream, c.scene, c.fc, c.paths, c.queues, cur, c.stats);
+  {
+    if(c.collectCounters)
+      hipLaunchKernelGGL((k_shade<true, false>), grid, block, 0, c.stream, c.scene, c.fc, c.paths, c.queues, cur, c.stats);
+    else
+      hipLaunchKernelGGL((k_shade<false, false>), grid, block, 0, c.stream, c.scene, c.fc, c.paths, c.queues, cur, c.stats);
+  }
 }
 void launchTraceShadow(const LaunchCtx& c)
 {

@@ -53,8 +53,8 @@ PT_DEV f4 sampleTexture(const DevScene& sc, int texIndex, f2 uv, bool useGrad, f
 {
   if(texIndex < 0 || texIndex >= sc.numTextures)
     return mk4(1.0f);
-  const DevTexture t   = sc.textures[texIndex];
-  float            lod = 0.0f;
+  const DevTexture& t  = sc.textures[texIndex];  // by reference: a by-value copy would put levelOffset[] in scratch
+  float             lod = 0.0f;
   if(useGrad)
   {
     float rx  = sqrtf(sqr(ddx.x * float(t.width)) + sqr(ddx.y * float(t.height)));

@@ -179,6 +179,11 @@ PT_DEV f3 convertSGToMR(f3 diffuseColor, f3 specularColor, float glossiness, flo
   roughness = mk2(r * r, r * r);
   return baseColor;
 }
+// SIMPLE: the scene has no material with transmission, diffuse transmission, clearcoat, sheen, iridescence, anisotropy or
+// retroreflection (isSimpleMaterial below, decided once per scene like the reference's scene-aware shader variants,
+// src/renderer_pathtracer.cpp feature macros): those inputs keep their neutral defaults as compile-time constants and
+// the lobes, volume tracking and texture fetches that depend on them fold away.
+template <bool SIMPLE>
 PT_DEV PbrMaterial evaluateMaterial(const DevScene& sc, const MiGltfShadeMaterial& m, const MeshState& st, unsigned& taps)  // :168-457
 {
 #define TEX(slot) getTexture(sc, slot, st.tc0, st.tc1, st.texGrad, taps)
@@ -240,11 +245,14 @@ PT_DEV PbrMaterial evaluateMaterial(const DevScene& sc, const MiGltfShadeMateria
   if(isTexturePresent(m.emissiveTexture))
     p.emissive *= xyz(TEX(m.emissiveTexture));
   p.emissive            = max3(mk3(0.0f), p.emissive);
-  p.attenuationColor    = mk3(m.attenuationColor);
-  p.attenuationDistance = m.attenuationDistance;
-  p.thickness           = m.thicknessFactor;
-  if(isTexturePresent(m.thicknessTexture))
-    p.thickness *= TEX(m.thicknessTexture).y;
+  if(!SIMPLE)
+  {
+    p.attenuationColor    = mk3(m.attenuationColor);
+    p.attenuationDistance = m.attenuationDistance;
+    p.thickness           = m.thicknessFactor;
+    if(isTexturePresent(m.thicknessTexture))
+      p.thickness *= TEX(m.thicknessTexture).y;
+  }
   p.specularColor = mk3(m.specularColorFactor);
   if(isTexturePresent(m.specularColorTexture))
     p.specularColor *= xyz(TEX(m.specularColorTexture));
@@ -252,13 +260,16 @@ PT_DEV PbrMaterial evaluateMaterial(const DevScene& sc, const MiGltfShadeMateria
   if(isTexturePresent(m.specularTexture))
     p.specular *= TEX(m.specularTexture).w;
   float ior1 = 1.0f, ior2 = m.ior;
-  if(st.isInside && (p.thickness > 0.0f))
+  if(!SIMPLE && st.isInside && (p.thickness > 0.0f))
   {
     ior1 = ior2;
     ior2 = 1.0f;
   }
   p.ior1         = ior1;
   p.ior2         = ior2;
+  bool needsTangentUpdateAniso = false;
+  if(!SIMPLE)
+  {
   p.transmission = m.transmissionFactor;
   if(isTexturePresent(m.transmissionTexture))
     p.transmission *= TEX(m.transmissionTexture).x;
@@ -309,8 +320,10 @@ PT_DEV PbrMaterial evaluateMaterial(const DevScene& sc, const MiGltfShadeMateria
     float s = m.anisotropyRotation[0], c = m.anisotropyRotation[1];
     dir                = mk2(c * dir.x + s * dir.y, c * dir.y - s * dir.x);
     p.T                = p.T * dir.x + p.B * dir.y;
-    needsTangentUpdate = true;
+    needsTangentUpdateAniso = true;
   }
+  }
+  needsTangentUpdate = needsTangentUpdate || needsTangentUpdateAniso;
   if(needsTangentUpdate)
   {
     p.B         = normalize(cross(p.N, p.T));
@@ -318,6 +331,8 @@ PT_DEV PbrMaterial evaluateMaterial(const DevScene& sc, const MiGltfShadeMateria
     p.B         = p.B * bsign;
     p.T         = normalize(cross(p.B, p.N) * bsign);
   }
+  if(!SIMPLE)
+  {
   p.sheenColor = mk3(m.sheenColorFactor);
   if(isTexturePresent(m.sheenColorTexture))
     p.sheenColor *= xyz(TEX(m.sheenColorTexture));
@@ -335,6 +350,7 @@ PT_DEV PbrMaterial evaluateMaterial(const DevScene& sc, const MiGltfShadeMateria
   p.retroreflection = m.retroreflectionFactor;
   if(isTexturePresent(m.retroreflectionTexture))
     p.retroreflection *= TEX(m.retroreflectionTexture).x;
+  }
 #undef TEX
   return p;
 }
