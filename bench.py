@@ -1,16 +1,18 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the path-trace hot path on N MI355X GPUs of one node.
 
-A "step" is one pass of the hot path over one batch of synthetic input: ONE frame (ptSamples = 1 sample per pixel,
-like the reference's headless run `--frames K --ptSamples 1`, docs/benchmarking.md:16-23) of the workload
-BASELINE.json's metric is quoted on and that fits one GPU: configs[1], DamagedHelmet-class + std_env.hdr,
-1920x1080, depth 8 (the asset itself is not available offline; vk_gltf_renderer_amd.scenegen writes a seeded stand-in
-of the same class as a .glb).  Metric = the reference's throughput_MSps (src/benchmarking.cpp:272-279):
-W*H*spp / wall_s / 1e6, inputs resident in HBM before the timed region.
+A "step" is one pass of the hot path over one batch of synthetic input: a batch of `--in-flight` (default 8) consecutive
+frames per GPU, each ptSamples = 1 sample per pixel like the reference's headless run `--frames K --ptSamples 1`
+(docs/benchmarking.md:16-23), issued through mi_pt_render_frames so that the frames share every wavefront launch
+(bit-identical to rendering them one after the other; --in-flight 1 gives exactly that), of the workload BASELINE.json's
+metric is quoted on and that fits one GPU: configs[1], DamagedHelmet-class + std_env.hdr, 1920x1080, depth 8 (the asset
+itself is not available offline; vk_gltf_renderer_amd.scenegen writes a seeded stand-in of the same class as a .glb).
+Metric = the reference's throughput_MSps (src/benchmarking.cpp:272-279): W*H*spp / wall_s / 1e6 with spp = all samples
+of the timed region, inputs resident in HBM before the timed region.
 
 N > 1: the image is split into interleaved 64x64 tiles (tile % N == rank), every rank renders its tiles with no data-path
 collective, and ONE RCCL reduce(sum) of the RGBA32F accumulator over xGMI closes the frame set (inside the timed
-region).  Total work is fixed as N grows -> "strong" scaling.
+region).  The batch is in_flight * N frames, i.e. the work per GPU is fixed as N grows -> "weak" scaling.
 
 Prints ONE JSON line on rank 0.
 """
@@ -74,15 +76,16 @@ def algorithmic_bytes(stats, kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="helmet", choices=sorted(WORKLOADS))
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bvh", type=int, default=0, help="bit0: 0 = 8-wide compressed BVH (default), 1 = plain BVH2; bit1: 0 = PLOC topology (default), 1 = LBVH")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--in-flight", type=int, default=1, help="frames in flight per step (mi_pt_render_frames); bit-identical to sequential frames")
+    ap.add_argument("--in-flight", type=int, default=8,
+                    help="frames in flight per GPU and step (mi_pt_render_frames, bit-identical to sequential frames); a step renders in_flight * n_gpus frames")
     args = ap.parse_args()
 
     import torch
@@ -136,7 +139,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    F = max(1, args.in_flight)  # a step = one batch of F frames (1 spp each) sharing every wavefront launch
+    # a step = one batch of F frames (1 spp each) sharing every wavefront launch.  Every rank owns 1/world of the tiles of each
+    # frame, so the batch grows with the world size to keep the rays in flight per GPU constant (weak scaling).
+    F = min(64, max(1, args.in_flight) * world)
     runner.render(args.warmup * F, stream.cuda_stream, in_flight=F)
     if dist is not None:  # warm the RCCL path too
         dist.reduce(accum.clone(), dst=0)
@@ -193,7 +198,7 @@ def main():
         result = {
             "metric": "Msamples/s (and ms/frame @ fixed spp) 1080p & 4K, 1/2/4/8 MI355X", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": w["config"] + " (seeded synthetic stand-in)" if w["gen"] else w["config"], "scene_triangles": scene.num_triangles,
                        "resolution": [W, H], "spp_per_step": F, "frames_in_flight": F, "max_depth": w["depth"], "tile": 64,
                        "parallelism": f"tiles{world}" if world > 1 else "single"},
@@ -201,8 +206,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_launch_ms": round(avg_launch_ms, 5),
                          "algorithmic_bytes_per_launch": round(bytes_per_launch),
                          "per_frame": {k: round(per_frame[k], 1) for k in ("segments", "shadowRays", "nodesClosest", "trisClosest", "nodesShadow", "trisShadow", "textureTaps")},
-                         "kernel_ms_per_frame": {k: round(timing[v[0]] / args.steps, 4) for k, v in kernels.items()},
-                         "frame_ms_device": round(timing["totalMs"] / args.steps, 4)},
+                         "kernel_ms_per_frame": {k: round(timing[v[0]] / (args.steps * F), 4) for k, v in kernels.items()},
+                         "frame_ms_device": round(timing["totalMs"] / (args.steps * F), 4)},
         }
         if not args.no_cpu_baseline and world == 1:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
