@@ -24,6 +24,9 @@ constexpr int SEL_BLOCK   = 256;
 #define TRACE_MIN_WAVES 1
 #endif
 constexpr int SHADE_BLOCK = 256;
+#ifndef SHADE_SIMPLE_WAVES
+#define SHADE_SIMPLE_WAVES 3
+#endif
 
 // ---- queues ------------------------------------------------------------------------------------------------------------------
 PT_DEV uint32_t laneId() { return __lane_id(); }
@@ -31,12 +34,21 @@ PT_DEV uint32_t laneId() { return __lane_id(); }
 // Exclusive prefix of the NSUB sub-queue counts into LDS (s_prefix[NSUB] = total).  Call from every thread of the block.
 PT_DEV void queuePrefix(const uint32_t* counts, uint32_t* s_prefix)
 {
-  if(threadIdx.x <= NSUB)
+  if(threadIdx.x < 64)  // first wave: one load per lane, shuffle scan (every block of every launch pays this latency)
   {
-    uint32_t sum = 0;
-    for(uint32_t q = 0; q < threadIdx.x; ++q)
-      sum += counts[q];
-    s_prefix[threadIdx.x] = sum;
+    const uint32_t lane = threadIdx.x;
+    uint32_t       v    = lane < NSUB ? counts[lane] : 0u;
+#pragma unroll
+    for(int d = 1; d < NSUB; d <<= 1)
+    {
+      const uint32_t t = uint32_t(__shfl_up(int(v), d));
+      if(lane >= uint32_t(d))
+        v += t;
+    }
+    if(lane < NSUB)
+      s_prefix[lane + 1] = v;
+    if(lane == 0)
+      s_prefix[0] = 0;
   }
   __syncthreads();
 }
@@ -628,7 +640,7 @@ __global__ void __launch_bounds__(SEL_BLOCK) k_selection(DevScene sc, FrameConst
 // k_shade: everything of pathTraceOneBounce / pathTrace between the two Trace calls (gltf_pathtrace.slang:104-430, 441-494)
 //================================================================================================================================
 template <bool COUNT, bool SIMPLE>
-__global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, FrameConsts fc, PathSoA P, Queues Q, int cur, StatCounters* stats)
+__global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) k_shade(DevScene sc, FrameConsts fc, PathSoA P, Queues Q, int cur, StatCounters* stats)
 {
   __shared__ uint32_t s_prefix[NSUB + 1];
   __shared__ uint32_t s_push[4];
