@@ -70,7 +70,8 @@ struct LaneStack
   int* lds;      // base of this block's LDS stack
   int  tid;      // thread index in block
   int  stride;   // block size
-  int  priv[BVH_STACK_PRIV];
+  int* priv;     // BVH_STACK_PRIV ints of overflow in scratch: a SEPARATE local array of the caller -- as a member array it
+                 // would drag the whole struct (sp, tid, stride) into scratch and turn every push/pop into memory round trips
   int  sp;
   PT_DEV void push(int v)
   {

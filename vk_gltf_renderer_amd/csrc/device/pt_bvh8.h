@@ -19,7 +19,7 @@ struct LaneStack2
 {
   int*     lds;  // 2 * BVH8_STACK_LDS * stride ints
   int      tid, stride;
-  uint32_t privBase[BVH8_STACK_PRIV], privBits[BVH8_STACK_PRIV];
+  uint32_t *privBase, *privBits;  // BVH8_STACK_PRIV words each, in a separate local array of the caller (see LaneStack::priv)
   int      sp;
   PT_DEV void push(NodeGroup g)
   {

@@ -387,8 +387,10 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
   const uint32_t cachedNodes = WIDE ? fillNodeCache(sc, s_nodes) : 0u;
   LaneStack  st;   // BVH2 walk state
   LaneStack2 st2;  // BVH8 walk state
-  st.lds = s_stack;  st.tid = int(threadIdx.x);  st.stride = TRACE_BLOCK;  st.sp = 0;
+  int        stackOverflow[WIDE ? 2 * BVH8_STACK_PRIV : BVH_STACK_PRIV];  // scratch; only touched beyond the LDS depth
+  st.lds = s_stack;  st.tid = int(threadIdx.x);  st.stride = TRACE_BLOCK;  st.sp = 0;  st.priv = stackOverflow;
   st2.lds = s_stack; st2.tid = int(threadIdx.x); st2.stride = TRACE_BLOCK; st2.sp = 0;
+  st2.privBase = reinterpret_cast<uint32_t*>(stackOverflow); st2.privBits = reinterpret_cast<uint32_t*>(stackOverflow) + (WIDE ? BVH8_STACK_PRIV : 0);
   bool        active = false;
   uint32_t    slot = 0, pos = 0;
   RaySetup    r{};
@@ -599,7 +601,9 @@ __global__ void __launch_bounds__(SEL_BLOCK) k_selection(DevScene sc, FrameConst
     if(WIDE)
     {
       LaneStack2 st2;
+      uint32_t   stackOverflow[2 * BVH8_STACK_PRIV];
       st2.lds = s_stack; st2.tid = int(threadIdx.x); st2.stride = SEL_BLOCK; st2.sp = 0;
+      st2.privBase = stackOverflow; st2.privBits = stackOverflow + BVH8_STACK_PRIV;
       const uint32_t octinv = rayOctInv(r.idir);
       NodeGroup      G      = rootGroup(octinv);
       for(;;)
@@ -626,7 +630,8 @@ __global__ void __launch_bounds__(SEL_BLOCK) k_selection(DevScene sc, FrameConst
     else
     {
       LaneStack st;
-      st.lds = s_stack; st.tid = int(threadIdx.x); st.stride = SEL_BLOCK; st.sp = 0;
+      int       stackOverflow[BVH_STACK_PRIV];
+      st.lds = s_stack; st.tid = int(threadIdx.x); st.stride = SEL_BLOCK; st.sp = 0; st.priv = stackOverflow;
       bvhWalk(sc, r, bestT, st, [&](int triIndex, float) -> float {
         testTri(triIndex);
         return bestT;
@@ -978,8 +983,10 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_shadow(D
   const uint32_t cachedNodes = WIDE ? fillNodeCache(sc, s_nodes) : 0u;
   LaneStack  st;
   LaneStack2 st2;
-  st.lds = s_stack;  st.tid = int(threadIdx.x);  st.stride = TRACE_BLOCK;  st.sp = 0;
+  int        stackOverflow[WIDE ? 2 * BVH8_STACK_PRIV : BVH_STACK_PRIV];  // scratch; only touched beyond the LDS depth
+  st.lds = s_stack;  st.tid = int(threadIdx.x);  st.stride = TRACE_BLOCK;  st.sp = 0;  st.priv = stackOverflow;
   st2.lds = s_stack; st2.tid = int(threadIdx.x); st2.stride = TRACE_BLOCK; st2.sp = 0;
+  st2.privBase = reinterpret_cast<uint32_t*>(stackOverflow); st2.privBits = reinterpret_cast<uint32_t*>(stackOverflow) + (WIDE ? BVH8_STACK_PRIV : 0);
   // per-lane state.  phase 0: any-hit walk (opaque geometry and non-transmissive alpha resolve here, order independent);
   // phase 1: one walk per transmissive candidate, in increasing (t, renderNode, primitive) order.
   bool      active = false;
