@@ -93,8 +93,13 @@ PT_DEV void bvh8Visit(const DevScene& sc, const RaySetup& r, float tmax, uint32_
   uint4 n0, n1, n2, n3, n4;
   if(nodeIndex < cached)
   {
-    const uint4* N = ldsNodes + nodeIndex * 5u;
-    n0 = N[0]; n1 = N[1]; n2 = N[2]; n3 = N[3]; n4 = N[4];
+    // explicit LDS address space: through a generic pointer the two branches merge into flat loads of a selected address
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(3))) u32x4* LdsNodePtr;
+    LdsNodePtr  N = (LdsNodePtr)(ldsNodes) + nodeIndex * 5u;
+    const u32x4 a = N[0], b = N[1], c = N[2], d = N[3], e = N[4];
+    n0 = make_uint4(a[0], a[1], a[2], a[3]); n1 = make_uint4(b[0], b[1], b[2], b[3]); n2 = make_uint4(c[0], c[1], c[2], c[3]);
+    n3 = make_uint4(d[0], d[1], d[2], d[3]); n4 = make_uint4(e[0], e[1], e[2], e[3]);
   }
   else
   {
