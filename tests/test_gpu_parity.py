@@ -50,6 +50,38 @@ def test_box_hdr(built, assets):
     _check(pu.render_oracle(s, 16), pu.render_gpu(s, 16))
 
 
+def _plane(catcher):
+    def edit(fi):
+        fi.flags |= capi.MI_SCENE_USE_INFINITE_PLANE | (capi.MI_SCENE_INFINITE_PLANE_SHADOW_CATCHER if catcher else 0)
+        fi.infinitePlaneDistance = -0.62
+        fi.infinitePlaneBaseColor[:] = [0.7, 0.6, 0.5]
+        fi.infinitePlaneMetallic, fi.infinitePlaneRoughness, fi.shadowCatcherDarkenAmount = 0.1, 0.45, 0.35
+    return edit
+
+
+def test_infinite_plane(built, assets):
+    """The ground plane of the reference's settings (checkInfinitePlaneIntersection, pathtrace_functions.h.slang:556-585)."""
+    hdr = os.path.join(assets, "std_env.hdr")
+    s = pu.Setup(os.path.join(assets, "Box.glb"), 192, 144, max_depth=5, hdr_path=hdr, frame_info_edit=_plane(False))
+    _check(pu.render_oracle(s, 8), pu.render_gpu(s, 8))
+    s = pu.Setup(os.path.join(assets, "Box.glb"), 192, 144, max_depth=5, frame_info_edit=_plane(False))  # sun + sky
+    _check(pu.render_oracle(s, 8), pu.render_gpu(s, 8), rel_l2=6e-3)
+
+
+def test_shadow_catcher_plane(built, assets):
+    """handleShadowCatcher (pathtrace_functions.h.slang:499-554): the wavefront finishes the bounce speculatively and the
+    shadow kernel settles it; counters and image must match the megakernel oracle, and frames in flight / both BVHs too."""
+    hdr = os.path.join(assets, "std_env.hdr")
+    for kw in (dict(hdr_path=hdr), dict()):
+        s = pu.Setup(os.path.join(assets, "Box.glb"), 192, 144, max_depth=4, frame_info_edit=_plane(True), **kw)
+        o, g = pu.render_oracle(s, 8), pu.render_gpu(s, 8)
+        _check(o, g, rel_l2=6e-3 if not kw else 2e-3)
+        assert (g["accum"] == pu.render_gpu(s, 8, in_flight=4, bvh=1)["accum"]).all()
+    # the catcher is not a no-op: with the sun up, the box's shadow darkens the plane relative to the sky behind it
+    s0 = pu.Setup(os.path.join(assets, "Box.glb"), 192, 144, max_depth=4)
+    assert np.abs(pu.render_gpu(s0, 8)["accum"][..., :3] - g["accum"][..., :3]).max() > 1e-3
+
+
 def test_box_multisample_frames(built, assets):
     """numSamples > 1 per frame: the seed threads through the samples of a pixel (gltf_pathtrace.slang:580-596)."""
     s = pu.Setup(os.path.join(assets, "Box.glb"), 128, 96, max_depth=5, spp_per_frame=4, hdr_path=os.path.join(assets, "std_env.hdr"))

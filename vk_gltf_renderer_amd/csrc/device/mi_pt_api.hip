@@ -163,7 +163,7 @@ int allocPathResources(MiPt* pt, int frames)
   const size_t subCap    = ((numChunks + pt::NSUB - 1) / pt::NSUB + 1) * pt::QCHUNK;
   const size_t qsize     = subCap * pt::NSUB;
   HIP_TRY(pt->queueMem.alloc(qsize * 3 + pt::QC_COUNT));
-  HIP_TRY(pt->queuePayload.alloc(qsize * 9));
+  HIP_TRY(pt->queuePayload.alloc(qsize * 10));
   pt::RayQueue* qs[3] = {&pt->queues.active[0], &pt->queues.active[1], &pt->queues.shadow};
   for(int i = 0; i < 3; ++i)
   {
@@ -172,6 +172,8 @@ int allocPathResources(MiPt* pt, int frames)
     qs[i]->dir  = pt->queuePayload.ptr + qsize * size_t(3 * i + 1);
     qs[i]->aux  = pt->queuePayload.ptr + qsize * size_t(3 * i + 2);
   }
+  pt->queues.active[0].aux2 = pt->queues.active[1].aux2 = nullptr;
+  pt->queues.shadow.aux2    = pt->queuePayload.ptr + qsize * 9;
   pt->queues.counters = pt->queueMem.ptr + 3 * qsize;
   pt->queues.subCap   = uint32_t(subCap);
   HIP_TRY(hipMemset(pt->queues.counters, 0, sizeof(uint32_t) * pt::QC_COUNT));
@@ -568,8 +570,6 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_render_frame: numSamples >= 1 and 0 <= maxDepth <= 255 required");
   if((pt->frameInfo.flags & MI_SCENE_USE_HDR_ENVIRONMENT) && !pt->scene.envPixels)
     return fail(MI_PT_ERR_STATE, "mi_pt_render_frame: HDR environment requested but none was set");
-  if((pt->frameInfo.flags & MI_SCENE_USE_INFINITE_PLANE) && (pt->frameInfo.flags & MI_SCENE_INFINITE_PLANE_SHADOW_CATCHER))
-    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_render_frame: the shadow-catcher plane is not implemented in the wavefront split yet");
   HIP_TRY(hipSetDevice(pt->device));
   hipStream_t stream = reinterpret_cast<hipStream_t>(hipStream);
   pt->lastStream     = stream;
@@ -642,6 +642,9 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
     // Every iteration either ends a path or consumes one unit of surfaceDepth, except volume scatter events
     // (pathtrace_functions.h.slang:925-931), which are free for VOLUME_FREE_BUDGET bounces and then Russian-rouletted.
     int maxIters = params->maxDepth;
+    // a shadow-catcher bounce does not consume surfaceDepth (eEarlyContinue) but is always followed by a miss or a surface hit
+    if((pt->frameInfo.flags & MI_SCENE_USE_INFINITE_PLANE) && (pt->frameInfo.flags & MI_SCENE_INFINITE_PLANE_SHADOW_CATCHER))
+      maxIters = 2 * params->maxDepth + 2;
     if(pt->hasVolumeScatter)
       maxIters = params->maxDepth * 66 + 512;
     for(int it = 0; it < maxIters; ++it)
@@ -677,7 +680,7 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
         double   tTrace = span([&] { pt::launchTraceClosest(c, cur); });
         double   tShade = span([&] { pt::launchShade(c, cur); });
         uint32_t nSh    = count(pt::QC_SHADOW);
-        double   tShadow = span([&] { pt::launchTraceShadow(c); });
+        double   tShadow = span([&] { pt::launchTraceShadow(c, cur ^ 1); });
         fprintf(stderr, "[mi_pt span] frame %d it %2d rays %8u trace %8.3f ms shade %8.3f ms | shadow rays %8u %8.3f ms\n", params->frameCount, it, nIn, tTrace,
                 tShade, nSh, tShadow);
       }
@@ -685,7 +688,7 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
       {
         timed(TK_TRACE, [&] { pt::launchTraceClosest(c, cur); });
         timed(TK_SHADE, [&] { pt::launchShade(c, cur); });
-        timed(TK_SHADOW, [&] { pt::launchTraceShadow(c); });
+        timed(TK_SHADOW, [&] { pt::launchTraceShadow(c, cur ^ 1); });
       }
       ++iterations; ++traceLaunches; ++shadeLaunches; ++shadowLaunches;
       cur ^= 1;

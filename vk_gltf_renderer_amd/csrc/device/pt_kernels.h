@@ -28,7 +28,7 @@ void launchResetCounters(const Queues& Q, hipStream_t s);
 void launchGenerate(const LaunchCtx& c, int sampleIndex);
 void launchTraceClosest(const LaunchCtx& c, int cur);
 void launchShade(const LaunchCtx& c, int cur);
-void launchTraceShadow(const LaunchCtx& c);
+void launchTraceShadow(const LaunchCtx& c, int nxt);  // nxt: active queue the preceding shade launch appended to
 void launchFinishSample(const LaunchCtx& c, int sampleIndex, float4* accum, float* depth, float4* albedo, float4* normal);
 void launchSelection(const LaunchCtx& c, uint32_t* selection);
 

@@ -668,7 +668,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
     bool           alive = false, pushShadow = false;
     unsigned       taps = 0;
     float4         nextOrg = make_float4(0, 0, 0, 0), nextDir = make_float4(0, 0, 0, 0);
-    float4         shOrg = make_float4(0, 0, 0, 0), shDir = make_float4(0, 0, 0, 0), shCon = make_float4(0, 0, 0, 0);
+    float4         shOrg = make_float4(0, 0, 0, 0), shDir = make_float4(0, 0, 0, 0), shCon = make_float4(0, 0, 0, 0), shCon2 = make_float4(0, 0, 0, 0);
+    bool           catcher = false;
     if(inRange)
     {
       const float4 hit4 = Q.active[cur].aux[inPos], o4 = Q.active[cur].org[inPos], d4 = Q.active[cur].dir[inPos];
@@ -765,6 +766,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
         // rayConeWorldFootprint, pathtrace_functions.h.slang:174-178
         float worldFoot = (coneWidth + fc.pc.pixelAngle * hitT) / fmaxf(fabsf(dot(hit.geonrm, -rayDir)), 1e-3f);
         bool  unlit     = false;
+        bool  catcherPlane = false;  // shadow-catcher hit: the rest of the bounce is skipped (eBreak / eEarlyContinue)
         if(hitInfinitePlane)
         {
           pbrMat           = defaultPbrMaterial();
@@ -774,7 +776,49 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
           pbrMat.roughness = mk2(r * r, r * r);
           pbrMat.N = hit.nrm; pbrMat.Ng = hit.nrm; pbrMat.Nc = hit.nrm;
           pbrMat.T = hit.tangent; pbrMat.B = hit.bitangent;
-          // the shadow-catcher variant needs the shadow result inside the bounce; not supported by this wavefront split yet
+          // handleShadowCatcher, pathtrace_functions.h.slang:499-554 (called from gltf_pathtrace.slang:169-187).  The reference
+          // needs the shadow factor inside the bounce; here the bounce is finished speculatively (the alpha draws of
+          // TraceShadow do not advance the seed, §6, so the continuation sample is the same) and k_trace_shadow applies the
+          // radiance terms and drops the continuation again when the point turns out to be unshadowed.
+          if(hasFlag(fc.frameInfo.flags, MI_SCENE_INFINITE_PLANE_SHADOW_CATCHER))
+          {
+            catcherPlane = true;
+            coneWidth    = worldFoot;
+            DirectLight dl;
+            sampleLights(sc, fc, hit.pos, seed, dl);
+            const bool traceIt = dot(dl.direction, hit.nrm) > 0.0f && dl.pdf != 0.0f;
+            f3         envColor;
+            float      envPdf;
+            sampleEnvironment(sc, fc, rayDir, envColor, envPdf);
+            const float mis         = computeEnvHitMisWeight(sc, fc, lastSamplePdf, envPdf);
+            const f3    unshadowed  = throughput * mis * envColor;
+            if(!traceIt)
+            {
+              radiance += unshadowed;
+              done = true;
+            }
+            else
+            {
+              shOrg = make_float4(hit.pos.x, hit.pos.y, hit.pos.z, INFINITE_F);
+              shDir = make_float4(dl.direction.x, dl.direction.y, dl.direction.z, __uint_as_float(2u));
+              shCon = make_float4(envColor.x, envColor.y, envColor.z, __uint_as_float(seed));
+              shCon2     = make_float4(unshadowed.x, unshadowed.y, unshadowed.z, 0.0f);
+              pushShadow = true;
+              catcher    = true;
+              float      r1 = rnd(seed), r2 = rnd(seed), r3 = rnd(seed);
+              BsdfSample sd = bsdfSampleSimple(-rayDir, mk3(r1, r2, r3), pbrMat);
+              if(sd.event_type == BSDF_EVENT_ABSORB)
+                done = true;
+              else
+              {
+                f3 offsetDir = dot(sd.k2, hit.geonrm) > 0.0f ? hit.geonrm : -hit.geonrm;
+                rayOrigin    = safeOffsetRay(hit.pos, offsetDir);
+                rayDir       = normalize(sd.k2);  // pathTrace loop head, gltf_pathtrace.slang:447
+                throughput *= sd.bsdf_over_pdf;
+                lastSamplePdf = sd.pdf;
+              }
+            }
+          }
         }
         else
         {
@@ -788,146 +832,149 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
           pbrMat                  = evaluateMaterial<SIMPLE>(sc, mat, mesh, taps);
           unlit                   = mat.unlit > 0;
         }
-        if(firstRay)  // gltf_pathtrace.slang:228-264
+        if(!catcherPlane)
         {
-          P.firstHit[slot] = make_float4(hit.pos.x, hit.pos.y, hit.pos.z, 0.0f);
-          if(P.guideAlbedo)
+          if(firstRay)  // gltf_pathtrace.slang:228-264
           {
-            float4 ga = P.guideAlbedo[slot], gn = P.guideNormal[slot];
-            P.guideAlbedo[slot] = make_float4(ga.x + pbrMat.baseColor.x, ga.y + pbrMat.baseColor.y, ga.z + pbrMat.baseColor.z, ga.w + 1.0f);
-            P.guideNormal[slot] = make_float4(gn.x + pbrMat.N.x, gn.y + pbrMat.N.y, gn.z + pbrMat.N.z, 0.0f);
-          }
-        }
-        maxRoughness     = mk2(fmaxf(pbrMat.roughness.x, maxRoughness.x), fmaxf(pbrMat.roughness.y, maxRoughness.y));  // :267-268
-        pbrMat.roughness = maxRoughness;
-        radiance += pbrMat.emissive * throughput;  // :293
-        if(unlit)                                  // :298-304
-        {
-          radiance += pbrMat.baseColor;
-          done = true;
-        }
-
-        // processVolumeSegment, pathtrace_functions.h.slang:904-939
-        bool volumeContinue = false;
-        if(!SIMPLE && !done && isInside)
-        {
-          f3    ext, scat;
-          float aniso;
-          unpackMedium(P.medium[slot], ext, scat, aniso);
-          if(maxComp(ext) > 0.0f || maxComp(scat) > 0.0f)
-          {
-            // handleVolumeScatter, :605-645
-            bool  scattered  = false;
-            float maxScatter = maxComp(scat);
-            f3    wiBefore = rayDir, originBefore = rayOrigin;
-            if(maxScatter > VOLUME_MIN_SCATTER)
+            P.firstHit[slot] = make_float4(hit.pos.x, hit.pos.y, hit.pos.z, 0.0f);
+            if(P.guideAlbedo)
             {
-              float maxExt      = maxComp(ext);
-              float scatterDist = -logf(fmaxf(rnd(seed), VOLUME_RAND_FLOOR)) / maxExt;
-              if(scatterDist < hitT)
+              float4 ga = P.guideAlbedo[slot], gn = P.guideNormal[slot];
+              P.guideAlbedo[slot] = make_float4(ga.x + pbrMat.baseColor.x, ga.y + pbrMat.baseColor.y, ga.z + pbrMat.baseColor.z, ga.w + 1.0f);
+              P.guideNormal[slot] = make_float4(gn.x + pbrMat.N.x, gn.y + pbrMat.N.y, gn.z + pbrMat.N.z, 0.0f);
+            }
+          }
+          maxRoughness     = mk2(fmaxf(pbrMat.roughness.x, maxRoughness.x), fmaxf(pbrMat.roughness.y, maxRoughness.y));  // :267-268
+          pbrMat.roughness = maxRoughness;
+          radiance += pbrMat.emissive * throughput;  // :293
+          if(unlit)                                  // :298-304
+          {
+            radiance += pbrMat.baseColor;
+            done = true;
+          }
+
+          // processVolumeSegment, pathtrace_functions.h.slang:904-939
+          bool volumeContinue = false;
+          if(!SIMPLE && !done && isInside)
+          {
+            f3    ext, scat;
+            float aniso;
+            unpackMedium(P.medium[slot], ext, scat, aniso);
+            if(maxComp(ext) > 0.0f || maxComp(scat) > 0.0f)
+            {
+              // handleVolumeScatter, :605-645
+              bool  scattered  = false;
+              float maxScatter = maxComp(scat);
+              f3    wiBefore = rayDir, originBefore = rayOrigin;
+              if(maxScatter > VOLUME_MIN_SCATTER)
               {
-                throughput *= mk3(1.0f) - (ext - scat) / maxExt;
-                rayOrigin     = rayOrigin + rayDir * scatterDist;
-                float r1 = rnd(seed), r2 = rnd(seed);
-                rayDir        = sampleHenyeyGreenstein(mk2(r1, r2), aniso, wiBefore);
-                lastSamplePdf = henyeyGreensteinPdf(dot(wiBefore, rayDir), aniso);
-                scattered     = true;
+                float maxExt      = maxComp(ext);
+                float scatterDist = -logf(fmaxf(rnd(seed), VOLUME_RAND_FLOOR)) / maxExt;
+                if(scatterDist < hitT)
+                {
+                  throughput *= mk3(1.0f) - (ext - scat) / maxExt;
+                  rayOrigin     = rayOrigin + rayDir * scatterDist;
+                  float r1 = rnd(seed), r2 = rnd(seed);
+                  rayDir        = sampleHenyeyGreenstein(mk2(r1, r2), aniso, wiBefore);
+                  lastSamplePdf = henyeyGreensteinPdf(dot(wiBefore, rayDir), aniso);
+                  scattered     = true;
+                }
+                else
+                  throughput *= exp3((mk3(maxExt) - ext) * hitT);
               }
               else
-                throughput *= exp3((mk3(maxExt) - ext) * hitT);
-            }
-            else
-              throughput *= exp3(ext * (-hitT));
-            if(scattered)
-            {
-              scatterBounces = min(scatterBounces + 1, 255);
-              coneWidth += fc.pc.pixelAngle * length(rayOrigin - originBefore);
-              // volumeScatterNEE, :651-672 (the shadow ray is deferred to k_trace_shadow; initialInside = true)
-              DirectLight dl;
-              sampleLights(sc, fc, rayOrigin, seed, dl);
-              if(dl.pdf > 0.0f)
+                throughput *= exp3(ext * (-hitT));
+              if(scattered)
               {
-                float phasePdf = henyeyGreensteinPdf(dot(wiBefore, dl.direction), aniso);
-                float mis      = dl.pdf / (dl.pdf + phasePdf);
-                f3    contrib  = throughput * dl.radianceOverPdf * mis * phasePdf;
-                shOrg = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, dl.distance);
-                shDir = make_float4(dl.direction.x, dl.direction.y, dl.direction.z, __uint_as_float(1u));
-                shCon = make_float4(contrib.x, contrib.y, contrib.z, __uint_as_float(seed));
-                pushShadow            = true;
+                scatterBounces = min(scatterBounces + 1, 255);
+                coneWidth += fc.pc.pixelAngle * length(rayOrigin - originBefore);
+                // volumeScatterNEE, :651-672 (the shadow ray is deferred to k_trace_shadow; initialInside = true)
+                DirectLight dl;
+                sampleLights(sc, fc, rayOrigin, seed, dl);
+                if(dl.pdf > 0.0f)
+                {
+                  float phasePdf = henyeyGreensteinPdf(dot(wiBefore, dl.direction), aniso);
+                  float mis      = dl.pdf / (dl.pdf + phasePdf);
+                  f3    contrib  = throughput * dl.radianceOverPdf * mis * phasePdf;
+                  shOrg = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, dl.distance);
+                  shDir = make_float4(dl.direction.x, dl.direction.y, dl.direction.z, __uint_as_float(1u));
+                  shCon = make_float4(contrib.x, contrib.y, contrib.z, __uint_as_float(seed));
+                  pushShadow            = true;
+                }
+                if(scatterBounces >= VOLUME_FREE_BUDGET)
+                {
+                  float rrPcont = fminf(maxComp(throughput) + RR_PCONT_FLOOR, RR_PCONT_CAP);
+                  if(rnd(seed) >= rrPcont)
+                    done = true;
+                  else
+                    throughput /= rrPcont;
+                }
+                volumeContinue = !done;
+                rayDir         = normalize(rayDir);
               }
-              if(scatterBounces >= VOLUME_FREE_BUDGET)
-              {
-                float rrPcont = fminf(maxComp(throughput) + RR_PCONT_FLOOR, RR_PCONT_CAP);
-                if(rnd(seed) >= rrPcont)
-                  done = true;
-                else
-                  throughput /= rrPcont;
-              }
-              volumeContinue = !done;
-              rayDir         = normalize(rayDir);
             }
           }
-        }
 
-        if(!done && !volumeContinue)
-        {
-          coneWidth = worldFoot;  // :313
-          DirectLight dl;
-          sampleLights(sc, fc, hit.pos, seed, dl);  // :319-320
-          bool nextEventValid = (dot(dl.direction, hit.nrm) > 0.0f || pbrMat.diffuseTransmissionFactor > 0.0f) && dl.pdf != 0.0f;
-          f3   contribution   = mk3(0.0f);
-          if(nextEventValid)  // :330-351
+          if(!done && !volumeContinue)
           {
-            float    r1 = rnd(seed), r2 = rnd(seed), r3 = rnd(seed);
-            BsdfEval ev = bsdfEvaluate(-rayDir, dl.direction, mk3(r1, r2, r3), pbrMat);
-            if(ev.pdf > 0.0f)
+            coneWidth = worldFoot;  // :313
+            DirectLight dl;
+            sampleLights(sc, fc, hit.pos, seed, dl);  // :319-320
+            bool nextEventValid = (dot(dl.direction, hit.nrm) > 0.0f || pbrMat.diffuseTransmissionFactor > 0.0f) && dl.pdf != 0.0f;
+            f3   contribution   = mk3(0.0f);
+            if(nextEventValid)  // :330-351
             {
-              float mis    = (dl.pdf == DIRAC) ? 1.0f : dl.pdf / (dl.pdf + ev.pdf);
-              contribution = throughput * dl.radianceOverPdf * mis * ev.bsdf;
-            }
-          }
-          {  // :357-416
-            float      r1 = rnd(seed), r2 = rnd(seed), r3 = rnd(seed);
-            BsdfSample sd = bsdfSample(-rayDir, mk3(r1, r2, r3), pbrMat);
-            throughput *= sd.bsdf_over_pdf;
-            rayDir        = sd.k2;
-            lastSamplePdf = sd.pdf;
-            if(sd.event_type != BSDF_EVENT_ABSORB)
-            {
-              f3 offsetDir = dot(rayDir, hit.geonrm) > 0.0f ? hit.geonrm : -hit.geonrm;
-              rayOrigin    = safeOffsetRay(hit.pos, offsetDir);
-              if(!SIMPLE && (sd.event_type & BSDF_EVENT_TRANSMISSION))
+              float    r1 = rnd(seed), r2 = rnd(seed), r3 = rnd(seed);
+              BsdfEval ev = bsdfEvaluate(-rayDir, dl.direction, mk3(r1, r2, r3), pbrMat);
+              if(ev.pdf > 0.0f)
               {
-                isInside = !isInside;
-                if(isInside)  // makeVolumeMedium, pathtrace_functions.h.slang:125-132
-                  P.medium[slot] = packMedium(volumeExtinctionCoefficient(pbrMat), pbrMat.scatterCoefficient, pbrMat.scatterAnisotropy);
+                float mis    = (dl.pdf == DIRAC) ? 1.0f : dl.pdf / (dl.pdf + ev.pdf);
+                contribution = throughput * dl.radianceOverPdf * mis * ev.bsdf;
               }
             }
-            else
-              surfaceDepth = maxDepth;
-          }
-          if(nextEventValid)  // :421-426 + the TraceShadow of pathTrace :462-471, deferred to k_trace_shadow
-          {
-            bool forward = dot(dl.direction, hit.nrm) > 0.0f;
-            f3   sOrg    = safeOffsetRay(forward ? hit.shadowPos : hit.pos, forward ? hit.geonrm : -hit.geonrm);
-            shOrg = make_float4(sOrg.x, sOrg.y, sOrg.z, dl.distance);
-            shDir = make_float4(dl.direction.x, dl.direction.y, dl.direction.z, __uint_as_float(0u));
-            shCon = make_float4(contribution.x, contribution.y, contribution.z, __uint_as_float(seed));
-            pushShadow            = true;
-          }
-          // Russian roulette, :476-482
-          if(surfaceDepth >= RR_MIN_DEPTH)
-          {
-            float rrPcont = fminf(maxComp(throughput) + 0.001f, 0.95f);
-            if(rnd(seed) >= rrPcont)
-              done = true;
-            else
-              throughput /= rrPcont;
-          }
-          if(!done)
-          {
-            surfaceDepth++;
-            rayDir = normalize(rayDir);
+            {  // :357-416
+              float      r1 = rnd(seed), r2 = rnd(seed), r3 = rnd(seed);
+              BsdfSample sd = bsdfSample(-rayDir, mk3(r1, r2, r3), pbrMat);
+              throughput *= sd.bsdf_over_pdf;
+              rayDir        = sd.k2;
+              lastSamplePdf = sd.pdf;
+              if(sd.event_type != BSDF_EVENT_ABSORB)
+              {
+                f3 offsetDir = dot(rayDir, hit.geonrm) > 0.0f ? hit.geonrm : -hit.geonrm;
+                rayOrigin    = safeOffsetRay(hit.pos, offsetDir);
+                if(!SIMPLE && (sd.event_type & BSDF_EVENT_TRANSMISSION))
+                {
+                  isInside = !isInside;
+                  if(isInside)  // makeVolumeMedium, pathtrace_functions.h.slang:125-132
+                    P.medium[slot] = packMedium(volumeExtinctionCoefficient(pbrMat), pbrMat.scatterCoefficient, pbrMat.scatterAnisotropy);
+                }
+              }
+              else
+                surfaceDepth = maxDepth;
+            }
+            if(nextEventValid)  // :421-426 + the TraceShadow of pathTrace :462-471, deferred to k_trace_shadow
+            {
+              bool forward = dot(dl.direction, hit.nrm) > 0.0f;
+              f3   sOrg    = safeOffsetRay(forward ? hit.shadowPos : hit.pos, forward ? hit.geonrm : -hit.geonrm);
+              shOrg = make_float4(sOrg.x, sOrg.y, sOrg.z, dl.distance);
+              shDir = make_float4(dl.direction.x, dl.direction.y, dl.direction.z, __uint_as_float(0u));
+              shCon = make_float4(contribution.x, contribution.y, contribution.z, __uint_as_float(seed));
+              pushShadow            = true;
+            }
+            // Russian roulette, :476-482
+            if(surfaceDepth >= RR_MIN_DEPTH)
+            {
+              float rrPcont = fminf(maxComp(throughput) + 0.001f, 0.95f);
+              if(rnd(seed) >= rrPcont)
+                done = true;
+              else
+                throughput /= rrPcont;
+            }
+            if(!done)
+            {
+              surfaceDepth++;
+              rayDir = normalize(rayDir);
+            }
           }
         }
         (void)earlyContinue;
@@ -961,6 +1008,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
       Q.shadow.org[posShadow]  = shOrg;
       Q.shadow.dir[posShadow]  = shDir;
       Q.shadow.aux[posShadow]  = shCon;
+      if(catcher)
+        Q.shadow.aux2[posShadow] = make_float4(shCon2.x, shCon2.y, shCon2.z, __uint_as_float(alive ? posNext : 0xffffffffu));
     }
   }
 }
@@ -969,7 +1018,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
 // k_trace_shadow: RayQueryRaytracer::TraceShadow (raytracer_interface.h.slang:139-187) + `pt.radiance += contribution * T`
 //================================================================================================================================
 template <bool WIDE, bool HAS_ALPHA, bool COUNT>
-__global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_shadow(DevScene sc, PathSoA P, Queues Q, StatCounters* stats)
+__global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_shadow(DevScene sc, PathSoA P, Queues Q, int nxt, float catcherDarken, StatCounters* stats)
 {
   __shared__ int      s_stack[BVH_STACK_LDS * TRACE_BLOCK];
   __shared__ uint32_t s_prefix[NSUB + 1];
@@ -1009,8 +1058,44 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_shadow(D
   unsigned nodes = 0, tris = 0, rays = 0;
   // prefetched next shadow ray
   bool     pValid = false;
-  uint32_t pSlot = QUEUE_DEAD;
+  uint32_t pSlot = QUEUE_DEAD, pQPos = 0, qpos = 0;
   float4   pO = make_float4(0, 0, 0, 0), pD = make_float4(0, 0, 0, 0), pC = make_float4(0, 0, 0, 0);
+  bool     catcherRay = false;
+
+  // end of a shadow ray: radiance += contribution * transmission (gltf_pathtrace.slang:462-471), or the two outcomes of
+  // handleShadowCatcher (pathtrace_functions.h.slang:520-534) for rays the shade kernel flagged as catcher probes
+  auto deposit = [&](bool occ) {
+    if(!catcherRay)
+    {
+      if(!occ)
+      {
+        float4 rad = P.radiance[slot];
+        rad.x += contrib.x * total.x;
+        rad.y += contrib.y * total.y;
+        rad.z += contrib.z * total.z;
+        P.radiance[slot] = rad;
+      }
+      return;
+    }
+    const float4 a2  = Q.shadow.aux2[qpos];
+    const f3     sf  = occ ? mk3(0.0f) : total;
+    float4       rad = P.radiance[slot];
+    if(sf.x == 1.0f && sf.y == 1.0f && sf.z == 1.0f)
+    {
+      rad.x += a2.x; rad.y += a2.y; rad.z += a2.z;  // unshadowed: environment seen through the plane, path ends
+      const uint32_t posNext = __float_as_uint(a2.w);
+      if(posNext != 0xffffffffu)
+        Q.active[nxt].slot[posNext] = QUEUE_DEAD;
+    }
+    else
+    {
+      f3 r3 = mk3(rad.x, rad.y, rad.z);
+      r3 += contrib * sf;
+      r3 -= contrib * (mk3(1.0f) - sf) * catcherDarken;
+      rad.x = r3.x; rad.y = r3.y; rad.z = r3.z;
+    }
+    P.radiance[slot] = rad;
+  };
 
   auto restartWalk = [&]() {
     if(WIDE)
@@ -1068,9 +1153,11 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_shadow(D
       if(pSlot != QUEUE_DEAD)
       {
         slot     = pSlot;
+        qpos     = pQPos;
         r        = makeRaySetup(xyz(pO), xyz(pD));
         tMax     = pO.w;
         isInside = (__float_as_uint(pD.w) & 1u) != 0u;
+        catcherRay = (__float_as_uint(pD.w) & 2u) != 0u;
         contrib  = xyz(pC);
         seed0    = __float_as_uint(pC.w);
         phase    = 0;
@@ -1086,10 +1173,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_shadow(D
         if(COUNT) ++rays;
         if(sc.bvhRoot == BVH_EMPTY)  // nothing to hit: unoccluded
         {
-          float4 rad = P.radiance[slot];
-          rad.x += contrib.x; rad.y += contrib.y; rad.z += contrib.z;
-          P.radiance[slot] = rad;
-          active           = false;
+          deposit(false);
+          active = false;
         }
       }
     }
@@ -1099,6 +1184,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_shadow(D
       if(flat != 0xffffffffu)
       {
         const uint32_t pPos = queuePos(Q.subCap, s_prefix, flat);
+        pQPos  = pPos;
         pSlot  = in.slot[pPos];
         pO     = in.org[pPos];
         pD     = in.dir[pPos];
@@ -1188,14 +1274,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_shadow(D
           }
           if(finished)
           {
-            if(!occluded)
-            {
-              float4 rad = P.radiance[slot];
-              rad.x += contrib.x * total.x;
-              rad.y += contrib.y * total.y;
-              rad.z += contrib.z * total.z;
-              P.radiance[slot] = rad;
-            }
+            deposit(occluded);
             active = false;
           }
         }
@@ -1372,22 +1451,23 @@ void launchTraceClosestT(const LaunchCtx& c, int cur)
   }
 }
 template <bool WIDE>
-void launchTraceShadowT(const LaunchCtx& c)
+void launchTraceShadowT(const LaunchCtx& c, int nxt)
 {
+  const float darken = c.fc.frameInfo.shadowCatcherDarkenAmount;
   dim3 grid(c.persistentBlocks * 256u / TRACE_BLOCK), block(TRACE_BLOCK);
   if(c.hasAlpha)
   {
     if(c.collectCounters)
-      hipLaunchKernelGGL((k_trace_shadow<WIDE, true, true>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, c.stats);
+      hipLaunchKernelGGL((k_trace_shadow<WIDE, true, true>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, nxt, darken, c.stats);
     else
-      hipLaunchKernelGGL((k_trace_shadow<WIDE, true, false>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, c.stats);
+      hipLaunchKernelGGL((k_trace_shadow<WIDE, true, false>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, nxt, darken, c.stats);
   }
   else
   {
     if(c.collectCounters)
-      hipLaunchKernelGGL((k_trace_shadow<WIDE, false, true>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, c.stats);
+      hipLaunchKernelGGL((k_trace_shadow<WIDE, false, true>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, nxt, darken, c.stats);
     else
-      hipLaunchKernelGGL((k_trace_shadow<WIDE, false, false>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, c.stats);
+      hipLaunchKernelGGL((k_trace_shadow<WIDE, false, false>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, nxt, darken, c.stats);
   }
 }
 }  // namespace
@@ -1416,12 +1496,12 @@ void launchShade(const LaunchCtx& c, int cur)
       hipLaunchKernelGGL((k_shade<false, false>), grid, block, 0, c.stream, c.scene, c.fc, c.paths, c.queues, cur, c.stats);
   }
 }
-void launchTraceShadow(const LaunchCtx& c)
+void launchTraceShadow(const LaunchCtx& c, int nxt)
 {
   if(c.wide)
-    launchTraceShadowT<true>(c);
+    launchTraceShadowT<true>(c, nxt);
   else
-    launchTraceShadowT<false>(c);
+    launchTraceShadowT<false>(c, nxt);
 }
 void launchFinishSample(const LaunchCtx& c, int sampleIndex, float4* accum, float* depth, float4* albedo, float4* normal)
 {

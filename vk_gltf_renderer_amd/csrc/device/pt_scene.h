@@ -141,6 +141,8 @@ struct RayQueue
   float4*   dir;   // direction.xyz, (closest: unused | shadow: uint bits, bit0 = initialInside)
   float4*   aux;   // closest: hit record written by k_trace_closest (t, triangle index bits or -1, u, v)
                    // shadow : contribution.rgb, seed bits (input of k_trace_shadow)
+  float4*   aux2;  // shadow queue only, shadow-catcher entries only (dir.w bit1): unshadowed term.rgb, position of the path's
+                   // continuation entry in the next active queue (or 0xffffffff)
 };
 struct Queues
 {
