@@ -108,6 +108,57 @@ def test_render_node_flattening_and_instancing(built, tmp_path):
     assert sorted(tuple(v) for v in inst) == sorted([(0, 0, 0), (0, 0, 0), (5, 0, 0), (5, 0, 0), (0, 0, 5), (0, 0, 5)])
 
 
+def _simple_tangents(pos, nrm, uv, idx):
+    """Independent numpy restatement of tinygltf::utils::simpleCreateTangents (reference: src/tinygltf_utils.cpp:878-998)."""
+    pos, nrm, uv = pos.astype(np.float32), nrm.astype(np.float32), uv.astype(np.float32)
+    t = np.zeros((len(pos), 4), np.float32)
+    for i0, i1, i2 in idx.reshape(-1, 3):
+        e1, e2 = pos[i1] - pos[i0], pos[i2] - pos[i0]
+        d1, d2 = uv[i1] - uv[i0], uv[i2] - uv[i0]
+        a = d1[0] * d2[1] - d2[0] * d1[1]
+        f = np.float32(1.0) / a if abs(a) > 0 else np.float32(1.0)
+        tg, bt = f * (d2[1] * e1 - d1[1] * e2), f * (d2[0] * e1 - d1[0] * e2)
+        hand = 1.0 if np.dot(np.cross(tg, bt), nrm[i0]) > 0 else -1.0
+        for v in (i0, i1, i2):
+            t[v, :3] += tg
+            t[v, 3] = hand
+    o = t[:, :3] - (nrm * t[:, :3]).sum(1, keepdims=True) * nrm
+    o /= np.linalg.norm(o, axis=1, keepdims=True)
+    return np.concatenate([o, t[:, 3:]], 1)
+
+
+def test_missing_tangents_are_created_for_normal_mapped_primitives(built, tmp_path):
+    """createMissingTangentsForModel (reference: src/gltf_scene.cpp:2431-2465): a primitive whose material has a normal
+    texture and no TANGENT attribute gets simpleCreateTangents() tangents and a RenderPrimitive of its own; the same geometry
+    under a material without a normal map keeps none; authored tangents are left alone."""
+    b = scenegen.GlbBuilder()
+    img = b.image(np.full((4, 4, 4), 128, np.uint8))
+    tex = b.texture(img, b.sampler())
+    m_nm = b.material({"normalTexture": {"index": tex}})
+    m_plain = b.material({})
+    pos, nrm, uv, idx = scenegen.uv_sphere(12, 8, 1.0)
+    prim = b.primitive(pos, idx, nrm, uv, material=m_nm)
+    same_geometry_plain = dict(prim)
+    same_geometry_plain["material"] = m_plain
+    authored = np.tile(np.array([[0, 0, 1, -1]], np.float32), (len(pos), 1))
+    with_tangents = b.primitive(pos, idx, nrm, uv, tangents=authored, material=m_nm)
+    b.node(mesh=b.mesh([prim, same_geometry_plain, with_tangents]))
+    sc = ptmod.Scene(b.save(str(tmp_path / "t.glb")))
+    d = sc.desc.contents
+    assert d.numRenderPrimitives == 3 and d.numRenderNodes == 3
+    rp = [d.renderPrimitives[d.renderNodes[i].renderPrimID] for i in range(3)]
+    n = rp[0].vertexCount
+    got = np.ctypeslib.as_array(rp[0].tangents, shape=(n, 4))
+    want = _simple_tangents(np.asarray(pos), np.asarray(nrm), np.asarray(uv), np.asarray(idx))
+    ok = np.isfinite(want).all(axis=1)  # the poles of the sphere have degenerate UV triangles: fast-tangent fallback there
+    assert ok.mean() > 0.8
+    assert np.abs(got[ok] - want[ok]).max() < 2e-4
+    assert np.isfinite(got).all() and np.allclose(np.linalg.norm(got[:, :3], axis=1), 1.0, atol=1e-4)
+    assert np.abs((got[:, :3] * np.asarray(nrm)).sum(1)).max() < 1e-4  # orthogonal to the normal
+    assert not rp[1].tangents
+    assert np.array_equal(np.ctypeslib.as_array(rp[2].tangents, shape=(n, 4)), authored)
+
+
 def test_texture_decode_mips_and_srgb(built, tmp_path):
     b = scenegen.GlbBuilder()
     rng = np.random.default_rng(3)

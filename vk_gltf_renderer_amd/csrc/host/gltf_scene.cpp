@@ -245,6 +245,120 @@ std::string primitiveKey(const Value& prim)
   return o.str();
 }
 
+// createMissingTangentsForModel's trigger rule (reference: src/gltf_scene.cpp:2431-2448): the primitive's material has a
+// normal texture and the primitive carries no TANGENT attribute.
+bool needsGeneratedTangents(const Value& doc, const Value& prim)
+{
+  const Value& mats  = doc["materials"];
+  const int    count = int(mats.size());
+  int          mat   = getInt(prim, "material", -1);
+  if(mat < 0 || mat >= count)
+    mat = 0;
+  if(mat >= count)
+    return false;
+  if(getInt(mats[size_t(mat)]["normalTexture"], "index", -1) < 0)
+    return false;
+  return !prim["attributes"].has("TANGENT");
+}
+// Such primitives get a TANGENT accessor of their own in the reference, i.e. a different primitive key than the same
+// geometry used without a normal map.
+std::string primitiveKeyWithTangents(const Value& doc, const Value& prim)
+{
+  return needsGeneratedTangents(doc, prim) ? primitiveKey(prim) + " TANGENT:generated" : primitiveKey(prim);
+}
+
+// shaderio::makeFastTangent as restated on the device (pt_bsdf.h): orthonormal basis of Duff et al. 2017
+void makeFastTangent(const float n[3], float t[4])
+{
+  float sign = std::copysign(1.0f, n[2]);
+  float a    = -1.0f / (sign + n[2]);
+  float b    = n[0] * n[1] * a;
+  t[0] = 1.0f + sign * n[0] * n[0] * a; t[1] = sign * b; t[2] = -sign * n[0]; t[3] = 1.0f;
+}
+
+// tinygltf::utils::simpleCreateTangents (reference: src/tinygltf_utils.cpp:878-998; Lengyel, FGED2 ch. 7): per-face UV-space
+// tangent accumulated on the three vertices, handedness of the LAST face touching a vertex (taken against the normal of
+// the face's first vertex, as the reference does), Gram-Schmidt against the vertex normal, fast-tangent fallback.
+void createSimpleTangents(RenderPrimitiveData& d)
+{
+  const size_t nv = d.vertexCount, nf = d.indices.size() / 3;
+  d.tangents.assign(nv * 4, 0.0f);
+  const bool         hasUV = !d.texCoords0.empty(), hasNormal = !d.normals.empty();
+  std::vector<float> geoNormal(hasNormal ? 0 : nv * 3, 0.0f);
+  auto P = [&](uint32_t i) { return &d.positions[size_t(i) * 3]; };
+  for(size_t f = 0; f < nf; ++f)
+  {
+    const uint32_t i0 = d.indices[f * 3], i1 = d.indices[f * 3 + 1], i2 = d.indices[f * 3 + 2];
+    const float *  p0 = P(i0), *p1 = P(i1), *p2 = P(i2);
+    const float    e1[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]}, e2[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+    float          n0[3];
+    if(hasNormal)
+    {
+      n0[0] = d.normals[size_t(i0) * 3]; n0[1] = d.normals[size_t(i0) * 3 + 1]; n0[2] = d.normals[size_t(i0) * 3 + 2];
+    }
+    else
+    {
+      float c[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+      float l    = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+      for(int a = 0; a < 3; ++a)
+        n0[a] = c[a] / l;
+      for(uint32_t v : {i0, i1, i2})
+        for(int a = 0; a < 3; ++a)
+          geoNormal[size_t(v) * 3 + a] = n0[a];
+    }
+    if(hasUV)
+    {
+      const float* u0 = &d.texCoords0[size_t(i0) * 2];
+      const float* u1 = &d.texCoords0[size_t(i1) * 2];
+      const float* u2 = &d.texCoords0[size_t(i2) * 2];
+      const float  d1[2] = {u1[0] - u0[0], u1[1] - u0[1]}, d2[2] = {u2[0] - u0[0], u2[1] - u0[1]};
+      float        fct = 1.0f;
+      const float  a   = d1[0] * d2[1] - d2[0] * d1[1];
+      if(std::fabs(a) > 0.0f)
+        fct = 1.0f / a;
+      float tg[3], bt[3];
+      for(int k = 0; k < 3; ++k)
+      {
+        tg[k] = fct * (d2[1] * e1[k] - d1[1] * e2[k]);
+        bt[k] = fct * (d2[0] * e1[k] - d1[0] * e2[k]);
+      }
+      const float cx[3] = {tg[1] * bt[2] - tg[2] * bt[1], tg[2] * bt[0] - tg[0] * bt[2], tg[0] * bt[1] - tg[1] * bt[0]};
+      const float hand  = (cx[0] * n0[0] + cx[1] * n0[1] + cx[2] * n0[2]) > 0.0f ? 1.0f : -1.0f;
+      for(uint32_t v : {i0, i1, i2})
+      {
+        float* t = &d.tangents[size_t(v) * 4];
+        t[0] += tg[0]; t[1] += tg[1]; t[2] += tg[2];
+        t[3] = hand;
+      }
+    }
+    else
+    {
+      float t[4];
+      makeFastTangent(n0, t);
+      for(uint32_t v : {i0, i1, i2})
+        std::memcpy(&d.tangents[size_t(v) * 4], t, sizeof(t));
+    }
+  }
+  for(size_t v = 0; v < nv; ++v)
+  {
+    float*       t = &d.tangents[v * 4];
+    const float* n = hasNormal ? &d.normals[v * 3] : &geoNormal[v * 3];
+    const float  dn = n[0] * t[0] + n[1] * t[1] + n[2] * t[2];
+    float        o[3] = {t[0] - dn * n[0], t[1] - dn * n[1], t[2] - dn * n[2]};
+    const float  l    = std::sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]);
+    for(int a = 0; a < 3; ++a)
+      o[a] /= l;  // glm::normalize: a zero vector yields NaN, caught below
+    const float l2 = o[0] * o[0] + o[1] * o[1] + o[2] * o[2];
+    if(!(l2 >= 0.1f) || std::isnan(o[0]) || std::isnan(o[1]) || std::isnan(o[2]))
+    {
+      float ft[4];
+      makeFastTangent(n, ft);
+      o[0] = ft[0]; o[1] = ft[1]; o[2] = ft[2];
+    }
+    t[0] = o[0]; t[1] = o[1]; t[2] = o[2];
+  }
+}
+
 }  // namespace
 
 //----------------------------------------------------------------------------------------------------------------------
@@ -703,7 +817,7 @@ void GltfScene::buildPrimitives(std::map<std::string, int>& primMap)  // referen
     for(size_t j = 0; j < prims.size(); ++j)
     {
       const Value& prim = prims[j];
-      std::string  key  = primitiveKey(prim);
+      std::string  key  = primitiveKeyWithTangents(m_doc, prim);
       if(primMap.count(key))
         continue;
       primMap[key] = int(m_primData.size());
@@ -758,6 +872,8 @@ void GltfScene::buildPrimitives(std::map<std::string, int>& primMap)  // referen
       for(uint32_t& ix : d.indices)  // defensive: never index past the vertex streams
         if(ix >= d.vertexCount)
           ix = 0;
+      if(d.tangents.empty() && d.vertexCount > 0 && needsGeneratedTangents(m_doc, prim))
+        createSimpleTangents(d);
       m_primData.push_back(std::move(d));
     }
   }
@@ -848,7 +964,7 @@ void GltfScene::traverse(int nodeID, const mx::mat4& parent, bool parentVisible,
     for(size_t p = 0; p < prims.size(); ++p)
     {
       const Value& prim = prims[p];
-      auto         it   = primMap.find(primitiveKey(prim));
+      auto         it   = primMap.find(primitiveKeyWithTangents(m_doc, prim));
       if(it == primMap.end())
         continue;
       int rprimID = it->second;
