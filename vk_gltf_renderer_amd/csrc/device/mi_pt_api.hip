@@ -94,6 +94,15 @@ struct MiPt
   bool                        wide      = true;
   pt::DevScene                scene{};
   bool                        hasAlpha = false, hasVolumeScatter = false, simpleMaterials = true;
+  // device-resident descriptor copies (see k_shade): the scene struct, re-uploaded when the environment changes, and a ring
+  // of per-batch frame constants fed from pinned host memory
+  static constexpr int        FC_RING = 32;
+  DevBuf<pt::DevScene>        sceneDev;
+  bool                        sceneDevDirty = true;
+  DevBuf<pt::FrameConsts>     fcRing;
+  pt::FrameConsts*            fcHost = nullptr;  // pinned, FC_RING entries
+  hipEvent_t                  fcDone[FC_RING] = {};
+  unsigned                    fcCursor = 0;
   MiPtStats                   staticStats{};
   // frame state
   int                     width = 0, height = 0;
@@ -138,6 +147,11 @@ struct MiPt
       (void)hipFree(bvh8Nodes);
     for(hipEvent_t e : eventPool)
       (void)hipEventDestroy(e);
+    for(hipEvent_t e : fcDone)
+      if(e)
+        (void)hipEventDestroy(e);
+    if(fcHost)
+      (void)hipHostFree(fcHost);
   }
 };
 
@@ -486,6 +500,7 @@ int mi_pt_set_environment(MiPt* pt, const MiPtEnvironment* env)
     pt->scene.envPixels = nullptr;
     pt->scene.envAccel  = nullptr;
     pt->scene.envWidth = pt->scene.envHeight = 0;
+    pt->sceneDevDirty  = true;
     return MI_PT_OK;
   }
   const size_t n = size_t(env->width) * size_t(env->height);
@@ -495,6 +510,7 @@ int mi_pt_set_environment(MiPt* pt, const MiPtEnvironment* env)
   pt->scene.envAccel  = pt->envAccel.ptr;
   pt->scene.envWidth  = env->width;
   pt->scene.envHeight = env->height;
+  pt->sceneDevDirty   = true;
   return MI_PT_OK;
 }
 
@@ -612,6 +628,27 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   c.simpleMaterials  = pt->simpleMaterials && getenv("MI_PT_GENERIC_SHADE") == nullptr;
   c.wide             = pt->wide;
   c.collectCounters  = pt->collectCounters;
+  // descriptor copies for the kernels that read them through a pointer
+  if(pt->sceneDevDirty)
+  {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(pt->sceneDev.upload(&pt->scene, 1));
+    pt->sceneDevDirty = false;
+  }
+  if(!pt->fcHost)
+  {
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&pt->fcHost), sizeof(pt::FrameConsts) * MiPt::FC_RING, hipHostMallocDefault));
+    HIP_TRY(pt->fcRing.alloc(MiPt::FC_RING));
+    for(hipEvent_t& e : pt->fcDone)
+      HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  const unsigned fcSlot = pt->fcCursor++ % unsigned(MiPt::FC_RING);
+  if(pt->fcCursor > unsigned(MiPt::FC_RING))
+    HIP_TRY(hipEventSynchronize(pt->fcDone[fcSlot]));  // the batch that used this slot FC_RING calls ago must have drained
+  pt->fcHost[fcSlot] = c.fc;
+  HIP_TRY(hipMemcpyAsync(pt->fcRing.ptr + fcSlot, pt->fcHost + fcSlot, sizeof(pt::FrameConsts), hipMemcpyHostToDevice, stream));
+  c.sceneDev = pt->sceneDev.ptr;
+  c.fcDev    = pt->fcRing.ptr + fcSlot;
 
   auto timed = [&](int kind, auto&& launch) {
     if(pt->timingEnabled)
@@ -700,6 +737,7 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   if(params->flags & MI_PT_FIRST_FRAME)
     pt::launchSelection(c, pt->selection.ptr);
   HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(pt->fcDone[fcSlot], stream));
   if(pt->timingEnabled)
   {
     (void)hipEventRecord(frameB, stream);

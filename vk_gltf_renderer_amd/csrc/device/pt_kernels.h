@@ -10,6 +10,8 @@ struct LaunchCtx
 {
   DevScene        scene;
   FrameConsts     fc;
+  const DevScene*    sceneDev;  // device-resident copies of `scene` / `fc` for kernels that hand them to non-inlined helpers
+  const FrameConsts* fcDev;
   PathSoA         paths;
   Queues          queues;
   const uint32_t* ownedTiles;

@@ -645,14 +645,18 @@ __global__ void __launch_bounds__(SEL_BLOCK) k_selection(DevScene sc, FrameConst
 // k_shade: everything of pathTraceOneBounce / pathTrace between the two Trace calls (gltf_pathtrace.slang:104-430, 441-494)
 //================================================================================================================================
 template <bool COUNT, bool SIMPLE>
-__global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) k_shade(DevScene sc, FrameConsts fc, PathSoA P, Queues Q, int cur, StatCounters* stats)
+__global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) k_shade(const DevScene* __restrict__ scp, const FrameConsts* __restrict__ fcp, PathSoA P, Queues Q, int cur, StatCounters* stats)
 {
+  // The scene / frame descriptors reach the non-inlined helpers (getTexture, sampleLights, the sky) by reference.  As
+  // by-value kernel arguments they would be copied to scratch (their address escapes) and every field read would become a
+  // memory round trip; as device-resident structs they are read through one uniform pointer.
+  const DevScene&    sc = *scp;
+  const FrameConsts& fc = *fcp;
   __shared__ uint32_t s_prefix[NSUB + 1];
   __shared__ uint32_t s_push[4];
   __shared__ float    s_srgb[256];  // sRGB decode table next to the ALU: 3 lookups per texel, up to 8 texels per tap
   s_srgb[threadIdx.x] = sc.srgbLut[threadIdx.x];
   static_assert(SHADE_BLOCK == 256, "one table entry per thread");
-  sc.srgbLut = s_srgb;
   if(blockIdx.x == 0 && threadIdx.x < 8)
     Q.counters[QC_HEADS_TRACE + threadIdx.x] = 0;  // for the next iteration's k_trace_closest
   queuePrefix(&Q.counters[cur ? QC_ACTIVE1 : QC_ACTIVE0], s_prefix);
@@ -829,6 +833,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
           mesh.isInside           = isInside;
           mesh.texGrad            = worldFoot * hit.texelDensity * fc.pc.texGradScale;
           mesh.baseColorVertexMul = hit.color;
+          mesh.srgbLut            = s_srgb;
           pbrMat                  = evaluateMaterial<SIMPLE>(sc, mat, mesh, taps);
           unlit                   = mat.unlit > 0;
         }
@@ -1484,16 +1489,16 @@ void launchShade(const LaunchCtx& c, int cur)
   if(c.simpleMaterials)
   {
     if(c.collectCounters)
-      hipLaunchKernelGGL((k_shade<true, true>), grid, block, 0, c.stream, c.scene, c.fc, c.paths, c.queues, cur, c.stats);
+      hipLaunchKernelGGL((k_shade<true, true>), grid, block, 0, c.stream, c.sceneDev, c.fcDev, c.paths, c.queues, cur, c.stats);
     else
-      hipLaunchKernelGGL((k_shade<false, true>), grid, block, 0, c.stream, c.scene, c.fc, c.paths, c.queues, cur, c.stats);
+      hipLaunchKernelGGL((k_shade<false, true>), grid, block, 0, c.stream, c.sceneDev, c.fcDev, c.paths, c.queues, cur, c.stats);
   }
   else
   {
     if(c.collectCounters)
-      hipLaunchKernelGGL((k_shade<true, false>), grid, block, 0, c.stream, c.scene, c.fc, c.paths, c.queues, cur, c.stats);
+      hipLaunchKernelGGL((k_shade<true, false>), grid, block, 0, c.stream, c.sceneDev, c.fcDev, c.paths, c.queues, cur, c.stats);
     else
-      hipLaunchKernelGGL((k_shade<false, false>), grid, block, 0, c.stream, c.scene, c.fc, c.paths, c.queues, cur, c.stats);
+      hipLaunchKernelGGL((k_shade<false, false>), grid, block, 0, c.stream, c.sceneDev, c.fcDev, c.paths, c.queues, cur, c.stats);
   }
 }
 void launchTraceShadow(const LaunchCtx& c, int nxt)

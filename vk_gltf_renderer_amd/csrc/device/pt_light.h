@@ -25,31 +25,32 @@ PT_DEV int wrapCoord(int i, int n, int mode)
   int m = i % n;
   return m < 0 ? m + n : m;
 }
-PT_DEV f4 fetchTexel(const DevScene& sc, const DevTexture& t, int level, int w, int x, int y)
+// `lut` = the 256-entry sRGB decode table to use (sc.srgbLut, or a copy of it that the caller staged in LDS)
+PT_DEV f4 fetchTexel(const DevScene& sc, const float* lut, const DevTexture& t, int level, int w, int x, int y)
 {
   uchar4 p = sc.texels[size_t(t.levelOffset[level]) + size_t(y) * size_t(w) + size_t(x)];
   if(t.srgb)
-    return mk4(sc.srgbLut[p.x], sc.srgbLut[p.y], sc.srgbLut[p.z], float(p.w) * (1.0f / 255.0f));
+    return mk4(lut[p.x], lut[p.y], lut[p.z], float(p.w) * (1.0f / 255.0f));
   return mk4(float(p.x) * (1.0f / 255.0f), float(p.y) * (1.0f / 255.0f), float(p.z) * (1.0f / 255.0f), float(p.w) * (1.0f / 255.0f));
 }
-PT_DEV f4 sampleLevel(const DevScene& sc, const DevTexture& t, f2 uv, int level, int filter)
+PT_DEV f4 sampleLevel(const DevScene& sc, const float* lut, const DevTexture& t, f2 uv, int level, int filter)
 {
   int   w = max(1, int(t.width) >> level), h = max(1, int(t.height) >> level);
   float fx = uv.x * float(w), fy = uv.y * float(h);
   if(filter == MI_FILTER_NEAREST)
-    return fetchTexel(sc, t, level, w, wrapCoord(int(floorf(fx)), w, t.wrapS), wrapCoord(int(floorf(fy)), h, t.wrapT));
+    return fetchTexel(sc, lut, t, level, w, wrapCoord(int(floorf(fx)), w, t.wrapS), wrapCoord(int(floorf(fy)), h, t.wrapT));
   fx -= 0.5f;
   fy -= 0.5f;
   float flx = floorf(fx), fly = floorf(fy);
   float tx = fx - flx, ty = fy - fly;
   int   x0 = wrapCoord(int(flx), w, t.wrapS), x1 = wrapCoord(int(flx) + 1, w, t.wrapS);
   int   y0 = wrapCoord(int(fly), h, t.wrapT), y1 = wrapCoord(int(fly) + 1, h, t.wrapT);
-  f4    a = fetchTexel(sc, t, level, w, x0, y0), b = fetchTexel(sc, t, level, w, x1, y0);
-  f4    c = fetchTexel(sc, t, level, w, x0, y1), d = fetchTexel(sc, t, level, w, x1, y1);
+  f4    a = fetchTexel(sc, lut, t, level, w, x0, y0), b = fetchTexel(sc, lut, t, level, w, x1, y0);
+  f4    c = fetchTexel(sc, lut, t, level, w, x0, y1), d = fetchTexel(sc, lut, t, level, w, x1, y1);
   return (a * (1.0f - tx) + b * tx) * (1.0f - ty) + (c * (1.0f - tx) + d * tx) * ty;
 }
 // SampleLevel(uv, 0) when !useGrad, SampleGrad(uv, ddx, ddy) otherwise
-PT_DEV f4 sampleTexture(const DevScene& sc, int texIndex, f2 uv, bool useGrad, f2 ddx, f2 ddy)
+PT_DEV f4 sampleTexture(const DevScene& sc, const float* lut, int texIndex, f2 uv, bool useGrad, f2 ddx, f2 ddy)
 {
   if(texIndex < 0 || texIndex >= sc.numTextures)
     return mk4(1.0f);
@@ -63,18 +64,23 @@ PT_DEV f4 sampleTexture(const DevScene& sc, int texIndex, f2 uv, bool useGrad, f
     lod       = rho > 0.0f ? log2f(rho) : -126.0f;
   }
   if(lod <= 0.0f)
-    return sampleLevel(sc, t, uv, 0, t.magFilter);
+    return sampleLevel(sc, lut, t, uv, 0, t.magFilter);
   float maxLevel = float(int(t.numLevels) - 1);
   lod            = fminf(lod, maxLevel);
   if(t.mipmapMode == MI_FILTER_NEAREST)
-    return sampleLevel(sc, t, uv, min(int(floorf(lod + 0.5f)), int(t.numLevels) - 1), t.minFilter);
+    return sampleLevel(sc, lut, t, uv, min(int(floorf(lod + 0.5f)), int(t.numLevels) - 1), t.minFilter);
   int   l0 = int(floorf(lod)), l1 = min(l0 + 1, int(t.numLevels) - 1);
   float f  = lod - float(l0);
-  f4    a  = sampleLevel(sc, t, uv, l0, t.minFilter);
+  f4    a  = sampleLevel(sc, lut, t, uv, l0, t.minFilter);
   if(f == 0.0f || l1 == l0)
     return a;
-  f4 b = sampleLevel(sc, t, uv, l1, t.minFilter);
+  f4 b = sampleLevel(sc, lut, t, uv, l1, t.minFilter);
   return a * (1.0f - f) + b * f;
+}
+
+PT_DEV f4 sampleTexture(const DevScene& sc, int texIndex, f2 uv, bool useGrad, f2 ddx, f2 ddy)
+{
+  return sampleTexture(sc, sc.srgbLut, texIndex, uv, useGrad, ddx, ddy);
 }
 
 // ---- HDR environment ------------------------------------------------------------------------------------------------------

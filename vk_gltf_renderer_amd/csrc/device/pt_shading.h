@@ -144,9 +144,10 @@ struct MeshState
   bool  isInside;
   float texGrad;
   f4    baseColorVertexMul;
+  const float* srgbLut;  // sRGB decode table for the texture fetches of this hit (the shade kernel stages it in LDS)
 };
 PT_DEV bool isTexturePresent(uint16_t t) { return t > 0; }
-__device__ __noinline__ f4 getTexture(const DevScene& sc, uint16_t slot, f2 tc0, f2 tc1, float texGrad, unsigned& taps)  // :76-110
+__device__ __noinline__ f4 getTexture(const DevScene& sc, const float* lut, uint16_t slot, f2 tc0, f2 tc1, float texGrad, unsigned& taps)  // :76-110
 {
   ++taps;
   const MiGltfTextureInfo ti = sc.texInfos[slot];
@@ -154,8 +155,8 @@ __device__ __noinline__ f4 getTexture(const DevScene& sc, uint16_t slot, f2 tc0,
   const float*            U  = ti.uvTransform;
   f2                      tt = mk2(t.x * U[0] + t.y * U[2] + U[4], t.x * U[1] + t.y * U[3] + U[5]);
   if(texGrad > 0.0f)
-    return sampleTexture(sc, ti.index, tt, true, mk2(U[0] * texGrad, U[1] * texGrad), mk2(U[2] * texGrad, U[3] * texGrad));
-  return sampleTexture(sc, ti.index, tt, false, mk2(0, 0), mk2(0, 0));
+    return sampleTexture(sc, lut, ti.index, tt, true, mk2(U[0] * texGrad, U[1] * texGrad), mk2(U[2] * texGrad, U[3] * texGrad));
+  return sampleTexture(sc, lut, ti.index, tt, false, mk2(0, 0), mk2(0, 0));
 }
 PT_DEV f3 multiToSingleScatterAlbedo(f3 rho)  // :125-129
 {
@@ -186,7 +187,7 @@ PT_DEV f3 convertSGToMR(f3 diffuseColor, f3 specularColor, float glossiness, flo
 template <bool SIMPLE>
 PT_DEV PbrMaterial evaluateMaterial(const DevScene& sc, const MiGltfShadeMaterial& m, const MeshState& st, unsigned& taps)  // :168-457
 {
-#define TEX(slot) getTexture(sc, slot, st.tc0, st.tc1, st.texGrad, taps)
+#define TEX(slot) getTexture(sc, st.srgbLut, slot, st.tc0, st.tc1, st.texGrad, taps)
   PbrMaterial p = defaultPbrMaterial();
   if(m.pbrModel == MI_PBR_SPECULAR_GLOSSINESS)
   {
