@@ -655,7 +655,6 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
   __shared__ uint32_t s_prefix[NSUB + 1];
   __shared__ uint32_t s_push[4];
   __shared__ float    s_srgb[256];  // sRGB decode table next to the ALU: 3 lookups per texel, up to 8 texels per tap
-  s_srgb[threadIdx.x] = sc.srgbLut[threadIdx.x];
   static_assert(SHADE_BLOCK == 256, "one table entry per thread");
   if(blockIdx.x == 0 && threadIdx.x < 8)
     Q.counters[QC_HEADS_TRACE + threadIdx.x] = 0;  // for the next iteration's k_trace_closest
@@ -663,6 +662,10 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
   const uint32_t count     = s_prefix[NSUB];
   const int      nxt       = cur ^ 1;
   const uint32_t numChunks = (count + SHADE_BLOCK - 1) / SHADE_BLOCK;  // SHADE_BLOCK == QCHUNK
+  if(blockIdx.x >= numChunks)
+    return;  // nothing for this block (late bounces launch the full grid on short or empty queues)
+  s_srgb[threadIdx.x] = sc.srgbLut[threadIdx.x];
+  __syncthreads();
   for(uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x)
   {
     const uint32_t i    = chunk * SHADE_BLOCK + threadIdx.x;
@@ -1023,8 +1026,10 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
 // k_trace_shadow: RayQueryRaytracer::TraceShadow (raytracer_interface.h.slang:139-187) + `pt.radiance += contribution * T`
 //================================================================================================================================
 template <bool WIDE, bool HAS_ALPHA, bool COUNT>
-__global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_shadow(DevScene sc, PathSoA P, Queues Q, int nxt, float catcherDarken, StatCounters* stats)
+__global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_shadow(DevScene sc, const DevScene* __restrict__ scp, PathSoA P, Queues Q, int nxt, float catcherDarken, StatCounters* stats)
 {
+  // `sc` (kernel argument, SGPRs) serves the inlined walk; the non-inlined material helpers of the transmissive path get the
+  // device-resident copy `*scp` so that the argument's address never escapes (no scratch copy, cf. k_shade)
   __shared__ int      s_stack[BVH_STACK_LDS * TRACE_BLOCK];
   __shared__ uint32_t s_prefix[NSUB + 1];
   __shared__ uint4    s_nodes[WIDE ? NODE_CACHE * 5 : 1];
@@ -1058,6 +1063,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_shadow(D
   // phase-1 search state
   float    bT = 0.0f, bU = 0.0f, bV = 0.0f, lastT = -1.0f, prevHitT = 0.0f;
   uint32_t bRnode = 0, bPrim = 0, lastRnode = 0, lastPrim = 0;
+  int      bTri = 0;
   bool     found = false, haveLast = false, isInside = false;
   f3       total = mk3(1.0f);
   unsigned nodes = 0, tris = 0, rays = 0;
@@ -1066,6 +1072,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_shadow(D
   uint32_t pSlot = QUEUE_DEAD, pQPos = 0, qpos = 0;
   float4   pO = make_float4(0, 0, 0, 0), pD = make_float4(0, 0, 0, 0), pC = make_float4(0, 0, 0, 0);
   bool     catcherRay = false;
+  uint32_t pBase = 0, pMask = 0, qBase = 0, qMask = 0;  // parked leaf hits of the 8-wide walk (see k_trace_closest)
 
   // end of a shadow ray: radiance += contribution * transmission (gltf_pathtrace.slang:462-471), or the two outcomes of
   // handleShadowCatcher (pathtrace_functions.h.slang:520-534) for rays the shade kernel flagged as catcher probes
@@ -1102,11 +1109,27 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_shadow(D
     P.radiance[slot] = rad;
   };
 
+  // one accepted-or-not transmissive candidate in order (raytracer_interface.h.slang:160-178)
+  auto processCandidate = [&](float t, int tri, uint32_t rnode, uint32_t prim, float u, float v) {
+    f3    bary    = mk3(1.0f - u - v, u, v);
+    float opacity = getOpacityFast(sc, tri, bary);
+    if(candidateRand(seed0, int(rnode), int(prim)) < opacity)
+    {
+      float segment = fmaxf(0.0f, t - prevHitT);
+      f3    curT    = getShadowTransmission(*scp, int(rnode), int(prim), bary, segment, r.dir, isInside);
+      prevHitT      = t;
+      total *= curT;
+      if(maxComp(total) <= MIN_TRANSMISSION)
+        occluded = true;
+    }
+  };
+
   auto restartWalk = [&]() {
     if(WIDE)
     {
       G      = rootGroup(octinv);
       st2.sp = 0;
+      pMask = qMask = 0u;
     }
     else
     {
@@ -1145,7 +1168,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_shadow(D
       const bool beforeBest = !found || h.t < bT || (h.t == bT && (rnode < bRnode || (rnode == bRnode && prim < bPrim)));
       if(afterLast && beforeBest)
       {
-        found = true; bT = h.t; bRnode = rnode; bPrim = prim; bU = h.u; bV = h.v;
+        found = true; bT = h.t; bTri = triIndex; bRnode = rnode; bPrim = prim; bU = h.u; bV = h.v;
       }
     }
   };
@@ -1206,12 +1229,14 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_shadow(D
     }
     for(;;)
     {
-      if(active)
+      bool walkDone = false;
+      if(WIDE)
       {
-        const float walkTmax = (HAS_ALPHA && phase == 1 && found) ? bT : tMax;
-        bool        walkDone = false;
-        if(WIDE)
+        // node step + dense triangle phase, as in k_trace_closest (any-hit and the phase-1 search are order independent)
+        bool visited = false;
+        if(active && qMask == 0u)
         {
+          const float walkTmax = (HAS_ALPHA && phase == 1 && found) ? bT : tMax;
           if((G.bits >> 8) == 0u && st2.sp > 0)
             G = st2.pop();
           if(G.bits >> 8)
@@ -1222,30 +1247,55 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_shadow(D
             uint32_t tBase, tMask;
             bvh8Visit(sc, r, walkTmax, octinv, child, G, tBase, tMask, s_nodes, cachedNodes);
             if(COUNT) ++nodes;
-            while(tMask && !occluded)
+            visited = true;
+            if(tMask)
             {
-              const int k = __ffs(int(tMask)) - 1;
-              tMask &= tMask - 1u;
-              testTri(int(tBase) + k);
+              if(pMask == 0u) { pBase = tBase; pMask = tMask; }
+              else            { qBase = tBase; qMask = tMask; }
             }
           }
-          walkDone = occluded || ((G.bits >> 8) == 0u && st2.sp == 0);
         }
-        else
+        unsigned long long pend = __ballot(active && pMask != 0u);
+        if(pend != 0ull)
         {
-#pragma unroll 1
-          for(int k = 0; k < 4 && node >= 0; ++k)
+          const int  visiting = __popcll(__ballot(visited));
+          const bool drain    = visiting < TRI_PHASE_LANES;
+          if(drain || __popcll(pend) >= TRI_PHASE_LANES || __ballot(active && qMask != 0u) != 0ull)
           {
-            node = bvhInnerStep(sc, r, walkTmax, node, st);
-            if(COUNT) ++nodes;
+            do
+            {
+              if(active && pMask != 0u)
+              {
+                const int k = __ffs(int(pMask)) - 1;
+                pMask &= pMask - 1u;
+                testTri(int(pBase) + k);
+                if(occluded) { pMask = 0u; qMask = 0u; }
+                else if(pMask == 0u) { pBase = qBase; pMask = qMask; qMask = 0u; }
+              }
+              pend = __ballot(active && pMask != 0u);
+            } while(pend != 0ull && (drain || __popcll(pend) >= TRI_PHASE_EXIT_LANES || __ballot(active && qMask != 0u) != 0ull));
           }
-          if(node < 0 && node != BVH_EMPTY)
-          {
-            testTri(~node);
-            node = bvhPop(st);
-          }
-          walkDone = occluded || node == BVH_EMPTY;
         }
+        walkDone = active && (occluded || ((G.bits >> 8) == 0u && st2.sp == 0 && pMask == 0u));
+      }
+      else if(active)
+      {
+        const float walkTmax = (HAS_ALPHA && phase == 1 && found) ? bT : tMax;
+#pragma unroll 1
+        for(int k = 0; k < 4 && node >= 0; ++k)
+        {
+          node = bvhInnerStep(sc, r, walkTmax, node, st);
+          if(COUNT) ++nodes;
+        }
+        if(node < 0 && node != BVH_EMPTY)
+        {
+          testTri(~node);
+          node = bvhPop(st);
+        }
+        walkDone = occluded || node == BVH_EMPTY;
+      }
+      if(active)
+      {
         if(walkDone)
         {
           bool finished = true;
@@ -1253,19 +1303,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_shadow(D
           {
             if(phase == 1)
             {
-              // process the candidate (raytracer_interface.h.slang:160-178)
               haveLast = true; lastT = bT; lastRnode = bRnode; lastPrim = bPrim;
-              f3    bary    = mk3(1.0f - bU - bV, bU, bV);
-              float opacity = getOpacity(sc, int(bRnode), int(bPrim), bary);
-              if(candidateRand(seed0, int(bRnode), int(bPrim)) < opacity)
-              {
-                float segment = fmaxf(0.0f, bT - prevHitT);
-                f3    curT    = getShadowTransmission(sc, int(bRnode), int(bPrim), bary, segment, r.dir, isInside);
-                prevHitT      = bT;
-                total *= curT;
-                if(maxComp(total) <= MIN_TRANSMISSION)
-                  occluded = true;
-              }
+              processCandidate(bT, bTri, bRnode, bPrim, bU, bV);
               --nTrans;
             }
             if(!occluded && nTrans > 0)
@@ -1463,16 +1502,16 @@ void launchTraceShadowT(const LaunchCtx& c, int nxt)
   if(c.hasAlpha)
   {
     if(c.collectCounters)
-      hipLaunchKernelGGL((k_trace_shadow<WIDE, true, true>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, nxt, darken, c.stats);
+      hipLaunchKernelGGL((k_trace_shadow<WIDE, true, true>), grid, block, 0, c.stream, c.scene, c.sceneDev, c.paths, c.queues, nxt, darken, c.stats);
     else
-      hipLaunchKernelGGL((k_trace_shadow<WIDE, true, false>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, nxt, darken, c.stats);
+      hipLaunchKernelGGL((k_trace_shadow<WIDE, true, false>), grid, block, 0, c.stream, c.scene, c.sceneDev, c.paths, c.queues, nxt, darken, c.stats);
   }
   else
   {
     if(c.collectCounters)
-      hipLaunchKernelGGL((k_trace_shadow<WIDE, false, true>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, nxt, darken, c.stats);
+      hipLaunchKernelGGL((k_trace_shadow<WIDE, false, true>), grid, block, 0, c.stream, c.scene, c.sceneDev, c.paths, c.queues, nxt, darken, c.stats);
     else
-      hipLaunchKernelGGL((k_trace_shadow<WIDE, false, false>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, nxt, darken, c.stats);
+      hipLaunchKernelGGL((k_trace_shadow<WIDE, false, false>), grid, block, 0, c.stream, c.scene, c.sceneDev, c.paths, c.queues, nxt, darken, c.stats);
   }
 }
 }  // namespace
