@@ -105,7 +105,7 @@ PT_DEV void feedInit(WaveFeed& f, uint32_t total)
   f.exhausted   = total == 0;
 }
 // blocks beyond the ones the queue can feed (one wave per fetch chunk) leave at once
-PT_DEV bool feedBlockHasWork(const WaveFeed& f) { return blockIdx.x * uint32_t(TRACE_BLOCK / 64) < f.numChunks; }
+PT_DEV bool feedBlockHasWork(const WaveFeed& f) { return blockIdx.x * (blockDim.x / 64u) < f.numChunks; }
 PT_DEV bool feedNextChunk(WaveFeed& f, uint32_t* heads)
 {
   uint32_t chunk = 0xffffffffu;
@@ -315,9 +315,9 @@ constexpr int TRI_PHASE_LANES      = 24;
 constexpr int TRI_PHASE_EXIT_LANES = 10;
 
 // Copies the top of the 8-wide BVH into this workgroup's LDS (whole block; contains a barrier).
-PT_DEV uint32_t fillNodeCache(const DevScene& sc, uint4* s_nodes)
+PT_DEV uint32_t fillNodeCache(const DevScene& sc, uint4* s_nodes, uint32_t capacity = NODE_CACHE)
 {
-  const uint32_t n = min(uint32_t(sc.bvh8NumNodes), uint32_t(NODE_CACHE));
+  const uint32_t n = min(uint32_t(sc.bvh8NumNodes), capacity);
   for(uint32_t i = threadIdx.x; i < n * 5u; i += blockDim.x)
     s_nodes[i] = sc.bvh8Nodes[i];
   __syncthreads();
@@ -1025,26 +1025,36 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
 //================================================================================================================================
 // k_trace_shadow: RayQueryRaytracer::TraceShadow (raytracer_interface.h.slang:139-187) + `pt.radiance += contribution * T`
 //================================================================================================================================
+// The alpha / transmission flavour of the shadow kernel carries the ordered-candidate state on top of the walk and does not
+// fit the 128 VGPRs of a 1024-thread workgroup without spilling into its hot loop: it runs as three 256-thread workgroups per
+// CU with a smaller LDS node cache instead.
+template <bool HAS_ALPHA>
+struct ShadowCfg
+{
+  static constexpr int BLOCK = HAS_ALPHA ? 256 : TRACE_BLOCK;
+  static constexpr int CACHE = HAS_ALPHA ? 320 : NODE_CACHE;
+};
 template <bool WIDE, bool HAS_ALPHA, bool COUNT>
-__global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_shadow(DevScene sc, const DevScene* __restrict__ scp, PathSoA P, Queues Q, int nxt, float catcherDarken, StatCounters* stats)
+__global__ void __launch_bounds__(ShadowCfg<HAS_ALPHA>::BLOCK, TRACE_MIN_WAVES) k_trace_shadow(DevScene sc, const DevScene* __restrict__ scp, PathSoA P, Queues Q, int nxt, float catcherDarken, StatCounters* stats)
 {
   // `sc` (kernel argument, SGPRs) serves the inlined walk; the non-inlined material helpers of the transmissive path get the
   // device-resident copy `*scp` so that the argument's address never escapes (no scratch copy, cf. k_shade)
-  __shared__ int      s_stack[BVH_STACK_LDS * TRACE_BLOCK];
+  constexpr int SBLOCK = ShadowCfg<HAS_ALPHA>::BLOCK;
+  __shared__ int      s_stack[BVH_STACK_LDS * SBLOCK];
   __shared__ uint32_t s_prefix[NSUB + 1];
-  __shared__ uint4    s_nodes[WIDE ? NODE_CACHE * 5 : 1];
+  __shared__ uint4    s_nodes[WIDE ? ShadowCfg<HAS_ALPHA>::CACHE * 5 : 1];
   queuePrefix(&Q.counters[QC_SHADOW], s_prefix);
   const RayQueue in = Q.shadow;
   WaveFeed feed;
   feedInit(feed, s_prefix[NSUB]);
   if(!feedBlockHasWork(feed))
     return;
-  const uint32_t cachedNodes = WIDE ? fillNodeCache(sc, s_nodes) : 0u;
+  const uint32_t cachedNodes = WIDE ? fillNodeCache(sc, s_nodes, uint32_t(ShadowCfg<HAS_ALPHA>::CACHE)) : 0u;
   LaneStack  st;
   LaneStack2 st2;
   int        stackOverflow[WIDE ? 2 * BVH8_STACK_PRIV : BVH_STACK_PRIV];  // scratch; only touched beyond the LDS depth
-  st.lds = s_stack;  st.tid = int(threadIdx.x);  st.stride = TRACE_BLOCK;  st.sp = 0;  st.priv = stackOverflow;
-  st2.lds = s_stack; st2.tid = int(threadIdx.x); st2.stride = TRACE_BLOCK; st2.sp = 0;
+  st.lds = s_stack;  st.tid = int(threadIdx.x);  st.stride = SBLOCK;  st.sp = 0;  st.priv = stackOverflow;
+  st2.lds = s_stack; st2.tid = int(threadIdx.x); st2.stride = SBLOCK; st2.sp = 0;
   st2.privBase = reinterpret_cast<uint32_t*>(stackOverflow); st2.privBits = reinterpret_cast<uint32_t*>(stackOverflow) + (WIDE ? BVH8_STACK_PRIV : 0);
   // per-lane state.  phase 0: any-hit walk (opaque geometry and non-transmissive alpha resolve here, order independent);
   // phase 1: one walk per transmissive candidate, in increasing (t, renderNode, primitive) order.
@@ -1498,7 +1508,8 @@ template <bool WIDE>
 void launchTraceShadowT(const LaunchCtx& c, int nxt)
 {
   const float darken = c.fc.frameInfo.shadowCatcherDarkenAmount;
-  dim3 grid(c.persistentBlocks * 256u / TRACE_BLOCK), block(TRACE_BLOCK);
+  const unsigned bs = c.hasAlpha ? unsigned(ShadowCfg<true>::BLOCK) : unsigned(ShadowCfg<false>::BLOCK);
+  dim3 grid(c.persistentBlocks * 256u / bs), block(bs);
   if(c.hasAlpha)
   {
     if(c.collectCounters)
