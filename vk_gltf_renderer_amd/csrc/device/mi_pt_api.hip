@@ -93,7 +93,7 @@ struct MiPt
   pt::DevTri*                 bvhTris   = nullptr;
   bool                        wide      = true;
   pt::DevScene                scene{};
-  bool                        hasAlpha = false, hasVolumeScatter = false, simpleMaterials = true;
+  bool                        hasAlpha = false, hasVolumeScatter = false, simpleMaterials = true, hasTransmissive = false;
   // device-resident descriptor copies (see k_shade): the scene struct, re-uploaded when the environment changes, and a ring
   // of per-batch frame constants fed from pinned host memory
   static constexpr int        FC_RING = 32;
@@ -337,7 +337,10 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
     if(mat.doubleSided == 1 || mat.thicknessFactor > 0.0f || mat.transmissionFactor > 0.0f)
       f |= pt::INST_CULL_DISABLE;
     if(mat.transmissionFactor > 0.01f)  // MIN_TRANSMISSION, shaders/pathtrace_functions.h.slang:36,256
+    {
       f |= pt::INST_TRANSMISSIVE;
+      pt->hasTransmissive = true;
+    }
     const float* M   = rn.objectToWorld;
     float        det = M[0] * (M[5] * M[10] - M[9] * M[6]) - M[4] * (M[1] * M[10] - M[9] * M[2]) + M[8] * (M[1] * M[6] - M[5] * M[2]);
     if(det < 0.0f)
@@ -625,6 +628,7 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   c.stream           = stream;
   c.persistentBlocks = unsigned(pt->numCUs) * 8u;
   c.hasAlpha         = pt->hasAlpha;
+  c.hasTransmissive  = pt->hasTransmissive;
   c.simpleMaterials  = pt->simpleMaterials && getenv("MI_PT_GENERIC_SHADE") == nullptr;
   c.wide             = pt->wide;
   c.collectCounters  = pt->collectCounters;

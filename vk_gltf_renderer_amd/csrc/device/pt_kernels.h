@@ -19,6 +19,7 @@ struct LaunchCtx
   hipStream_t     stream;
   unsigned        persistentBlocks;
   bool            hasAlpha;
+  bool            hasTransmissive;  // some instance carries INST_TRANSMISSIVE (ordered shadow transmission needed)
   bool            simpleMaterials;  // no material needs the transmission / clearcoat / sheen / iridescence / anisotropy paths
   bool            wide;  // traverse the 8-wide compressed BVH (scene.bvh8Nodes) instead of the BVH2
   bool            collectCounters;

@@ -1028,28 +1028,31 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
 // The alpha / transmission flavour of the shadow kernel carries the ordered-candidate state on top of the walk and does not
 // fit the 128 VGPRs of a 1024-thread workgroup without spilling into its hot loop: it runs as three 256-thread workgroups per
 // CU with a smaller LDS node cache instead.
-template <bool HAS_ALPHA>
+// MODE 0: every instance is FORCE_OPAQUE; 1: alpha-tested materials but no transmissive instance (no ordered candidates at all);
+// 2: transmissive instances present (ordered accumulation of getShadowTransmission).
+template <int MODE>
 struct ShadowCfg
 {
-  static constexpr int BLOCK = HAS_ALPHA ? 256 : TRACE_BLOCK;
-  static constexpr int CACHE = HAS_ALPHA ? 320 : NODE_CACHE;
+  static constexpr int BLOCK = MODE == 2 ? 256 : TRACE_BLOCK;
+  static constexpr int CACHE = MODE == 2 ? 320 : NODE_CACHE;
 };
-template <bool WIDE, bool HAS_ALPHA, bool COUNT>
-__global__ void __launch_bounds__(ShadowCfg<HAS_ALPHA>::BLOCK, TRACE_MIN_WAVES) k_trace_shadow(DevScene sc, const DevScene* __restrict__ scp, PathSoA P, Queues Q, int nxt, float catcherDarken, StatCounters* stats)
+template <bool WIDE, int MODE, bool COUNT>
+__global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_trace_shadow(DevScene sc, const DevScene* __restrict__ scp, PathSoA P, Queues Q, int nxt, float catcherDarken, StatCounters* stats)
 {
   // `sc` (kernel argument, SGPRs) serves the inlined walk; the non-inlined material helpers of the transmissive path get the
   // device-resident copy `*scp` so that the argument's address never escapes (no scratch copy, cf. k_shade)
-  constexpr int SBLOCK = ShadowCfg<HAS_ALPHA>::BLOCK;
+  constexpr int  SBLOCK    = ShadowCfg<MODE>::BLOCK;
+  constexpr bool HAS_ALPHA = MODE >= 1, HAS_TRANS = MODE == 2;
   __shared__ int      s_stack[BVH_STACK_LDS * SBLOCK];
   __shared__ uint32_t s_prefix[NSUB + 1];
-  __shared__ uint4    s_nodes[WIDE ? ShadowCfg<HAS_ALPHA>::CACHE * 5 : 1];
+  __shared__ uint4    s_nodes[WIDE ? ShadowCfg<MODE>::CACHE * 5 : 1];
   queuePrefix(&Q.counters[QC_SHADOW], s_prefix);
   const RayQueue in = Q.shadow;
   WaveFeed feed;
   feedInit(feed, s_prefix[NSUB]);
   if(!feedBlockHasWork(feed))
     return;
-  const uint32_t cachedNodes = WIDE ? fillNodeCache(sc, s_nodes, uint32_t(ShadowCfg<HAS_ALPHA>::CACHE)) : 0u;
+  const uint32_t cachedNodes = WIDE ? fillNodeCache(sc, s_nodes, uint32_t(ShadowCfg<MODE>::CACHE)) : 0u;
   LaneStack  st;
   LaneStack2 st2;
   int        stackOverflow[WIDE ? 2 * BVH8_STACK_PRIV : BVH_STACK_PRIV];  // scratch; only touched beyond the LDS depth
@@ -1119,6 +1122,13 @@ __global__ void __launch_bounds__(ShadowCfg<HAS_ALPHA>::BLOCK, TRACE_MIN_WAVES) 
     P.radiance[slot] = rad;
   };
 
+  // Transmissive candidates met by the any-hit walk, kept so that the common case (a few glass surfaces on the way to the
+  // light) is settled by ordering this list instead of one search walk per candidate.  Separate local arrays: scratch, only
+  // touched on such hits.
+  constexpr unsigned SHADOW_CANDS = 8;
+  float    cT[HAS_TRANS ? SHADOW_CANDS : 1], cU[HAS_TRANS ? SHADOW_CANDS : 1], cV[HAS_TRANS ? SHADOW_CANDS : 1];
+  uint32_t cR[HAS_TRANS ? SHADOW_CANDS : 1], cP[HAS_TRANS ? SHADOW_CANDS : 1];
+  int      cI[HAS_TRANS ? SHADOW_CANDS : 1];
   // one accepted-or-not transmissive candidate in order (raytracer_interface.h.slang:160-178)
   auto processCandidate = [&](float t, int tri, uint32_t rnode, uint32_t prim, float u, float v) {
     f3    bary    = mk3(1.0f - u - v, u, v);
@@ -1153,16 +1163,22 @@ __global__ void __launch_bounds__(ShadowCfg<HAS_ALPHA>::BLOCK, TRACE_MIN_WAVES) 
     if(COUNT) ++tris;
     const uint32_t flags = __float_as_uint(T.c.w);
     TriHit         h;
-    const bool consider = !HAS_ALPHA || phase == 0 || ((flags & INST_TRANSMISSIVE) && !(flags & INST_FORCE_OPAQUE));
+    const bool consider = !HAS_TRANS || phase == 0 || ((flags & INST_TRANSMISSIVE) && !(flags & INST_FORCE_OPAQUE));
     if(!(consider && intersectTri(xyz(T.a), xyz(T.b), xyz(T.c), r.org, r.dir, h) && h.t > 0.0f && h.t < tMax))
       return;
     const uint32_t rnode = __float_as_uint(T.a.w), prim = __float_as_uint(T.b.w);
-    if(!HAS_ALPHA || phase == 0)
+    if(!HAS_TRANS || phase == 0)
     {
       if(!HAS_ALPHA || (flags & INST_FORCE_OPAQUE))
         occluded = true;  // RAY_FLAG_NONE: no culling; opaque geometry commits
-      else if(flags & INST_TRANSMISSIVE)
+      else if(HAS_TRANS && (flags & INST_TRANSMISSIVE))
+      {
+        if(nTrans < SHADOW_CANDS)
+        {
+          cT[nTrans] = h.t; cI[nTrans] = triIndex; cR[nTrans] = rnode; cP[nTrans] = prim; cU[nTrans] = h.u; cV[nTrans] = h.v;
+        }
         ++nTrans;
+      }
       else
       {
         // non-transmissive alpha material: an accepted candidate multiplies the transmission by
@@ -1246,7 +1262,7 @@ __global__ void __launch_bounds__(ShadowCfg<HAS_ALPHA>::BLOCK, TRACE_MIN_WAVES) 
         bool visited = false;
         if(active && qMask == 0u)
         {
-          const float walkTmax = (HAS_ALPHA && phase == 1 && found) ? bT : tMax;
+          const float walkTmax = (HAS_TRANS && phase == 1 && found) ? bT : tMax;
           if((G.bits >> 8) == 0u && st2.sp > 0)
             G = st2.pop();
           if(G.bits >> 8)
@@ -1290,7 +1306,7 @@ __global__ void __launch_bounds__(ShadowCfg<HAS_ALPHA>::BLOCK, TRACE_MIN_WAVES) 
       }
       else if(active)
       {
-        const float walkTmax = (HAS_ALPHA && phase == 1 && found) ? bT : tMax;
+        const float walkTmax = (HAS_TRANS && phase == 1 && found) ? bT : tMax;
 #pragma unroll 1
         for(int k = 0; k < 4 && node >= 0; ++k)
         {
@@ -1309,7 +1325,27 @@ __global__ void __launch_bounds__(ShadowCfg<HAS_ALPHA>::BLOCK, TRACE_MIN_WAVES) 
         if(walkDone)
         {
           bool finished = true;
-          if(HAS_ALPHA && !occluded && !(phase == 1 && !found))
+          if(HAS_TRANS && !occluded && phase == 0 && nTrans > 0 && nTrans <= SHADOW_CANDS)
+          {
+            // every candidate is on the list: take them in increasing (t, renderNode, primitive) order
+            for(unsigned k = 0; k < nTrans && !occluded; ++k)
+            {
+              int best = -1;
+              for(unsigned j = 0; j < nTrans; ++j)
+              {
+                const bool afterLast  = !haveLast || cT[j] > lastT || (cT[j] == lastT && (cR[j] > lastRnode || (cR[j] == lastRnode && cP[j] > lastPrim)));
+                const bool beforeBest = best < 0 || cT[j] < cT[best] || (cT[j] == cT[best] && (cR[j] < cR[best] || (cR[j] == cR[best] && cP[j] < cP[best])));
+                if(afterLast && beforeBest)
+                  best = int(j);
+              }
+              if(best < 0)
+                break;
+              haveLast = true; lastT = cT[best]; lastRnode = cR[best]; lastPrim = cP[best];
+              processCandidate(cT[best], cI[best], cR[best], cP[best], cU[best], cV[best]);
+            }
+            nTrans = 0;
+          }
+          if(HAS_TRANS && !occluded && !(phase == 1 && !found))
           {
             if(phase == 1)
             {
@@ -1508,22 +1544,15 @@ template <bool WIDE>
 void launchTraceShadowT(const LaunchCtx& c, int nxt)
 {
   const float darken = c.fc.frameInfo.shadowCatcherDarkenAmount;
-  const unsigned bs = c.hasAlpha ? unsigned(ShadowCfg<true>::BLOCK) : unsigned(ShadowCfg<false>::BLOCK);
+  const int   mode   = !c.hasAlpha ? 0 : (c.hasTransmissive ? 2 : 1);
+  const unsigned bs  = mode == 2 ? unsigned(ShadowCfg<2>::BLOCK) : unsigned(ShadowCfg<0>::BLOCK);
   dim3 grid(c.persistentBlocks * 256u / bs), block(bs);
-  if(c.hasAlpha)
-  {
-    if(c.collectCounters)
-      hipLaunchKernelGGL((k_trace_shadow<WIDE, true, true>), grid, block, 0, c.stream, c.scene, c.sceneDev, c.paths, c.queues, nxt, darken, c.stats);
-    else
-      hipLaunchKernelGGL((k_trace_shadow<WIDE, true, false>), grid, block, 0, c.stream, c.scene, c.sceneDev, c.paths, c.queues, nxt, darken, c.stats);
-  }
-  else
-  {
-    if(c.collectCounters)
-      hipLaunchKernelGGL((k_trace_shadow<WIDE, false, true>), grid, block, 0, c.stream, c.scene, c.sceneDev, c.paths, c.queues, nxt, darken, c.stats);
-    else
-      hipLaunchKernelGGL((k_trace_shadow<WIDE, false, false>), grid, block, 0, c.stream, c.scene, c.sceneDev, c.paths, c.queues, nxt, darken, c.stats);
-  }
+#define MI_LAUNCH_SHADOW(M, C) \
+  hipLaunchKernelGGL((k_trace_shadow<WIDE, M, C>), grid, block, 0, c.stream, c.scene, c.sceneDev, c.paths, c.queues, nxt, darken, c.stats)
+  if(mode == 0)      { if(c.collectCounters) MI_LAUNCH_SHADOW(0, true); else MI_LAUNCH_SHADOW(0, false); }
+  else if(mode == 1) { if(c.collectCounters) MI_LAUNCH_SHADOW(1, true); else MI_LAUNCH_SHADOW(1, false); }
+  else               { if(c.collectCounters) MI_LAUNCH_SHADOW(2, true); else MI_LAUNCH_SHADOW(2, false); }
+#undef MI_LAUNCH_SHADOW
 }
 }  // namespace
 void launchTraceClosest(const LaunchCtx& c, int cur)
