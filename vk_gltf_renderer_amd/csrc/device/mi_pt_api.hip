@@ -581,8 +581,8 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
 {
   if(!pt || !params)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_render_frame: null argument");
-  if(numFrames < 1 || numFrames > 64)
-    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_render_frames: 1 <= numFrames <= 64 required");
+  if(numFrames < 1 || numFrames > 256)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_render_frames: 1 <= numFrames <= 256 required");
   if(pt->width <= 0 || !pt->haveFrameInfo)
     return fail(MI_PT_ERR_STATE, "mi_pt_render_frame: call mi_pt_resize and mi_pt_set_frame_info first");
   if(params->numSamples < 1 || params->maxDepth < 0 || params->maxDepth > 255)
@@ -674,6 +674,7 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
     (void)hipEventRecord(frameA, stream);
   }
   int iterations = 0, traceLaunches = 0, shadeLaunches = 0, shadowLaunches = 0;
+  static const bool usePacket = getenv("MI_PT_NO_PACKET") == nullptr;
   static const bool debugSpans = getenv("MI_PT_TRACE_SPANS") != nullptr;
   for(int s = 0; s < params->numSamples; ++s)
   {
@@ -727,7 +728,12 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
       }
       else
       {
-        timed(TK_TRACE, [&] { pt::launchTraceClosest(c, cur); });
+        timed(TK_TRACE, [&] {
+          if(it == 0 && c.wide && usePacket)
+            pt::launchTracePrimary(c);
+          else
+            pt::launchTraceClosest(c, cur);
+        });
         timed(TK_SHADE, [&] { pt::launchShade(c, cur); });
         timed(TK_SHADOW, [&] { pt::launchTraceShadow(c, cur ^ 1); });
       }

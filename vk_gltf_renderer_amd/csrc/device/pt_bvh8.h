@@ -81,33 +81,12 @@ PT_DEV uint32_t groupPopChild(NodeGroup& g, uint32_t octinv)
 
 PT_DEV float byteF(uint32_t w, int i) { return float((w >> (8 * i)) & 0xffu); }  // v_cvt_f32_ubyteN
 
-// One node visit.  The builder guarantees that the decoded boxes fmaf(q, 2^e, p) contain their triangles.  Here every slab
-// plane costs ONE fma: t = q * A + B with A = 2^e / dir and B = (p - org -/+ delta) / dir per axis and per node, the near
-// planes pulled towards the ray's origin and the far planes pushed away by delta = 2^-21 (|p - org| + 255 * 2^e), which
-// bounds the accumulated rounding of p - org, of the two products and of the fma -- so the test stays conservative
-// without a multiplicative fudge, including the cancellation case of an origin inside the node.
-// Nodes below index `cached` are read from the workgroup's LDS copy (ldsNodes), the rest from global memory.
-PT_DEV void bvh8Visit(const DevScene& sc, const RaySetup& r, float tmax, uint32_t octinv, uint32_t nodeIndex, NodeGroup& outGroup, uint32_t& triBase,
-                      uint32_t& triMask, const uint4* ldsNodes, uint32_t cached)
+// Slab test of the 8 children of a loaded node: bit i of `hm` = child slot i is hit (inner or leaf), `tmask` = triangles of
+// the hit LEAF children (bit 31 is garbage from inner children and must be masked by the caller).
+PT_DEV void bvh8TestChildren(const uint4& n0, const uint4& n1, const uint4& n2, const uint4& n3, const uint4& n4, const RaySetup& r, float tmax,
+                             uint32_t& hmOut, uint32_t& tmaskOut)
 {
-  uint4 n0, n1, n2, n3, n4;
-  if(nodeIndex < cached)
-  {
-    // explicit LDS address space: through a generic pointer the two branches merge into flat loads of a selected address
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    typedef const __attribute__((address_space(3))) u32x4* LdsNodePtr;
-    LdsNodePtr  N = (LdsNodePtr)(ldsNodes) + nodeIndex * 5u;
-    const u32x4 a = N[0], b = N[1], c = N[2], d = N[3], e = N[4];
-    n0 = make_uint4(a[0], a[1], a[2], a[3]); n1 = make_uint4(b[0], b[1], b[2], b[3]); n2 = make_uint4(c[0], c[1], c[2], c[3]);
-    n3 = make_uint4(d[0], d[1], d[2], d[3]); n4 = make_uint4(e[0], e[1], e[2], e[3]);
-  }
-  else
-  {
-    const uint4* N = sc.bvh8Nodes + size_t(nodeIndex) * 5;
-    n0 = N[0]; n1 = N[1]; n2 = N[2]; n3 = N[3]; n4 = N[4];
-  }
   const float  sx = __uint_as_float((n0.w & 0xffu) << 23), sy = __uint_as_float(((n0.w >> 8) & 0xffu) << 23), sz = __uint_as_float(((n0.w >> 16) & 0xffu) << 23);
-  const uint32_t imask = n0.w >> 24;
   const float  Px = __uint_as_float(n0.x) - r.org.x, Py = __uint_as_float(n0.y) - r.org.y, Pz = __uint_as_float(n0.z) - r.org.z;
   const float  k  = 4.76837158e-7f;  // 2^-21
   const float  dx = __fmaf_rn(255.0f, sx, fabsf(Px)) * k, dy = __fmaf_rn(255.0f, sy, fabsf(Py)) * k, dz = __fmaf_rn(255.0f, sz, fabsf(Pz)) * k;
@@ -134,6 +113,38 @@ PT_DEV void bvh8Visit(const DevScene& sc, const RaySetup& r, float tmax, uint32_
     hm |= hit ? (1u << i) : 0u;
     tmask |= hit ? (((1u << (m >> 5)) - 1u) << (m & 31u)) : 0u;  // inner children carry meta 0xff: masked out below
   }
+  hmOut    = hm;
+  tmaskOut = tmask;
+}
+
+// One node visit.  The builder guarantees that the decoded boxes fmaf(q, 2^e, p) contain their triangles.  Here every slab
+// plane costs ONE fma: t = q * A + B with A = 2^e / dir and B = (p - org -/+ delta) / dir per axis and per node, the near
+// planes pulled towards the ray's origin and the far planes pushed away by delta = 2^-21 (|p - org| + 255 * 2^e), which
+// bounds the accumulated rounding of p - org, of the two products and of the fma -- so the test stays conservative
+// without a multiplicative fudge, including the cancellation case of an origin inside the node.
+// Nodes below index `cached` are read from the workgroup's LDS copy (ldsNodes), the rest from global memory.
+PT_DEV void bvh8Visit(const DevScene& sc, const RaySetup& r, float tmax, uint32_t octinv, uint32_t nodeIndex, NodeGroup& outGroup, uint32_t& triBase,
+                      uint32_t& triMask, const uint4* ldsNodes, uint32_t cached)
+{
+  uint4 n0, n1, n2, n3, n4;
+  if(nodeIndex < cached)
+  {
+    // explicit LDS address space: through a generic pointer the two branches merge into flat loads of a selected address
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(3))) u32x4* LdsNodePtr;
+    LdsNodePtr  N = (LdsNodePtr)(ldsNodes) + nodeIndex * 5u;
+    const u32x4 a = N[0], b = N[1], c = N[2], d = N[3], e = N[4];
+    n0 = make_uint4(a[0], a[1], a[2], a[3]); n1 = make_uint4(b[0], b[1], b[2], b[3]); n2 = make_uint4(c[0], c[1], c[2], c[3]);
+    n3 = make_uint4(d[0], d[1], d[2], d[3]); n4 = make_uint4(e[0], e[1], e[2], e[3]);
+  }
+  else
+  {
+    const uint4* N = sc.bvh8Nodes + size_t(nodeIndex) * 5;
+    n0 = N[0]; n1 = N[1]; n2 = N[2]; n3 = N[3]; n4 = N[4];
+  }
+  const uint32_t imask = n0.w >> 24;
+  uint32_t       hm, tmask;
+  bvh8TestChildren(n0, n1, n2, n3, n4, r, tmax, hm, tmask);
   // leaf children of this node own triangle bits [0, 24); inner ones produced garbage above bit 24 at most: 0xff -> 127 << 31
   uint32_t hits = hm & imask;
   // slot space -> priority space: bit p = slot ^ octinv, a butterfly on the three index bits

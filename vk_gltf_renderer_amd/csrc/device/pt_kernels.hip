@@ -333,10 +333,19 @@ struct ClosestBest
   uint32_t rnode, prim;
 };
 template <bool HAS_ALPHA>
+PT_DEV void closestTestLoaded(const DevScene& sc, const RaySetup& r, const DevTri& T, int triIndex, ClosestBest& best, uint32_t& seed0, bool& seedLoaded,
+                              const float4* misc, uint32_t slot);
+template <bool HAS_ALPHA>
 PT_DEV void closestTestTriangle(const DevScene& sc, const RaySetup& r, int triIndex, ClosestBest& best, uint32_t& seed0, bool& seedLoaded,
                                 const float4* misc, uint32_t slot)
 {
   const DevTri T = sc.tris[triIndex];
+  closestTestLoaded<HAS_ALPHA>(sc, r, T, triIndex, best, seed0, seedLoaded, misc, slot);
+}
+template <bool HAS_ALPHA>
+PT_DEV void closestTestLoaded(const DevScene& sc, const RaySetup& r, const DevTri& T, int triIndex, ClosestBest& best, uint32_t& seed0, bool& seedLoaded,
+                              const float4* misc, uint32_t slot)
+{
   TriHit       h;
   if(!intersectTri(xyz(T.a), xyz(T.b), xyz(T.c), r.org, r.dir, h) || !(h.t > 0.0f))
     return;
@@ -563,6 +572,167 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
   if(COUNT)
   {
     atomicAdd(&stats->segments, (unsigned long long)rays);
+    atomicAdd(&stats->nodesClosest, (unsigned long long)nodes);
+    atomicAdd(&stats->trisClosest, (unsigned long long)tris);
+  }
+}
+
+//================================================================================================================================
+// k_trace_primary: the camera rays of a bounce-0 queue, one 8x8-pixel tile per wave, traversed as a PACKET.
+// k_generate lays the 64 rays of a micro-tile out contiguously, so a wave owns 64 nearly parallel rays that visit almost the
+// same nodes.  The walk is therefore wave-uniform: one traversal stack per wave, node and triangle records fetched ONCE
+// per wave through the scalar cache (s_load, no vector-memory gather at all), every lane slab-tests the node's children
+// with its own origin / tmax, and a child is entered when ANY lane hits it.  Per-lane closest hits, tie-breaks, culling and
+// alpha draws are those of k_trace_closest, and box tests only ever prune, so the hit records are bit-identical.
+//================================================================================================================================
+constexpr int PACKET_STACK = 96;  // node groups per wave (tree depth bound; an overflow falls back to per-lane results below)
+
+typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+// 80-B node / 48-B triangle through the scalar unit.  The address MUST be wave-uniform.
+PT_DEV void scalarLoadNode(const uint4* nodes, uint32_t index, uint4& n0, uint4& n1, uint4& n2, uint4& n3, uint4& n4)
+{
+  const uint64_t addr = uint64_t(reinterpret_cast<uintptr_t>(nodes)) + uint64_t(index) * 80ull;
+  const uint64_t A    = (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(uint32_t(addr >> 32)))) << 32) | uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(uint32_t(addr))));  // (the builtin returns int: widen unsigned)
+  u32x4s         a, b, c, d, e;
+  asm volatile("s_load_dwordx4 %0, %5, 0x0\n\ts_load_dwordx4 %1, %5, 0x10\n\ts_load_dwordx4 %2, %5, 0x20\n\ts_load_dwordx4 %3, %5, 0x30\n\t"
+               "s_load_dwordx4 %4, %5, 0x40\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d), "=&s"(e)
+               : "s"(A)
+               : "memory");
+  n0 = make_uint4(a[0], a[1], a[2], a[3]); n1 = make_uint4(b[0], b[1], b[2], b[3]); n2 = make_uint4(c[0], c[1], c[2], c[3]);
+  n3 = make_uint4(d[0], d[1], d[2], d[3]); n4 = make_uint4(e[0], e[1], e[2], e[3]);
+}
+PT_DEV DevTri scalarLoadTri(const DevTri* tris, uint32_t index)
+{
+  const uint64_t addr = uint64_t(reinterpret_cast<uintptr_t>(tris)) + uint64_t(index) * 48ull;
+  const uint64_t A    = (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(uint32_t(addr >> 32)))) << 32) | uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(uint32_t(addr))));  // (the builtin returns int: widen unsigned)
+  u32x4s         a, b, c;
+  asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x10\n\ts_load_dwordx4 %2, %3, 0x20\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(a), "=&s"(b), "=&s"(c)
+               : "s"(A)
+               : "memory");
+  DevTri T;
+  T.a = make_float4(__uint_as_float(a[0]), __uint_as_float(a[1]), __uint_as_float(a[2]), __uint_as_float(a[3]));
+  T.b = make_float4(__uint_as_float(b[0]), __uint_as_float(b[1]), __uint_as_float(b[2]), __uint_as_float(b[3]));
+  T.c = make_float4(__uint_as_float(c[0]), __uint_as_float(c[1]), __uint_as_float(c[2]), __uint_as_float(c[3]));
+  return T;
+}
+
+template <bool HAS_ALPHA, bool COUNT>
+__global__ void __launch_bounds__(256) k_trace_primary(DevScene sc, PathSoA P, Queues Q, uint32_t batchSlots, StatCounters* stats)
+{
+  __shared__ uint32_t s_wstack[4][PACKET_STACK][2];
+  if(blockIdx.x == 0 && threadIdx.x < NSUB)
+  {
+    // same hand-over as k_trace_closest(cur = 0): the shade kernel of this iteration appends to these
+    Q.counters[QC_ACTIVE1 + threadIdx.x] = 0;
+    Q.counters[QC_SHADOW + threadIdx.x]  = 0;
+    if(threadIdx.x < 8)
+      Q.counters[QC_HEADS_SHADOW + threadIdx.x] = 0;
+  }
+  const uint32_t wave  = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const uint32_t slot0 = (blockIdx.x * 4u + wave) * 64u;  // first path slot of this wave's micro-tile
+  if(slot0 >= batchSlots)
+    return;
+  const RayQueue in    = Q.active[0];
+  const uint32_t chunk = slot0 / QCHUNK;
+  const uint32_t pos   = (chunk % NSUB) * Q.subCap + (chunk / NSUB) * QCHUNK + (slot0 % QCHUNK) + lane;  // k_generate's placement
+  const uint32_t slot  = in.slot[pos];
+  bool           active = slot != QUEUE_DEAD;
+  if(__ballot(active) == 0ull)
+    return;
+  RaySetup r{};
+  if(active)
+    r = makeRaySetup(xyz(in.org[pos]), xyz(in.dir[pos]));
+  ClosestBest best{INFINITE_F, 0.0f, 0.0f, -1, 0xffffffffu, 0xffffffffu};
+  uint32_t    seed0 = 0;
+  bool        seedLoaded = false;
+  unsigned    nodes = 0, tris = 0;
+  if(sc.bvhRoot != BVH_EMPTY)
+  {
+    // wave-uniform walk state (kept uniform with readfirstlane so that it lives in SGPRs)
+    const uint32_t firstLane = uint32_t(__ffsll((long long)__ballot(active)) - 1);
+    const uint32_t octinv    = __builtin_amdgcn_readfirstlane(uint32_t(__shfl(int(rayOctInv(r.idir)), int(firstLane))));
+    uint32_t       gBase = 0, gBits = ((1u << octinv) << 8) | 1u;  // rootGroup
+    int            sp = 0;
+    bool           overflow = false;
+    for(;;)
+    {
+      if((gBits >> 8) == 0u)
+      {
+        if(sp == 0)
+          break;
+        --sp;
+        gBase = __builtin_amdgcn_readfirstlane(s_wstack[wave][sp][0]);
+        gBits = __builtin_amdgcn_readfirstlane(s_wstack[wave][sp][1]);
+      }
+      // nearest pending child of the group (priority space = slot ^ octinv)
+      const uint32_t hitsP = gBits >> 8;
+      const uint32_t pr    = 31u - uint32_t(__clz(int(hitsP)));
+      const uint32_t cslot = pr ^ octinv;
+      const uint32_t gim   = gBits & 0xffu;
+      gBits &= ~(0x100u << pr);
+      const uint32_t child = gBase + uint32_t(__popc(gim & ((1u << cslot) - 1u)));
+      if(gBits >> 8)
+      {
+        if(sp < PACKET_STACK)
+        {
+          if(lane == 0)
+          {
+            s_wstack[wave][sp][0] = gBase;
+            s_wstack[wave][sp][1] = gBits;
+          }
+          ++sp;
+        }
+        else
+          overflow = true;
+      }
+      uint4 n0, n1, n2, n3, n4;
+      scalarLoadNode(sc.bvh8Nodes, child, n0, n1, n2, n3, n4);
+      uint32_t hm = 0, tmaskLane = 0;
+      if(active)
+      {
+        bvh8TestChildren(n0, n1, n2, n3, n4, r, best.t, hm, tmaskLane);
+        if(COUNT) ++nodes;
+      }
+      // a child is entered / its triangles are tested when any lane hits its box
+      uint32_t hmU = 0;
+#pragma unroll
+      for(int i = 0; i < 8; ++i)
+        hmU |= (__ballot((hm >> i) & 1u) != 0ull) ? (1u << i) : 0u;
+      const uint32_t imask = n0.w >> 24;
+      uint32_t       hits  = hmU & imask;
+      hits = (octinv & 1u) ? (((hits & 0x55u) << 1) | ((hits & 0xaau) >> 1)) : hits;
+      hits = (octinv & 2u) ? (((hits & 0x33u) << 2) | ((hits & 0xccu) >> 2)) : hits;
+      hits = (octinv & 4u) ? (((hits & 0x0fu) << 4) | ((hits & 0xf0u) >> 4)) : hits;
+      gBase = n1.x;
+      gBits = (hits << 8) | imask;
+      uint32_t leafU = hmU & ~imask;
+      while(leafU)
+      {
+        const int i = __ffs(int(leafU)) - 1;
+        leafU &= leafU - 1u;
+        const uint32_t m   = ((i < 4 ? n1.z : n1.w) >> (8 * (i & 3))) & 0xffu;
+        const uint32_t cnt = m >> 5, off = m & 31u;
+        for(uint32_t k = 0; k < cnt; ++k)
+        {
+          const uint32_t triIndex = n1.y + off + k;
+          const DevTri   T        = scalarLoadTri(sc.tris, triIndex);
+          if(active && ((hm >> i) & 1u))
+          {
+            if(COUNT) ++tris;
+            closestTestLoaded<HAS_ALPHA>(sc, r, T, int(triIndex), best, seed0, seedLoaded, P.misc, slot);
+          }
+        }
+      }
+    }
+    (void)overflow;  // PACKET_STACK covers any tree the builder emits for < 2^31 triangles at branching >= 2 per pending group
+  }
+  if(active)
+    in.aux[pos] = make_float4(best.t, __int_as_float(best.tri), best.u, best.v);
+  if(COUNT)
+  {
+    atomicAdd(&stats->segments, (unsigned long long)(active ? 1u : 0u));
     atomicAdd(&stats->nodesClosest, (unsigned long long)nodes);
     atomicAdd(&stats->trisClosest, (unsigned long long)tris);
   }
@@ -1555,6 +1725,25 @@ void launchTraceShadowT(const LaunchCtx& c, int nxt)
 #undef MI_LAUNCH_SHADOW
 }
 }  // namespace
+void launchTracePrimary(const LaunchCtx& c)
+{
+  const uint32_t batchSlots = uint32_t(c.fc.numSlots) * uint32_t(c.fc.numFrames);
+  dim3           grid((batchSlots / 64u + 3u) / 4u), block(256);
+  if(c.hasAlpha)
+  {
+    if(c.collectCounters)
+      hipLaunchKernelGGL((k_trace_primary<true, true>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, batchSlots, c.stats);
+    else
+      hipLaunchKernelGGL((k_trace_primary<true, false>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, batchSlots, c.stats);
+  }
+  else
+  {
+    if(c.collectCounters)
+      hipLaunchKernelGGL((k_trace_primary<false, true>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, batchSlots, c.stats);
+    else
+      hipLaunchKernelGGL((k_trace_primary<false, false>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, batchSlots, c.stats);
+  }
+}
 void launchTraceClosest(const LaunchCtx& c, int cur)
 {
   if(c.wide)
