@@ -191,8 +191,8 @@ def main():
         if os.path.exists(pmc_file):
             try:
                 pmc = json.load(open(pmc_file))
-                if pmc.get("workload") == args.workload and pmc.get("kernel") == dominant:
-                    traffic = pmc.get("hbm_bytes_per_launch")
+                if pmc.get("workload") == args.workload and pmc.get("frames_in_flight") == F:
+                    traffic = pmc.get("bench_kernel_traffic", {}).get(dominant)
             except Exception:
                 traffic = None
         result = {

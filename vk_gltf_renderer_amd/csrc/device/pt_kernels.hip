@@ -691,10 +691,8 @@ __global__ void __launch_bounds__(256) k_trace_primary(DevScene sc, PathSoA P, Q
       scalarLoadNode(sc.bvh8Nodes, child, n0, n1, n2, n3, n4);
       uint32_t hm = 0, tmaskLane = 0;
       if(active)
-      {
         bvh8TestChildren(n0, n1, n2, n3, n4, r, best.t, hm, tmaskLane);
-        if(COUNT) ++nodes;
-      }
+      if(COUNT && lane == firstLane) ++nodes;  // counters = records FETCHED: one per wave here, one per lane in the per-lane kernels
       // a child is entered / its triangles are tested when any lane hits its box
       uint32_t hmU = 0;
 #pragma unroll
@@ -718,9 +716,9 @@ __global__ void __launch_bounds__(256) k_trace_primary(DevScene sc, PathSoA P, Q
         {
           const uint32_t triIndex = n1.y + off + k;
           const DevTri   T        = scalarLoadTri(sc.tris, triIndex);
+          if(COUNT && lane == firstLane) ++tris;
           if(active && ((hm >> i) & 1u))
           {
-            if(COUNT) ++tris;
             closestTestLoaded<HAS_ALPHA>(sc, r, T, int(triIndex), best, seed0, seedLoaded, P.misc, slot);
           }
         }
