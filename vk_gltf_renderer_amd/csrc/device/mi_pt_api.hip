@@ -720,7 +720,7 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
         };
         uint32_t nIn = count(cur ? pt::QC_ACTIVE1 : pt::QC_ACTIVE0);
         double   tTrace = span([&] { pt::launchTraceClosest(c, cur); });
-        double   tShade = span([&] { pt::launchShade(c, cur); });
+        double   tShade = span([&] { pt::launchShade(c, cur, it == 0); });
         uint32_t nSh    = count(pt::QC_SHADOW);
         double   tShadow = span([&] { pt::launchTraceShadow(c, cur ^ 1); });
         fprintf(stderr, "[mi_pt span] frame %d it %2d rays %8u trace %8.3f ms shade %8.3f ms | shadow rays %8u %8.3f ms\n", params->frameCount, it, nIn, tTrace,
@@ -734,7 +734,7 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
           else
             pt::launchTraceClosest(c, cur);
         });
-        timed(TK_SHADE, [&] { pt::launchShade(c, cur); });
+        timed(TK_SHADE, [&] { pt::launchShade(c, cur, it == 0); });
         timed(TK_SHADOW, [&] { pt::launchTraceShadow(c, cur ^ 1); });
       }
       ++iterations; ++traceLaunches; ++shadeLaunches; ++shadowLaunches;

@@ -31,7 +31,7 @@ void launchResetCounters(const Queues& Q, hipStream_t s);
 void launchGenerate(const LaunchCtx& c, int sampleIndex);
 void launchTraceClosest(const LaunchCtx& c, int cur);
 void launchTracePrimary(const LaunchCtx& c);  // bounce 0 of an 8-wide-BVH scene: packet walk of k_generate's camera rays (queue 0)
-void launchShade(const LaunchCtx& c, int cur);
+void launchShade(const LaunchCtx& c, int cur, bool first);  // first: bounce 0 (paths still carry k_generate's initial state)
 void launchTraceShadow(const LaunchCtx& c, int nxt);  // nxt: active queue the preceding shade launch appended to
 void launchFinishSample(const LaunchCtx& c, int sampleIndex, float4* accum, float* depth, float4* albedo, float4* normal);
 void launchSelection(const LaunchCtx& c, uint32_t* selection);

@@ -235,7 +235,6 @@ __global__ void __launch_bounds__(256) k_generate(DevScene sc, FrameConsts fc, P
       float r     = sqrtf(-2.0f * logf(fmaxf(1e-38f, u1)));
       float theta = 2.0f * K_PI * u2;
       jitter      = mk2(0.5f + ANTIALIASING_STANDARD_DEVIATION * (r * cosf(theta)), 0.5f + ANTIALIASING_STANDARD_DEVIATION * (r * sinf(theta)));
-      P.pixelSum[slot] = make_float4(0, 0, 0, 0);
       if(P.guideAlbedo)
       {
         P.guideAlbedo[slot] = make_float4(0, 0, 0, 0);
@@ -266,11 +265,10 @@ __global__ void __launch_bounds__(256) k_generate(DevScene sc, FrameConsts fc, P
     direction          = normalize(direction);  // pathTrace loop head, gltf_pathtrace.slang:447
     genOrg = make_float4(origin.x, origin.y, origin.z, 0.0f);
     genDir = make_float4(direction.x, direction.y, direction.z, 0.0f);
-    P.throughput[slot] = make_float4(1.0f, 1.0f, 1.0f, DIRAC);
-    P.radiance[slot]   = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    P.misc[slot]       = make_float4(0.0f, __uint_as_float(PF_ALIVE), __uint_as_float(seed), 0.0f);  // cone.width = 0
-    P.medium[slot]     = make_uint4(0, 0, 0, 0);
-    P.firstHit[slot]   = make_float4(1e34f, 1e34f, 1e34f, 0.0f);
+    // PathTracerState{} of gltf_pathtrace.slang:443: throughput 1, lastSamplePdf DIRAC, radiance 0, maxRoughness 0, not inside, depth 0.
+    // Only the seed (and the flags word) is stored: the bounce-0 shade launch knows the rest as constants (k_shade<FIRST>), the
+    // medium is written when a path first enters one, firstHit by the first shade of the path, pixelSum by k_finish_sample.
+    P.misc[slot] = make_float4(0.0f, __uint_as_float(PF_ALIVE), __uint_as_float(seed), 0.0f);  // cone.width = 0
     if(stats)
       atomicAdd(&stats->cameraPaths, 1ull);
   }
@@ -812,7 +810,8 @@ __global__ void __launch_bounds__(SEL_BLOCK) k_selection(DevScene sc, FrameConst
 //================================================================================================================================
 // k_shade: everything of pathTraceOneBounce / pathTrace between the two Trace calls (gltf_pathtrace.slang:104-430, 441-494)
 //================================================================================================================================
-template <bool COUNT, bool SIMPLE>
+// FIRST: the launch shades bounce 0 (every queued path still has its initial state, see k_generate).
+template <bool COUNT, bool SIMPLE, bool FIRST>
 __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) k_shade(const DevScene* __restrict__ scp, const FrameConsts* __restrict__ fcp, PathSoA P, Queues Q, int cur, StatCounters* stats)
 {
   // The scene / frame descriptors reach the non-inlined helpers (getTexture, sampleLights, the sky) by reference.  As
@@ -848,7 +847,9 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
     if(inRange)
     {
       const float4 hit4 = Q.active[cur].aux[inPos], o4 = Q.active[cur].org[inPos], d4 = Q.active[cur].dir[inPos];
-      const float4 tp4 = P.throughput[slot], rad4 = P.radiance[slot], misc4 = P.misc[slot];
+      const float4 misc4 = P.misc[slot];
+      const float4 tp4   = FIRST ? make_float4(1.0f, 1.0f, 1.0f, DIRAC) : P.throughput[slot];
+      const float4 rad4  = FIRST ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : P.radiance[slot];
       f3       rayOrigin = xyz(o4), rayDir = xyz(d4);
       float    coneWidth = misc4.w;
       f3       throughput = xyz(tp4), radiance = xyz(rad4);
@@ -860,6 +861,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
       bool     isInside = !SIMPLE && (flags & PF_INSIDE) != 0u, solid = !(flags & PF_NOT_SOLID);
       const bool firstRay = (surfaceDepth == 0);
       const int  maxDepth = fc.pc.maxDepth;
+      // the first-hit position only feeds the NDC depth of a first frame (k_finish_sample), i.e. frame 0 of the batch
+      const bool needFirstHit = hasFlag(fc.pc.flags, MI_PT_FIRST_FRAME) && slot < uint32_t(fc.numSlots);
 
       float hitT   = hit4.x;
       int   triIdx = __float_as_int(hit4.y);
@@ -911,7 +914,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
         if(firstRay)  // tryPrimaryMissBackplate, pathtrace_functions.h.slang:944-971
         {
           solid             = false;
-          P.firstHit[slot]  = make_float4(rayDir.x, rayDir.y, rayDir.z, 0.0f);
+          if(needFirstHit)
+            P.firstHit[slot] = make_float4(rayDir.x, rayDir.y, rayDir.z, 0.0f);
           if(hasFlag(fc.frameInfo.flags, MI_SCENE_USE_SOLID_BACKGROUND))
           {
             radiance  = mk3(fc.frameInfo.backgroundColor);
@@ -959,6 +963,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
           {
             catcherPlane = true;
             coneWidth    = worldFoot;
+            if(FIRST && needFirstHit)  // the reference leaves SampleResult::hitPosition at its 1e34 default on this path
+              P.firstHit[slot] = make_float4(1e34f, 1e34f, 1e34f, 0.0f);
             DirectLight dl;
             sampleLights(sc, fc, hit.pos, seed, dl);
             const bool traceIt = dot(dl.direction, hit.nrm) > 0.0f && dl.pdf != 0.0f;
@@ -1012,7 +1018,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
         {
           if(firstRay)  // gltf_pathtrace.slang:228-264
           {
-            P.firstHit[slot] = make_float4(hit.pos.x, hit.pos.y, hit.pos.z, 0.0f);
+            if(needFirstHit)
+              P.firstHit[slot] = make_float4(hit.pos.x, hit.pos.y, hit.pos.z, 0.0f);
             if(P.guideAlbedo)
             {
               float4 ga = P.guideAlbedo[slot], gn = P.guideNormal[slot];
@@ -1579,7 +1586,7 @@ __global__ void __launch_bounds__(256) k_finish_sample(FrameConsts fc, PathSoA P
     float          lum   = dot(xyz(r), mk3(1.0f / 3.0f));
     if(lum > fc.pc.fireflyClampThreshold)
       r *= fc.pc.fireflyClampThreshold / lum;
-    float4 sum = P.pixelSum[slot];
+    float4 sum = sampleIndex == 0 ? make_float4(0, 0, 0, 0) : P.pixelSum[slot];
     sum        = make_float4(sum.x + r.x, sum.y + r.y, sum.z + r.z, sum.w + r.w);
     if(!lastSample)
     {
@@ -1749,23 +1756,22 @@ void launchTraceClosest(const LaunchCtx& c, int cur)
   else
     launchTraceClosestT<false>(c, cur);
 }
-void launchShade(const LaunchCtx& c, int cur)
+void launchShade(const LaunchCtx& c, int cur, bool first)
 {
   dim3 grid(c.persistentBlocks), block(SHADE_BLOCK);
+#define MI_LAUNCH_SHADE(C, S, F) \
+  hipLaunchKernelGGL((k_shade<C, S, F>), grid, block, 0, c.stream, c.sceneDev, c.fcDev, c.paths, c.queues, cur, c.stats)
+#define MI_LAUNCH_SHADE_F(C, S) do { if(first) MI_LAUNCH_SHADE(C, S, true); else MI_LAUNCH_SHADE(C, S, false); } while(0)
   if(c.simpleMaterials)
   {
-    if(c.collectCounters)
-      hipLaunchKernelGGL((k_shade<true, true>), grid, block, 0, c.stream, c.sceneDev, c.fcDev, c.paths, c.queues, cur, c.stats);
-    else
-      hipLaunchKernelGGL((k_shade<false, true>), grid, block, 0, c.stream, c.sceneDev, c.fcDev, c.paths, c.queues, cur, c.stats);
+    if(c.collectCounters) MI_LAUNCH_SHADE_F(true, true); else MI_LAUNCH_SHADE_F(false, true);
   }
   else
   {
-    if(c.collectCounters)
-      hipLaunchKernelGGL((k_shade<true, false>), grid, block, 0, c.stream, c.sceneDev, c.fcDev, c.paths, c.queues, cur, c.stats);
-    else
-      hipLaunchKernelGGL((k_shade<false, false>), grid, block, 0, c.stream, c.sceneDev, c.fcDev, c.paths, c.queues, cur, c.stats);
+    if(c.collectCounters) MI_LAUNCH_SHADE_F(true, false); else MI_LAUNCH_SHADE_F(false, false);
   }
+#undef MI_LAUNCH_SHADE_F
+#undef MI_LAUNCH_SHADE
 }
 void launchTraceShadow(const LaunchCtx& c, int nxt)
 {
