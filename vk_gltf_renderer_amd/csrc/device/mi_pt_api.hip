@@ -77,6 +77,7 @@ struct MiPt
   // scene
   DevBuf<MiGltfShadeMaterial> materials;
   DevBuf<MiGltfTextureInfo>   texInfos;
+  DevBuf<pt::DevTexRef>       texRefs;
   DevBuf<MiGltfRenderNode>    nodes;
   DevBuf<pt::DevPrim>         prims;
   DevBuf<MiGltfLight>         lights;
@@ -402,6 +403,23 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
     }
     HIP_TRY(pt->textures.upload(dt.data(), dt.size()));
     HIP_TRY(pt->texels.upload(pool.data(), pool.size()));
+    // texture info + descriptor, flattened per texture slot (pt_scene.h: DevTexRef)
+    std::vector<pt::DevTexRef> refs(size_t(std::max(sd->numTextureInfos, 1)));
+    memset(refs.data(), 0, refs.size() * sizeof(pt::DevTexRef));
+    for(int i = 0; i < sd->numTextureInfos; ++i)
+    {
+      const MiGltfTextureInfo& ti = sd->textureInfos[i];
+      pt::DevTexRef&           r  = refs[size_t(i)];
+      memcpy(r.uv, ti.uvTransform, sizeof(r.uv));
+      r.texCoord = uint8_t(ti.texCoord);
+      if(ti.index >= 0 && ti.index < sd->numTextures)
+      {
+        const pt::DevTexture& d = dt[size_t(ti.index)];
+        r.level0 = d.levelOffset[0]; r.width = d.width; r.height = d.height; r.numLevels = d.numLevels; r.srgb = d.srgb;
+        r.magFilter = d.magFilter; r.minFilter = d.minFilter; r.mipmapMode = d.mipmapMode; r.wrapS = d.wrapS; r.wrapT = d.wrapT;
+      }
+    }
+    HIP_TRY(pt->texRefs.upload(refs.data(), refs.size()));
   }
   {
     float lut[256];
@@ -455,7 +473,7 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
   pt::DevScene& S = pt->scene;
   S.materials = pt->materials.ptr; S.texInfos = pt->texInfos.ptr; S.nodes = pt->nodes.ptr; S.prims = pt->prims.ptr; S.lights = pt->lights.ptr;
   S.textures = pt->textures.ptr; S.texels = pt->texels.ptr; S.envPixels = nullptr; S.envAccel = nullptr; S.bvhNodes = pt->bvhNodes; S.bvh8Nodes = pt->bvh8Nodes; S.tris = pt->bvhTris;
-  S.alphaTris = nullptr; S.srgbLut = pt->srgbLut.ptr; S.numMaterials = sd->numMaterials; S.numTextures = sd->numTextures; S.numLights = sd->numLights; S.numNodes = sd->numRenderNodes;
+  S.texRefs = pt->texRefs.ptr; S.alphaTris = nullptr; S.srgbLut = pt->srgbLut.ptr; S.numMaterials = sd->numMaterials; S.numTextures = sd->numTextures; S.numLights = sd->numLights; S.numNodes = sd->numRenderNodes;
   S.envWidth = 0; S.envHeight = 0;
 
   if(pt->hasAlpha && S.numTris > 0)

@@ -1010,7 +1010,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
           mesh.isInside           = isInside;
           mesh.texGrad            = worldFoot * hit.texelDensity * fc.pc.texGradScale;
           mesh.baseColorVertexMul = hit.color;
-          mesh.srgbLut            = s_srgb;
+          mesh.tex                = TexCtx{sc.texRefs, sc.texels, s_srgb};
           pbrMat                  = evaluateMaterial<SIMPLE>(sc, mat, mesh, taps);
           unlit                   = mat.unlit > 0;
         }

@@ -19,6 +19,25 @@ struct DevTexture  // 80 B
   uint8_t  _pad[5];
 };
 
+// GltfTextureInfo + the descriptor of the texture behind it, flattened and indexed like GltfTextureInfo (the texture slots of
+// a material): the shade kernel reaches the texels in two dependent loads (this record, the texels) instead of five
+// (table pointers, texture info, descriptor, mip offset, texels).  The mip chain is contiguous in the texel pool, so the
+// offset of a level is level0 + sum of the sizes of the levels before it.
+struct DevTexRef  // 48 B
+{
+  float    uv[6];          // uvTransform (column-major 3x2)
+  uint32_t level0;         // texel offset of mip 0
+  uint16_t width, height;  // 0 x 0: no valid texture behind this slot (sampling yields 1, like an out-of-range index)
+  uint8_t  numLevels, srgb, magFilter, minFilter, mipmapMode, wrapS, wrapT, texCoord;
+  uint32_t _pad;
+};
+struct TexCtx  // what a texture fetch needs, passed BY VALUE (registers) into the non-inlined fetch
+{
+  const DevTexRef* refs;
+  const uchar4*    texels;
+  const float*     lut;  // sRGB decode table (global, or the shade kernel's LDS copy)
+};
+
 // GltfRenderPrimitive with device pointers (reference: shaders/gltf_scene_io.h.slang:50-64)
 struct DevPrim
 {
@@ -79,6 +98,7 @@ struct DevScene
   const float4*              bvhNodes;  // BVH2: 4 x float4 per node (see pt_bvh.h); null when the wide BVH is active
   const uint4*               bvh8Nodes; // BVH8: 5 x uint4 per node (see pt_bvh8.h)
   const DevTri*              tris;      // triangles in the order of the ACTIVE structure (hit records index this array)
+  const DevTexRef*           texRefs;   // numTextureInfos entries
   const DevAlphaTri*         alphaTris; // same indexing as tris; valid for triangles of non-FORCE_OPAQUE instances
   const float*               srgbLut;  // 256 floats
   int                        numMaterials, numTextures, numLights, numNodes;

@@ -144,7 +144,7 @@ struct MeshState
   bool  isInside;
   float texGrad;
   f4    baseColorVertexMul;
-  const float* srgbLut;  // sRGB decode table for the texture fetches of this hit (the shade kernel stages it in LDS)
+  TexCtx tex;  // texture tables for the fetches of this hit (the shade kernel stages the sRGB table in LDS)
 };
 PT_DEV bool isTexturePresent(uint16_t t) { return t > 0; }
 __device__ __noinline__ f4 getTexture(const DevScene& sc, const float* lut, uint16_t slot, f2 tc0, f2 tc1, float texGrad, unsigned& taps)  // :76-110
@@ -157,6 +157,65 @@ __device__ __noinline__ f4 getTexture(const DevScene& sc, const float* lut, uint
   if(texGrad > 0.0f)
     return sampleTexture(sc, lut, ti.index, tt, true, mk2(U[0] * texGrad, U[1] * texGrad), mk2(U[2] * texGrad, U[3] * texGrad));
   return sampleTexture(sc, lut, ti.index, tt, false, mk2(0, 0), mk2(0, 0));
+}
+// getTexture on the flattened DevTexRef table: same arithmetic as getTexture -> sampleTexture -> sampleLevel -> fetchTexel
+// (pt_light.h), two dependent loads instead of five.
+PT_DEV f4 fetchTexelRef(const TexCtx& tc, const DevTexRef& R, uint32_t levelOffset, int w, int x, int y)
+{
+  uchar4 p = tc.texels[size_t(levelOffset) + size_t(y) * size_t(w) + size_t(x)];
+  if(R.srgb)
+    return mk4(tc.lut[p.x], tc.lut[p.y], tc.lut[p.z], float(p.w) * (1.0f / 255.0f));
+  return mk4(float(p.x) * (1.0f / 255.0f), float(p.y) * (1.0f / 255.0f), float(p.z) * (1.0f / 255.0f), float(p.w) * (1.0f / 255.0f));
+}
+PT_DEV f4 sampleLevelRef(const TexCtx& tc, const DevTexRef& R, f2 uv, int level, int filter)
+{
+  uint32_t off = R.level0;
+  for(int l = 0; l < level; ++l)
+    off += uint32_t(max(1, int(R.width) >> l)) * uint32_t(max(1, int(R.height) >> l));
+  int   w = max(1, int(R.width) >> level), h = max(1, int(R.height) >> level);
+  float fx = uv.x * float(w), fy = uv.y * float(h);
+  if(filter == MI_FILTER_NEAREST)
+    return fetchTexelRef(tc, R, off, w, wrapCoord(int(floorf(fx)), w, R.wrapS), wrapCoord(int(floorf(fy)), h, R.wrapT));
+  fx -= 0.5f;
+  fy -= 0.5f;
+  float flx = floorf(fx), fly = floorf(fy);
+  float tx = fx - flx, ty = fy - fly;
+  int   x0 = wrapCoord(int(flx), w, R.wrapS), x1 = wrapCoord(int(flx) + 1, w, R.wrapS);
+  int   y0 = wrapCoord(int(fly), h, R.wrapT), y1 = wrapCoord(int(fly) + 1, h, R.wrapT);
+  f4    a = fetchTexelRef(tc, R, off, w, x0, y0), b = fetchTexelRef(tc, R, off, w, x1, y0);
+  f4    c = fetchTexelRef(tc, R, off, w, x0, y1), d = fetchTexelRef(tc, R, off, w, x1, y1);
+  return (a * (1.0f - tx) + b * tx) * (1.0f - ty) + (c * (1.0f - tx) + d * tx) * ty;
+}
+__device__ __noinline__ f4 getTextureRef(TexCtx tc, uint32_t slot, f2 tc0, f2 tc1, float texGrad)
+{
+  const DevTexRef R  = tc.refs[slot];
+  f2              t  = R.texCoord == 0 ? tc0 : tc1;
+  const float*    U  = R.uv;
+  f2              uv = mk2(t.x * U[0] + t.y * U[2] + U[4], t.x * U[1] + t.y * U[3] + U[5]);
+  if(R.width == 0)
+    return mk4(1.0f);
+  float lod = 0.0f;
+  if(texGrad > 0.0f)
+  {
+    f2    ddx = mk2(U[0] * texGrad, U[1] * texGrad), ddy = mk2(U[2] * texGrad, U[3] * texGrad);
+    float rx  = sqrtf(sqr(ddx.x * float(R.width)) + sqr(ddx.y * float(R.height)));
+    float ry  = sqrtf(sqr(ddy.x * float(R.width)) + sqr(ddy.y * float(R.height)));
+    float rho = fmaxf(rx, ry);
+    lod       = rho > 0.0f ? log2f(rho) : -126.0f;
+  }
+  if(lod <= 0.0f)
+    return sampleLevelRef(tc, R, uv, 0, R.magFilter);
+  float maxLevel = float(int(R.numLevels) - 1);
+  lod            = fminf(lod, maxLevel);
+  if(R.mipmapMode == MI_FILTER_NEAREST)
+    return sampleLevelRef(tc, R, uv, min(int(floorf(lod + 0.5f)), int(R.numLevels) - 1), R.minFilter);
+  int   l0 = int(floorf(lod)), l1 = min(l0 + 1, int(R.numLevels) - 1);
+  float f  = lod - float(l0);
+  f4    a  = sampleLevelRef(tc, R, uv, l0, R.minFilter);
+  if(f == 0.0f || l1 == l0)
+    return a;
+  f4 b = sampleLevelRef(tc, R, uv, l1, R.minFilter);
+  return a * (1.0f - f) + b * f;
 }
 PT_DEV f3 multiToSingleScatterAlbedo(f3 rho)  // :125-129
 {
@@ -187,7 +246,7 @@ PT_DEV f3 convertSGToMR(f3 diffuseColor, f3 specularColor, float glossiness, flo
 template <bool SIMPLE>
 PT_DEV PbrMaterial evaluateMaterial(const DevScene& sc, const MiGltfShadeMaterial& m, const MeshState& st, unsigned& taps)  // :168-457
 {
-#define TEX(slot) getTexture(sc, st.srgbLut, slot, st.tc0, st.tc1, st.texGrad, taps)
+#define TEX(slot) (++taps, getTextureRef(st.tex, slot, st.tc0, st.tc1, st.texGrad))
   PbrMaterial p = defaultPbrMaterial();
   if(m.pbrModel == MI_PBR_SPECULAR_GLOSSINESS)
   {
