@@ -193,6 +193,10 @@ MI_PT_API int mi_pt_synchronize(MiPt* pt);
 
 /* Read-backs (the reference reads gBuffers images back for screenshots: src/renderer.cpp:557-573). */
 MI_PT_API int mi_pt_read_accum(MiPt* pt, float* hostRGBA32F);          /* eImgRendered   */
+/* Denoiser guide layers accumulated while MI_PT_USE_OPTIX_DENOISER is set in params->flags (first-hit albedo.rgb + hit
+ * fraction, first-hit shading normal.xyz; reference capture points: shaders/gltf_pathtrace.slang:228-264, the OptiX guide
+ * images of src/optix_denoiser.hpp:128-153).  Either pointer may be NULL. */
+MI_PT_API int mi_pt_read_guides(MiPt* pt, float* hostAlbedoRGBA32F, float* hostNormalRGBA32F);
 MI_PT_API int mi_pt_read_selection(MiPt* pt, uint32_t* hostObjectIds); /* eImgSelection: renderNode+1, 0 = none */
 MI_PT_API int mi_pt_read_depth(MiPt* pt, float* hostDepth);            /* NDC depth of frame 0 */
 MI_PT_API void* mi_pt_accum_device_ptr(MiPt* pt);

@@ -796,6 +796,19 @@ int mi_pt_read_accum(MiPt* pt, float* host)
   HIP_TRY(hipMemcpy(host, pt->accum, size_t(pt->width) * size_t(pt->height) * sizeof(float4), hipMemcpyDeviceToHost));
   return MI_PT_OK;
 }
+int mi_pt_read_guides(MiPt* pt, float* albedo, float* normal)
+{
+  if(!pt || pt->width <= 0)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_read_guides: bad arguments");
+  HIP_TRY(hipSetDevice(pt->device));
+  HIP_TRY(hipDeviceSynchronize());
+  const size_t bytes = size_t(pt->width) * size_t(pt->height) * sizeof(float4);
+  if(albedo)
+    HIP_TRY(hipMemcpy(albedo, pt->albedo.ptr, bytes, hipMemcpyDeviceToHost));
+  if(normal)
+    HIP_TRY(hipMemcpy(normal, pt->normal.ptr, bytes, hipMemcpyDeviceToHost));
+  return MI_PT_OK;
+}
 int mi_pt_read_selection(MiPt* pt, uint32_t* host)
 {
   if(!pt || !host || pt->width <= 0)

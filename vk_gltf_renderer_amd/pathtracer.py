@@ -163,6 +163,13 @@ class PathTracer:
         _check_pt(self._l.mi_pt_read_accum(self._p, out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
 
+    def read_guides(self):
+        """(albedo RGBA, normal RGBA) guide layers of the denoiser (valid when MI_PT_USE_OPTIX_DENOISER was set)."""
+        a = np.empty((self.height, self.width, 4), dtype=np.float32)
+        n = np.empty((self.height, self.width, 4), dtype=np.float32)
+        _check_pt(self._l.mi_pt_read_guides(self._p, a.ctypes.data_as(C.POINTER(C.c_float)), n.ctypes.data_as(C.POINTER(C.c_float))))
+        return a, n
+
     def read_selection(self):
         out = np.empty((self.height, self.width), dtype=np.uint32)
         _check_pt(self._l.mi_pt_read_selection(self._p, out.ctypes.data_as(C.POINTER(C.c_uint32))))
