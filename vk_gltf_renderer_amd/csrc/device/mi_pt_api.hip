@@ -89,6 +89,7 @@ struct MiPt
   DevBuf<float4>              envPixels;
   DevBuf<MiEnvAccel>          envAccel;
   DevBuf<pt::DevAlphaTri>     alphaTris;
+  DevBuf<pt::DevShadeTri>     shadeTris;
   float4*                     bvhNodes  = nullptr;
   uint4*                      bvh8Nodes = nullptr;
   pt::DevTri*                 bvhTris   = nullptr;
@@ -476,6 +477,15 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
   S.texRefs = pt->texRefs.ptr; S.alphaTris = nullptr; S.srgbLut = pt->srgbLut.ptr; S.numMaterials = sd->numMaterials; S.numTextures = sd->numTextures; S.numLights = sd->numLights; S.numNodes = sd->numRenderNodes;
   S.envWidth = 0; S.envHeight = 0;
 
+  S.shadeTris = nullptr;
+  if(S.numTris > 0)
+  {
+    HIP_TRY(pt->shadeTris.alloc(size_t(S.numTris)));
+    pt::launchBuildShadeRecords(S, uint32_t(S.numTris), pt->shadeTris.ptr, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    S.shadeTris = pt->shadeTris.ptr;
+  }
   if(pt->hasAlpha && S.numTris > 0)
   {
     HIP_TRY(pt->alphaTris.alloc(size_t(S.numTris)));

@@ -25,6 +25,7 @@ struct LaunchCtx
   bool            collectCounters;
 };
 
+void launchBuildShadeRecords(const DevScene& scene, uint32_t numTris, DevShadeTri* out, hipStream_t s);
 void launchBuildAlphaRecords(const DevScene& scene, uint32_t numTris, DevAlphaTri* out, hipStream_t s);
 void dumpTraceProfile();  // prints the -DTRACE_PROFILE section timers (no-op in the product build)
 void launchResetCounters(const Queues& Q, hipStream_t s);

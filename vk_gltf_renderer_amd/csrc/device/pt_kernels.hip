@@ -871,16 +871,17 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
 
       HitState hit;
       int      rnodeID = -1, primitiveID = -1, materialID = 0;
+      (void)primitiveID;
       const bool meshHit = triIdx >= 0;
       if(meshHit)
       {
-        const DevTri T = sc.tris[triIdx];
-        rnodeID        = int(__float_as_uint(T.a.w));
-        primitiveID    = int(__float_as_uint(T.b.w));
+        const DevShadeTri S = sc.shadeTris[triIdx];
+        rnodeID             = int(S.rnode);
+        primitiveID         = int(S.prim);
+        materialID          = S.materialID;
         const MiGltfRenderNode& rn = sc.nodes[rnodeID];
-        materialID                 = max(0, rn.materialID);
-        const DevPrim rp           = sc.prims[rn.renderPrimID];
-        hit = getHitState(rp, mk3(1.0f - hit4.z - hit4.w, hit4.z, hit4.w), rn.worldToObject, rn.objectToWorld, primitiveID, rayDir);
+        const DevPrim           rp = sc.prims[S.renderPrimID];
+        hit = getHitState(rp, mk3(1.0f - hit4.z - hit4.w, hit4.z, hit4.w), rn.worldToObject, rn.objectToWorld, u3{S.i0, S.i1, S.i2}, rayDir);
       }
       else
         hitT = INFINITE_F;
@@ -1657,6 +1658,12 @@ __global__ void k_alpha_records(DevScene sc, uint32_t n, DevAlphaTri* out)
   if(i < n)
     out[i] = makeAlphaRecord(sc, sc.tris[i]);
 }
+__global__ void k_shade_records(DevScene sc, uint32_t n, DevShadeTri* out)
+{
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < n)
+    out[i] = makeShadeRecord(sc, sc.tris[i]);
+}
 
 __global__ void k_reset_counters(uint32_t* counters)
 {
@@ -1684,6 +1691,11 @@ void dumpTraceProfile()
   fprintf(stderr, "[mi_pt trace profile] waves %llu total ticks %.4g: feed %.1f%% node %.1f%% tri %.1f%% other %.1f%%\n", h[4], tot, 100.0 * h[0] / tot,
           100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * (tot - h[0] - h[1] - h[2]) / tot);
 #endif
+}
+void launchBuildShadeRecords(const DevScene& scene, uint32_t numTris, DevShadeTri* out, hipStream_t s)
+{
+  if(numTris)
+    hipLaunchKernelGGL(k_shade_records, dim3((numTris + 255) / 256), dim3(256), 0, s, scene, numTris, out);
 }
 void launchResetCounters(const Queues& Q, hipStream_t s)
 {

@@ -84,6 +84,19 @@ enum : uint32_t
   AT_HAS_COLORS  = 1u << 8,
 };
 
+// What the shade kernel needs to start fetching the hit's attributes, per triangle (same index as tris): without it the
+// chain is triangle -> render node -> primitive record -> indices -> vertices; with it record -> {node, primitive, material}
+// -> vertices.
+struct DevShadeTri  // 32 B
+{
+  uint32_t i0, i1, i2;    // vertex indices of the triangle inside its primitive
+  uint32_t rnode;         // GltfRenderNode index
+  int32_t  renderPrimID;  // GltfRenderNode::renderPrimID
+  int32_t  materialID;    // max(0, GltfRenderNode::materialID)
+  uint32_t prim;          // triangle index inside the primitive (PrimitiveIndex())
+  uint32_t _pad;
+};
+
 struct DevScene
 {
   const MiGltfShadeMaterial* materials;
@@ -99,6 +112,7 @@ struct DevScene
   const uint4*               bvh8Nodes; // BVH8: 5 x uint4 per node (see pt_bvh8.h)
   const DevTri*              tris;      // triangles in the order of the ACTIVE structure (hit records index this array)
   const DevTexRef*           texRefs;   // numTextureInfos entries
+  const DevShadeTri*         shadeTris; // same indexing as tris
   const DevAlphaTri*         alphaTris; // same indexing as tris; valid for triangles of non-FORCE_OPAQUE instances
   const float*               srgbLut;  // 256 floats
   int                        numMaterials, numTextures, numLights, numNodes;

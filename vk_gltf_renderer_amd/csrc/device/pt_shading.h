@@ -68,10 +68,14 @@ PT_DEV f3 pointOffset(f3 p, f3 p0, f3 p1, f3 p2, f3 n0, f3 n1, f3 n2, f3 bary)  
   tmpw -= n2 * dotw;
   return p + tmpu * bary.x + tmpv * bary.y + tmpw * bary.z;
 }
+PT_DEV HitState getHitState(const DevPrim& rp, f3 bary, const float* w2o, const float* o2w, u3 ti, f3 worldRayDir);
 PT_DEV HitState getHitState(const DevPrim& rp, f3 bary, const float* w2o, const float* o2w, int triangleID, f3 worldRayDir)
 {
+  return getHitState(rp, bary, w2o, o2w, getTriangleIndices(rp, triangleID), worldRayDir);
+}
+PT_DEV HitState getHitState(const DevPrim& rp, f3 bary, const float* w2o, const float* o2w, u3 ti, f3 worldRayDir)
+{
   HitState hit;
-  u3 ti   = getTriangleIndices(rp, triangleID);
   f3 pos0 = getVertexPosition(rp, ti.x), pos1 = getVertexPosition(rp, ti.y), pos2 = getVertexPosition(rp, ti.z);
   f3 position  = pos0 * bary.x + pos1 * bary.y + pos2 * bary.z;
   hit.pos      = mulPoint(o2w, position);
@@ -503,6 +507,21 @@ PT_DEV float getOpacityFast(const DevScene& sc, int triIndex, f3 bary)
   if(mode == MI_ALPHA_MASK)
     return alpha >= rec.b.w ? 1.0f : 0.0f;
   return alpha;
+}
+PT_DEV DevShadeTri makeShadeRecord(const DevScene& sc, const DevTri& T)
+{
+  DevShadeTri             r;
+  const uint32_t          rnode = __float_as_uint(T.a.w), prim = __float_as_uint(T.b.w);
+  const MiGltfRenderNode& rn    = sc.nodes[rnode];
+  const DevPrim           rp    = sc.prims[rn.renderPrimID];
+  const u3                ti    = getTriangleIndices(rp, int(prim));
+  r.i0 = ti.x; r.i1 = ti.y; r.i2 = ti.z;
+  r.rnode        = rnode;
+  r.renderPrimID = rn.renderPrimID;
+  r.materialID   = max(0, rn.materialID);
+  r.prim         = prim;
+  r._pad         = 0;
+  return r;
 }
 // Fills the record of one triangle (run once after the BVH build, for every triangle of the active order).
 PT_DEV DevAlphaTri makeAlphaRecord(const DevScene& sc, const DevTri& T)
