@@ -151,19 +151,8 @@ struct MeshState
   TexCtx tex;  // texture tables for the fetches of this hit (the shade kernel stages the sRGB table in LDS)
 };
 PT_DEV bool isTexturePresent(uint16_t t) { return t > 0; }
-__device__ __noinline__ f4 getTexture(const DevScene& sc, const float* lut, uint16_t slot, f2 tc0, f2 tc1, float texGrad, unsigned& taps)  // :76-110
-{
-  ++taps;
-  const MiGltfTextureInfo ti = sc.texInfos[slot];
-  f2                      t  = ti.texCoord == 0 ? tc0 : tc1;
-  const float*            U  = ti.uvTransform;
-  f2                      tt = mk2(t.x * U[0] + t.y * U[2] + U[4], t.x * U[1] + t.y * U[3] + U[5]);
-  if(texGrad > 0.0f)
-    return sampleTexture(sc, lut, ti.index, tt, true, mk2(U[0] * texGrad, U[1] * texGrad), mk2(U[2] * texGrad, U[3] * texGrad));
-  return sampleTexture(sc, lut, ti.index, tt, false, mk2(0, 0), mk2(0, 0));
-}
-// getTexture on the flattened DevTexRef table: same arithmetic as getTexture -> sampleTexture -> sampleLevel -> fetchTexel
-// (pt_light.h), two dependent loads instead of five.
+// getTexture (gltf_material_eval.h.slang:76-110) on the flattened DevTexRef table: the arithmetic of sampleTexture ->
+// sampleLevel -> fetchTexel (pt_light.h) with two dependent loads (record, texels) instead of five.
 PT_DEV f4 fetchTexelRef(const TexCtx& tc, const DevTexRef& R, uint32_t levelOffset, int w, int x, int y)
 {
   uchar4 p = tc.texels[size_t(levelOffset) + size_t(y) * size_t(w) + size_t(x)];
@@ -431,42 +420,8 @@ PT_DEV f3 safeOffsetRay(f3 p, f3 dir)  // :151-167
              fabsf(p.z) < origin ? p.z + floatScale * dir.z : op.z);
 }
 
-// getOpacity, :189-234.  Returns 1 for opaque materials.
-__device__ __noinline__ float getOpacity(const DevScene& sc, int rnode, int triangleID, f3 bary)
-{
-  const MiGltfRenderNode& rn  = sc.nodes[rnode];
-  const int               mi  = max(0, rn.materialID);
-  const int               alphaMode = sc.materials[mi].alphaMode;
-  if(alphaMode == MI_ALPHA_OPAQUE)
-    return 1.0f;
-  const MiGltfShadeMaterial& mat = sc.materials[mi];
-  const DevPrim              rp  = sc.prims[rn.renderPrimID];
-  u3                         ti  = getTriangleIndices(rp, triangleID);
-  float                      alpha;
-  uint16_t                   slot;
-  if(mat.pbrModel == MI_PBR_SPECULAR_GLOSSINESS)
-  {
-    alpha = mat.pbrDiffuseFactor[3];
-    slot  = mat.pbrDiffuseTexture;
-  }
-  else
-  {
-    alpha = mat.pbrBaseColorFactor[3];
-    slot  = mat.pbrBaseColorTexture;
-  }
-  if(isTexturePresent(slot))
-  {
-    const MiGltfTextureInfo info = sc.texInfos[slot];
-    f2                      uv   = getInterpolatedVertexTexCoord(rp, info.texCoord, ti, bary);
-    alpha *= sampleTexture(sc, info.index, uv, false, mk2(0, 0), mk2(0, 0)).w;
-  }
-  alpha *= getInterpolatedVertexColor(rp, ti, bary).w;
-  if(alphaMode == MI_ALPHA_MASK)
-    return alpha >= mat.alphaCutoff ? 1.0f : 0.0f;
-  return alpha;
-}
-
-// getOpacity through the per-triangle alpha record (same arithmetic, two dependent loads instead of eight)
+// getOpacity (pathtrace_functions.h.slang:189-234; 1 for opaque materials) through the per-triangle alpha record: record ->
+// texels instead of instance -> material -> primitive -> indices -> uvs -> texture info -> texture -> texels
 PT_DEV float getOpacityFast(const DevScene& sc, int triIndex, f3 bary)
 {
   const DevAlphaTri rec  = sc.alphaTris[triIndex];
