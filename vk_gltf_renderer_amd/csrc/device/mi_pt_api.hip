@@ -746,13 +746,22 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
           (void)hipStreamSynchronize(stream);
           return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         };
+        auto segs = [&]() {
+          pt::StatCounters h{};
+          (void)hipMemcpy(&h, pt->stats.ptr, sizeof(h), hipMemcpyDeviceToHost);
+          return h;
+        };
         uint32_t nIn = count(cur ? pt::QC_ACTIVE1 : pt::QC_ACTIVE0);
+        const pt::StatCounters s0 = segs();
         double   tTrace = span([&] { pt::launchTraceClosest(c, cur); });
+        const pt::StatCounters s1 = segs();
         double   tShade = span([&] { pt::launchShade(c, cur, it == 0); });
         uint32_t nSh    = count(pt::QC_SHADOW);
         double   tShadow = span([&] { pt::launchTraceShadow(c, cur ^ 1); });
-        fprintf(stderr, "[mi_pt span] frame %d it %2d rays %8u trace %8.3f ms shade %8.3f ms | shadow rays %8u %8.3f ms\n", params->frameCount, it, nIn, tTrace,
-                tShade, nSh, tShadow);
+        const pt::StatCounters s2 = segs();
+        fprintf(stderr, "[mi_pt span] frame %d it %2d rays %8u (traced %8llu) trace %8.3f ms shade %8.3f ms | shadow rays %8u (traced %8llu) %8.3f ms\n",
+                params->frameCount, it, nIn, (unsigned long long)(s1.segments - s0.segments), tTrace, tShade, nSh,
+                (unsigned long long)(s2.shadowRays - s1.shadowRays), tShadow);
       }
       else
       {

@@ -10,6 +10,7 @@
 #include "pt_shading.h"
 #include "pt_bvh.h"
 #include "pt_bvh8.h"
+#include "pt_feed.h"
 
 namespace pt {
 
@@ -37,7 +38,10 @@ PT_DEV void queuePrefix(const uint32_t* counts, uint32_t* s_prefix)
   if(threadIdx.x < 64)  // first wave: one load per lane, shuffle scan (every block of every launch pays this latency)
   {
     const uint32_t lane = threadIdx.x;
-    uint32_t       v    = lane < NSUB ? counts[lane] : 0u;
+    // The tails were advanced by agent-scope atomics of the previous kernel, which are served beyond the XCD's L2 and leave a
+    // copy of the line that this L2 may still hold from an earlier launch untouched: a plain load can return the counts of
+    // two iterations ago.  Read them coherently.
+    uint32_t       v    = lane < NSUB ? __hip_atomic_load(&counts[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 #pragma unroll
     for(int d = 1; d < NSUB; d <<= 1)
     {
@@ -85,76 +89,6 @@ PT_DEV uint32_t queuePushBlock(bool pred, uint32_t subCap, uint32_t* counts, uin
     s_tmp[1] = s_tmp[0] ? atomicAdd(&counts[sub], s_tmp[0]) : 0u;
   __syncthreads();
   return sub * subCap + s_tmp[1] + wbase + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
-}
-
-// Wave-level dynamic work fetch (persistent waves): a wave owns a private range [cur, end) of flat queue indices and takes
-// the next chunk of QCHUNK indices from one of 8 head counters (own XCD's first) when the range runs dry.
-struct WaveFeed
-{
-  uint32_t cur, end, total, numChunks, chunk;  // chunk = indices fetched per head atomic
-  bool     exhausted;
-};
-// Long queues are fetched QCHUNK indices at a time (few atomics); queues shorter than the machine (fewer rays than resident
-// lanes) are fetched one wave-load at a time so that they spread over every CU instead of serialising in a few waves.
-PT_DEV void feedInit(WaveFeed& f, uint32_t total)
-{
-  f.cur = f.end = 0;
-  f.total       = total;
-  f.chunk       = total >= 512u * 1024u ? uint32_t(QCHUNK) : 64u;
-  f.numChunks   = (total + f.chunk - 1) / f.chunk;
-  f.exhausted   = total == 0;
-}
-// blocks beyond the ones the queue can feed (one wave per fetch chunk) leave at once
-PT_DEV bool feedBlockHasWork(const WaveFeed& f) { return blockIdx.x * (blockDim.x / 64u) < f.numChunks; }
-PT_DEV bool feedNextChunk(WaveFeed& f, uint32_t* heads)
-{
-  uint32_t chunk = 0xffffffffu;
-  if(laneId() == 0)
-  {
-    const uint32_t h0 = blockIdx.x & 7u;
-    for(uint32_t k = 0; k < 8u; ++k)
-    {
-      uint32_t h = (h0 + k) & 7u;
-      // peek first: a head that already ran past the end must not be hammered by every idle wave of the grid
-      if(__hip_atomic_load(&heads[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 8u + h >= f.numChunks)
-        continue;
-      uint32_t fc = atomicAdd(&heads[h], 1u) * 8u + h;
-      if(fc < f.numChunks)
-      {
-        chunk = fc;
-        break;
-      }
-    }
-  }
-  chunk = uint32_t(__shfl(int(chunk), 0));
-  if(chunk == 0xffffffffu)
-  {
-    f.exhausted = true;
-    return false;
-  }
-  f.cur = chunk * f.chunk;
-  f.end = min(f.cur + f.chunk, f.total);
-  return true;
-}
-// Hands flat indices to the lanes whose `idle` predicate is set; returns the index or 0xffffffff (none left for this lane).
-PT_DEV uint32_t feedTake(WaveFeed& f, bool idle, uint32_t* heads)
-{
-  unsigned long long mask = __ballot(idle);
-  uint32_t           need = uint32_t(__popcll(mask));
-  uint32_t           rank = uint32_t(__popcll(mask & ((1ull << laneId()) - 1ull)));
-  uint32_t           mine = 0xffffffffu, assigned = 0;
-  while(need > 0 && !f.exhausted)
-  {
-    if(f.cur == f.end && !feedNextChunk(f, heads))
-      break;
-    uint32_t take = min(need, f.end - f.cur);
-    if(idle && rank >= assigned && rank < assigned + take)
-      mine = f.cur + (rank - assigned);
-    assigned += take;
-    f.cur += take;
-    need -= take;
-  }
-  return mine;
 }
 
 // ---- slot <-> pixel -----------------------------------------------------------------------------------------------------------
@@ -414,7 +348,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
   uint32_t pPos = 0, pSlot = QUEUE_DEAD;
   float4   pO = make_float4(0, 0, 0, 0), pD = make_float4(0, 0, 0, 0);
 #ifdef TRACE_PROFILE
-  unsigned long long profAcc[4] = {0, 0, 0, 0};
+  unsigned long long profAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long profStart = PROF_T();
 #endif
   for(;;)
@@ -448,9 +382,13 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
         if(COUNT) ++rays;
       }
     }
+    PROF_ADD(4, tFeed);
     if(!feed.exhausted)
     {
+      const unsigned long long tTake = PROF_T();
       uint32_t flat = feedTake(feed, !pValid, &Q.counters[QC_HEADS_TRACE]);
+      PROF_ADD(5, tTake);
+      const unsigned long long tIssue = PROF_T();
       if(flat != 0xffffffffu)
       {
         pPos   = queuePos(Q.subCap, s_prefix, flat);
@@ -459,6 +397,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
         pD     = in.dir[pPos];
         pValid = true;
       }
+      PROF_ADD(6, tIssue);
     }
     const bool moreWork = !feed.exhausted || __ballot(pValid) != 0ull;
     if(__ballot(active) == 0ull)
@@ -565,6 +504,9 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
     atomicAdd(&g_traceProf[2], profAcc[2]);
     atomicAdd(&g_traceProf[3], PROF_T() - profStart);
     atomicAdd(&g_traceProf[4], 1ull);
+    atomicAdd(&g_traceProf[5], profAcc[4]);
+    atomicAdd(&g_traceProf[6], profAcc[5]);
+    atomicAdd(&g_traceProf[7], profAcc[6]);
   }
 #endif
   if(COUNT)
@@ -1688,6 +1630,8 @@ void dumpTraceProfile()
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_traceProf), sizeof(h));
   const double tot = double(h[3]) > 0 ? double(h[3]) : 1.0;
+  fprintf(stderr, "[mi_pt trace profile] feed split: start-ray (waits for the prefetch) %.1f%% take %.1f%% issue %.1f%%\n", 100.0 * h[5] / tot, 100.0 * h[6] / tot,
+          100.0 * h[7] / tot);
   fprintf(stderr, "[mi_pt trace profile] waves %llu total ticks %.4g: feed %.1f%% node %.1f%% tri %.1f%% other %.1f%%\n", h[4], tot, 100.0 * h[0] / tot,
           100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * (tot - h[0] - h[1] - h[2]) / tot);
 #endif

@@ -187,12 +187,15 @@ struct Queues
 };
 enum : int
 {
-  QC_ACTIVE0      = 0,            // NSUB counts
-  QC_ACTIVE1      = NSUB,         // NSUB counts
-  QC_SHADOW       = 2 * NSUB,     // NSUB counts
-  QC_HEADS_TRACE  = 3 * NSUB,     // 8 dynamic-fetch heads (one per XCD by convention) of k_trace_closest
-  QC_HEADS_SHADOW = 3 * NSUB + 8, // 8 heads of k_trace_shadow
-  QC_COUNT        = 3 * NSUB + 16
+  // Every group lives in its own 128-byte line: a kernel may reset one group with plain stores while other waves run
+  // atomics on another, and the XCDs' L2s are not coherent with each other -- a line that is dirty in one L2 and the target
+  // of atomics from elsewhere at the same time loses updates (seen as queue pieces handed out twice).
+  QC_ACTIVE0      = 0,    // NSUB counts
+  QC_ACTIVE1      = 32,   // NSUB counts
+  QC_SHADOW       = 64,   // NSUB counts
+  QC_HEADS_TRACE  = 96,   // 8 dynamic-fetch heads (one per XCD by convention) of k_trace_closest
+  QC_HEADS_SHADOW = 128,  // 8 heads of k_trace_shadow
+  QC_COUNT        = 160
 };
 
 struct StatCounters  // device mirror of MiPtStats' dynamic part
