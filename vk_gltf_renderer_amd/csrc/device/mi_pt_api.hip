@@ -721,22 +721,22 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
     {
       if(pt->hasVolumeScatter && it >= params->maxDepth && (it % 8) == 0)
       {
-        uint32_t counts[pt::NSUB];
-        HIP_TRY(hipMemcpyAsync(counts, &c.queues.counters[cur ? pt::QC_ACTIVE1 : pt::QC_ACTIVE0], sizeof(counts), hipMemcpyDeviceToHost, stream));
+        uint32_t counts[2 * pt::NSUB];
+        HIP_TRY(hipMemcpyAsync(counts, &c.queues.counters[cur ? pt::QC_PAIR1 : pt::QC_PAIR0], sizeof(counts), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         uint32_t remaining = 0;
-        for(uint32_t v : counts)
-          remaining += v;
+        for(int q = 0; q < pt::NSUB; ++q)
+          remaining += counts[2 * q];
         if(remaining == 0)
           break;
       }
       if(debugSpans)  // MI_PT_TRACE_SPANS=1: per-launch wall time and queue lengths (synchronising; diagnostics only)
       {
-        auto count = [&](int base) {
-          uint32_t v[pt::NSUB];
-          (void)hipMemcpy(v, &c.queues.counters[base], sizeof(v), hipMemcpyDeviceToHost);
+        auto count = [&](int base) {  // base: first of 16 tails stored 2 words apart
+          uint32_t v[2 * pt::NSUB];
+          (void)hipMemcpy(v, &c.queues.counters[base], sizeof(uint32_t) * (2 * pt::NSUB - 1), hipMemcpyDeviceToHost);
           uint32_t t = 0;
-          for(uint32_t x : v) t += x;
+          for(int q = 0; q < pt::NSUB; ++q) t += v[2 * q];
           return t;
         };
         auto span = [&](auto&& launch) {
@@ -751,12 +751,12 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
           (void)hipMemcpy(&h, pt->stats.ptr, sizeof(h), hipMemcpyDeviceToHost);
           return h;
         };
-        uint32_t nIn = count(cur ? pt::QC_ACTIVE1 : pt::QC_ACTIVE0);
+        uint32_t nIn = count(cur ? pt::QC_PAIR1 : pt::QC_PAIR0);
         const pt::StatCounters s0 = segs();
         double   tTrace = span([&] { pt::launchTraceClosest(c, cur); });
         const pt::StatCounters s1 = segs();
         double   tShade = span([&] { pt::launchShade(c, cur, it == 0); });
-        uint32_t nSh    = count(pt::QC_SHADOW);
+        uint32_t nSh    = count((cur ? pt::QC_PAIR0 : pt::QC_PAIR1) + 1);
         double   tShadow = span([&] { pt::launchTraceShadow(c, cur ^ 1); });
         const pt::StatCounters s2 = segs();
         fprintf(stderr, "[mi_pt span] frame %d it %2d rays %8u (traced %8llu) trace %8.3f ms shade %8.3f ms | shadow rays %8u (traced %8llu) %8.3f ms\n",

@@ -33,7 +33,7 @@ constexpr int SHADE_BLOCK = 256;
 PT_DEV uint32_t laneId() { return __lane_id(); }
 
 // Exclusive prefix of the NSUB sub-queue counts into LDS (s_prefix[NSUB] = total).  Call from every thread of the block.
-PT_DEV void queuePrefix(const uint32_t* counts, uint32_t* s_prefix)
+PT_DEV void queuePrefix(const uint32_t* counts, uint32_t* s_prefix)  // counts: 16 tails, 2 words apart (see QC_PAIR*)
 {
   if(threadIdx.x < 64)  // first wave: one load per lane, shuffle scan (every block of every launch pays this latency)
   {
@@ -41,7 +41,7 @@ PT_DEV void queuePrefix(const uint32_t* counts, uint32_t* s_prefix)
     // The tails were advanced by agent-scope atomics of the previous kernel, which are served beyond the XCD's L2 and leave a
     // copy of the line that this L2 may still hold from an earlier launch untouched: a plain load can return the counts of
     // two iterations ago.  Read them coherently.
-    uint32_t       v    = lane < NSUB ? __hip_atomic_load(&counts[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    uint32_t       v    = lane < NSUB ? __hip_atomic_load(&counts[2u * lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 #pragma unroll
     for(int d = 1; d < NSUB; d <<= 1)
     {
@@ -66,29 +66,50 @@ PT_DEV uint32_t queuePos(uint32_t subCap, const uint32_t* s_prefix, uint32_t fla
       q += step;
   return q * subCap + (flat - s_prefix[q]);
 }
-// Block-aggregated append of the survivors of one chunk: one LDS atomic per wave, ONE global atomic per block and queue.
-// Must be called by every thread of the block (contains __syncthreads).  s_tmp: 2 words of LDS per call site.
-// Returns the array position reserved for this thread's entry (meaningless when !pred).
-PT_DEV uint32_t queuePushBlock(bool pred, uint32_t subCap, uint32_t* counts, uint32_t sub, uint32_t* s_tmp)
+// Block-aggregated append of the survivors of one chunk to BOTH output queues of a shade launch: one LDS atomic per wave and
+// queue, ONE 64-bit global atomic per block for the two tails (`pair` = &counters[QC_PAIRq + 2 * sub]).  Must be called by
+// every thread of the block (contains __syncthreads).  s_tmp: 4 words of LDS.  Returns the array positions reserved for this
+// thread's entries (meaningless when the predicate is false).
+struct PushPos
+{
+  uint32_t next, shadow;
+};
+PT_DEV PushPos queuePushBlock2(bool predNext, bool predShadow, uint32_t subCap, uint32_t* pair, uint32_t sub, uint32_t* s_tmp)
 {
   if(threadIdx.x == 0)
-    s_tmp[0] = 0;
-  __syncthreads();
-  unsigned long long mask = __ballot(pred);
-  uint32_t           lane = laneId();
-  uint32_t           wbase = 0;
-  if(mask != 0ull)
   {
-    uint32_t leader = uint32_t(__ffsll((long long)mask) - 1);
-    if(lane == leader)
-      wbase = atomicAdd(&s_tmp[0], uint32_t(__popcll(mask)));
-    wbase = uint32_t(__shfl(int(wbase), int(leader)));
+    s_tmp[0] = 0;
+    s_tmp[1] = 0;
   }
   __syncthreads();
-  if(threadIdx.x == 0)
-    s_tmp[1] = s_tmp[0] ? atomicAdd(&counts[sub], s_tmp[0]) : 0u;
+  const unsigned long long maskN = __ballot(predNext), maskS = __ballot(predShadow);
+  const uint32_t           lane  = laneId();
+  uint32_t                 wbaseN = 0, wbaseS = 0;
+  if(lane == 0)
+  {
+    if(maskN != 0ull)
+      wbaseN = atomicAdd(&s_tmp[0], uint32_t(__popcll(maskN)));
+    if(maskS != 0ull)
+      wbaseS = atomicAdd(&s_tmp[1], uint32_t(__popcll(maskS)));
+  }
+  wbaseN = uint32_t(__shfl(int(wbaseN), 0));
+  wbaseS = uint32_t(__shfl(int(wbaseS), 0));
   __syncthreads();
-  return sub * subCap + s_tmp[1] + wbase + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
+  if(threadIdx.x == 0)
+  {
+    const uint32_t     nN = s_tmp[0], nS = s_tmp[1];
+    unsigned long long base = 0ull;
+    if((nN | nS) != 0u)
+      base = atomicAdd(reinterpret_cast<unsigned long long*>(pair), (static_cast<unsigned long long>(nS) << 32) | nN);
+    s_tmp[2] = uint32_t(base);
+    s_tmp[3] = uint32_t(base >> 32);
+  }
+  __syncthreads();
+  const unsigned long long below = (1ull << lane) - 1ull;
+  PushPos                  p;
+  p.next   = sub * subCap + s_tmp[2] + wbaseN + uint32_t(__popcll(maskN & below));
+  p.shadow = sub * subCap + s_tmp[3] + wbaseS + uint32_t(__popcll(maskS & below));
+  return p;
 }
 
 // ---- slot <-> pixel -----------------------------------------------------------------------------------------------------------
@@ -221,7 +242,7 @@ __global__ void __launch_bounds__(256) k_generate(DevScene sc, FrameConsts fc, P
   if(blockIdx.x == 0 && threadIdx.x < NSUB)
   {
     const uint32_t numChunks = batchSlots / QCHUNK;
-    Q.counters[QC_ACTIVE0 + threadIdx.x] = QCHUNK * (numChunks / NSUB + (threadIdx.x < numChunks % NSUB ? 1u : 0u));
+    Q.counters[QC_PAIR0 + 2 * threadIdx.x] = QCHUNK * (numChunks / NSUB + (threadIdx.x < numChunks % NSUB ? 1u : 0u));
   }
   if(blockIdx.x == 0 && threadIdx.x < 8)
     Q.counters[QC_HEADS_TRACE + threadIdx.x] = 0;
@@ -314,13 +335,13 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
   if(blockIdx.x == 0 && threadIdx.x < NSUB)
   {
     // the shade kernel of this iteration appends to these; zero them here (the kernel boundary orders the writes)
-    Q.counters[(cur ? QC_ACTIVE0 : QC_ACTIVE1) + threadIdx.x] = 0;
-    Q.counters[QC_SHADOW + threadIdx.x]                        = 0;
+    Q.counters[(cur ? QC_PAIR0 : QC_PAIR1) + 2 * threadIdx.x]     = 0;
+    Q.counters[(cur ? QC_PAIR0 : QC_PAIR1) + 2 * threadIdx.x + 1] = 0;
     if(threadIdx.x < 8)
       Q.counters[QC_HEADS_SHADOW + threadIdx.x] = 0;
   }
   const RayQueue in = Q.active[cur];
-  queuePrefix(&Q.counters[cur ? QC_ACTIVE1 : QC_ACTIVE0], s_prefix);
+  queuePrefix(&Q.counters[cur ? QC_PAIR1 : QC_PAIR0], s_prefix);
   WaveFeed feed;
   feedInit(feed, s_prefix[NSUB]);
   if(!feedBlockHasWork(feed))
@@ -565,8 +586,8 @@ __global__ void __launch_bounds__(256) k_trace_primary(DevScene sc, PathSoA P, Q
   if(blockIdx.x == 0 && threadIdx.x < NSUB)
   {
     // same hand-over as k_trace_closest(cur = 0): the shade kernel of this iteration appends to these
-    Q.counters[QC_ACTIVE1 + threadIdx.x] = 0;
-    Q.counters[QC_SHADOW + threadIdx.x]  = 0;
+    Q.counters[QC_PAIR1 + 2 * threadIdx.x]     = 0;
+    Q.counters[QC_PAIR1 + 2 * threadIdx.x + 1] = 0;
     if(threadIdx.x < 8)
       Q.counters[QC_HEADS_SHADOW + threadIdx.x] = 0;
   }
@@ -767,7 +788,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
   static_assert(SHADE_BLOCK == 256, "one table entry per thread");
   if(blockIdx.x == 0 && threadIdx.x < 8)
     Q.counters[QC_HEADS_TRACE + threadIdx.x] = 0;  // for the next iteration's k_trace_closest
-  queuePrefix(&Q.counters[cur ? QC_ACTIVE1 : QC_ACTIVE0], s_prefix);
+  queuePrefix(&Q.counters[cur ? QC_PAIR1 : QC_PAIR0], s_prefix);
   const uint32_t count     = s_prefix[NSUB];
   const int      nxt       = cur ^ 1;
   const uint32_t numChunks = (count + SHADE_BLOCK - 1) / SHADE_BLOCK;  // SHADE_BLOCK == QCHUNK
@@ -1120,14 +1141,14 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
       if(COUNT && taps)
         atomicAdd(&stats->textureTaps, (unsigned long long)taps);
     }
-    const uint32_t posNext = queuePushBlock(alive, Q.subCap, &Q.counters[nxt ? QC_ACTIVE1 : QC_ACTIVE0], chunk % NSUB, s_push);
+    const PushPos  pp      = queuePushBlock2(alive, pushShadow, Q.subCap, &Q.counters[(nxt ? QC_PAIR1 : QC_PAIR0) + 2 * (chunk % NSUB)], chunk % NSUB, s_push);
+    const uint32_t posNext = pp.next, posShadow = pp.shadow;
     if(alive)
     {
       Q.active[nxt].slot[posNext] = slot;
       Q.active[nxt].org[posNext]  = nextOrg;
       Q.active[nxt].dir[posNext]  = nextDir;
     }
-    const uint32_t posShadow = queuePushBlock(pushShadow, Q.subCap, &Q.counters[QC_SHADOW], chunk % NSUB, s_push + 2);
     if(pushShadow)
     {
       Q.shadow.slot[posShadow] = slot;
@@ -1164,7 +1185,7 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
   __shared__ int      s_stack[BVH_STACK_LDS * SBLOCK];
   __shared__ uint32_t s_prefix[NSUB + 1];
   __shared__ uint4    s_nodes[WIDE ? ShadowCfg<MODE>::CACHE * 5 : 1];
-  queuePrefix(&Q.counters[QC_SHADOW], s_prefix);
+  queuePrefix(&Q.counters[(nxt ? QC_PAIR1 : QC_PAIR0) + 1], s_prefix);  // the shadow tails written next to active queue `nxt`
   const RayQueue in = Q.shadow;
   WaveFeed feed;
   feedInit(feed, s_prefix[NSUB]);

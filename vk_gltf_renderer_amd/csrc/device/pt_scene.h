@@ -187,12 +187,13 @@ struct Queues
 };
 enum : int
 {
-  // Every group lives in its own 128-byte line: a kernel may reset one group with plain stores while other waves run
-  // atomics on another, and the XCDs' L2s are not coherent with each other -- a line that is dirty in one L2 and the target
-  // of atomics from elsewhere at the same time loses updates (seen as queue pieces handed out twice).
-  QC_ACTIVE0      = 0,    // NSUB counts
-  QC_ACTIVE1      = 32,   // NSUB counts
-  QC_SHADOW       = 64,   // NSUB counts
+  // Queue tails.  PAIR q holds, per sub-queue s, two adjacent words: [2s] = entries appended to active queue q, [2s+1] =
+  // shadow rays appended by the same shade launch -- so that one 64-bit atomic per block and chunk reserves space in both
+  // queues (a device-scope atomic on these lines is served beyond the XCD's L2 and costs microseconds).  Every group lives
+  // in its own 128-byte line(s): a kernel may reset one group with plain stores while other waves run atomics on another,
+  // and the XCDs' L2s are not coherent with each other.
+  QC_PAIR0        = 0,    // 2 * NSUB words
+  QC_PAIR1        = 32,   // 2 * NSUB words
   QC_HEADS_TRACE  = 96,   // 8 dynamic-fetch heads (one per XCD by convention) of k_trace_closest
   QC_HEADS_SHADOW = 128,  // 8 heads of k_trace_shadow
   QC_COUNT        = 160
