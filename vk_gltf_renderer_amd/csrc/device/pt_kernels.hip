@@ -472,10 +472,18 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
             {
               if(active && pMask != 0u)
               {
-                const int k = __ffs(int(pMask)) - 1;
+                // two triangles per round: both records are in flight together (one dependent-load latency for the pair)
+                const int k0 = __ffs(int(pMask)) - 1;
                 pMask &= pMask - 1u;
-                if(COUNT) ++tris;
-                closestTestTriangle<HAS_ALPHA>(sc, r, int(pBase) + k, best, seed0, seedLoaded, P.misc, slot);
+                const bool two = pMask != 0u;
+                const int  k1  = two ? __ffs(int(pMask)) - 1 : k0;
+                if(two)
+                  pMask &= pMask - 1u;
+                const DevTri T0 = sc.tris[int(pBase) + k0], T1 = sc.tris[int(pBase) + k1];
+                if(COUNT) tris += two ? 2u : 1u;
+                closestTestLoaded<HAS_ALPHA>(sc, r, T0, int(pBase) + k0, best, seed0, seedLoaded, P.misc, slot);
+                if(two)
+                  closestTestLoaded<HAS_ALPHA>(sc, r, T1, int(pBase) + k1, best, seed0, seedLoaded, P.misc, slot);
                 if(pMask == 0u) { pBase = qBase; pMask = qMask; qMask = 0u; }
               }
               pend = __ballot(active && pMask != 0u);
@@ -1297,8 +1305,7 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
     }
   };
   // one shadow candidate (raytracer_interface.h.slang:149-179); returns true when the ray is decided (occluded)
-  auto testTri = [&](int triIndex) {
-    const DevTri T = sc.tris[triIndex];
+  auto testTriLoaded = [&](const DevTri& T, int triIndex) {
     if(COUNT) ++tris;
     const uint32_t flags = __float_as_uint(T.c.w);
     TriHit         h;
@@ -1337,6 +1344,8 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
       }
     }
   };
+
+  auto testTri = [&](int triIndex) { testTriLoaded(sc.tris[triIndex], triIndex); };
 
   for(;;)
   {
@@ -1431,9 +1440,17 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
             {
               if(active && pMask != 0u)
               {
-                const int k = __ffs(int(pMask)) - 1;
+                // two triangles per round, both records in flight together (as in k_trace_closest)
+                const int k0 = __ffs(int(pMask)) - 1;
                 pMask &= pMask - 1u;
-                testTri(int(pBase) + k);
+                const bool two = pMask != 0u;
+                const int  k1  = two ? __ffs(int(pMask)) - 1 : k0;
+                if(two)
+                  pMask &= pMask - 1u;
+                const DevTri T0 = sc.tris[int(pBase) + k0], T1 = sc.tris[int(pBase) + k1];
+                testTriLoaded(T0, int(pBase) + k0);
+                if(two && !occluded)
+                  testTriLoaded(T1, int(pBase) + k1);
                 if(occluded) { pMask = 0u; qMask = 0u; }
                 else if(pMask == 0u) { pBase = qBase; pMask = qMask; qMask = 0u; }
               }
