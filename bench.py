@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the path-trace hot path on N MI355X GPUs of one node.
 
-A "step" is one pass of the hot path over one batch of synthetic input: a batch of `--in-flight` (default 16) consecutive
+A "step" is one pass of the hot path over one batch of synthetic input: a batch of `--in-flight` (default 32) consecutive
 frames per GPU, each ptSamples = 1 sample per pixel like the reference's headless run `--frames K --ptSamples 1`
 (docs/benchmarking.md:16-23), issued through mi_pt_render_frames so that the frames share every wavefront launch
 (bit-identical to rendering them one after the other; --in-flight 1 gives exactly that), of the workload BASELINE.json's
@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bvh", type=int, default=0, help="bit0: 0 = 8-wide compressed BVH (default), 1 = plain BVH2; bit1: 0 = PLOC topology (default), 1 = LBVH")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--in-flight", type=int, default=16,
+    ap.add_argument("--in-flight", type=int, default=32,
                     help="frames in flight per GPU and step (mi_pt_render_frames, bit-identical to sequential frames); a step renders in_flight * n_gpus frames")
     args = ap.parse_args()
 
