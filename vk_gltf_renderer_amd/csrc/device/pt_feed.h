@@ -65,7 +65,11 @@ PT_DEV bool feedNextChunk(WaveFeed& f, uint32_t* heads)
         want = ((len - min(homeSeen, len)) / (2u * wavesPerHead)) & ~63u;
         want = min(max(want, 64u), 1024u);
       }
-      if(len != 0u)
+      // Heads are looked at before they are touched (a coherent load; loads do not queue up behind each other the way
+      // thousands of atomics on one exhausted counter do at the end of every launch) ...
+      // The home head is taken from blindly while the wave knows that plenty is left, and looked at first near its end.
+      const bool blind = k == 0u && len - min(homeSeen, len) > 32u * wavesPerHead;
+      if(len != 0u && (blind || __hip_atomic_load(&heads[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < len))
       {
         const uint32_t s0 = atomicAdd(&heads[h], want);
         if(k == 0u)

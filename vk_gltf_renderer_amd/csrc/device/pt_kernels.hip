@@ -38,10 +38,9 @@ PT_DEV void queuePrefix(const uint32_t* counts, uint32_t* s_prefix)  // counts: 
   if(threadIdx.x < 64)  // first wave: one load per lane, shuffle scan (every block of every launch pays this latency)
   {
     const uint32_t lane = threadIdx.x;
-    // The tails were advanced by agent-scope atomics of the previous kernel, which are served beyond the XCD's L2 and leave a
-    // copy of the line that this L2 may still hold from an earlier launch untouched: a plain load can return the counts of
-    // two iterations ago.  Read them coherently.
-    uint32_t       v    = lane < NSUB ? __hip_atomic_load(&counts[2u * lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    // (plain cached loads: every block of every launch reads these 16 words; coherent agent-scope loads are served beyond the
+    // XCD's L2 one by one and cost ~100 us per launch on short queues)
+    uint32_t       v    = lane < NSUB ? counts[2u * lane] : 0u;
 #pragma unroll
     for(int d = 1; d < NSUB; d <<= 1)
     {
