@@ -204,6 +204,9 @@ def main():
                        "parallelism": f"tiles{world}" if world > 1 else "single"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_launch_ms": round(avg_launch_ms, 5),
+                         # measured HBM bytes (profiles/pmc_latest.json) over the same launch time: what actually crossed the memory
+                         # interface; `achieved` counts the records the algorithm touches whether or not a cache served them
+                         "traffic_GBps": (round(traffic / (avg_launch_ms * 1e-3) / 1e9, 1) if traffic else None),
                          "algorithmic_bytes_per_launch": round(bytes_per_launch),
                          "per_frame": {k: round(per_frame[k], 1) for k in ("segments", "shadowRays", "nodesClosest", "trisClosest", "nodesShadow", "trisShadow", "textureTaps")},
                          "kernel_ms_per_frame": {k: round(timing[v[0]] / (args.steps * F), 4) for k, v in kernels.items()},
