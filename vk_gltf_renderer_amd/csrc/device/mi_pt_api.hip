@@ -291,6 +291,7 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
     if(p.tangents) geomBytes += align16(size_t(p.vertexCount) * 16);
     if(p.texCoords0) geomBytes += align16(size_t(p.vertexCount) * 8);
     if(p.texCoords1) geomBytes += align16(size_t(p.vertexCount) * 8);
+    geomBytes += align16(size_t(p.vertexCount) * 48);  // interleaved copy (DevPrim::verts)
   }
   HIP_TRY(pt->geometry.alloc(std::max<size_t>(geomBytes, 16)));
   std::vector<uint8_t>     staging(std::max<size_t>(geomBytes, 16));
@@ -316,6 +317,18 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
       d.tangents   = reinterpret_cast<const float*>(put(p.tangents, size_t(p.vertexCount) * 16));
       d.texCoords0 = reinterpret_cast<const float*>(put(p.texCoords0, size_t(p.vertexCount) * 8));
       d.texCoords1 = reinterpret_cast<const float*>(put(p.texCoords1, size_t(p.vertexCount) * 8));
+      {
+        std::vector<float> iv(size_t(p.vertexCount) * 12, 0.0f);
+        for(uint32_t v = 0; v < p.vertexCount; ++v)
+        {
+          float* o = &iv[size_t(v) * 12];
+          o[0] = p.positions[3 * size_t(v)]; o[1] = p.positions[3 * size_t(v) + 1]; o[2] = p.positions[3 * size_t(v) + 2];
+          if(p.normals) { o[3] = p.normals[3 * size_t(v)]; o[4] = p.normals[3 * size_t(v) + 1]; o[5] = p.normals[3 * size_t(v) + 2]; }
+          if(p.texCoords0) { o[6] = p.texCoords0[2 * size_t(v)]; o[7] = p.texCoords0[2 * size_t(v) + 1]; }
+          if(p.tangents) memcpy(o + 8, p.tangents + 4 * size_t(v), 16);
+        }
+        d.verts = reinterpret_cast<const float4*>(put(iv.data(), iv.size() * sizeof(float)));
+      }
     }
     HIP_TRY(hipMemcpy(pt->geometry.ptr, staging.data(), staging.size(), hipMemcpyHostToDevice));
   }

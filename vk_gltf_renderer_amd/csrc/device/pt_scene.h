@@ -48,6 +48,10 @@ struct DevPrim
   const float*    tangents;
   const float*    texCoords0;
   const float*    texCoords1;
+  // position + normal + uv0 + tangent of a vertex interleaved in 48 bytes (3 x float4: {p.xyz, n.x} {n.y, n.z, uv0} {tangent}):
+  // the hit-attribute fetch of the shade kernel touches 3 cache lines per hit instead of 12 (the separate streams above stay
+  // for the builders, the alpha records, uv1 and colours).  Absent attributes are zero; the stream pointers say which exist.
+  const float4*   verts;
 };
 
 enum : uint32_t

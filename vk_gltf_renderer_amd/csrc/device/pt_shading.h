@@ -76,7 +76,10 @@ PT_DEV HitState getHitState(const DevPrim& rp, f3 bary, const float* w2o, const 
 PT_DEV HitState getHitState(const DevPrim& rp, f3 bary, const float* w2o, const float* o2w, u3 ti, f3 worldRayDir)
 {
   HitState hit;
-  f3 pos0 = getVertexPosition(rp, ti.x), pos1 = getVertexPosition(rp, ti.y), pos2 = getVertexPosition(rp, ti.z);
+  // the three interleaved vertices (DevPrim::verts): 9 x 16 B in flight at once
+  const float4 *V0 = rp.verts + 3 * size_t(ti.x), *V1 = rp.verts + 3 * size_t(ti.y), *V2 = rp.verts + 3 * size_t(ti.z);
+  const float4 a0 = V0[0], a1 = V0[1], a2 = V0[2], b0 = V1[0], b1 = V1[1], b2 = V1[2], c0 = V2[0], c1 = V2[1], c2 = V2[2];
+  f3 pos0 = mk3(a0.x, a0.y, a0.z), pos1 = mk3(b0.x, b0.y, b0.z), pos2 = mk3(c0.x, c0.y, c0.z);
   f3 position  = pos0 * bary.x + pos1 * bary.y + pos2 * bary.z;
   hit.pos      = mulPoint(o2w, position);
   f3 geoNormal = normalize(cross(pos1 - pos0, pos2 - pos0));
@@ -84,9 +87,9 @@ PT_DEV HitState getHitState(const DevPrim& rp, f3 bary, const float* w2o, const 
   f3 nrm0 = geoNormal, nrm1 = geoNormal, nrm2 = geoNormal, normal = geoNormal;
   if(rp.normals)
   {
-    nrm0   = mk3(rp.normals + 3 * size_t(ti.x));
-    nrm1   = mk3(rp.normals + 3 * size_t(ti.y));
-    nrm2   = mk3(rp.normals + 3 * size_t(ti.z));
+    nrm0   = mk3(a0.w, a1.x, a1.y);
+    nrm1   = mk3(b0.w, b1.x, b1.y);
+    nrm2   = mk3(c0.w, c1.x, c1.y);
     normal = nrm0 * bary.x + nrm1 * bary.y + nrm2 * bary.z;
   }
   hit.nrm         = normalize(mulTransposed(w2o, normal));
@@ -94,12 +97,11 @@ PT_DEV HitState getHitState(const DevPrim& rp, f3 bary, const float* w2o, const 
   float sideFlip  = frontFace ? 1.0f : -1.0f;
   f3    shadowPos = pointOffset(position, pos0, pos1, pos2, nrm0 * sideFlip, nrm1 * sideFlip, nrm2 * sideFlip, bary);
   hit.shadowPos   = mulPoint(o2w, shadowPos);
-  hit.uv0         = getInterpolatedVertexTexCoord(rp, 0, ti, bary);
-  hit.uv1         = getInterpolatedVertexTexCoord(rp, 1, ti, bary);
+  hit.uv0 = rp.texCoords0 ? mk2(a1.z, a1.w) * bary.x + mk2(b1.z, b1.w) * bary.y + mk2(c1.z, c1.w) * bary.z : mk2(0.0f, 0.0f);
+  hit.uv1 = getInterpolatedVertexTexCoord(rp, 1, ti, bary);
   if(rp.texCoords0)
   {
-    const float2* t2 = reinterpret_cast<const float2*>(rp.texCoords0);
-    float2        a = t2[ti.x], b = t2[ti.y], c = t2[ti.z];
+    const float2 a = make_float2(a1.z, a1.w), b = make_float2(b1.z, b1.w), c = make_float2(c1.z, c1.w);
     // computeTexelDensity, get_hit.h.slang:44-56
     f3    we1 = mulVector(o2w, pos1 - pos0), we2 = mulVector(o2w, pos2 - pos0);
     float wArea = length(cross(we1, we2));
@@ -113,10 +115,9 @@ PT_DEV HitState getHitState(const DevPrim& rp, f3 bary, const float* w2o, const 
   f4 tng0, tng1, tng2;
   if(rp.tangents)
   {
-    const float4* t4 = reinterpret_cast<const float4*>(rp.tangents);
-    tng0 = mk4(t4[ti.x]);
-    tng1 = mk4(t4[ti.y]);
-    tng2 = mk4(t4[ti.z]);
+    tng0 = mk4(a2);
+    tng1 = mk4(b2);
+    tng2 = mk4(c2);
   }
   else
   {
