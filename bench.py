@@ -32,7 +32,7 @@ import numpy as np  # noqa: E402
 WORKLOADS = {
     # name: (BASELINE config, generator kwargs, width, height, maxDepth, env)
     "helmet": dict(config="configs[1]: DamagedHelmet-class + std_env.hdr, 1920x1080, depth 8", gen="scene_helmet_class",
-                   kw=dict(seed=1234, tess=272, tex_size=1024), width=1920, height=1080, depth=8, hdr=True),
+                   kw=dict(seed=1234, tess=272, tex_size=2048), width=1920, height=1080, depth=8, hdr=True),
     "atrium": dict(config="configs[2]: Sponza-class, 1920x1080, depth 12, NEE+MIS (directional light + sky)", gen="scene_atrium_class",
                    kw=dict(seed=4321, detail=0.8, tex_size=512), width=1920, height=1080, depth=12, hdr=False),
     "glass": dict(config="configs[4]: TransmissionTest-class, 1920x1080, depth 24", gen="scene_glass_class",

@@ -208,7 +208,8 @@ def pt_lib():
     """libmi_pt.so — the HIP path tracer.  There is no CPU fallback: a missing library is a hard error."""
     global _pt
     if _pt is None:
-        path = os.path.join(LIB_DIR, "libmi_pt.so")
+        # MI_PT_LIB selects another build of the same library (e.g. the -DTRACE_PROFILE diagnostics build, tools/profile_lanes.sh)
+        path = os.environ.get("MI_PT_LIB") or os.path.join(LIB_DIR, "libmi_pt.so")
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: the HIP extension was not built; the product path has no fallback")
         _pt = _bind(C.CDLL(path), PT_SYMBOLS)

@@ -668,7 +668,7 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   c.stats            = pt->stats.ptr;
   c.stream           = stream;
   c.persistentBlocks = unsigned(pt->numCUs) * 8u;
-  c.hasAlpha         = pt->hasAlpha;
+  c.hasAlpha         = pt->hasAlpha && getenv("MI_PT_DIAG_IGNORE_ALPHA") == nullptr;  // diagnostics: what the alpha tests cost (wrong image)
   c.hasTransmissive  = pt->hasTransmissive;
   c.simpleMaterials  = pt->simpleMaterials && getenv("MI_PT_GENERIC_SHADE") == nullptr;
   c.wide             = pt->wide;

@@ -101,18 +101,31 @@ PT_DEV void bvh8TestChildren(const uint4& n0, const uint4& n1, const uint4& n2, 
   const uint32_t qny[2] = {ny ? n4.x : n2.z, ny ? n4.y : n2.w}, qfy[2] = {ny ? n2.z : n4.x, ny ? n2.w : n4.y};
   const uint32_t qnz[2] = {nz ? n4.z : n3.x, nz ? n4.w : n3.y}, qfz[2] = {nz ? n3.x : n4.z, nz ? n3.y : n4.w};
   const uint32_t meta[2] = {n1.z, n1.w};
-  uint32_t       hm = 0, tmask = 0;  // hm: hit children, SLOT space
+  // The loop is VALU-bound (it is the traversal's inner loop), so it is written for instruction count: the near and far
+  // plane of an axis go through one packed fma; a child's miss is the sign of tf - tn, shifted into the mask by one alignbit
+  // (empty slots hold inverted boxes and miss by themselves); a leaf child's triangle range is one bit-field mask.
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 A2x = {Ax, Ax}, A2y = {Ay, Ay}, A2z = {Az, Az}, B2x = {Bnx, Bfx}, B2y = {Bny, Bfy}, B2z = {Bnz, Bfz};
+  uint32_t    miss = 0, tmiss = 0, tall = 0;
 #pragma unroll
-  for(int i = 0; i < 8; ++i)
+  for(int j = 0; j < 8; ++j)
   {
-    const int      w = i >> 2, b = i & 3;
-    const uint32_t m = (meta[w] >> (8 * b)) & 0xffu;
-    const float tn = fmaxf(fmaxf(__fmaf_rn(byteF(qnx[w], b), Ax, Bnx), __fmaf_rn(byteF(qny[w], b), Ay, Bny)), fmaxf(__fmaf_rn(byteF(qnz[w], b), Az, Bnz), 0.0f));
-    const float tf = fminf(fminf(__fmaf_rn(byteF(qfx[w], b), Ax, Bfx), __fmaf_rn(byteF(qfy[w], b), Ay, Bfy)), fminf(__fmaf_rn(byteF(qfz[w], b), Az, Bfz), tmax));
-    const bool  hit = (m != 0u) && (tn <= tf);
-    hm |= hit ? (1u << i) : 0u;
-    tmask |= hit ? (((1u << (m >> 5)) - 1u) << (m & 31u)) : 0u;  // inner children carry meta 0xff: masked out below
+    const int   i = 7 - j, w = i >> 2, b = i & 3;  // child 7 first: child 0 ends up in bit 0
+    const f32x2 tx = __builtin_elementwise_fma(f32x2{byteF(qnx[w], b), byteF(qfx[w], b)}, A2x, B2x);
+    const f32x2 ty = __builtin_elementwise_fma(f32x2{byteF(qny[w], b), byteF(qfy[w], b)}, A2y, B2y);
+    const f32x2 tz = __builtin_elementwise_fma(f32x2{byteF(qnz[w], b), byteF(qfz[w], b)}, A2z, B2z);
+    const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, 0.0f));
+    const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, tmax));
+    const uint32_t d = __float_as_uint(tf - tn);  // sign set: tn > tf, a miss
+    miss             = __builtin_amdgcn_alignbit(miss, d, 31);
+    // range = ((1 << count) - 1) << offset; v_bfm_b32 reads 5 bits of each operand (inner children: 7 / 31, masked out below)
+    const uint32_t cnt = (meta[w] >> (8 * b + 5)) & 7u, off = meta[w] >> (8 * b);
+    uint32_t       range;
+    asm("v_bfm_b32 %0, %1, %2" : "=v"(range) : "v"(cnt), "v"(off));
+    tall |= range;
+    tmiss |= range & uint32_t(int32_t(d) >> 31);
   }
+  const uint32_t hm = ~miss & 0xffu, tmask = tall & ~tmiss;
   hmOut    = hm;
   tmaskOut = tmask;
 }

@@ -19,7 +19,7 @@ namespace {
 // One trace workgroup per CU: 16 waves share one LDS copy of the top of the 8-wide BVH (the first nodes of the BFS-ordered
 // node array), next to the per-lane traversal stacks.  96 KiB of stacks + 60 KiB of nodes of the CU's 160 KiB.
 constexpr int TRACE_BLOCK = 1024;
-constexpr int NODE_CACHE  = 768;  // BVH8 nodes (80 B each) resident in LDS
+constexpr int NODE_CACHE  = 764;  // BVH8 nodes (80 B each) resident in LDS
 constexpr int SEL_BLOCK   = 256;
 #ifndef TRACE_MIN_WAVES
 #define TRACE_MIN_WAVES 1
@@ -252,12 +252,16 @@ __global__ void __launch_bounds__(256) k_generate(DevScene sc, FrameConsts fc, P
 //================================================================================================================================
 #ifdef TRACE_PROFILE
 // Diagnostics build only (-DTRACE_PROFILE): shader-clock ticks per wave spent in the sections of k_trace_closest.
-__device__ unsigned long long g_traceProf[8];
+// [8..15]: lane occupancy -- node steps / lanes visiting / triangle rounds / lanes testing / refills / lanes idle at refill /
+// triangle phases / lanes blocked (both park records full) per node step
+__device__ unsigned long long g_traceProf[18];
 #define PROF_T() __builtin_amdgcn_s_memtime()
 #define PROF_ADD(i, t0) profAcc[i] += PROF_T() - (t0)
+#define PROF_CNT(i, n) profCnt[i] += (unsigned long long)(n)
 #else
 #define PROF_T() 0ull
 #define PROF_ADD(i, t0) (void)(t0)
+#define PROF_CNT(i, n) (void)0
 #endif
 
 // Refill policy of the persistent trace waves: go back for new rays once this many lanes of the wave are idle.
@@ -265,6 +269,15 @@ constexpr int REFILL_IDLE_LANES = 16;
 // Dense triangle phase of the 8-wide walk: start once this many lanes have parked triangles, leave below the exit count.
 constexpr int TRI_PHASE_LANES      = 24;
 constexpr int TRI_PHASE_EXIT_LANES = 10;
+// Triangle rounds of the closest-hit walk (triRoundClosest): start one once this many lanes have parked triangles, and let
+// a lane hand in at most this many triangles per round.
+#ifndef TRI_ROUND_LANES
+#define TRI_ROUND_LANES 20
+#endif
+#ifndef TRI_ROUND_BLOCKED
+#define TRI_ROUND_BLOCKED 4  // ... or this many lanes have both of their park records in use
+#endif
+constexpr int TRI_ROUND_LANE_CAP = 7;
 
 // Copies the top of the 8-wide BVH into this workgroup's LDS (whole block; contains a barrier).
 PT_DEV uint32_t fillNodeCache(const DevScene& sc, uint4* s_nodes, uint32_t capacity = NODE_CACHE)
@@ -323,12 +336,121 @@ PT_DEV void closestTestLoaded(const DevScene& sc, const RaySetup& r, const DevTr
   }
 }
 
+PT_DEV uint32_t laneCountBelow(unsigned long long mask)  // set bits of `mask` in the lanes below this one
+{
+  return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+}
+PT_DEV float laneRead(float v, uint32_t lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(int(lane << 2), __float_as_int(v))); }
+PT_DEV uint32_t laneRead(uint32_t v, uint32_t lane) { return uint32_t(__builtin_amdgcn_ds_bpermute(int(lane << 2), int(v))); }
+
+// One round of triangle tests for the whole wave.  After a node step the parked triangles are spread very unevenly over the
+// lanes (a few rays sit in front of a big leaf, most have nothing), and testing them lane by lane kept a sixth of the wave
+// busy.  Here the owners publish up to 64 parked triangles to a wave-private list, every lane tests ONE of them for the ray
+// of the lane that parked it (the ray comes over by lane permute), and the owners read their results back.  The closest hit
+// is the minimum over accepted candidates under a total order (t, then renderNode, then primitive) and the alpha draw is a
+// pure function of (seed, renderNode, primitive), so the outcome does not depend on who tests what or in which order.
+// The round is split in two so that the triangle records are in flight while the wave does its next node step:
+// triRoundPublish (owners publish, every lane issues the loads of its triangle) ... node step ... triRoundFinish.
+struct TriRound
+{
+  uint32_t off, n;   // owner: first published item and how many
+  uint32_t item;     // worker: triangle | owner lane << 26
+  bool     has;
+  DevTri   T;
+};
+PT_DEV void triRoundPublish(const DevScene& sc, bool active, uint32_t& pBase, uint32_t& pMask, uint32_t& qBase, uint32_t& qMask, uint32_t* waveItems, TriRound& tr)
+{
+  const uint32_t lane = laneId();
+  // how many triangles each lane hands in, and where (exclusive prefix over the lanes from the count's bit planes)
+  const uint32_t c = active ? min(uint32_t(__popc(pMask) + __popc(qMask)), uint32_t(TRI_ROUND_LANE_CAP)) : 0u;
+  const unsigned long long b0 = __ballot((c & 1u) != 0u), b1 = __ballot((c & 2u) != 0u), b2 = __ballot((c & 4u) != 0u);
+  const uint32_t off   = laneCountBelow(b0) + 2u * laneCountBelow(b1) + 4u * laneCountBelow(b2);
+  const uint32_t total = min(64u, uint32_t(__popcll(b0)) + 2u * uint32_t(__popcll(b1)) + 4u * uint32_t(__popcll(b2)));
+  const uint32_t n     = off >= 64u ? 0u : min(c, 64u - off);
+  for(uint32_t k = 0; __ballot(k < n) != 0ull; ++k)
+  {
+    if(k < n)
+    {
+      if(pMask == 0u) { pBase = qBase; pMask = qMask; qMask = 0u; }
+      const uint32_t bit = uint32_t(__ffs(int(pMask)) - 1);
+      pMask &= pMask - 1u;
+      waveItems[off + k] = (pBase + bit) | (lane << 26);
+    }
+  }
+  if(pMask == 0u) { pBase = qBase; pMask = qMask; qMask = 0u; }
+  __builtin_amdgcn_wave_barrier();
+  tr.off  = off;
+  tr.n    = n;
+  tr.has  = lane < total;
+  tr.item = tr.has ? waveItems[lane] : 0u;
+  __builtin_amdgcn_wave_barrier();
+  if(tr.has)
+    tr.T = sc.tris[tr.item & 0x3ffffffu];
+}
+template <bool HAS_ALPHA, bool COUNT>
+PT_DEV void triRoundFinish(const DevScene& sc, const RaySetup& r, ClosestBest& best, uint32_t seed0, const TriRound& tr, unsigned& tris,
+                           unsigned long long* profAcc = nullptr)
+{
+  const unsigned long long tTest = PROF_T();
+  // ---- every lane tests its triangle for the owner's ray
+  const uint32_t src = tr.item >> 26, tri = tr.item & 0x3ffffffu;
+  const f3       org = mk3(laneRead(r.org.x, src), laneRead(r.org.y, src), laneRead(r.org.z, src));
+  const f3       dir = mk3(laneRead(r.dir.x, src), laneRead(r.dir.y, src), laneRead(r.dir.z, src));
+  const float    tmaxSrc = laneRead(best.t, src);
+  const uint32_t seedSrc = HAS_ALPHA ? laneRead(seed0, src) : 0u;
+  float          rt = INFINITE_F, ru = 0.0f, rv = 0.0f;
+  if(tr.has)
+  {
+    const DevTri& T = tr.T;
+    TriHit        h;
+    if(intersectTri(xyz(T.a), xyz(T.b), xyz(T.c), org, dir, h) && h.t > 0.0f && h.t <= tmaxSrc)
+    {
+      const uint32_t rnode = __float_as_uint(T.a.w), prim = __float_as_uint(T.b.w), flags = __float_as_uint(T.c.w);
+      // RAY_FLAG_CULL_BACK_FACING_TRIANGLES unless TRIANGLE_FACING_CULL_DISABLE; facing is decided in object space
+      const bool front = h.front != ((flags & INST_FLIP_FACING) != 0u);
+      bool       ok    = front || (flags & INST_CULL_DISABLE);
+      if(HAS_ALPHA && ok && !(flags & INST_FORCE_OPAQUE))
+        ok = candidateRand(seedSrc, int(rnode), int(prim)) <= getOpacityFast(sc, int(tri), mk3(1.0f - h.u - h.v, h.u, h.v));
+      if(ok)
+      {
+        rt = h.t; ru = h.u; rv = h.v;
+      }
+    }
+  }
+  PROF_ADD(3, tTest);
+  const unsigned long long tGather = PROF_T();
+  if(COUNT) tris += tr.has ? 1u : 0u;
+  // ---- owners collect: smaller t wins, exact ties by (renderNode, primitive) -- looked up only in that rare case
+  for(uint32_t k = 0; __ballot(k < tr.n) != 0ull; ++k)
+  {
+    const uint32_t j  = (tr.off + k) & 63u;
+    const float    tk = laneRead(rt, j), uk = laneRead(ru, j), vk = laneRead(rv, j);
+    const uint32_t ik = laneRead(tri, j);
+    if(k < tr.n && tk < INFINITE_F)
+    {
+      bool better = tk < best.t;
+      if(tk == best.t && best.tri >= 0)
+      {
+        const DevTri A = sc.tris[ik], B = sc.tris[best.tri];
+        const uint32_t ra = __float_as_uint(A.a.w), pa = __float_as_uint(A.b.w), rb = __float_as_uint(B.a.w), pb = __float_as_uint(B.b.w);
+        better = ra < rb || (ra == rb && pa < pb);
+      }
+      if(better)
+      {
+        best.t = tk; best.u = uk; best.v = vk; best.tri = int(ik);
+      }
+    }
+  }
+  PROF_ADD(7, tGather);
+}
+
 template <bool WIDE, bool HAS_ALPHA, bool COUNT>
 __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(DevScene sc, PathSoA P, Queues Q, int cur, StatCounters* stats)
 {
   __shared__ int      s_stack[BVH_STACK_LDS * TRACE_BLOCK];  // BVH2: 24 ints/lane; BVH8: 12 node groups x 2 ints/lane
   __shared__ uint32_t s_prefix[NSUB + 1];
   __shared__ uint4    s_nodes[WIDE ? NODE_CACHE * 5 : 1];
+  __shared__ uint32_t s_items[WIDE ? TRACE_BLOCK : 1];  // triangle rounds: 64 published triangles per wave
 
   static_assert(2 * BVH8_STACK_LDS == BVH_STACK_LDS, "both stack flavours share one LDS allocation");
   if(blockIdx.x == 0 && threadIdx.x < NSUB)
@@ -359,6 +481,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
   NodeGroup   G{0, 0};
   uint32_t    octinv = 0;
   uint32_t    pBase = 0, pMask = 0, qBase = 0, qMask = 0;  // parked leaf hits (8-wide walk): triangle base + bit mask
+  int         lastVisiting = 64;                           // lanes that visited a node in the previous step
   ClosestBest best{INFINITE_F, 0.0f, 0.0f, -1, 0xffffffffu, 0xffffffffu};
   uint32_t    seed0 = 0;
   bool        seedLoaded = false;
@@ -369,11 +492,14 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
   float4   pO = make_float4(0, 0, 0, 0), pD = make_float4(0, 0, 0, 0);
 #ifdef TRACE_PROFILE
   unsigned long long profAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long profCnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long profStart = PROF_T();
 #endif
   for(;;)
   {
     const unsigned long long tFeed = PROF_T();
+    PROF_CNT(4, 1);
+    PROF_CNT(5, 64 - __popcll(__ballot(active)));
     // ---- idle lanes start their prefetched ray; every lane without a prefetched ray takes the next queue index
     if(!active && pValid)
     {
@@ -390,6 +516,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
           octinv = rayOctInv(r.idir);
           G      = rootGroup(octinv);
           st2.sp = 0;
+          if(HAS_ALPHA)
+            seed0 = __float_as_uint(P.misc[slot].z);  // the alpha draws of this ray (first used in a triangle round)
         }
         else
         {
@@ -432,6 +560,24 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
     {
       if(WIDE)
       {
+        // Triangle round, first half: once enough lanes have parked triangles (or a lane has no room left, or few lanes are
+        // still walking) they are published and every lane starts loading one; the loads fly during the node step below.
+        const unsigned long long tTri0 = PROF_T();
+        TriRound           tr;
+        bool               round = false;
+        unsigned long long pend  = __ballot(active && pMask != 0u);
+        if(pend != 0ull)
+        {
+          const bool drain = lastVisiting < TRI_PHASE_LANES;  // few lanes left walking: nothing to wait for
+          round            = drain || __popcll(pend) >= TRI_ROUND_LANES || __popcll(__ballot(active && qMask != 0u)) >= TRI_ROUND_BLOCKED;
+          if(round)
+          {
+            PROF_CNT(2, 1);
+            PROF_CNT(3, __popcll(pend));
+            triRoundPublish(sc, active, pBase, pMask, qBase, qMask, s_items + (threadIdx.x & ~63u), tr);
+          }
+        }
+        PROF_ADD(2, tTri0);
         const unsigned long long tNode = PROF_T();
         // Node step: lanes with room for one more leaf record visit their next node.  Triangles are NOT tested here: a
         // memory instruction costs the CU's address unit the same 64 lane-slots whether 3 or 64 lanes are active, and
@@ -459,36 +605,17 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
           }
         }
         PROF_ADD(1, tNode);
+        PROF_CNT(0, 1);
+        PROF_CNT(1, __popcll(__ballot(visited)));
+        PROF_CNT(7, __popcll(__ballot(active && qMask != 0u)));
+        lastVisiting = __popcll(__ballot(visited));
         const unsigned long long tTri = PROF_T();
-        unsigned long long pend = __ballot(active && pMask != 0u);
-        if(pend != 0ull)
-        {
-          const int  visiting = __popcll(__ballot(visited));
-          const bool drain    = visiting < TRI_PHASE_LANES;  // few lanes left walking: nothing to wait for
-          if(drain || __popcll(pend) >= TRI_PHASE_LANES || __ballot(active && qMask != 0u) != 0ull)
-          {
-            do
-            {
-              if(active && pMask != 0u)
-              {
-                // two triangles per round: both records are in flight together (one dependent-load latency for the pair)
-                const int k0 = __ffs(int(pMask)) - 1;
-                pMask &= pMask - 1u;
-                const bool two = pMask != 0u;
-                const int  k1  = two ? __ffs(int(pMask)) - 1 : k0;
-                if(two)
-                  pMask &= pMask - 1u;
-                const DevTri T0 = sc.tris[int(pBase) + k0], T1 = sc.tris[int(pBase) + k1];
-                if(COUNT) tris += two ? 2u : 1u;
-                closestTestLoaded<HAS_ALPHA>(sc, r, T0, int(pBase) + k0, best, seed0, seedLoaded, P.misc, slot);
-                if(two)
-                  closestTestLoaded<HAS_ALPHA>(sc, r, T1, int(pBase) + k1, best, seed0, seedLoaded, P.misc, slot);
-                if(pMask == 0u) { pBase = qBase; pMask = qMask; qMask = 0u; }
-              }
-              pend = __ballot(active && pMask != 0u);
-            } while(pend != 0ull && (drain || __popcll(pend) >= TRI_PHASE_EXIT_LANES || __ballot(active && qMask != 0u) != 0ull));
-          }
-        }
+        if(round)
+#ifdef TRACE_PROFILE
+          triRoundFinish<HAS_ALPHA, COUNT>(sc, r, best, seed0, tr, tris, profAcc);
+#else
+          triRoundFinish<HAS_ALPHA, COUNT>(sc, r, best, seed0, tr, tris);
+#endif
         PROF_ADD(2, tTri);
         if(active && pMask == 0u && (G.bits >> 8) == 0u && st2.sp == 0)
         {
@@ -535,6 +662,10 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
     atomicAdd(&g_traceProf[5], profAcc[4]);
     atomicAdd(&g_traceProf[6], profAcc[5]);
     atomicAdd(&g_traceProf[7], profAcc[6]);
+    for(int i = 0; i < 8; ++i)
+      atomicAdd(&g_traceProf[8 + i], profCnt[i]);
+    atomicAdd(&g_traceProf[16], profAcc[3]);
+    atomicAdd(&g_traceProf[17], profAcc[7]);
   }
 #endif
   if(COUNT)
@@ -1663,7 +1794,7 @@ void launchBuildAlphaRecords(const DevScene& scene, uint32_t numTris, DevAlphaTr
 void dumpTraceProfile()
 {
 #ifdef TRACE_PROFILE
-  unsigned long long h[8] = {};
+  unsigned long long h[18] = {};
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_traceProf), sizeof(h));
   const double tot = double(h[3]) > 0 ? double(h[3]) : 1.0;
@@ -1671,6 +1802,11 @@ void dumpTraceProfile()
           100.0 * h[7] / tot);
   fprintf(stderr, "[mi_pt trace profile] waves %llu total ticks %.4g: feed %.1f%% node %.1f%% tri %.1f%% other %.1f%%\n", h[4], tot, 100.0 * h[0] / tot,
           100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * (tot - h[0] - h[1] - h[2]) / tot);
+  fprintf(stderr, "[mi_pt trace profile] triangle rounds: test (permutes, intersection, alpha) %.1f%% gather %.1f%% of total\n", 100.0 * h[16] / tot, 100.0 * h[17] / tot);
+  const auto per = [](unsigned long long a, unsigned long long b) { return b ? double(a) / double(b) : 0.0; };
+  fprintf(stderr, "[mi_pt trace profile] lanes: %.1f of 64 visit per node step (%llu steps, %.1f blocked); %.1f test per triangle round (%llu rounds in %llu phases); "
+                  "%.1f idle at each of %llu refills\n",
+          per(h[9], h[8]), h[8], per(h[15], h[8]), per(h[11], h[10]), h[10], h[14], per(h[13], h[12]), h[12]);
 #endif
 }
 void launchBuildShadeRecords(const DevScene& scene, uint32_t numTris, DevShadeTri* out, hipStream_t s)
