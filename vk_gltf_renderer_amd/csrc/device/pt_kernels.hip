@@ -444,6 +444,41 @@ PT_DEV void triRoundFinish(const DevScene& sc, const RaySetup& r, ClosestBest& b
   PROF_ADD(7, tGather);
 }
 
+// Second half of a triangle round of the any-hit (shadow) walk without transmissive instances: a candidate that commits
+// decides its ray (raytracer_interface.h.slang:149-179), so the owners only need to know whether any of theirs did.
+template <bool HAS_ALPHA, bool COUNT>
+PT_DEV void triRoundFinishShadow(const DevScene& sc, const RaySetup& r, float tMax, uint32_t seed0, const TriRound& tr, bool& occluded, unsigned& tris)
+{
+  const uint32_t src = tr.item >> 26, tri = tr.item & 0x3ffffffu;
+  const f3       org = mk3(laneRead(r.org.x, src), laneRead(r.org.y, src), laneRead(r.org.z, src));
+  const f3       dir = mk3(laneRead(r.dir.x, src), laneRead(r.dir.y, src), laneRead(r.dir.z, src));
+  const float    tmaxSrc = laneRead(tMax, src);
+  const uint32_t seedSrc = HAS_ALPHA ? laneRead(seed0, src) : 0u;
+  bool           commits = false;
+  if(tr.has)
+  {
+    const DevTri& T = tr.T;
+    TriHit        h;
+    if(intersectTri(xyz(T.a), xyz(T.b), xyz(T.c), org, dir, h) && h.t > 0.0f && h.t < tmaxSrc)
+    {
+      const uint32_t flags = __float_as_uint(T.c.w);
+      if(!HAS_ALPHA || (flags & INST_FORCE_OPAQUE))
+        commits = true;  // RAY_FLAG_NONE: no culling; opaque geometry commits
+      else
+      {
+        // non-transmissive alpha material: an accepted candidate multiplies the transmission by
+        // getShadowTransmission() == 0 (pathtrace_functions.h.slang:256-261) whatever its position in the order
+        const uint32_t rnode = __float_as_uint(T.a.w), prim = __float_as_uint(T.b.w);
+        commits = candidateRand(seedSrc, int(rnode), int(prim)) < getOpacityFast(sc, int(tri), mk3(1.0f - h.u - h.v, h.u, h.v));
+      }
+    }
+  }
+  if(COUNT) tris += tr.has ? 1u : 0u;
+  const unsigned long long mine = tr.n ? (((tr.n >= 64u ? 0ull : (1ull << tr.n)) - 1ull) << tr.off) : 0ull;  // this owner's items: lanes [off, off + n)
+  if(__ballot(commits) & mine)
+    occluded = true;
+}
+
 template <bool WIDE, bool HAS_ALPHA, bool COUNT>
 __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(DevScene sc, PathSoA P, Queues Q, int cur, StatCounters* stats)
 {
@@ -1323,6 +1358,7 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
   __shared__ int      s_stack[BVH_STACK_LDS * SBLOCK];
   __shared__ uint32_t s_prefix[NSUB + 1];
   __shared__ uint4    s_nodes[WIDE ? ShadowCfg<MODE>::CACHE * 5 : 1];
+  __shared__ uint32_t s_items[(WIDE && !HAS_TRANS) ? SBLOCK : 1];  // triangle rounds (see triRoundPublish)
   queuePrefix(&Q.counters[(nxt ? QC_PAIR1 : QC_PAIR0) + 1], s_prefix);  // the shadow tails written next to active queue `nxt`
   const RayQueue in = Q.shadow;
   WaveFeed feed;
@@ -1560,7 +1596,28 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
           }
         }
         unsigned long long pend = __ballot(active && pMask != 0u);
-        if(pend != 0ull)
+        if(!HAS_TRANS)
+        {
+          // without transmissive instances a committing candidate simply decides its ray: the triangle tests are spread over
+          // the whole wave (triRoundPublish / triRoundFinishShadow), as in k_trace_closest
+          if(pend != 0ull)
+          {
+            const int  visiting = __popcll(__ballot(visited));
+            const bool drain    = visiting < TRI_PHASE_LANES;
+            if(drain || __popcll(pend) >= TRI_ROUND_LANES || __popcll(__ballot(active && qMask != 0u)) >= TRI_ROUND_BLOCKED)
+            {
+              do
+              {
+                TriRound tr;
+                triRoundPublish(sc, active, pBase, pMask, qBase, qMask, s_items + (threadIdx.x & ~63u), tr);
+                triRoundFinishShadow<HAS_ALPHA, COUNT>(sc, r, tMax, seed0, tr, occluded, tris);
+                if(occluded) { pMask = 0u; qMask = 0u; }
+                pend = __ballot(active && pMask != 0u);
+              } while(pend != 0ull && (drain || __popcll(pend) >= TRI_ROUND_LANES));
+            }
+          }
+        }
+        else if(pend != 0ull)
         {
           const int  visiting = __popcll(__ballot(visited));
           const bool drain    = visiting < TRI_PHASE_LANES;
