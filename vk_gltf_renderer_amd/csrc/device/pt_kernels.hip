@@ -20,6 +20,7 @@ namespace {
 // node array), next to the per-lane traversal stacks.  96 KiB of stacks + 60 KiB of nodes of the CU's 160 KiB.
 constexpr int TRACE_BLOCK = 1024;
 constexpr int NODE_CACHE  = 764;  // BVH8 nodes (80 B each) resident in LDS
+constexpr int NODE_CACHE_ALPHA = 556;  // ... in the kernels that also keep a list of deferred alpha tests there (16 B x 1024)
 constexpr int SEL_BLOCK   = 256;
 #ifndef TRACE_MIN_WAVES
 #define TRACE_MIN_WAVES 1
@@ -278,6 +279,13 @@ constexpr int TRI_PHASE_EXIT_LANES = 10;
 #define TRI_ROUND_BLOCKED 4  // ... or this many lanes have both of their park records in use
 #endif
 constexpr int TRI_ROUND_LANE_CAP = 7;
+// Deferred alpha tests (alphaRound*): flush the wave's list at this many entries, or once this many lanes wait for it.
+#ifndef ALPHA_ROUND_MIN
+#define ALPHA_ROUND_MIN 32
+#endif
+#ifndef ALPHA_ROUND_WAITING
+#define ALPHA_ROUND_WAITING 8
+#endif
 
 // Copies the top of the 8-wide BVH into this workgroup's LDS (whole block; contains a barrier).
 PT_DEV uint32_t fillNodeCache(const DevScene& sc, uint4* s_nodes, uint32_t capacity = NODE_CACHE)
@@ -387,9 +395,81 @@ PT_DEV void triRoundPublish(const DevScene& sc, bool active, uint32_t& pBase, ui
   if(tr.has)
     tr.T = sc.tris[tr.item & 0x3ffffffu];
 }
+// Candidates on alpha-tested materials are not resolved where they are found: the test is a chain of two dependent fetches
+// (alpha record, then texels) for what is usually one or two lanes of the wave.  They go on a wave-private list (owner lane,
+// triangle, t, u, v) and the list is worked off by the whole wave at once -- an alpha round -- when it is long enough or
+// rays are waiting for it.  A ray is not finished while it has entries on the list; until then its tmax is merely not as
+// tight as it could be.  The draw is a pure function of (seed, renderNode, primitive): deferring does not change it.
+PT_DEV void closestUpdate(const DevScene& sc, ClosestBest& best, float tk, float uk, float vk, uint32_t ik)
+{
+  // smaller t wins, exact ties by (renderNode, primitive) -- looked up only in that rare case
+  bool better = tk < best.t;
+  if(tk == best.t && best.tri >= 0)
+  {
+    const DevTri A = sc.tris[ik], B = sc.tris[best.tri];
+    const uint32_t ra = __float_as_uint(A.a.w), pa = __float_as_uint(A.b.w), rb = __float_as_uint(B.a.w), pb = __float_as_uint(B.b.w);
+    better = ra < rb || (ra == rb && pa < pb);
+  }
+  if(better)
+  {
+    best.t = tk; best.u = uk; best.v = vk; best.tri = int(ik);
+  }
+}
+// SHADOW: any-hit semantics (an accepted candidate occludes, draw < opacity); otherwise closest-hit (draw <= opacity).
+template <bool SHADOW>
+PT_DEV void alphaRound(const DevScene& sc, uint32_t seed0, uint4* waveAlpha, uint32_t& aCount, bool& aPending, ClosestBest& best, bool& occluded)
+{
+  const uint32_t lane = laneId();
+  const bool     has  = lane < aCount;
+  const uint4    e    = has ? waveAlpha[lane] : make_uint4(0u, 0u, 0u, 0u);
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t owner = e.x >> 26, tri = e.x & 0x3ffffffu;
+  const uint32_t seedSrc = laneRead(seed0, owner);
+  bool           accept  = false;
+  if(has)
+  {
+    const float    u = __uint_as_float(e.z), v = __uint_as_float(e.w);
+    const uint32_t rnode = __float_as_uint(sc.tris[tri].a.w), prim = __float_as_uint(sc.tris[tri].b.w);
+    const float    draw = candidateRand(seedSrc, int(rnode), int(prim)), opacity = getOpacityFast(sc, int(tri), mk3(1.0f - u - v, u, v));
+    accept = SHADOW ? draw < opacity : draw <= opacity;
+  }
+  unsigned long long acc = __ballot(accept);
+  while(acc != 0ull)
+  {
+    const int k = __ffsll((long long)acc) - 1;
+    acc &= acc - 1ull;
+    const uint32_t item = uint32_t(__builtin_amdgcn_readlane(int(e.x), k));
+    if(lane == (item >> 26))
+    {
+      if(SHADOW)
+        occluded = true;
+      else
+        closestUpdate(sc, best, __int_as_float(__builtin_amdgcn_readlane(int(e.y), k)), __int_as_float(__builtin_amdgcn_readlane(int(e.z), k)),
+                      __int_as_float(__builtin_amdgcn_readlane(int(e.w), k)), item & 0x3ffffffu);
+    }
+  }
+  aCount   = 0u;
+  aPending = false;
+}
+// puts this round's alpha candidates on the list (flushing it first when they would not fit)
+template <bool SHADOW>
+PT_DEV void alphaDefer(const DevScene& sc, bool needAlpha, uint32_t item, float t, float u, float v, uint32_t seed0, uint4* waveAlpha, uint32_t& aCount,
+                       bool& aPending, ClosestBest& best, bool& occluded)
+{
+  const unsigned long long m = __ballot(needAlpha);
+  if(m == 0ull)
+    return;
+  if(aCount + uint32_t(__popcll(m)) > 64u)
+    alphaRound<SHADOW>(sc, seed0, waveAlpha, aCount, aPending, best, occluded);
+  if(needAlpha)
+    waveAlpha[aCount + laneCountBelow(m)] = make_uint4(item, __float_as_uint(t), __float_as_uint(u), __float_as_uint(v));
+  aCount += uint32_t(__popcll(m));
+  __builtin_amdgcn_wave_barrier();
+}
+
 template <bool HAS_ALPHA, bool COUNT>
-PT_DEV void triRoundFinish(const DevScene& sc, const RaySetup& r, ClosestBest& best, uint32_t seed0, const TriRound& tr, unsigned& tris,
-                           unsigned long long* profAcc = nullptr)
+PT_DEV void triRoundFinish(const DevScene& sc, const RaySetup& r, ClosestBest& best, uint32_t seed0, const TriRound& tr, unsigned& tris, uint4* waveAlpha,
+                           uint32_t& aCount, bool& aPending, unsigned long long* profAcc = nullptr)
 {
   const unsigned long long tTest = PROF_T();
   // ---- every lane tests its triangle for the owner's ray
@@ -397,48 +477,47 @@ PT_DEV void triRoundFinish(const DevScene& sc, const RaySetup& r, ClosestBest& b
   const f3       org = mk3(laneRead(r.org.x, src), laneRead(r.org.y, src), laneRead(r.org.z, src));
   const f3       dir = mk3(laneRead(r.dir.x, src), laneRead(r.dir.y, src), laneRead(r.dir.z, src));
   const float    tmaxSrc = laneRead(best.t, src);
-  const uint32_t seedSrc = HAS_ALPHA ? laneRead(seed0, src) : 0u;
-  float          rt = INFINITE_F, ru = 0.0f, rv = 0.0f;
+  float          rt = INFINITE_F, ru = 0.0f, rv = 0.0f, tHit = 0.0f;
+  bool           needAlpha = false;
   if(tr.has)
   {
     const DevTri& T = tr.T;
     TriHit        h;
     if(intersectTri(xyz(T.a), xyz(T.b), xyz(T.c), org, dir, h) && h.t > 0.0f && h.t <= tmaxSrc)
     {
-      const uint32_t rnode = __float_as_uint(T.a.w), prim = __float_as_uint(T.b.w), flags = __float_as_uint(T.c.w);
+      const uint32_t flags = __float_as_uint(T.c.w);
       // RAY_FLAG_CULL_BACK_FACING_TRIANGLES unless TRIANGLE_FACING_CULL_DISABLE; facing is decided in object space
       const bool front = h.front != ((flags & INST_FLIP_FACING) != 0u);
-      bool       ok    = front || (flags & INST_CULL_DISABLE);
-      if(HAS_ALPHA && ok && !(flags & INST_FORCE_OPAQUE))
-        ok = candidateRand(seedSrc, int(rnode), int(prim)) <= getOpacityFast(sc, int(tri), mk3(1.0f - h.u - h.v, h.u, h.v));
-      if(ok)
+      if(front || (flags & INST_CULL_DISABLE))
       {
-        rt = h.t; ru = h.u; rv = h.v;
+        needAlpha = HAS_ALPHA && !(flags & INST_FORCE_OPAQUE);
+        tHit      = h.t;
+        rt        = needAlpha ? -1.0f : h.t;  // negative tells the owner "deferred"
+        ru        = h.u;
+        rv        = h.v;
       }
     }
   }
   PROF_ADD(3, tTest);
   const unsigned long long tGather = PROF_T();
   if(COUNT) tris += tr.has ? 1u : 0u;
-  // ---- owners collect: smaller t wins, exact ties by (renderNode, primitive) -- looked up only in that rare case
+  if(HAS_ALPHA)
+  {
+    bool none = false;
+    alphaDefer<false>(sc, needAlpha, tr.item, tHit, ru, rv, seed0, waveAlpha, aCount, aPending, best, none);
+  }
+  // ---- owners collect
   for(uint32_t k = 0; __ballot(k < tr.n) != 0ull; ++k)
   {
     const uint32_t j  = (tr.off + k) & 63u;
     const float    tk = laneRead(rt, j), uk = laneRead(ru, j), vk = laneRead(rv, j);
     const uint32_t ik = laneRead(tri, j);
-    if(k < tr.n && tk < INFINITE_F)
+    if(k < tr.n)
     {
-      bool better = tk < best.t;
-      if(tk == best.t && best.tri >= 0)
-      {
-        const DevTri A = sc.tris[ik], B = sc.tris[best.tri];
-        const uint32_t ra = __float_as_uint(A.a.w), pa = __float_as_uint(A.b.w), rb = __float_as_uint(B.a.w), pb = __float_as_uint(B.b.w);
-        better = ra < rb || (ra == rb && pa < pb);
-      }
-      if(better)
-      {
-        best.t = tk; best.u = uk; best.v = vk; best.tri = int(ik);
-      }
+      if(tk < 0.0f)
+        aPending = true;
+      else if(tk < INFINITE_F)
+        closestUpdate(sc, best, tk, uk, vk, ik);
     }
   }
   PROF_ADD(7, tGather);
@@ -447,14 +526,15 @@ PT_DEV void triRoundFinish(const DevScene& sc, const RaySetup& r, ClosestBest& b
 // Second half of a triangle round of the any-hit (shadow) walk without transmissive instances: a candidate that commits
 // decides its ray (raytracer_interface.h.slang:149-179), so the owners only need to know whether any of theirs did.
 template <bool HAS_ALPHA, bool COUNT>
-PT_DEV void triRoundFinishShadow(const DevScene& sc, const RaySetup& r, float tMax, uint32_t seed0, const TriRound& tr, bool& occluded, unsigned& tris)
+PT_DEV void triRoundFinishShadow(const DevScene& sc, const RaySetup& r, float tMax, uint32_t seed0, const TriRound& tr, bool& occluded, unsigned& tris,
+                                 uint4* waveAlpha, uint32_t& aCount, bool& aPending)
 {
-  const uint32_t src = tr.item >> 26, tri = tr.item & 0x3ffffffu;
+  const uint32_t src = tr.item >> 26;
   const f3       org = mk3(laneRead(r.org.x, src), laneRead(r.org.y, src), laneRead(r.org.z, src));
   const f3       dir = mk3(laneRead(r.dir.x, src), laneRead(r.dir.y, src), laneRead(r.dir.z, src));
   const float    tmaxSrc = laneRead(tMax, src);
-  const uint32_t seedSrc = HAS_ALPHA ? laneRead(seed0, src) : 0u;
-  bool           commits = false;
+  bool           commits = false, needAlpha = false;
+  float          hu = 0.0f, hv = 0.0f;
   if(tr.has)
   {
     const DevTri& T = tr.T;
@@ -462,19 +542,24 @@ PT_DEV void triRoundFinishShadow(const DevScene& sc, const RaySetup& r, float tM
     if(intersectTri(xyz(T.a), xyz(T.b), xyz(T.c), org, dir, h) && h.t > 0.0f && h.t < tmaxSrc)
     {
       const uint32_t flags = __float_as_uint(T.c.w);
-      if(!HAS_ALPHA || (flags & INST_FORCE_OPAQUE))
-        commits = true;  // RAY_FLAG_NONE: no culling; opaque geometry commits
-      else
-      {
-        // non-transmissive alpha material: an accepted candidate multiplies the transmission by
-        // getShadowTransmission() == 0 (pathtrace_functions.h.slang:256-261) whatever its position in the order
-        const uint32_t rnode = __float_as_uint(T.a.w), prim = __float_as_uint(T.b.w);
-        commits = candidateRand(seedSrc, int(rnode), int(prim)) < getOpacityFast(sc, int(tri), mk3(1.0f - h.u - h.v, h.u, h.v));
-      }
+      // RAY_FLAG_NONE: no culling; opaque geometry commits.  Non-transmissive alpha material: an accepted candidate multiplies
+      // the transmission by getShadowTransmission() == 0 (pathtrace_functions.h.slang:256-261) whatever its position in the
+      // order -- the draw is deferred to an alpha round
+      needAlpha = HAS_ALPHA && !(flags & INST_FORCE_OPAQUE);
+      commits   = !needAlpha;
+      hu        = h.u;
+      hv        = h.v;
     }
   }
   if(COUNT) tris += tr.has ? 1u : 0u;
   const unsigned long long mine = tr.n ? (((tr.n >= 64u ? 0ull : (1ull << tr.n)) - 1ull) << tr.off) : 0ull;  // this owner's items: lanes [off, off + n)
+  if(HAS_ALPHA)
+  {
+    ClosestBest none{};
+    alphaDefer<true>(sc, needAlpha, tr.item, 0.0f, hu, hv, seed0, waveAlpha, aCount, aPending, none, occluded);
+    if(__ballot(needAlpha) & mine)
+      aPending = true;
+  }
   if(__ballot(commits) & mine)
     occluded = true;
 }
@@ -484,8 +569,10 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
 {
   __shared__ int      s_stack[BVH_STACK_LDS * TRACE_BLOCK];  // BVH2: 24 ints/lane; BVH8: 12 node groups x 2 ints/lane
   __shared__ uint32_t s_prefix[NSUB + 1];
-  __shared__ uint4    s_nodes[WIDE ? NODE_CACHE * 5 : 1];
-  __shared__ uint32_t s_items[WIDE ? TRACE_BLOCK : 1];  // triangle rounds: 64 published triangles per wave
+  constexpr int CACHE = HAS_ALPHA ? NODE_CACHE_ALPHA : NODE_CACHE;
+  __shared__ uint4    s_nodes[WIDE ? CACHE * 5 : 1];
+  __shared__ uint32_t s_items[WIDE ? TRACE_BLOCK : 1];                // triangle rounds: 64 published triangles per wave
+  __shared__ uint4    s_alpha[(WIDE && HAS_ALPHA) ? TRACE_BLOCK : 1];  // deferred alpha tests: 64 entries per wave
 
   static_assert(2 * BVH8_STACK_LDS == BVH_STACK_LDS, "both stack flavours share one LDS allocation");
   if(blockIdx.x == 0 && threadIdx.x < NSUB)
@@ -502,7 +589,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
   feedInit(feed, s_prefix[NSUB]);
   if(!feedBlockHasWork(feed))
     return;
-  const uint32_t cachedNodes = WIDE ? fillNodeCache(sc, s_nodes) : 0u;
+  const uint32_t cachedNodes = WIDE ? fillNodeCache(sc, s_nodes, uint32_t(CACHE)) : 0u;
   LaneStack  st;   // BVH2 walk state
   LaneStack2 st2;  // BVH8 walk state
   int        stackOverflow[WIDE ? 2 * BVH8_STACK_PRIV : BVH_STACK_PRIV];  // scratch; only touched beyond the LDS depth
@@ -517,6 +604,9 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
   uint32_t    octinv = 0;
   uint32_t    pBase = 0, pMask = 0, qBase = 0, qMask = 0;  // parked leaf hits (8-wide walk): triangle base + bit mask
   int         lastVisiting = 64;                           // lanes that visited a node in the previous step
+  uint32_t    aCount   = 0;                                // deferred alpha tests on this wave's list (wave-uniform)
+  bool        aPending = false;                            // ... some of them this lane's
+  uint4*      waveAlpha = s_alpha + ((WIDE && HAS_ALPHA) ? (threadIdx.x & ~63u) : 0u);
   ClosestBest best{INFINITE_F, 0.0f, 0.0f, -1, 0xffffffffu, 0xffffffffu};
   uint32_t    seed0 = 0;
   bool        seedLoaded = false;
@@ -647,12 +737,23 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
         const unsigned long long tTri = PROF_T();
         if(round)
 #ifdef TRACE_PROFILE
-          triRoundFinish<HAS_ALPHA, COUNT>(sc, r, best, seed0, tr, tris, profAcc);
+          triRoundFinish<HAS_ALPHA, COUNT>(sc, r, best, seed0, tr, tris, waveAlpha, aCount, aPending, profAcc);
 #else
-          triRoundFinish<HAS_ALPHA, COUNT>(sc, r, best, seed0, tr, tris);
+          triRoundFinish<HAS_ALPHA, COUNT>(sc, r, best, seed0, tr, tris, waveAlpha, aCount, aPending);
 #endif
+        if(HAS_ALPHA && aCount != 0u)
+        {
+          // alpha round: the list is long enough, or the walk is running dry, or rays have nothing left to do but wait for it
+          const bool walked  = active && pMask == 0u && (G.bits >> 8) == 0u && st2.sp == 0;
+          const int  waiting = __popcll(__ballot(walked && aPending));
+          if(aCount >= ALPHA_ROUND_MIN || lastVisiting < TRI_PHASE_LANES || waiting >= ALPHA_ROUND_WAITING)
+          {
+            bool none = false;
+            alphaRound<false>(sc, seed0, waveAlpha, aCount, aPending, best, none);
+          }
+        }
         PROF_ADD(2, tTri);
-        if(active && pMask == 0u && (G.bits >> 8) == 0u && st2.sp == 0)
+        if(active && pMask == 0u && (G.bits >> 8) == 0u && st2.sp == 0 && !(HAS_ALPHA && aPending))
         {
           in.aux[pos] = make_float4(best.t, __int_as_float(best.tri), best.u, best.v);
           active      = false;
@@ -1346,7 +1447,7 @@ template <int MODE>
 struct ShadowCfg
 {
   static constexpr int BLOCK = MODE == 2 ? 256 : TRACE_BLOCK;
-  static constexpr int CACHE = MODE == 2 ? 320 : NODE_CACHE;
+  static constexpr int CACHE = MODE == 2 ? 320 : (MODE == 1 ? NODE_CACHE_ALPHA : NODE_CACHE);
 };
 template <bool WIDE, int MODE, bool COUNT>
 __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_trace_shadow(DevScene sc, const DevScene* __restrict__ scp, PathSoA P, Queues Q, int nxt, float catcherDarken, StatCounters* stats)
@@ -1359,6 +1460,7 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
   __shared__ uint32_t s_prefix[NSUB + 1];
   __shared__ uint4    s_nodes[WIDE ? ShadowCfg<MODE>::CACHE * 5 : 1];
   __shared__ uint32_t s_items[(WIDE && !HAS_TRANS) ? SBLOCK : 1];  // triangle rounds (see triRoundPublish)
+  __shared__ uint4    s_alpha[(WIDE && MODE == 1) ? SBLOCK : 1];   // deferred alpha tests (see alphaRound)
   queuePrefix(&Q.counters[(nxt ? QC_PAIR1 : QC_PAIR0) + 1], s_prefix);  // the shadow tails written next to active queue `nxt`
   const RayQueue in = Q.shadow;
   WaveFeed feed;
@@ -1399,6 +1501,9 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
   float4   pO = make_float4(0, 0, 0, 0), pD = make_float4(0, 0, 0, 0), pC = make_float4(0, 0, 0, 0);
   bool     catcherRay = false;
   uint32_t pBase = 0, pMask = 0, qBase = 0, qMask = 0;  // parked leaf hits of the 8-wide walk (see k_trace_closest)
+  uint32_t aCount   = 0;                                // deferred alpha tests of this wave / some of them this lane's (MODE 1)
+  bool     aPending = false;
+  uint4*   waveAlpha = s_alpha + ((WIDE && MODE == 1) ? (threadIdx.x & ~63u) : 0u);
 
   // end of a shadow ray: radiance += contribution * transmission (gltf_pathtrace.slang:462-471), or the two outcomes of
   // handleShadowCatcher (pathtrace_functions.h.slang:520-534) for rays the shade kernel flagged as catcher probes
@@ -1574,7 +1679,7 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
       {
         // node step + dense triangle phase, as in k_trace_closest (any-hit and the phase-1 search are order independent)
         bool visited = false;
-        if(active && qMask == 0u)
+        if(active && qMask == 0u && !(MODE == 1 && occluded))  // (an occluded MODE-1 ray may still wait for its deferred alpha tests)
         {
           const float walkTmax = (HAS_TRANS && phase == 1 && found) ? bT : tMax;
           if((G.bits >> 8) == 0u && st2.sp > 0)
@@ -1610,10 +1715,21 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
               {
                 TriRound tr;
                 triRoundPublish(sc, active, pBase, pMask, qBase, qMask, s_items + (threadIdx.x & ~63u), tr);
-                triRoundFinishShadow<HAS_ALPHA, COUNT>(sc, r, tMax, seed0, tr, occluded, tris);
+                triRoundFinishShadow<HAS_ALPHA, COUNT>(sc, r, tMax, seed0, tr, occluded, tris, waveAlpha, aCount, aPending);
                 if(occluded) { pMask = 0u; qMask = 0u; }
                 pend = __ballot(active && pMask != 0u);
               } while(pend != 0ull && (drain || __popcll(pend) >= TRI_ROUND_LANES));
+            }
+          }
+          if(MODE == 1 && aCount != 0u)
+          {
+            const bool walked  = active && (occluded || ((G.bits >> 8) == 0u && st2.sp == 0 && pMask == 0u));
+            const int  waiting = __popcll(__ballot(walked && aPending));
+            if(aCount >= ALPHA_ROUND_MIN || __popcll(__ballot(visited)) < TRI_PHASE_LANES || waiting >= ALPHA_ROUND_WAITING)
+            {
+              ClosestBest none{};
+              alphaRound<true>(sc, seed0, waveAlpha, aCount, aPending, none, occluded);
+              if(occluded) { pMask = 0u; qMask = 0u; }
             }
           }
         }
@@ -1645,7 +1761,7 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
             } while(pend != 0ull && (drain || __popcll(pend) >= TRI_PHASE_EXIT_LANES || __ballot(active && qMask != 0u) != 0ull));
           }
         }
-        walkDone = active && (occluded || ((G.bits >> 8) == 0u && st2.sp == 0 && pMask == 0u));
+        walkDone = active && !(MODE == 1 && aPending) && (occluded || ((G.bits >> 8) == 0u && st2.sp == 0 && pMask == 0u));
       }
       else if(active)
       {
