@@ -19,8 +19,8 @@ namespace {
 // One trace workgroup per CU: 16 waves share one LDS copy of the top of the 8-wide BVH (the first nodes of the BFS-ordered
 // node array), next to the per-lane traversal stacks.  96 KiB of stacks + 60 KiB of nodes of the CU's 160 KiB.
 constexpr int TRACE_BLOCK = 1024;
-constexpr int NODE_CACHE  = 764;  // BVH8 nodes (80 B each) resident in LDS
-constexpr int NODE_CACHE_ALPHA = 556;  // ... in the kernels that also keep a list of deferred alpha tests there (16 B x 1024)
+constexpr int NODE_CACHE  = 712;  // BVH8 nodes (80 B each) resident in LDS
+constexpr int NODE_CACHE_ALPHA = 504;  // ... in the kernels that also keep a list of deferred alpha tests there (16 B x 1024)
 constexpr int SEL_BLOCK   = 256;
 #ifndef TRACE_MIN_WAVES
 #define TRACE_MIN_WAVES 1
@@ -468,8 +468,8 @@ PT_DEV void alphaDefer(const DevScene& sc, bool needAlpha, uint32_t item, float 
 }
 
 template <bool HAS_ALPHA, bool COUNT>
-PT_DEV void triRoundFinish(const DevScene& sc, const RaySetup& r, ClosestBest& best, uint32_t seed0, const TriRound& tr, unsigned& tris, uint4* waveAlpha,
-                           uint32_t& aCount, bool& aPending, unsigned long long* profAcc = nullptr)
+PT_DEV void triRoundFinish(const DevScene& sc, const RaySetup& r, ClosestBest& best, uint32_t seed0, const TriRound& tr, unsigned& tris,
+                           unsigned long long* waveSlots, uint4* waveAlpha, uint32_t& aCount, bool& aPending, unsigned long long* profAcc = nullptr)
 {
   const unsigned long long tTest = PROF_T();
   // ---- every lane tests its triangle for the owner's ray
@@ -506,17 +506,38 @@ PT_DEV void triRoundFinish(const DevScene& sc, const RaySetup& r, ClosestBest& b
     bool none = false;
     alphaDefer<false>(sc, needAlpha, tr.item, tHit, ru, rv, seed0, waveAlpha, aCount, aPending, best, none);
   }
-  // ---- owners collect
-  for(uint32_t k = 0; __ballot(k < tr.n) != 0ull; ++k)
+  // ---- owners collect.  Each lane's best candidate of this round is found by a 64-bit minimum (t | testing lane) on the
+  // owner's slot of the wave's LDS list; u, v and the triangle then come from the winning lane.  Two candidates of one ray
+  // at exactly the same t must be ordered by (renderNode, primitive): that case (coincident geometry) takes the slow way.
+  const uint32_t           lane = laneId();
+  const unsigned long long mine = tr.n ? (((tr.n >= 64u ? 0ull : (1ull << tr.n)) - 1ull) << tr.off) : 0ull;  // this owner's items: lanes [off, off + n)
+  if(HAS_ALPHA && (__ballot(needAlpha) & mine))
+    aPending = true;
+  const bool cand = rt >= 0.0f && rt < INFINITE_F;
+  waveSlots[lane] = ~0ull;
+  __builtin_amdgcn_wave_barrier();
+  if(cand)
+    (void)__hip_atomic_fetch_min(&waveSlots[src], ((unsigned long long)__float_as_uint(rt) << 32) | lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __builtin_amdgcn_wave_barrier();
+  const unsigned long long won = waveSlots[lane], wonSrc = waveSlots[src];
+  __builtin_amdgcn_wave_barrier();
+  const bool tie = cand && uint32_t(wonSrc >> 32) == __float_as_uint(rt) && uint32_t(wonSrc) != lane;
+  if(__ballot(tie) == 0ull)
   {
-    const uint32_t j  = (tr.off + k) & 63u;
-    const float    tk = laneRead(rt, j), uk = laneRead(ru, j), vk = laneRead(rv, j);
+    const uint32_t j  = uint32_t(won) & 63u;
+    const float    uk = laneRead(ru, j), vk = laneRead(rv, j);
     const uint32_t ik = laneRead(tri, j);
-    if(k < tr.n)
+    if(won != ~0ull)
+      closestUpdate(sc, best, __uint_as_float(uint32_t(won >> 32)), uk, vk, ik);
+  }
+  else
+  {
+    for(uint32_t k = 0; __ballot(k < tr.n) != 0ull; ++k)
     {
-      if(tk < 0.0f)
-        aPending = true;
-      else if(tk < INFINITE_F)
+      const uint32_t j  = (tr.off + k) & 63u;
+      const float    tk = laneRead(rt, j), uk = laneRead(ru, j), vk = laneRead(rv, j);
+      const uint32_t ik = laneRead(tri, j);
+      if(k < tr.n && tk >= 0.0f && tk < INFINITE_F)
         closestUpdate(sc, best, tk, uk, vk, ik);
     }
   }
@@ -571,7 +592,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
   __shared__ uint32_t s_prefix[NSUB + 1];
   constexpr int CACHE = HAS_ALPHA ? NODE_CACHE_ALPHA : NODE_CACHE;
   __shared__ uint4    s_nodes[WIDE ? CACHE * 5 : 1];
-  __shared__ uint32_t s_items[WIDE ? TRACE_BLOCK : 1];                // triangle rounds: 64 published triangles per wave
+  __shared__ unsigned long long s_slots[WIDE ? TRACE_BLOCK : 1];     // triangle rounds: 64 published triangles per wave (first half
+                                                                      // of the wave's 512 bytes), then the 64 result slots
   __shared__ uint4    s_alpha[(WIDE && HAS_ALPHA) ? TRACE_BLOCK : 1];  // deferred alpha tests: 64 entries per wave
 
   static_assert(2 * BVH8_STACK_LDS == BVH_STACK_LDS, "both stack flavours share one LDS allocation");
@@ -699,7 +721,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
           {
             PROF_CNT(2, 1);
             PROF_CNT(3, __popcll(pend));
-            triRoundPublish(sc, active, pBase, pMask, qBase, qMask, s_items + (threadIdx.x & ~63u), tr);
+            triRoundPublish(sc, active, pBase, pMask, qBase, qMask, reinterpret_cast<uint32_t*>(s_slots + (threadIdx.x & ~63u)), tr);
           }
         }
         PROF_ADD(2, tTri0);
@@ -737,9 +759,9 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
         const unsigned long long tTri = PROF_T();
         if(round)
 #ifdef TRACE_PROFILE
-          triRoundFinish<HAS_ALPHA, COUNT>(sc, r, best, seed0, tr, tris, waveAlpha, aCount, aPending, profAcc);
+          triRoundFinish<HAS_ALPHA, COUNT>(sc, r, best, seed0, tr, tris, s_slots + (threadIdx.x & ~63u), waveAlpha, aCount, aPending, profAcc);
 #else
-          triRoundFinish<HAS_ALPHA, COUNT>(sc, r, best, seed0, tr, tris, waveAlpha, aCount, aPending);
+          triRoundFinish<HAS_ALPHA, COUNT>(sc, r, best, seed0, tr, tris, s_slots + (threadIdx.x & ~63u), waveAlpha, aCount, aPending);
 #endif
         if(HAS_ALPHA && aCount != 0u)
         {
