@@ -266,7 +266,9 @@ __device__ unsigned long long g_traceProf[18];
 #endif
 
 // Refill policy of the persistent trace waves: go back for new rays once this many lanes of the wave are idle.
-constexpr int REFILL_IDLE_LANES = 16;
+#ifndef REFILL_IDLE_LANES
+#define REFILL_IDLE_LANES 16
+#endif
 // Dense triangle phase of the 8-wide walk: start once this many lanes have parked triangles, leave below the exit count.
 constexpr int TRI_PHASE_LANES      = 24;
 constexpr int TRI_PHASE_EXIT_LANES = 10;

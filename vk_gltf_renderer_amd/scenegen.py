@@ -450,6 +450,141 @@ def scene_atrium_class(path, seed=4321, detail=1.0, tex_size=512):
     return b.save(path)
 
 
+def scene_street_class(path, seed=777, detail=1.0, tex_size=256):
+    """BistroExterior-class street: two rows of buildings along a street, every building an instance of
+    one of 24 facade meshes (EXT_mesh_gpu_instancing: ~1000 render nodes from ~60 glTF nodes), street furniture and trees with
+    alpha-MASK foliage, ~130 materials over 24 textures, sun + sky.  detail=1.27 gives ~2.8 M triangles."""
+    rng = np.random.default_rng(seed)
+    b = GlbBuilder()
+    b.ext_used.add("EXT_mesh_gpu_instancing")
+    smp = b.sampler()
+
+    def tex(rgb, alpha=None):
+        a = np.ones(rgb.shape[:2]) if alpha is None else alpha
+        img = np.concatenate([rgb, a[..., None]], -1)
+        return b.texture(b.image((np.clip(img, 0, 1) * 255 + 0.5).astype(np.uint8)), smp)
+
+    textures = []
+    for k in range(23):
+        hue = rng.uniform(0.45, 0.95, 3) * rng.uniform(0.7, 1.0)
+        textures.append(tex(np.clip(hue * (0.5 + 0.5 * value_noise(rng, tex_size, 5, 3)), 0, 1)))
+    mats = []
+    for k in range(128):
+        m = {"pbrMetallicRoughness": {"baseColorTexture": {"index": textures[k % len(textures)]},
+                                      "baseColorFactor": [float(v) for v in rng.uniform(0.6, 1.0, 3)] + [1.0],
+                                      "metallicFactor": float(rng.random() < 0.12), "roughnessFactor": float(rng.uniform(0.2, 0.95))}}
+        if k % 7 == 0:
+            m["doubleSided"] = True
+        if k % 16 == 3:
+            m["emissiveFactor"] = [float(v) for v in rng.uniform(0.0, 0.6, 3)]
+        mats.append(b.material(m))
+    leaf_n = value_noise(rng, tex_size, 4, 1)[..., 0]
+    yy, xx = np.mgrid[0:tex_size, 0:tex_size] / tex_size - 0.5
+    leaf_a = ((np.sqrt(xx * xx * 3 + yy * yy) + 0.15 * (leaf_n - 0.5)) < 0.42).astype(np.float64)
+    t_leaf = tex(np.clip(np.stack([0.15 + 0.2 * leaf_n, 0.4 + 0.4 * leaf_n, 0.1 + 0.1 * leaf_n], -1), 0, 1), leaf_a)
+    m_leaf = b.material({"pbrMetallicRoughness": {"baseColorTexture": {"index": t_leaf}, "metallicFactor": 0.0, "roughnessFactor": 0.7},
+                         "alphaMode": "MASK", "alphaCutoff": 0.5, "doubleSided": True})
+    m_road = b.material({"pbrMetallicRoughness": {"baseColorTexture": {"index": textures[0]}, "baseColorFactor": [0.35, 0.35, 0.37, 1.0],
+                                                  "metallicFactor": 0.0, "roughnessFactor": 0.85}})
+
+    def instanced(mesh, translations, rotations_y=None, scales=None):
+        """One glTF node carrying an EXT_mesh_gpu_instancing attribute set."""
+        attrs = {"TRANSLATION": b.accessor(np.asarray(translations, np.float32))}
+        if rotations_y is not None:
+            h = np.asarray(rotations_y, np.float64) / 2
+            attrs["ROTATION"] = b.accessor(np.stack([np.zeros_like(h), np.sin(h), np.zeros_like(h), np.cos(h)], 1).astype(np.float32))
+        if scales is not None:
+            attrs["SCALE"] = b.accessor(np.asarray(scales, np.float32))
+        b.node(mesh=mesh, extensions={"EXT_mesh_gpu_instancing": {"attributes": attrs}})
+
+    L, Wd = 240.0, 18.0
+    g = max(2, int(40 * detail))
+    pos, nrm, uv, idx = grid(g * 4, g, (L, Wd * 3), "y")
+    b.node(mesh=b.mesh([b.primitive(pos, idx, nrm, uv * np.array([L / 4, Wd], np.float32), material=m_road)]))
+    # 24 building types: a displaced facade slab with window bays (4 primitives of different materials each)
+    fx, fy = max(4, int(28 * detail)), max(4, int(40 * detail))
+    building_meshes = []
+    for t in range(24):
+        prims = []
+        w, h, d = rng.uniform(8, 14), rng.uniform(10, 26), rng.uniform(8, 12)
+        for face, (sz, axis, off, flip) in enumerate((((w, h), "z", (0, h / 2, d / 2), False), ((w, h), "z", (0, h / 2, -d / 2), True),
+                                                      ((d, h), "x", (w / 2, h / 2, 0), False), ((d, h), "x", (-w / 2, h / 2, 0), True))):
+            pos, nrm, uv, idx = grid(fx, fy, sz, axis)
+            bays = np.sin(uv[:, 0] * np.pi * rng.integers(3, 7)) * np.sin(uv[:, 1] * np.pi * rng.integers(4, 10))
+            relief = (0.12 * np.clip(bays, 0, 1) + 0.03 * np.sin(uv[:, 1] * 90.0)).astype(np.float32)
+            pos = pos + nrm * relief[:, None]
+            if flip:
+                idx = idx[:, [0, 2, 1]]
+                pos = pos * np.array([-1, 1, -1], np.float32) if axis == "x" else pos * np.array([1, 1, -1], np.float32)
+            n2 = _vertex_normals(pos.astype(np.float64), idx).astype(np.float32)
+            prims.append(b.primitive(pos + np.array(off, np.float32), idx, n2,
+                                     uv * np.array([sz[0] / 3, sz[1] / 3], np.float32), material=mats[(t * 5 + face) % 120]))
+        pos, nrm, uv, idx = grid(4, 4, (w, d), "y")
+        prims.append(b.primitive(pos + np.array([0, h, 0], np.float32), idx, nrm, uv, material=mats[(t * 5 + 4) % 120]))
+        building_meshes.append((b.mesh(prims), w))
+    # two rows of buildings, ~20 instances per type
+    per_type = [[] for _ in building_meshes]
+    for side in (-1, 1):
+        x = -L / 2
+        while x < L / 2:
+            t = int(rng.integers(len(building_meshes)))
+            w = building_meshes[t][1]
+            per_type[t].append(((x + w / 2, 0.0, side * (Wd / 2 + 6.0)), 0.0 if side < 0 else np.pi))
+            x += w + rng.uniform(0.2, 1.5)
+        # a second row behind, seen through the gaps and above the roofs
+        x = -L / 2
+        while x < L / 2:
+            t = int(rng.integers(len(building_meshes)))
+            w = building_meshes[t][1]
+            per_type[t].append(((x + w / 2, 0.0, side * (Wd / 2 + 22.0)), 0.0 if side < 0 else np.pi))
+            x += w + rng.uniform(1.0, 4.0)
+    for (mesh, _), inst in zip(building_meshes, per_type):
+        if inst:
+            instanced(mesh, [i[0] for i in inst], [i[1] for i in inst])
+    # street furniture: lamp posts, bollards, planters (instanced displaced blobs)
+    for k in range(8):
+        fr = rng.normal(size=(5, 3)) * 3.0
+        amp = rng.uniform(0.05, 0.3)
+
+        def displace(d, amp=amp, fr=fr):
+            return 1.0 + amp * np.sin(d @ fr.T).sum(1) / 3.0
+
+        pos, nrm, uv, idx = uv_sphere(max(8, int(36 * detail)), max(6, int(20 * detail)), 1.0, displace)
+        pos = pos * np.array([0.25, rng.uniform(0.5, 2.5), 0.25], np.float32)
+        nrm = _vertex_normals(pos.astype(np.float64), idx).astype(np.float32)
+        mesh = b.mesh([b.primitive(pos, idx, nrm, uv, material=mats[120 + k])])
+        n = 60
+        tr = np.stack([rng.uniform(-L / 2, L / 2, n), np.full(n, 1.0), rng.choice([-1, 1], n) * rng.uniform(Wd / 2 - 2.5, Wd / 2 - 0.8, n)], 1)
+        instanced(mesh, tr, rng.uniform(0, 6.28, n), np.tile(rng.uniform(0.6, 1.4, (n, 1)), (1, 3)))
+    # trees: trunk + a cloud of alpha-masked leaf quads, 3 tree meshes x 16 instances
+    for k in range(3):
+        n = int(4500 * detail)
+        centers = rng.normal(size=(n, 3)) * np.array([1.6, 1.2, 1.6]) + np.array([0, 5.0, 0])
+        ax = rng.normal(size=(n, 3))
+        ax /= np.linalg.norm(ax, axis=1, keepdims=True)
+        bx = np.cross(ax, rng.normal(size=(n, 3)))
+        bx /= np.linalg.norm(bx, axis=1, keepdims=True)
+        sz = np.exp(rng.uniform(np.log(0.12), np.log(0.45), (n, 1)))
+        quad = np.stack([centers - ax * sz - bx * sz, centers + ax * sz - bx * sz, centers + ax * sz + bx * sz, centers - ax * sz + bx * sz], 1)
+        base = np.arange(n)[:, None] * 4
+        idx = np.concatenate([base + np.array([0, 1, 2]), base + np.array([0, 2, 3])], 1).reshape(-1, 3)
+        leaves = b.primitive(quad.reshape(-1, 3).astype(np.float32), idx.astype(np.uint32), np.repeat(np.cross(ax, bx), 4, 0).astype(np.float32),
+                             np.tile(np.array([[0, 1], [1, 1], [1, 0], [0, 0]], np.float32), (n, 1)), material=m_leaf)
+        pos, nrm, uv, idx = uv_sphere(16, 24, 1.0)
+        pos = pos * np.array([0.22, 2.6, 0.22], np.float32) + np.array([0, 2.6, 0], np.float32)
+        trunk = b.primitive(pos, idx, _vertex_normals(pos.astype(np.float64), idx).astype(np.float32), uv, material=mats[100 + k])
+        n_inst = 16
+        tr = np.stack([np.linspace(-L / 2 + 8, L / 2 - 8, n_inst) + rng.uniform(-2, 2, n_inst), np.zeros(n_inst),
+                       np.where(np.arange(n_inst) % 2 == 0, -1, 1) * (Wd / 2 - 1.6)], 1)
+        instanced(b.mesh([leaves, trunk]), tr, rng.uniform(0, 6.28, n_inst), np.tile(rng.uniform(0.8, 1.3, (n_inst, 1)), (1, 3)))
+    li = b.light({"type": "directional", "intensity": 6.0, "color": [1.0, 0.95, 0.88]})
+    ang = 0.9
+    b.node(extensions={"KHR_lights_punctual": {"light": li}},
+           rotation=[-float(np.sin((np.pi / 2 - ang) / 2)) * 0.94, 0.34 * float(np.sin((np.pi / 2 - ang) / 2)), 0.0, float(np.cos((np.pi / 2 - ang) / 2))])
+    b.camera_node((-L / 2 + 6.0, 1.8, 1.2), (L / 2, 6.0, -0.6), yfov=0.95, znear=0.05, zfar=1000.0)
+    return b.save(path)
+
+
 def scene_glass_class(path, seed=99, tess=48):
     """TransmissionTest-class: a grid of spheres sweeping transmission / roughness / IOR / attenuation / dispersion /
     volume scatter, plus opaque reference spheres, on a diffuse floor with one point light."""
