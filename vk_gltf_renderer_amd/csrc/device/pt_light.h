@@ -10,25 +10,42 @@
 namespace pt {
 
 // ---- textures -------------------------------------------------------------------------------------------------------------
+// Sampler address modes.  Texture sizes are almost always powers of two, where the modulo is a mask; the general integer
+// modulo (some thirty instructions on this hardware, four of them per bilinear fetch) is kept for the other sizes.
+PT_DEV int posMod(int i, int n)
+{
+  if((n & (n - 1)) == 0)
+    return i & (n - 1);
+  const int m = i % n;
+  return m < 0 ? m + n : m;
+}
 PT_DEV int wrapCoord(int i, int n, int mode)
 {
   if(mode == MI_WRAP_CLAMP_TO_EDGE)
     return min(max(i, 0), n - 1);
   if(mode == MI_WRAP_MIRRORED_REPEAT)
   {
-    int period = 2 * n;
-    int m      = i % period;
-    if(m < 0)
-      m += period;
+    const int period = 2 * n;
+    const int m      = posMod(i, period);
     return m < n ? m : period - 1 - m;
   }
-  int m = i % n;
-  return m < 0 ? m + n : m;
+  return posMod(i, n);
 }
+// wrapCoord(i) and wrapCoord(i + 1) of a bilinear footprint
+PT_DEV void wrapCoordPair(int i, int n, int mode, int& c0, int& c1)
+{
+  c0 = wrapCoord(i, n, mode);
+  if(mode == MI_WRAP_REPEAT)
+    c1 = c0 + 1 == n ? 0 : c0 + 1;
+  else
+    c1 = wrapCoord(i + 1, n, mode);
+}
+// texel index inside the pool: 32-bit with a 24-bit multiply (a level is at most 16384 texels wide, the pool offsets are 32-bit)
+PT_DEV uint32_t texelIndex(uint32_t levelOffset, int w, int x, int y) { return levelOffset + __umul24(uint32_t(y), uint32_t(w)) + uint32_t(x); }
 // `lut` = the 256-entry sRGB decode table to use (sc.srgbLut, or a copy of it that the caller staged in LDS)
 PT_DEV f4 fetchTexel(const DevScene& sc, const float* lut, const DevTexture& t, int level, int w, int x, int y)
 {
-  uchar4 p = sc.texels[size_t(t.levelOffset[level]) + size_t(y) * size_t(w) + size_t(x)];
+  uchar4 p = sc.texels[texelIndex(t.levelOffset[level], w, x, y)];
   if(t.srgb)
     return mk4(lut[p.x], lut[p.y], lut[p.z], float(p.w) * (1.0f / 255.0f));
   return mk4(float(p.x) * (1.0f / 255.0f), float(p.y) * (1.0f / 255.0f), float(p.z) * (1.0f / 255.0f), float(p.w) * (1.0f / 255.0f));
@@ -43,8 +60,9 @@ PT_DEV f4 sampleLevel(const DevScene& sc, const float* lut, const DevTexture& t,
   fy -= 0.5f;
   float flx = floorf(fx), fly = floorf(fy);
   float tx = fx - flx, ty = fy - fly;
-  int   x0 = wrapCoord(int(flx), w, t.wrapS), x1 = wrapCoord(int(flx) + 1, w, t.wrapS);
-  int   y0 = wrapCoord(int(fly), h, t.wrapT), y1 = wrapCoord(int(fly) + 1, h, t.wrapT);
+  int   x0, x1, y0, y1;
+  wrapCoordPair(int(flx), w, t.wrapS, x0, x1);
+  wrapCoordPair(int(fly), h, t.wrapT, y0, y1);
   f4    a = fetchTexel(sc, lut, t, level, w, x0, y0), b = fetchTexel(sc, lut, t, level, w, x1, y0);
   f4    c = fetchTexel(sc, lut, t, level, w, x0, y1), d = fetchTexel(sc, lut, t, level, w, x1, y1);
   return (a * (1.0f - tx) + b * tx) * (1.0f - ty) + (c * (1.0f - tx) + d * tx) * ty;

@@ -156,7 +156,7 @@ PT_DEV bool isTexturePresent(uint16_t t) { return t > 0; }
 // sampleLevel -> fetchTexel (pt_light.h) with two dependent loads (record, texels) instead of five.
 PT_DEV f4 fetchTexelRef(const TexCtx& tc, const DevTexRef& R, uint32_t levelOffset, int w, int x, int y)
 {
-  uchar4 p = tc.texels[size_t(levelOffset) + size_t(y) * size_t(w) + size_t(x)];
+  uchar4 p = tc.texels[texelIndex(levelOffset, w, x, y)];
   if(R.srgb)
     return mk4(tc.lut[p.x], tc.lut[p.y], tc.lut[p.z], float(p.w) * (1.0f / 255.0f));
   return mk4(float(p.x) * (1.0f / 255.0f), float(p.y) * (1.0f / 255.0f), float(p.z) * (1.0f / 255.0f), float(p.w) * (1.0f / 255.0f));
@@ -174,8 +174,9 @@ PT_DEV f4 sampleLevelRef(const TexCtx& tc, const DevTexRef& R, f2 uv, int level,
   fy -= 0.5f;
   float flx = floorf(fx), fly = floorf(fy);
   float tx = fx - flx, ty = fy - fly;
-  int   x0 = wrapCoord(int(flx), w, R.wrapS), x1 = wrapCoord(int(flx) + 1, w, R.wrapS);
-  int   y0 = wrapCoord(int(fly), h, R.wrapT), y1 = wrapCoord(int(fly) + 1, h, R.wrapT);
+  int   x0, x1, y0, y1;
+  wrapCoordPair(int(flx), w, R.wrapS, x0, x1);
+  wrapCoordPair(int(fly), h, R.wrapT, y0, y1);
   f4    a = fetchTexelRef(tc, R, off, w, x0, y0), b = fetchTexelRef(tc, R, off, w, x1, y0);
   f4    c = fetchTexelRef(tc, R, off, w, x0, y1), d = fetchTexelRef(tc, R, off, w, x1, y1);
   return (a * (1.0f - tx) + b * tx) * (1.0f - ty) + (c * (1.0f - tx) + d * tx) * ty;
@@ -440,17 +441,18 @@ PT_DEV float getOpacityFast(const DevScene& sc, int triIndex, f3 bary)
     float       fx = uv.x * float(w), fy = uv.y * float(h);
     float       ta;
     if(!(flg & AT_LINEAR))
-      ta = float(texels[size_t(wrapCoord(int(floorf(fy)), h, wrapT)) * size_t(w) + size_t(wrapCoord(int(floorf(fx)), w, wrapS))].w) * (1.0f / 255.0f);
+      ta = float(texels[texelIndex(0u, w, wrapCoord(int(floorf(fx)), w, wrapS), wrapCoord(int(floorf(fy)), h, wrapT))].w) * (1.0f / 255.0f);
     else
     {
       fx -= 0.5f;
       fy -= 0.5f;
       float flx = floorf(fx), fly = floorf(fy);
       float tx = fx - flx, ty = fy - fly;
-      int   x0 = wrapCoord(int(flx), w, wrapS), x1 = wrapCoord(int(flx) + 1, w, wrapS);
-      int   y0 = wrapCoord(int(fly), h, wrapT), y1 = wrapCoord(int(fly) + 1, h, wrapT);
-      float a = float(texels[size_t(y0) * size_t(w) + size_t(x0)].w) * (1.0f / 255.0f), b = float(texels[size_t(y0) * size_t(w) + size_t(x1)].w) * (1.0f / 255.0f);
-      float c = float(texels[size_t(y1) * size_t(w) + size_t(x0)].w) * (1.0f / 255.0f), d = float(texels[size_t(y1) * size_t(w) + size_t(x1)].w) * (1.0f / 255.0f);
+      int   x0, x1, y0, y1;
+      wrapCoordPair(int(flx), w, wrapS, x0, x1);
+      wrapCoordPair(int(fly), h, wrapT, y0, y1);
+      float a = float(texels[texelIndex(0u, w, x0, y0)].w) * (1.0f / 255.0f), b = float(texels[texelIndex(0u, w, x1, y0)].w) * (1.0f / 255.0f);
+      float c = float(texels[texelIndex(0u, w, x0, y1)].w) * (1.0f / 255.0f), d = float(texels[texelIndex(0u, w, x1, y1)].w) * (1.0f / 255.0f);
       ta      = (a * (1.0f - tx) + b * tx) * (1.0f - ty) + (c * (1.0f - tx) + d * tx) * ty;
     }
     alpha *= ta;
