@@ -193,7 +193,7 @@ def main():
         if os.path.exists(pmc_file):
             try:
                 pmc = json.load(open(pmc_file))
-                if pmc.get("workload") == args.workload and pmc.get("frames_in_flight") == F:
+                if pmc.get("workload") == args.workload and pmc.get("frames_in_flight") == F and pmc.get("resolution") == [W, H] and world == 1:
                     traffic = pmc.get("bench_kernel_traffic", {}).get(dominant)
             except Exception:
                 traffic = None

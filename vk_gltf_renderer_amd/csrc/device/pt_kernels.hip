@@ -17,7 +17,8 @@ namespace pt {
 namespace {
 
 // One trace workgroup per CU: 16 waves share one LDS copy of the top of the 8-wide BVH (the first nodes of the BFS-ordered
-// node array), next to the per-lane traversal stacks.  96 KiB of stacks + 60 KiB of nodes of the CU's 160 KiB.
+// node array), next to the per-lane traversal stacks (96 KiB), the waves' triangle-round lists (8 KiB) and, in the kernels
+// that defer alpha tests, their alpha lists (16 KiB): 55 or 39 KiB of nodes of the CU's 160 KiB.
 constexpr int TRACE_BLOCK = 1024;
 constexpr int NODE_CACHE  = 712;  // BVH8 nodes (80 B each) resident in LDS
 constexpr int NODE_CACHE_ALPHA = 504;  // ... in the kernels that also keep a list of deferred alpha tests there (16 B x 1024)
