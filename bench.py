@@ -35,7 +35,7 @@ WORKLOADS = {
                    kw=dict(seed=1234, tess=272, tex_size=2048), width=1920, height=1080, depth=8, hdr=True),
     "atrium": dict(config="configs[2]: Sponza-class, 1920x1080, depth 12, NEE+MIS (directional light + sky)", gen="scene_atrium_class",
                    kw=dict(seed=4321, detail=0.8, tex_size=512), width=1920, height=1080, depth=12, hdr=False),
-    "street": dict(config="configs[3]: BistroExterior-class (instanced street, ~2.8 M triangles, ~1500 render nodes, 130 materials), 3840x2160, depth 8",
+    "street": dict(config="configs[3]: BistroExterior-class (instanced street, ~2.8 M triangles, ~1000 render nodes, 130 materials), 3840x2160, depth 8",
                    gen="scene_street_class", kw=dict(seed=777, detail=1.27, tex_size=256), width=3840, height=2160, depth=8, hdr=False),
     "glass": dict(config="configs[4]: TransmissionTest-class, 1920x1080, depth 24", gen="scene_glass_class",
                   kw=dict(seed=99, tess=96), width=1920, height=1080, depth=24, hdr=True),

@@ -108,6 +108,28 @@ def test_render_node_flattening_and_instancing(built, tmp_path):
     assert sorted(tuple(v) for v in inst) == sorted([(0, 0, 0), (0, 0, 0), (5, 0, 0), (5, 0, 0), (0, 0, 5), (0, 0, 5)])
 
 
+def test_street_class_scene_tables(built, tmp_path):
+    """The config-4 stand-in through the loader: EXT_mesh_gpu_instancing with TRANSLATION + ROTATION + SCALE expands to one
+    RenderNode per instance x primitive (src/gltf_scene.cpp:2338-2429), matrices stay rigid-plus-scale and invertible."""
+    path = scenegen.scene_street_class(str(tmp_path / "street.glb"), seed=3, detail=0.1, tex_size=16)
+    sc = ptmod.Scene(path)
+    d = sc.desc.contents
+    assert d.numMaterials == 128 + 2
+    assert d.numRenderPrimitives == 24 * 5 + 1 + 8 + 3 * 2  # facades + roofs, road, furniture, leaves + trunks
+    assert d.numRenderNodes > 900
+    assert sc.num_triangles > 50000
+    dets = []
+    for i in range(0, d.numRenderNodes, 37):
+        n = d.renderNodes[i]
+        o2w = np.array(n.objectToWorld[:]).reshape(4, 4).T
+        w2o = np.array(n.worldToObject[:]).reshape(4, 4).T
+        assert np.allclose(w2o @ o2w, np.eye(4), atol=2e-5)
+        r = o2w[:3, :3]
+        assert np.allclose(r.T @ r, np.eye(3) * (r.T @ r)[0, 0], atol=1e-4 * (r.T @ r)[0, 0])  # rotation x uniform scale
+        dets.append(np.linalg.det(r))
+    assert min(dets) > 0
+
+
 def _simple_tangents(pos, nrm, uv, idx):
     """Independent numpy restatement of tinygltf::utils::simpleCreateTangents (reference: src/tinygltf_utils.cpp:878-998)."""
     pos, nrm, uv = pos.astype(np.float32), nrm.astype(np.float32), uv.astype(np.float32)

@@ -452,7 +452,7 @@ def scene_atrium_class(path, seed=4321, detail=1.0, tex_size=512):
 
 def scene_street_class(path, seed=777, detail=1.0, tex_size=256):
     """BistroExterior-class street: two rows of buildings along a street, every building an instance of
-    one of 24 facade meshes (EXT_mesh_gpu_instancing: ~1000 render nodes from ~60 glTF nodes), street furniture and trees with
+    one of 24 facade meshes (EXT_mesh_gpu_instancing: ~1000 render nodes from ~40 glTF nodes), street furniture and trees with
     alpha-MASK foliage, ~130 materials over 24 textures, sun + sky.  detail=1.27 gives ~2.8 M triangles."""
     rng = np.random.default_rng(seed)
     b = GlbBuilder()
