@@ -1365,7 +1365,11 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
           {
             coneWidth = worldFoot;  // :313
             DirectLight dl;
+#ifdef MI_PT_DIAG_NO_NEE  // cost-attribution build (tools/attribution.sh): wrong image, no next-event estimation
+            dl = DirectLight{};
+#else
             sampleLights(sc, fc, hit.pos, seed, dl);  // :319-320
+#endif
             bool nextEventValid = (dot(dl.direction, hit.nrm) > 0.0f || pbrMat.diffuseTransmissionFactor > 0.0f) && dl.pdf != 0.0f;
             f3   contribution   = mk3(0.0f);
             if(nextEventValid)  // :330-351
@@ -1380,7 +1384,13 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
             }
             {  // :357-416
               float      r1 = rnd(seed), r2 = rnd(seed), r3 = rnd(seed);
+#ifdef MI_PT_DIAG_NO_SAMPLE  // cost-attribution build: mirror direction at half weight instead of the BSDF sample
+              BsdfSample sd{};
+              sd.k2 = rayDir - hit.nrm * (2.0f * dot(rayDir, hit.nrm)); sd.bsdf_over_pdf = mk3(0.5f * r1 + 0.25f); sd.pdf = 1.0f + r2 + r3;
+              sd.event_type = BSDF_EVENT_GLOSSY_REFLECTION;
+#else
               BsdfSample sd = bsdfSample(-rayDir, mk3(r1, r2, r3), pbrMat);
+#endif
               throughput *= sd.bsdf_over_pdf;
               rayDir        = sd.k2;
               lastSamplePdf = sd.pdf;

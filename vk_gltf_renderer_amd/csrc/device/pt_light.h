@@ -144,7 +144,17 @@ PT_DEV f4 environmentSample(const DevScene& sc, f3 xi, f3& toLight)
     envIdx = a.alias;
     xi.y   = (xi.y - a.q) / (1.0f - a.q);
   }
-  uint32_t py = envIdx / width, px = envIdx % width;
+  uint32_t py, px;  // (the integer division is some forty instructions here; lat-long maps are nearly always 2^n wide)
+  if((width & (width - 1u)) == 0u)
+  {
+    py = envIdx >> uint32_t(__ffs(int(width)) - 1);
+    px = envIdx & (width - 1u);
+  }
+  else
+  {
+    py = envIdx / width;
+    px = envIdx % width;
+  }
   float    u   = (float(px) + xi.y) / float(width);
   float    phi = u * K_TWO_PI - K_PI;
   float    sinPhi = sinf(phi), cosPhi = cosf(phi);

@@ -183,6 +183,9 @@ PT_DEV f4 sampleLevelRef(const TexCtx& tc, const DevTexRef& R, f2 uv, int level,
 }
 __device__ __noinline__ f4 getTextureRef(TexCtx tc, uint32_t slot, f2 tc0, f2 tc1, float texGrad)
 {
+#ifdef MI_PT_DIAG_NO_TEX  // cost-attribution build (tools/attribution.sh): wrong image, no texture filtering
+  return mk4(0.5f + 1e-3f * (tc0.x + tc1.y + texGrad + float(slot)));
+#endif
   const DevTexRef R  = tc.refs[slot];
   f2              t  = R.texCoord == 0 ? tc0 : tc1;
   const float*    U  = R.uv;
