@@ -203,6 +203,54 @@ def test_texture_decode_mips_and_srgb(built, tmp_path):
     assert np.abs(lvl1 - box).max() <= 0.5 + 1e-6  # linear image: 2x2 box filter, rounded to nearest
 
 
+def test_jpeg_decode(built, tmp_path):
+    """Baseline and progressive JPEG, 4:4:4 / 4:2:2 / 4:2:0 / grayscale, odd sizes, restart intervals, against libjpeg (via
+    Pillow) on the same bytes.  The entropy decoding is exact by definition; the inverse DCT, chroma upsampling and colour
+    conversion follow stb_image's integer arithmetic (what the reference uploads, src/gltf_image_loader.cpp:163-236), which
+    differs from libjpeg's by rounding only -- hence a small tolerance."""
+    PIL_Image = pytest.importorskip("PIL.Image")
+    import io
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:61, 0:83]
+    base = np.stack([127 + 120 * np.sin(xx / 9.0), 127 + 120 * np.cos(yy / 7.0 + xx / 23.0), (xx * 3 + yy * 2) % 256], -1)
+    base = np.clip(base + rng.normal(0, 6, base.shape), 0, 255).astype(np.uint8)
+    cases = [dict(quality=92, subsampling=0), dict(quality=85, subsampling=1), dict(quality=90, subsampling=2),
+             dict(quality=90, subsampling=2, progressive=True), dict(quality=75, subsampling=0, progressive=True),
+             dict(quality=88, subsampling=2, restart_marker_blocks=3), dict(quality=90, gray=True), dict(quality=90, gray=True, progressive=True)]
+    b = scenegen.GlbBuilder()
+    refs = []
+    for k, c in enumerate(cases):
+        c = dict(c)
+        gray = c.pop("gray", False)
+        im = PIL_Image.fromarray(base[..., 0] if gray else base, "L" if gray else "RGB")
+        buf = io.BytesIO()
+        im.save(buf, "JPEG", **c)
+        refs.append(np.asarray(PIL_Image.open(io.BytesIO(buf.getvalue())).convert("RGB")).astype(np.int32))
+        t = b.texture(b.image_bytes(buf.getvalue(), "image/jpeg"))
+        b.material({"pbrMetallicRoughness": {"metallicRoughnessTexture": {"index": t}}})  # a linear (non-sRGB) slot
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    b.node(mesh=b.mesh([b.primitive(pos, np.array([0, 1, 2]), material=m) for m in range(len(cases))]))
+    sc = ptmod.Scene(b.save(str(tmp_path / "j.glb")))
+    d = sc.desc.contents
+    assert d.numTextures == len(cases)
+    for k, ref in enumerate(refs):
+        t = d.textures[k]
+        assert (t.width, t.height) == (83, 61), cases[k]
+        got = np.ctypeslib.as_array(t.levels[0], shape=(61, 83, 4)).astype(np.int32)
+        assert (got[..., 3] == 255).all()
+        diff = np.abs(got[..., :3] - ref)
+        if cases[k].get("subsampling") == 1:
+            diff = diff[:, :-1]  # 4:2:2: stb_image weights the last output pair of a row the other way round than libjpeg
+        assert diff.max() <= 6 and diff.mean() <= 0.8, (cases[k], int(diff.max()), float(diff.mean()))
+    # garbage after the signature must fail cleanly into the 1x1 magenta placeholder, not crash
+    b2 = scenegen.GlbBuilder()
+    b2.material({"pbrMetallicRoughness": {"baseColorTexture": {"index": b2.texture(b2.image_bytes(b"\xff\xd8\xff\xe0" + bytes(40), "image/jpeg"))}}})
+    b2.node(mesh=b2.mesh([b2.primitive(pos, np.array([0, 1, 2]), material=0)]))
+    sc2 = ptmod.Scene(b2.save(str(tmp_path / "bad.glb")))
+    d2 = sc2.desc.contents
+    assert (d2.textures[0].width, d2.textures[0].height) == (1, 1)
+
+
 def test_hdr_importance_table(built, assets):
     hdr = ptmod.HdrEnvironment(path=os.path.join(assets, "std_env.hdr"))
     e = hdr.env.contents

@@ -70,6 +70,11 @@ class GlbBuilder:
         self.doc.setdefault("images", []).append({"bufferView": self._view(png_bytes(rgba)), "mimeType": "image/png"})
         return len(self.doc["images"]) - 1
 
+    def image_bytes(self, data, mime):
+        """An already encoded image (e.g. JPEG bytes) embedded as is."""
+        self.doc.setdefault("images", []).append({"bufferView": self._view(bytes(data)), "mimeType": mime})
+        return len(self.doc["images"]) - 1
+
     def sampler(self, mag=9729, min_=9987, wrap_s=10497, wrap_t=10497):
         self.doc.setdefault("samplers", []).append({"magFilter": mag, "minFilter": min_, "wrapS": wrap_s, "wrapT": wrap_t})
         return len(self.doc["samplers"]) - 1
