@@ -16,6 +16,8 @@ PT_DEV int posMod(int i, int n)
 {
   if((n & (n - 1)) == 0)
     return i & (n - 1);
+  if(i >= -n && i < 2 * n)  // one period either side (a lat-long environment map, uv in [0, 1] +- a texel)
+    return i < 0 ? i + n : (i >= n ? i - n : i);
   const int m = i % n;
   return m < 0 ? m + n : m;
 }
