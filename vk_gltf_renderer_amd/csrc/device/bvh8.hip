@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <vector>
@@ -45,7 +46,19 @@ struct Node8  // 80 bytes, see header
 };
 static_assert(sizeof(Node8) == 80, "Node8 must be 80 bytes");
 
-constexpr int MAX_LEAF_TRIS = 3;
+// Largest leaf child.  A node addresses its triangles through a 31-bit mask, so eight children of 3 always fit; with 4 a node
+// whose leaves would hold more than 31 falls back to 3 (MI_PT_LEAF_TRIS: tuning knob, the images do not depend on it).
+constexpr int MAX_LEAF_TRIS_DEFAULT = 2;  // measured: 2 beats 1, 3 and 4 on the helmet, atrium and street workloads (+0.4 .. +2.5 % over 3)
+
+static int maxLeafTris()
+{
+  static const int v = [] {
+    const char* e = getenv("MI_PT_LEAF_TRIS");
+    const int   n = e ? atoi(e) : MAX_LEAF_TRIS_DEFAULT;
+    return n < 1 ? 1 : (n > 4 ? 4 : n);
+  }();
+  return v;
+}
 
 struct Cand
 {
@@ -196,29 +209,41 @@ bool buildBvh8(const BvhBuildOutput& b2, Bvh8Output& out, hipStream_t stream, st
   }
   for(size_t qi = 0; qi < queue.size(); ++qi)
   {
-    std::vector<Cand> cands = std::move(queue[qi].cands);
-    const uint32_t    self  = queue[qi].node8;
-    // greedy: open the largest inner child that is too big to be a leaf until 8 children are reached
-    while(cands.size() < 8)
+    const std::vector<Cand> cands0 = std::move(queue[qi].cands);
+    std::vector<Cand>       cands;
+    const uint32_t          self = queue[qi].node8;
+    uint32_t                MAX_LEAF_TRIS = uint32_t(maxLeafTris());
+    for(;;)
     {
-      int   best = -1;
-      float bestA = -1.0f;
-      for(size_t k = 0; k < cands.size(); ++k)
-        if(cands[k].ref >= 0 && triCount(cands[k].ref) > uint32_t(MAX_LEAF_TRIS) && areaOf(cands[k]) > bestA)
-        {
-          bestA = areaOf(cands[k]);
-          best  = int(k);
-        }
-      if(best < 0)
+      cands = cands0;
+      // greedy: open the largest inner child that is too big to be a leaf until 8 children are reached
+      while(cands.size() < 8)
+      {
+        int   best = -1;
+        float bestA = -1.0f;
+        for(size_t k = 0; k < cands.size(); ++k)
+          if(cands[k].ref >= 0 && triCount(cands[k].ref) > MAX_LEAF_TRIS && areaOf(cands[k]) > bestA)
+          {
+            bestA = areaOf(cands[k]);
+            best  = int(k);
+          }
+        if(best < 0)
+          break;
+        int  ref = cands[size_t(best)].ref;
+        Cand a, b;
+        a.ref = childRef(ref, 0);
+        b.ref = childRef(ref, 1);
+        childBox(ref, 0, a.lo, a.hi);
+        childBox(ref, 1, b.lo, b.hi);
+        cands[size_t(best)] = a;
+        cands.push_back(b);
+      }
+      uint32_t leafTris = 0;
+      for(const Cand& c : cands)
+        leafTris += c.ref < 0 ? 1u : (triCount(c.ref) <= MAX_LEAF_TRIS ? triCount(c.ref) : 0u);
+      if(leafTris <= 31u || MAX_LEAF_TRIS <= 3u)
         break;
-      int  ref = cands[size_t(best)].ref;
-      Cand a, b;
-      a.ref = childRef(ref, 0);
-      b.ref = childRef(ref, 1);
-      childBox(ref, 0, a.lo, a.hi);
-      childBox(ref, 1, b.lo, b.hi);
-      cands[size_t(best)] = a;
-      cands.push_back(b);
+      MAX_LEAF_TRIS = 3u;  // would not fit the node's triangle mask
     }
     // node frame
     float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
@@ -317,7 +342,7 @@ bool buildBvh8(const BvhBuildOutput& b2, Bvh8Output& out, hipStream_t stream, st
       if(candOfSlot[s] < 0)
         continue;
       const Cand& c = cands[size_t(candOfSlot[s])];
-      if(c.ref >= 0 && triCount(c.ref) > uint32_t(MAX_LEAF_TRIS))
+      if(c.ref >= 0 && triCount(c.ref) > MAX_LEAF_TRIS)
       {
         N.imask |= uint8_t(1u << s);
         N.meta[s] = 0xff;
