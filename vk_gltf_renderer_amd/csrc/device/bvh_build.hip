@@ -263,7 +263,9 @@ __global__ void k_emit_nodes(int n, const uint32_t* vals, const float4* boxLo, c
 // (the Karras topology above only follows the Morton prefix and is ~1.5-2x worse on architectural scenes), and every
 // round is three flat kernels plus a prefix sum.  All decisions are tie-broken by position, node indices come from the
 // scan (no atomics), so the tree is a pure function of the input.
-constexpr int PLOC_RADIUS = 16;
+#ifndef PLOC_RADIUS
+#define PLOC_RADIUS 16
+#endif
 
 __global__ void k_ploc_init(int n, const uint32_t* vals, const float4* boxLo, const float4* boxHi, int* cid, float4* clo, float4* chi)
 {

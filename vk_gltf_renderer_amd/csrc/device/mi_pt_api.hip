@@ -102,6 +102,9 @@ struct MiPt
   DevBuf<pt::DevScene>        sceneDev;
   bool                        sceneDevDirty = true;
   DevBuf<pt::FrameConsts>     fcRing;
+  DevBuf<pt::SkyPrecomp>      skyPre;  // constants of the sky model for `skyPreFor` (k_sky_precomp)
+  MiSkyPhysicalParameters     skyPreFor{};
+  bool                        skyPreValid = false;
   pt::FrameConsts*            fcHost = nullptr;  // pinned, FC_RING entries
   hipEvent_t                  fcDone[FC_RING] = {};
   unsigned                    fcCursor = 0;
@@ -647,6 +650,16 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   memset(&c.fc, 0, sizeof(c.fc));
   c.fc.frameInfo = pt->frameInfo;
   c.fc.sky       = pt->sky;
+  if(!pt->skyPreValid || memcmp(&pt->skyPreFor, &pt->sky, sizeof(pt->sky)) != 0)
+  {
+    // stream-ordered behind the batches that still read the previous values
+    if(!pt->skyPre.ptr)
+      HIP_TRY(pt->skyPre.alloc(1));
+    pt::launchSkyPrecomp(pt->sky, pt->skyPre.ptr, stream);
+    pt->skyPreFor   = pt->sky;
+    pt->skyPreValid = true;
+  }
+  c.fc.skyPre    = pt->skyPre.ptr;
   c.fc.pc        = *params;
   c.fc.width     = pt->width;
   c.fc.height    = pt->height;

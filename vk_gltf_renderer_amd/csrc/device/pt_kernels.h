@@ -29,6 +29,7 @@ void launchBuildShadeRecords(const DevScene& scene, uint32_t numTris, DevShadeTr
 void launchBuildAlphaRecords(const DevScene& scene, uint32_t numTris, DevAlphaTri* out, hipStream_t s);
 void dumpTraceProfile();  // prints the -DTRACE_PROFILE section timers (no-op in the product build)
 void launchResetCounters(const Queues& Q, hipStream_t s);
+void launchSkyPrecomp(const MiSkyPhysicalParameters& sky, SkyPrecomp* out, hipStream_t stream);
 void launchGenerate(const LaunchCtx& c, int sampleIndex);
 void launchTraceClosest(const LaunchCtx& c, int cur);
 void launchTracePrimary(const LaunchCtx& c);  // bounce 0 of an 8-wide-BVH scene: packet walk of k_generate's camera rays (queue 0)

@@ -2026,6 +2026,17 @@ void launchResetCounters(const Queues& Q, hipStream_t s)
 {
   hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(64), 0, s, Q.counters);
 }
+// the per-parameter-set constants of the physical sky (FrameConsts::skyPre), with the device's own arithmetic
+__global__ void k_sky_precomp(MiSkyPhysicalParameters sky, SkyPrecomp* out)
+{
+  if(blockIdx.x == 0 && threadIdx.x == 0)
+    *out = makeSkyPrecomp(sky);
+}
+void launchSkyPrecomp(const MiSkyPhysicalParameters& sky, SkyPrecomp* out, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_sky_precomp, dim3(1), dim3(64), 0, stream, sky, out);
+}
+
 void launchGenerate(const LaunchCtx& c, int sampleIndex)
 {
   unsigned grid = (unsigned(c.fc.numSlots) * unsigned(c.fc.numFrames) + 255u) / 256u;

@@ -173,29 +173,60 @@ PT_DEV f4 environmentSample(const DevScene& sc, f3 xi, f3& toLight)
 // ---- physical sun & sky -----------------------------------------------------------------------------------------------------
 // Preetham/Shirley/Smits 1999 Perez sky + limb-darkened sun disc with glow + Lambertian ground; importance sampling is a
 // 50/50 mixture of the sun cone and the uniform sphere.  (nvshaders/sky_functions.h.slang is external to the reference.)
-PT_DEV float perez(float cosTheta, float gamma, float cosGamma, float c0, float c1, float c2, float c3, float c4)
-{
-  return (1.0f + c0 * expf(c1 / fmaxf(cosTheta, 0.01f))) * (1.0f + c2 * expf(c3 * gamma) + c4 * cosGamma * cosGamma);
-}
 PT_DEV f3    skyUp(const MiSkyPhysicalParameters& s) { return s.yIsUp ? mk3(0, 1, 0) : mk3(0, 0, 1); }
-PT_DEV float skySunAngularRadius(const MiSkyPhysicalParameters& s) { return 0.00465f * fmaxf(s.sunDiskScale, 0.0f) + 1e-6f; }
-PT_DEV float skySunConeAngle(const MiSkyPhysicalParameters& s) { return fminf(skySunAngularRadius(s) * 4.0f, 1.5f); }
-PT_DEV float skySunConeOneMinusCos(const MiSkyPhysicalParameters& s) { return 2.0f * sqr(sinf(0.5f * skySunConeAngle(s))); }
 PT_DEV float angleBetween(f3 a, f3 b) { return atan2f(length(cross(a, b)), dot(a, b)); }
-__device__ __noinline__ f3 evalPhysicalSky(const MiSkyPhysicalParameters& s, f3 dir)
+PT_DEV float skyPerez(float cosTheta, float gamma, float cosGamma, const float* c)
+{
+  return (1.0f + c[0] * expf(c[1] / fmaxf(cosTheta, 0.01f))) * (1.0f + c[2] * expf(c[3] * gamma) + c[4] * cosGamma * cosGamma);
+}
+PT_DEV SkyPrecomp makeSkyPrecomp(const MiSkyPhysicalParameters& s)
+{
+  SkyPrecomp k{};
+  const f3 up = skyUp(s), sunDir = normalize(mk3(s.sunDirection));
+  k.sunDir[0] = sunDir.x; k.sunDir[1] = sunDir.y; k.sunDir[2] = sunDir.z;
+  const float T = 2.0f + fmaxf(s.haze, 0.0f);
+  k.T      = T;
+  k.cosS   = clampf(dot(sunDir, up), -1.0f, 1.0f);
+  k.thetaS = acosf(k.cosS);
+  const float airmass = 1.0f / (fmaxf(k.cosS, 0.0f) + 0.15f * powf(fmaxf(93.885f - k.thetaS * 57.29578f, 1.0f), -1.253f));
+  const f3    tau     = mk3(0.06f, 0.11f, 0.22f) * (T * 0.5f);
+  const f3    sunE    = (k.cosS > -0.05f) ? exp3(-tau * airmass) * 100000.0f : mk3(0.0f);
+  k.sunE[0] = sunE.x; k.sunE[1] = sunE.y; k.sunE[2] = sunE.z;
+  k.tS = fminf(k.thetaS, 1.5f);
+  const float tS = k.tS, chi = (4.0f / 9.0f - T / 120.0f) * (K_PI - 2.0f * tS);
+  k.Yz = fmaxf((4.0453f * T - 4.9710f) * tanf(chi) - 0.2155f * T + 2.4192f, 0.0f);
+  const float t2 = tS * tS, t3 = t2 * tS, T2 = T * T;
+  k.xz = (0.00166f * t3 - 0.00375f * t2 + 0.00209f * tS) * T2 + (-0.02903f * t3 + 0.06377f * t2 - 0.03202f * tS + 0.00394f) * T
+         + (0.11693f * t3 - 0.21196f * t2 + 0.06052f * tS + 0.25886f);
+  k.yz = (0.00275f * t3 - 0.00610f * t2 + 0.00317f * tS) * T2 + (-0.04214f * t3 + 0.08970f * t2 - 0.04153f * tS + 0.00516f) * T
+         + (0.15346f * t3 - 0.26756f * t2 + 0.06670f * tS + 0.26688f);
+  k.cosTs = cosf(tS);
+  const float cY[5]  = {0.1787f * T - 1.4630f, -0.3554f * T + 0.4275f, -0.0227f * T + 5.3251f, 0.1206f * T - 2.5771f, -0.0670f * T + 0.3703f};
+  const float cX[5]  = {-0.0193f * T - 0.2592f, -0.0665f * T + 0.0008f, -0.0004f * T + 0.2125f, -0.0641f * T - 0.8989f, -0.0033f * T + 0.0452f};
+  const float cYy[5] = {-0.0167f * T - 0.2608f, -0.0950f * T + 0.0092f, -0.0079f * T + 0.2102f, -0.0441f * T - 1.6537f, -0.0109f * T + 0.0529f};
+  for(int i = 0; i < 5; ++i)
+  {
+    k.cY[i] = cY[i]; k.cX[i] = cX[i]; k.cYy[i] = cYy[i];
+  }
+  k.denY  = skyPerez(1.0f, tS, k.cosTs, cY);
+  k.denX  = skyPerez(1.0f, tS, k.cosTs, cX);
+  k.denYy = skyPerez(1.0f, tS, k.cosTs, cYy);
+  k.sunRadius       = 0.00465f * fmaxf(s.sunDiskScale, 0.0f) + 1e-6f;
+  k.coneAngle       = fminf(k.sunRadius * 4.0f, 1.5f);
+  k.coneOneMinusCos = 2.0f * sqr(sinf(0.5f * k.coneAngle));
+  k.omega           = K_TWO_PI * 2.0f * sqr(sinf(0.5f * k.sunRadius));
+  return k;
+}
+__device__ __noinline__ f3 evalPhysicalSky(const MiSkyPhysicalParameters& s, const SkyPrecomp& k, f3 dir)
 {
   if(s.multiplier <= 0.0f)
     return mk3(0.0f);
   f3    up     = skyUp(s);
-  f3    sunDir = normalize(mk3(s.sunDirection));
+  f3    sunDir = mk3(k.sunDir);
   f3    scale  = mk3(s.rgbUnitConversion) * s.multiplier;
-  float T      = 2.0f + fmaxf(s.haze, 0.0f);
-  float cosS   = clampf(dot(sunDir, up), -1.0f, 1.0f);
-  float thetaS = acosf(cosS);
+  float cosS   = k.cosS;
   float cosT   = dot(dir, up) - s.horizonHeight * 0.1f;
-  float airmass = 1.0f / (fmaxf(cosS, 0.0f) + 0.15f * powf(fmaxf(93.885f - thetaS * 57.29578f, 1.0f), -1.253f));
-  f3    tau     = mk3(0.06f, 0.11f, 0.22f) * (T * 0.5f);
-  f3    sunE    = (cosS > -0.05f) ? exp3(-tau * airmass) * 100000.0f : mk3(0.0f);
+  f3    sunE   = mk3(k.sunE);
   f3    result;
   if(cosT <= 0.0f)
   {
@@ -213,30 +244,17 @@ __device__ __noinline__ f3 evalPhysicalSky(const MiSkyPhysicalParameters& s, f3 
   {
     float cosGamma = clampf(dot(dir, sunDir), -1.0f, 1.0f);
     float gamma    = angleBetween(dir, sunDir);
-    float tS       = fminf(thetaS, 1.5f);
-    float chi      = (4.0f / 9.0f - T / 120.0f) * (K_PI - 2.0f * tS);
-    float Yz       = fmaxf((4.0453f * T - 4.9710f) * tanf(chi) - 0.2155f * T + 2.4192f, 0.0f);
-    float t2 = tS * tS, t3 = t2 * tS, T2 = T * T;
-    float xz = (0.00166f * t3 - 0.00375f * t2 + 0.00209f * tS) * T2 + (-0.02903f * t3 + 0.06377f * t2 - 0.03202f * tS + 0.00394f) * T
-               + (0.11693f * t3 - 0.21196f * t2 + 0.06052f * tS + 0.25886f);
-    float yz = (0.00275f * t3 - 0.00610f * t2 + 0.00317f * tS) * T2 + (-0.04214f * t3 + 0.08970f * t2 - 0.04153f * tS + 0.00516f) * T
-               + (0.15346f * t3 - 0.26756f * t2 + 0.06670f * tS + 0.26688f);
-    float cosTs = cosf(tS);
-    float Y = Yz * perez(cosT, gamma, cosGamma, 0.1787f * T - 1.4630f, -0.3554f * T + 0.4275f, -0.0227f * T + 5.3251f, 0.1206f * T - 2.5771f, -0.0670f * T + 0.3703f)
-              / perez(1.0f, tS, cosTs, 0.1787f * T - 1.4630f, -0.3554f * T + 0.4275f, -0.0227f * T + 5.3251f, 0.1206f * T - 2.5771f, -0.0670f * T + 0.3703f);
-    float x = xz * perez(cosT, gamma, cosGamma, -0.0193f * T - 0.2592f, -0.0665f * T + 0.0008f, -0.0004f * T + 0.2125f, -0.0641f * T - 0.8989f, -0.0033f * T + 0.0452f)
-              / perez(1.0f, tS, cosTs, -0.0193f * T - 0.2592f, -0.0665f * T + 0.0008f, -0.0004f * T + 0.2125f, -0.0641f * T - 0.8989f, -0.0033f * T + 0.0452f);
-    float y = yz * perez(cosT, gamma, cosGamma, -0.0167f * T - 0.2608f, -0.0950f * T + 0.0092f, -0.0079f * T + 0.2102f, -0.0441f * T - 1.6537f, -0.0109f * T + 0.0529f)
-              / perez(1.0f, tS, cosTs, -0.0167f * T - 0.2608f, -0.0950f * T + 0.0092f, -0.0079f * T + 0.2102f, -0.0441f * T - 1.6537f, -0.0109f * T + 0.0529f);
+    float Y = k.Yz * skyPerez(cosT, gamma, cosGamma, k.cY) / k.denY;
+    float x = k.xz * skyPerez(cosT, gamma, cosGamma, k.cX) / k.denX;
+    float y = k.yz * skyPerez(cosT, gamma, cosGamma, k.cYy) / k.denYy;
     Y       = fmaxf(Y, 0.0f) * 1000.0f * saturatef((cosS + 0.05f) * 10.0f);
     float X = (y > 1e-4f) ? x / y * Y : 0.0f, Z = (y > 1e-4f) ? (1.0f - x - y) / y * Y : 0.0f;
     result  = mk3(3.2406f * X - 1.5372f * Y - 0.4986f * Z, -0.9689f * X + 1.8758f * Y + 0.0415f * Z, 0.0557f * X - 0.2040f * Y + 1.0570f * Z);
     result  = max3(result, mk3(0.0f)) + mk3(s.nightColor) * 80000.0f;
-    float r = skySunAngularRadius(s);
+    float r = k.sunRadius;
     if(s.sunDiskIntensity > 0.0f && gamma < r * 4.0f)
     {
-      float omega = K_TWO_PI * 2.0f * sqr(sinf(0.5f * r));
-      f3    Lsun  = sunE / omega * s.sunDiskIntensity;
+      f3 Lsun = sunE / k.omega * s.sunDiskIntensity;
       if(gamma < r)
       {
         float mu = sqrtf(fmaxf(0.0f, 1.0f - sqr(gamma / r)));
@@ -253,12 +271,12 @@ __device__ __noinline__ f3 evalPhysicalSky(const MiSkyPhysicalParameters& s, f3 
   return result * scale;
 }
 PT_DEV float skySunWeight(const MiSkyPhysicalParameters& s) { return (s.sunDiskIntensity > 0.0f && s.multiplier > 0.0f) ? 0.5f : 0.0f; }
-PT_DEV float samplePhysicalSkyPDF(const MiSkyPhysicalParameters& s, f3 dir)
+PT_DEV float samplePhysicalSkyPDF(const MiSkyPhysicalParameters& s, const SkyPrecomp& k, f3 dir)
 {
   float wSun   = skySunWeight(s);
   float pdf    = (1.0f - wSun) * (0.25f * K_1_OVER_PI);
-  if(wSun > 0.0f && angleBetween(dir, normalize(mk3(s.sunDirection))) <= skySunConeAngle(s))
-    pdf += wSun / (K_TWO_PI * skySunConeOneMinusCos(s));
+  if(wSun > 0.0f && angleBetween(dir, mk3(k.sunDir)) <= k.coneAngle)
+    pdf += wSun / (K_TWO_PI * k.coneOneMinusCos);
   return pdf;
 }
 // Uniform direction inside a cone given 1 - cos(halfAngle); sin^2 = s (2 - s) keeps tiny cones (the sun) well conditioned.
@@ -272,12 +290,12 @@ PT_DEV f3 sampleCone(f2 xi, float oneMinusCosMax, f3 axis)
   f3    B        = cross(axis, T);
   return normalize(T * (sinTheta * cosf(phi)) + B * (sinTheta * sinf(phi)) + axis * cosTheta);
 }
-PT_DEV void samplePhysicalSky(const MiSkyPhysicalParameters& s, f2 xi, f3& direction, float& pdf, f3& radiance)
+PT_DEV void samplePhysicalSky(const MiSkyPhysicalParameters& s, const SkyPrecomp& k, f2 xi, f3& direction, float& pdf, f3& radiance)
 {
   float wSun = skySunWeight(s);
   float u    = xi.x;
   if(splitRandom(u, wSun))
-    direction = sampleCone(mk2(u, xi.y), skySunConeOneMinusCos(s), normalize(mk3(s.sunDirection)));
+    direction = sampleCone(mk2(u, xi.y), k.coneOneMinusCos, mk3(k.sunDir));
   else
   {
     float z   = 1.0f - 2.0f * u;
@@ -285,8 +303,8 @@ PT_DEV void samplePhysicalSky(const MiSkyPhysicalParameters& s, f2 xi, f3& direc
     float phi = K_TWO_PI * xi.y;
     direction = mk3(rr * cosf(phi), z, rr * sinf(phi));
   }
-  pdf      = samplePhysicalSkyPDF(s, direction);
-  radiance = evalPhysicalSky(s, direction);
+  pdf      = samplePhysicalSkyPDF(s, k, direction);
+  radiance = evalPhysicalSky(s, k, direction);
 }
 
 // ---- punctual lights (KHR_lights_punctual; reference call site pathtrace_functions.h.slang:406-412) -------------------------

@@ -127,10 +127,24 @@ struct DevScene
 };
 
 // ---- per-frame constants (kernel argument, ~600 B) ---------------------------------------------------------------------
+// What the physical sky model derives from its parameters alone (makeSkyPrecomp, pt_light.h): the same for every ray, so it
+// is computed once per parameter change by a one-thread kernel -- with the device's own arithmetic, i.e. bit-identical to
+// evaluating it in place -- instead of in every evaluation (an acos, a pow, a tan, two sines and nine exponentials per call).
+struct SkyPrecomp
+{
+  float sunDir[3], cosS;
+  float thetaS, tS, T, cosTs;
+  float sunE[3], Yz;
+  float xz, yz, sunRadius, coneAngle;
+  float coneOneMinusCos, omega, denY, denX;
+  float denYy, pad0, pad1, pad2;
+  float cY[5], cX[5], cYy[5], pad3;  // Perez coefficients of Y, x, y
+};
 struct FrameConsts
 {
   MiSceneFrameInfo        frameInfo;
   MiSkyPhysicalParameters sky;
+  const SkyPrecomp*       skyPre;  // device-resident, refreshed by k_sky_precomp when the sky parameters change
   MiPathtraceParams       pc;
   int                     width, height;
   int                     tileSize, tileShift;  // tileSize = 1 << tileShift, >= 16

@@ -627,11 +627,11 @@ __device__ __noinline__ void sampleLights(const DevScene& sc, const FrameConsts&
       {
         float r1 = rnd(seed), r2 = rnd(seed);
         f3    skyRadiance;
-        samplePhysicalSky(fc.sky, mk2(r1, r2), dl.direction, envPdf, skyRadiance);
+        samplePhysicalSky(fc.sky, *fc.skyPre, mk2(r1, r2), dl.direction, envPdf, skyRadiance);
         radiance = skyRadiance / (envPdf * envWeight);
       }
       else
-        envPdf = samplePhysicalSkyPDF(fc.sky, dl.direction);
+        envPdf = samplePhysicalSkyPDF(fc.sky, *fc.skyPre, dl.direction);
     }
     else
     {
@@ -670,8 +670,8 @@ PT_DEV void sampleEnvironment(const DevScene& sc, const FrameConsts& fc, f3 dire
 {
   if(!hasFlag(fc.frameInfo.flags, MI_SCENE_USE_HDR_ENVIRONMENT))
   {
-    envColor = evalPhysicalSky(fc.sky, direction);
-    envPdf   = samplePhysicalSkyPDF(fc.sky, direction);
+    envColor = evalPhysicalSky(fc.sky, *fc.skyPre, direction);
+    envPdf   = samplePhysicalSkyPDF(fc.sky, *fc.skyPre, direction);
   }
   else
   {
