@@ -217,7 +217,8 @@ PT_DEV SkyPrecomp makeSkyPrecomp(const MiSkyPhysicalParameters& s)
   k.omega           = K_TWO_PI * 2.0f * sqr(sinf(0.5f * k.sunRadius));
   return k;
 }
-__device__ __noinline__ f3 evalPhysicalSky(const MiSkyPhysicalParameters& s, const SkyPrecomp& k, f3 dir)
+// `gamma` = angleBetween(dir, sun direction): the caller has it from the pdf (samplePhysicalSkyPDF) -- one atan2 instead of two
+__device__ __noinline__ f3 evalPhysicalSky(const MiSkyPhysicalParameters& s, const SkyPrecomp& k, f3 dir, float gamma)
 {
   if(s.multiplier <= 0.0f)
     return mk3(0.0f);
@@ -243,7 +244,6 @@ __device__ __noinline__ f3 evalPhysicalSky(const MiSkyPhysicalParameters& s, con
   else
   {
     float cosGamma = clampf(dot(dir, sunDir), -1.0f, 1.0f);
-    float gamma    = angleBetween(dir, sunDir);
     float Y = k.Yz * skyPerez(cosT, gamma, cosGamma, k.cY) / k.denY;
     float x = k.xz * skyPerez(cosT, gamma, cosGamma, k.cX) / k.denX;
     float y = k.yz * skyPerez(cosT, gamma, cosGamma, k.cYy) / k.denYy;
@@ -271,14 +271,15 @@ __device__ __noinline__ f3 evalPhysicalSky(const MiSkyPhysicalParameters& s, con
   return result * scale;
 }
 PT_DEV float skySunWeight(const MiSkyPhysicalParameters& s) { return (s.sunDiskIntensity > 0.0f && s.multiplier > 0.0f) ? 0.5f : 0.0f; }
-PT_DEV float samplePhysicalSkyPDF(const MiSkyPhysicalParameters& s, const SkyPrecomp& k, f3 dir)
+PT_DEV float samplePhysicalSkyPDF(const MiSkyPhysicalParameters& s, const SkyPrecomp& k, float gamma)
 {
   float wSun   = skySunWeight(s);
   float pdf    = (1.0f - wSun) * (0.25f * K_1_OVER_PI);
-  if(wSun > 0.0f && angleBetween(dir, mk3(k.sunDir)) <= k.coneAngle)
+  if(wSun > 0.0f && gamma <= k.coneAngle)
     pdf += wSun / (K_TWO_PI * k.coneOneMinusCos);
   return pdf;
 }
+PT_DEV float skyGamma(const SkyPrecomp& k, f3 dir) { return angleBetween(dir, mk3(k.sunDir)); }
 // Uniform direction inside a cone given 1 - cos(halfAngle); sin^2 = s (2 - s) keeps tiny cones (the sun) well conditioned.
 PT_DEV f3 sampleCone(f2 xi, float oneMinusCosMax, f3 axis)
 {
@@ -303,8 +304,9 @@ PT_DEV void samplePhysicalSky(const MiSkyPhysicalParameters& s, const SkyPrecomp
     float phi = K_TWO_PI * xi.y;
     direction = mk3(rr * cosf(phi), z, rr * sinf(phi));
   }
-  pdf      = samplePhysicalSkyPDF(s, k, direction);
-  radiance = evalPhysicalSky(s, k, direction);
+  const float gamma = skyGamma(k, direction);
+  pdf      = samplePhysicalSkyPDF(s, k, gamma);
+  radiance = evalPhysicalSky(s, k, direction, gamma);
 }
 
 // ---- punctual lights (KHR_lights_punctual; reference call site pathtrace_functions.h.slang:406-412) -------------------------

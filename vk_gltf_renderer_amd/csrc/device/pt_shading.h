@@ -631,7 +631,7 @@ __device__ __noinline__ void sampleLights(const DevScene& sc, const FrameConsts&
         radiance = skyRadiance / (envPdf * envWeight);
       }
       else
-        envPdf = samplePhysicalSkyPDF(fc.sky, *fc.skyPre, dl.direction);
+        envPdf = samplePhysicalSkyPDF(fc.sky, *fc.skyPre, skyGamma(*fc.skyPre, dl.direction));
     }
     else
     {
@@ -670,8 +670,9 @@ PT_DEV void sampleEnvironment(const DevScene& sc, const FrameConsts& fc, f3 dire
 {
   if(!hasFlag(fc.frameInfo.flags, MI_SCENE_USE_HDR_ENVIRONMENT))
   {
-    envColor = evalPhysicalSky(fc.sky, *fc.skyPre, direction);
-    envPdf   = samplePhysicalSkyPDF(fc.sky, *fc.skyPre, direction);
+    const float gamma = skyGamma(*fc.skyPre, direction);
+    envColor = evalPhysicalSky(fc.sky, *fc.skyPre, direction, gamma);
+    envPdf   = samplePhysicalSkyPDF(fc.sky, *fc.skyPre, gamma);
   }
   else
   {
