@@ -106,6 +106,37 @@ def test_ragged_resolution_and_tiles(built, assets):
     assert (np.sum(parts, axis=0) == full).all()  # disjoint tiles, bit-identical to the 1-rank frame
 
 
+def test_edge_cases_empty_view_degenerate_triangles_tiny_images(built, tmp_path):
+    """Nothing in view (every ray misses: the image is the environment, bit for bit what the oracle computes), a scene with
+    no geometry at all, zero-area triangles next to real ones, and 1x1 / 3x2 images (a single partial wave)."""
+    env = np.full((32, 64, 3), 0.7, np.float32)
+    b = scenegen.GlbBuilder()
+    b.material({})
+    pos = np.array([[100, 100, 100], [101, 100, 100], [100, 101, 100]], np.float32)  # far away from the view
+    b.node(mesh=b.mesh([b.primitive(pos, np.array([0, 1, 2]), material=0)]))
+    b.camera_node((0, 0, 3), (0, 0, 0))
+    s = pu.Setup(b.save(str(tmp_path / "miss.glb")), 70, 45, hdr_pixels=env)
+    g = pu.render_gpu(s, 2)
+    assert np.allclose(g["accum"][..., :3], 0.7, rtol=1e-6) and (g["accum"][..., 3] == 0).all()
+    assert (g["selection"] == 0).all() and (g["depth"] == 1.0).all()
+    _check(pu.render_oracle(s, 2), g)
+    b = scenegen.GlbBuilder()  # no mesh at all: empty acceleration structure
+    b.camera_node((0, 0, 3), (0, 0, 0))
+    s = pu.Setup(b.save(str(tmp_path / "nothing.glb")), 33, 17, hdr_pixels=env)
+    g = pu.render_gpu(s, 3, in_flight=3)
+    assert np.allclose(g["accum"][..., :3], 0.7, rtol=1e-6) and g["stats"]["segments"] == g["stats"]["cameraPaths"]
+    b = scenegen.GlbBuilder()
+    m = b.material(scenegen.lambert_material((0.8, 0.6, 0.4)))
+    p, n, uv, idx = scenegen.grid(4, 4, (2.0, 2.0), "z")
+    idx = np.concatenate([idx, np.array([[0, 0, 0], [1, 1, 6], [2, 7, 12]], np.uint32)])  # point, line and collinear triangles
+    b.node(mesh=b.mesh([b.primitive(p, idx, n, uv, material=m)]))
+    b.camera_node((0.3, 0.2, 3), (0, 0, 0))
+    path = b.save(str(tmp_path / "degenerate.glb"))
+    for w, h in ((64, 48), (1, 1), (3, 2)):
+        s = pu.Setup(path, w, h, hdr_pixels=env, max_depth=3)
+        _check(pu.render_oracle(s, 4), pu.render_gpu(s, 4), within_1e4=0.0 if w < 8 else 0.97, within_1e2=0.0 if w < 8 else 0.99)
+
+
 def test_textured_helmet_class(built, tmp_path):
     """Textures (sRGB + linear, normal map, occlusion, emissive), ray-cone LOD, tangents: DamagedHelmet-class stand-in."""
     path = scenegen.scene_helmet_class(str(tmp_path / "helmet.glb"), seed=7, tess=48, tex_size=128)
