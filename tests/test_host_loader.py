@@ -251,6 +251,76 @@ def test_jpeg_decode(built, tmp_path):
     assert (d2.textures[0].width, d2.textures[0].height) == (1, 1)
 
 
+def _dds(width, height, payload, fourcc=None, dxgi=None, bits=0, masks=(0, 0, 0, 0), pf_flags=None):
+    """A minimal DDS container (124-byte header, optional DX10 extension) around `payload`."""
+    import struct
+    if dxgi is not None:
+        fourcc = b"DX10"
+    flags = pf_flags if pf_flags is not None else (0x4 if fourcc else 0x41)
+    pf = struct.pack("<II4sIIIII", 32, flags, fourcc or b"\0\0\0\0", bits, *masks)
+    hdr = struct.pack("<IIIIIII44x", 124, 0x1007, height, width, 0, 0, 1) + pf + struct.pack("<IIIII", 0x1000, 0, 0, 0, 0)
+    assert len(hdr) == 124
+    ext = struct.pack("<IIIII", dxgi, 3, 0, 1, 0) if dxgi is not None else b""
+    return b"DDS " + hdr + ext + bytes(payload)
+
+
+def test_dds_decode_and_texture_extension_sources(built, tmp_path):
+    """MSFT_texture_dds images (BC1-BC5 and uncompressed layouts, decoded on the host since there is no texture unit on this
+    path) and the reference's rule for a texture's effective image (src/tinygltf_utils.cpp:718-732); a container this front
+    end cannot decode falls back to the texture's core `source`."""
+    import struct
+    red, blue = 0xF800, 0x001F
+    idx = sum(((i % 4) << (2 * i)) for i in range(16))  # texel i uses palette entry i % 4
+    bc1 = struct.pack("<HHI", red, blue, idx)
+    bc1_punch = struct.pack("<HHI", blue, red, idx)
+    a_idx = sum(((i % 8) << (3 * i)) for i in range(16))
+    ramp = bytes([255, 0]) + a_idx.to_bytes(6, "little")
+    ramp_lo = bytes([10, 200]) + a_idx.to_bytes(6, "little")  # a0 <= a1: six-entry ramp + 0 and 255
+    bc2 = bytes([(i % 16) | (((i + 1) % 16) << 4) for i in range(0, 16, 2)]) + bc1
+    cases = {
+        "bc1": _dds(4, 4, bc1, b"DXT1"), "bc1p": _dds(4, 4, bc1_punch, b"DXT1"), "bc2": _dds(4, 4, bc2, b"DXT3"),
+        "bc3": _dds(4, 4, ramp + bc1_punch, dxgi=77), "bc4": _dds(4, 4, ramp_lo, b"ATI1"), "bc5": _dds(4, 4, ramp + ramp_lo, dxgi=83),
+        "bgra": _dds(3, 2, bytes(range(24)), bits=32, masks=(0xff0000, 0xff00, 0xff, 0xff000000)),
+        "rgb565": _dds(2, 1, struct.pack("<HH", red, 0x07E0), bits=16, masks=(0xF800, 0x07E0, 0x001F, 0), pf_flags=0x40),
+        "crop": _dds(5, 3, bc1 * 2, b"DXT1"),
+    }
+    b = scenegen.GlbBuilder()
+    b.ext_used.add("MSFT_texture_dds")
+    png = b.image(np.full((2, 2, 4), 99, np.uint8))
+    for k, data in cases.items():
+        img = b.image_bytes(data, "image/vnd-ms.dds")
+        b.doc.setdefault("textures", []).append({"source": png, "extensions": {"MSFT_texture_dds": {"source": img}}})
+    junk = b.image_bytes(b"\xabKTX 20\xbb\r\n\x1a\n" + bytes(64), "image/ktx2")
+    b.doc["textures"].append({"source": png, "extensions": {"KHR_texture_basisu": {"source": junk}}})  # falls back to the PNG
+    b.doc["textures"].append({"extensions": {"KHR_texture_basisu": {"source": junk}}})                   # nothing to fall back to
+    b.material({"pbrMetallicRoughness": {"metallicRoughnessTexture": {"index": 0}}})
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    b.node(mesh=b.mesh([b.primitive(pos, np.array([0, 1, 2]), material=0)]))
+    sc = ptmod.Scene(b.save(str(tmp_path / "d.glb")))
+    d = sc.desc.contents
+    tex = {}
+    for i, k in enumerate(list(cases) + ["fallback", "magenta"]):
+        t = d.textures[i]
+        tex[k] = np.ctypeslib.as_array(t.levels[0], shape=(t.height, t.width, 4)).astype(int)
+    pal = [(255, 0, 0, 255), (0, 0, 255, 255), (170, 0, 85, 255), (85, 0, 170, 255)]
+    assert [tuple(v) for v in tex["bc1"].reshape(16, 4)] == [pal[i % 4] for i in range(16)]
+    palp = [(0, 0, 255, 255), (255, 0, 0, 255), (128, 0, 128, 255), (0, 0, 0, 0)]
+    assert [tuple(v) for v in tex["bc1p"].reshape(16, 4)] == [palp[i % 4] for i in range(16)]
+    assert [tuple(v) for v in tex["bc2"].reshape(16, 4)] == [pal[i % 4][:3] + ((i % 16) * 17,) for i in range(16)]
+    ramp8 = [255, 0, 219, 182, 146, 109, 73, 36]
+    pal3 = [(0, 0, 255), (255, 0, 0), (85, 0, 170), (170, 0, 85)]  # BC3 colour blocks have no punch-through mode
+    assert [tuple(v) for v in tex["bc3"].reshape(16, 4)] == [pal3[i % 4] + (ramp8[i % 8],) for i in range(16)]
+    ramp6 = [10, 200, 48, 86, 124, 162, 0, 255]
+    assert [tuple(v) for v in tex["bc4"].reshape(16, 4)] == [(ramp6[i % 8], 0, 0, 255) for i in range(16)]
+    assert [tuple(v) for v in tex["bc5"].reshape(16, 4)] == [(ramp8[i % 8], ramp6[i % 8], 0, 255) for i in range(16)]
+    raw = np.arange(24).reshape(2, 3, 4)
+    assert (tex["bgra"] == raw[..., [2, 1, 0, 3]]).all()
+    assert [tuple(v) for v in tex["rgb565"].reshape(2, 4)] == [(255, 0, 0, 255), (0, 255, 0, 255)]
+    assert tex["crop"].shape == (3, 5, 4) and tuple(tex["crop"][2, 4]) == pal[(2 * 4 + 0) % 4]
+    assert tex["fallback"].shape == (2, 2, 4) and (tex["fallback"] == 99).all()
+    assert tex["magenta"].shape == (1, 1, 4) and tuple(tex["magenta"][0, 0]) == (255, 0, 255, 255)
+
+
 def test_hdr_importance_table(built, assets):
     hdr = ptmod.HdrEnvironment(path=os.path.join(assets, "std_env.hdr"))
     e = hdr.env.contents

@@ -712,10 +712,21 @@ void GltfScene::buildTextures(const std::string& baseDir)
 {
   // sRGB image set (reference: src/gltf_scene_vk.cpp:1102-1154)
   std::vector<bool> srgbImage(m_doc["images"].size(), false);
-  auto textureImage = [&](int texID) -> int {
-    const Value& t = m_doc["textures"][size_t(texID)];
-    return t.isObject() ? getInt(t, "source", -1) : -1;
+  // Effective image of a texture: `source`, overridden by the `source` of EXT_texture_webp, MSFT_texture_dds,
+  // KHR_texture_basisu in that order, the last one present winning (reference: src/tinygltf_utils.cpp:42-47, :718-732)
+  auto textureImageOf = [&](const Value& t) -> int {
+    if(!t.isObject())
+      return -1;
+    int img = getInt(t, "source", -1);
+    for(const char* name : {"EXT_texture_webp", "MSFT_texture_dds", "KHR_texture_basisu"})
+    {
+      const Value& e = ext(t, name);
+      if(e.isObject())
+        img = getInt(e, "source", img);
+    }
+    return img;
   };
+  auto textureImage = [&](int texID) -> int { return textureImageOf(m_doc["textures"][size_t(texID)]); };
   auto markSrgb = [&](const Value& tinfo) {
     if(!tinfo.isObject())
       return;
@@ -741,7 +752,7 @@ void GltfScene::buildTextures(const std::string& baseDir)
   for(size_t i = 0; i < texs.size(); ++i)
     if(texs[i]["extras"]["gamma"].number(0.0) > 1.0)
     {
-      int img = getInt(texs[i], "source", -1);
+      int img = textureImageOf(texs[i]);
       if(img >= 0 && size_t(img) < srgbImage.size())
         srgbImage[size_t(img)] = true;
     }
@@ -749,6 +760,7 @@ void GltfScene::buildTextures(const std::string& baseDir)
   // Decode every image once.
   const Value&       images = m_doc["images"];
   std::vector<Image> decoded(images.size());
+  std::vector<bool>  decodedOk(images.size(), false);
   for(size_t i = 0; i < images.size(); ++i)
   {
     std::vector<uint8_t> bytes;
@@ -772,6 +784,8 @@ void GltfScene::buildTextures(const std::string& baseDir)
       fprintf(stderr, "[mihost] image %zu not decodable (%s): using 1x1 magenta\n", i, err.c_str());
       decoded[i] = magentaImage();  // reference: src/gltf_scene_vk.cpp:1057-1060
     }
+    else
+      decodedOk[i] = true;
   }
 
   m_textures.clear();
@@ -779,7 +793,18 @@ void GltfScene::buildTextures(const std::string& baseDir)
   for(size_t i = 0; i < texs.size(); ++i)
   {
     TextureData& t   = m_textures[i];
-    int          img = getInt(texs[i], "source", -1);
+    int          img = textureImageOf(texs[i]);
+    // The containers this front end does not decode (KTX2 / Basis, WebP, BC6H / BC7 DDS): where the file also carries the
+    // core PNG / JPEG `source` as its fallback, that one is used instead of the magenta placeholder (the reference decodes
+    // the extension image itself).  The sRGB classification goes with the image actually used.
+    const int core = getInt(texs[i], "source", -1);
+    if(img != core && img >= 0 && size_t(img) < decoded.size() && !decodedOk[size_t(img)] && core >= 0 && size_t(core) < decoded.size()
+       && decodedOk[size_t(core)])
+    {
+      if(srgbImage[size_t(img)])
+        srgbImage[size_t(core)] = true;
+      img = core;
+    }
     Image        base = (img >= 0 && size_t(img) < decoded.size()) ? decoded[size_t(img)] : magentaImage();
     t.srgb            = (img >= 0 && size_t(img) < srgbImage.size()) ? bool(srgbImage[size_t(img)]) : false;
     t.width           = base.width;

@@ -1,8 +1,8 @@
 // Image decode for the glTF front end: PNG (all colour types / bit depths, non-interlaced and Adam7) -> RGBA8 here, JPEG in
 // jpeg_decoder.cpp, plus mip-chain generation.  Mirrors what the reference obtains from stb_image in src/gltf_image_loader.cpp:163-236 and
 // from the blit chain in src/gltf_scene_vk.cpp:1247-1347 (nvvk::cmdGenerateMipmaps: each level is a LINEAR-filtered
-// 2:1 blit of the previous one; for sRGB formats the hardware filters in linear light).
-// KTX2/DDS/WebP are a "next" row; an undecodable image becomes the reference's 1x1 magenta
+// 2:1 blit of the previous one; for sRGB formats the hardware filters in linear light).  DDS: dds_decoder.cpp.
+// KTX2/WebP are a "next" row; an undecodable image becomes the reference's 1x1 magenta
 // (src/gltf_scene_vk.cpp:1057-1060).
 #include "image_loader.hpp"
 
@@ -301,8 +301,10 @@ bool decodeImage(const uint8_t* data, size_t size, Image& out, std::string* erro
     return decodePng(data, size, out, error);
   if(isJpeg(data, size))
     return decodeJpeg(data, size, out, error);
+  if(isDds(data, size))
+    return decodeDds(data, size, out, error);
   if(error)
-    *error = "unsupported image container (PNG and JPEG are decoded; KTX2/DDS/WebP are not implemented yet)";
+    *error = "unsupported image container (PNG, JPEG and DDS are decoded; KTX2 and WebP are not)";
   return false;
 }
 

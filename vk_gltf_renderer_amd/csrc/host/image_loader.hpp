@@ -16,6 +16,8 @@ bool    isPng(const uint8_t* data, size_t size);
 bool    decodePng(const uint8_t* data, size_t size, Image& out, std::string* error);
 bool    isJpeg(const uint8_t* data, size_t size);
 bool    decodeJpeg(const uint8_t* data, size_t size, Image& out, std::string* error);  // jpeg_decoder.cpp
+bool    isDds(const uint8_t* data, size_t size);
+bool    decodeDds(const uint8_t* data, size_t size, Image& out, std::string* error);  // dds_decoder.cpp
 bool    decodeImage(const uint8_t* data, size_t size, Image& out, std::string* error);
 Image   magentaImage();
 float   srgbToLinear(uint8_t v);
