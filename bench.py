@@ -10,7 +10,7 @@ itself is not available offline; vk_gltf_renderer_amd.scenegen writes a seeded s
 Metric = the reference's throughput_MSps (src/benchmarking.cpp:272-279): W*H*spp / wall_s / 1e6 with spp = all samples
 of the timed region, inputs resident in HBM before the timed region.
 
-N > 1: the image is split into interleaved 64x64 tiles (tile % N == rank), every rank renders its tiles with no data-path
+N > 1: the image is split into interleaved 32x32 tiles (--tile; tile % N == rank), every rank renders its tiles with no data-path
 collective, and ONE RCCL reduce(sum) of the RGBA32F accumulator over xGMI closes the frame set (inside the timed
 region).  The batch is in_flight * N frames, i.e. the work per GPU is fixed as N grows -> "weak" scaling.
 
@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tile", type=int, default=32,
+                    help="edge of the interleaved tiles the image is dealt out in (tile %% world == rank); 32 balances the 8 ranks of the "
+                         "helmet workload to 4 %% (64: 19 %%, tools/check_rank_of_8.py)")
     ap.add_argument("--bvh", type=int, default=0, help="bit0: 0 = 8-wide compressed BVH (default), 1 = plain BVH2; bit1: 0 = PLOC topology (default), 1 = LBVH")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--in-flight", type=int, default=32,
@@ -124,7 +127,7 @@ def main():
         t = ptmod.PathTracer(scene, device=local_rank, collect_counters=counters, bvh=args.bvh)
         if hdr is not None:
             t.set_environment(hdr)
-        t.set_tile_partition(rank, world, 64)
+        t.set_tile_partition(rank, world, args.tile)
         t.resize(W, H)
         t.set_frame_info(frame_info)
         t.set_sky(ptmod.default_sky())
@@ -202,7 +205,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": w["config"] + " (seeded synthetic stand-in)" if w["gen"] else w["config"], "scene_triangles": scene.num_triangles,
-                       "resolution": [W, H], "spp_per_step": F, "frames_in_flight": F, "max_depth": w["depth"], "tile": 64,
+                       "resolution": [W, H], "spp_per_step": F, "frames_in_flight": F, "max_depth": w["depth"], "tile": args.tile,
                        "parallelism": f"tiles{world}" if world > 1 else "single"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_launch_ms": round(avg_launch_ms, 5),
