@@ -361,7 +361,7 @@ struct Decoder
 
   bool readScan(const uint8_t* s, int len)
   {
-    int ns = s[0];
+    int ns = len >= 1 ? s[0] : 0;
     if(ns < 1 || ns > ncomp || len < 1 + 2 * ns + 3)
       return fail("bad SOS");
     Component* sc[3];
