@@ -104,13 +104,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # (BENCH_SHARE_GPU=1 + BENCH_DIST_BACKEND=gloo: all ranks on one device over gloo -- a functional check of the N > 1 code on
+    #  a single-GPU box, not a measurement)
+    if os.environ.get("BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     w = WORKLOADS[args.workload]
     W, H = args.width or w["width"], args.height or w["height"]
