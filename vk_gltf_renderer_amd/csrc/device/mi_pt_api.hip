@@ -469,6 +469,9 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
     pt->staticStats.bvhNodeBytes     = 64;
     pt->staticStats.bvhTriangleBytes = sizeof(pt::DevTri);
     pt->wide = !(options && (options->bvhBuilder & 1) != 0);
+    // the triangle rounds of the 8-wide walk pack (triangle index | owner lane << 26) into one word (pt_kernels.hip)
+    if(pt->wide && bo.numTris >= (1u << 26))
+      return fail(MI_PT_ERR_ARGUMENT, "scene has 2^26 or more triangles: beyond what the 8-wide BVH walk indexes (select the BVH2 walk, bvhBuilder bit 0)");
     if(pt->wide && bo.numTris > 0)
     {
       pt::Bvh8Output b8;
