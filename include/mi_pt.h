@@ -148,7 +148,8 @@ typedef struct MiPt MiPt;
 
 /* replaces PathTracer::onAttach + SceneVk::create + SceneRtx BLAS/TLAS build
  * (reference: src/renderer_pathtracer.cpp:150-260, src/gltf_scene_vk.cpp:218, src/gltf_scene_rtx.cpp:173-385).
- * Uploads the tables, builds the BVH on the device. */
+ * Uploads the tables, builds the BVH on the device.  MI_PT_ERR_ARGUMENT: inconsistent tables, a texture pool of 2^32 texels
+ * or more, or -- with the default 8-wide BVH -- 2^26 or more flattened triangles (the BVH2 walk, bvhBuilder bit 0, has no such limit). */
 MI_PT_API int mi_pt_create(const MiPtSceneDesc* scene, const MiPtCreateOptions* options, MiPt** out);
 
 /* replaces PathTracer::onDetach (reference: src/renderer_base.hpp:40) */
