@@ -2923,4 +2923,10 @@ void oracle_bsdf_sample(const float* m, const float* k1, const float* xi, float*
   out8[7] = float(d.event_type);
 }
 float oracle_round_to_half(float f) { return roundToHalf(f); }
+void oracle_light_contribution(const MiGltfLight* light, const float* pos, const float* xi, float* out8)
+{
+  LightContrib c = singleLightContribution(*light, float3(pos), float3(0, 0, 1), float2(xi[0], xi[1]));
+  out8[0] = c.incidentVector.x; out8[1] = c.incidentVector.y; out8[2] = c.incidentVector.z; out8[3] = c.distance;
+  out8[4] = c.intensity.x; out8[5] = c.intensity.y; out8[6] = c.intensity.z; out8[7] = c.pdf;
+}
 }

@@ -38,6 +38,8 @@ void     oracle_sky_sample(const MiSkyPhysicalParameters* s, float u, float v, f
 void  oracle_bsdf_eval(const float* m, const float* k1, const float* k2, const float* xi, float* out7);
 void  oracle_bsdf_sample(const float* m, const float* k1, const float* xi, float* out8);
 float oracle_round_to_half(float f);
+/* out8 = incidentVector[3] distance intensity[3] pdf of singleLightContribution(light, pos, xi) */
+void  oracle_light_contribution(const MiGltfLight* light, const float* pos, const float* xi, float* out8);
 #ifdef __cplusplus
 }
 #endif

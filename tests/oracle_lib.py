@@ -46,6 +46,7 @@ def lib():
             "oracle_bsdf_eval": (None, [P(f32), P(f32), P(f32), P(f32), P(f32)]),
             "oracle_bsdf_sample": (None, [P(f32), P(f32), P(f32), P(f32)]),
             "oracle_round_to_half": (f32, [f32]),
+            "oracle_light_contribution": (None, [P(capi.MiGltfLight), P(f32), P(f32), P(f32)]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)

@@ -46,6 +46,21 @@ def test_pt_library_exports_header():
     assert "oracle" not in needed
 
 
+def test_pt_library_is_built_from_this_tree():
+    """Stale-binary guard: libmi_pt.so is git-ignored and travels prebuilt to the GPU box; its baked-in source id
+    (csrc/Makefile: sha1 over csrc/device/* + include/mi_pt*.h) must be the one of the sources in this tree."""
+    lib = os.path.join(capi.LIB_DIR, "libmi_pt.so")
+    if not os.path.exists(lib):
+        pytest.skip("libmi_pt.so not built yet (run __graft_entry__.build())")
+    version = capi.pt_lib().mi_pt_version().decode()
+    assert f"src={capi.device_source_id()}" in version, (version, capi.device_source_id())
+
+
+@pytest.mark.gpu
+def test_pt_library_is_built_from_this_tree_on_the_gpu_box():
+    test_pt_library_is_built_from_this_tree()
+
+
 def test_product_fails_loudly_without_gpu(built, assets):
     """No CPU fallback: without a HIP device mi_pt_create must return MI_PT_ERR_NO_DEVICE, never render on the host."""
     lib = os.path.join(capi.LIB_DIR, "libmi_pt.so")

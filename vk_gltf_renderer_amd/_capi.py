@@ -132,6 +132,7 @@ assert C.sizeof(MiSceneFrameInfo) == 396
 MI_PT_USE_DLSS, MI_PT_USE_OPTIX_DENOISER, MI_PT_FIRST_FRAME = 1, 2, 4
 MI_SCENE_IS_ORTHOGRAPHIC, MI_SCENE_USE_SOLID_BACKGROUND, MI_SCENE_USE_HDR_ENVIRONMENT = 1, 2, 4
 MI_SCENE_USE_INFINITE_PLANE, MI_SCENE_INFINITE_PLANE_SHADOW_CATCHER = 8, 16
+MI_LIGHT_NONE, MI_LIGHT_DIRECTIONAL, MI_LIGHT_SPOT, MI_LIGHT_POINT = 0, 1, 2, 3  # shaders/gltf_scene_io.h.slang:72-78
 
 P = C.POINTER
 VP = C.c_void_p
@@ -214,3 +215,18 @@ def pt_lib():
             raise RuntimeError(f"{path} is missing: the HIP extension was not built; the product path has no fallback")
         _pt = _bind(C.CDLL(path), PT_SYMBOLS)
     return _pt
+
+
+def device_source_id():
+    """sha1 (first 16 hex digits) over the device sources + public headers, exactly as csrc/Makefile bakes it into libmi_pt.so:
+    mi_pt_version() of a library built from this tree contains "src=<this>"."""
+    import glob
+    import hashlib
+    root = os.path.dirname(_HERE)
+    dev = os.path.join(_HERE, "csrc", "device")
+    files = sorted(glob.glob(os.path.join(dev, "*.hip")) + glob.glob(os.path.join(dev, "*.h")), key=os.path.basename)
+    files += [os.path.join(root, "include", "mi_pt.h"), os.path.join(root, "include", "mi_pt_shaderio.h")]
+    h = hashlib.sha1()
+    for f in files:
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]

@@ -253,7 +253,14 @@ const char* mi_pt_last_error(void)
 }
 const char* mi_pt_version(void)
 {
-  return "mi_pt 0.1 (gfx950 wavefront path tracer)";
+#ifndef MI_PT_SRC_ID
+#define MI_PT_SRC_ID "unknown"
+#endif
+#ifndef MI_PT_GIT_ID
+#define MI_PT_GIT_ID "nogit"
+#endif
+  // src = sha1 of the device sources + public headers this binary was compiled from (csrc/Makefile), git = HEAD at build time
+  return "mi_pt 0.2 (gfx950 wavefront path tracer) src=" MI_PT_SRC_ID " git=" MI_PT_GIT_ID;
 }
 
 int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt** out)

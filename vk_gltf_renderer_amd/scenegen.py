@@ -132,8 +132,12 @@ class GlbBuilder:
         self.doc.setdefault("cameras", []).append({"type": "perspective", "perspective": {"yfov": yfov, "znear": znear, "zfar": zfar, "aspectRatio": aspect}})
         return len(self.doc["cameras"]) - 1
 
-    def camera_node(self, eye, center, up=(0, 1, 0), yfov=0.7854, znear=0.05, zfar=1000.0):
-        cam = self.camera(yfov, znear, zfar)
+    def camera_ortho(self, xmag, ymag, znear, zfar):
+        self.doc.setdefault("cameras", []).append({"type": "orthographic", "orthographic": {"xmag": xmag, "ymag": ymag, "znear": znear, "zfar": zfar}})
+        return len(self.doc["cameras"]) - 1
+
+    def camera_node(self, eye, center, up=(0, 1, 0), yfov=0.7854, znear=0.05, zfar=1000.0, ortho=None):
+        cam = self.camera(yfov, znear, zfar) if ortho is None else self.camera_ortho(ortho[0], ortho[1], znear, zfar)
         eye, center, up = (np.asarray(v, np.float64) for v in (eye, center, up))
         f = center - eye
         f /= np.linalg.norm(f)
@@ -619,4 +623,203 @@ def scene_glass_class(path, seed=99, tess=48):
     li = b.light({"type": "point", "intensity": 300.0, "color": [1, 1, 1], "extras": {"radius": 0.25}})
     b.node(extensions={"KHR_lights_punctual": {"light": li}}, translation=[0.0, 5.0, 2.0])
     b.camera_node((0.0, 3.2, 5.2), (0, 0.3, 0), yfov=0.75)
+    return b.save(path)
+
+
+# ---- material zoo: one small scene per glTF material extension / renderer feature (parity tests of every BSDF lobe) -------------
+def _sphere_tangents(pos):
+    d = pos / np.maximum(np.linalg.norm(pos, axis=1, keepdims=True), 1e-12)
+    tan = np.stack([-d[:, 2], np.zeros(len(d)), d[:, 0]], 1)
+    ln = np.linalg.norm(tan, axis=1, keepdims=True)
+    tan = np.where(ln > 1e-6, tan / np.maximum(ln, 1e-6), np.array([1.0, 0, 0]))
+    return np.concatenate([tan, np.ones((len(tan), 1))], 1).astype(np.float32)
+
+
+ZOO_GROUPS = ("clearcoat", "sheen", "iridescence", "anisotropy", "specgloss", "specular", "diffuse_transmission", "retroreflection",
+              "unlit_emissive", "blend", "texture_transform", "vertex_streams")
+
+
+def zoo_materials(b, group, rng, tex_size=64):
+    """The materials of one zoo group (list of glTF material dicts); textures are added to builder `b`."""
+    smp = b.sampler()
+    smp_clamp = b.sampler(wrap_s=33071, wrap_t=33648)  # CLAMP_TO_EDGE / MIRRORED_REPEAT
+
+    def tex(rgb, alpha=None, sampler=smp):
+        rgb = np.asarray(rgb, np.float64)
+        if rgb.ndim == 2:
+            rgb = np.repeat(rgb[..., None], 3, -1)
+        a = np.ones(rgb.shape[:2]) if alpha is None else alpha
+        img = np.concatenate([rgb, a[..., None]], -1)
+        return b.texture(b.image((np.clip(img, 0, 1) * 255 + 0.5).astype(np.uint8)), sampler)
+
+    def noise(ch=3, oct_=4):
+        n = value_noise(rng, tex_size, oct_, ch)
+        return n if ch > 1 else n[..., 0]
+
+    def nmap(strength=6.0):
+        h = noise(1, 5)
+        gx, gy = np.roll(h, -1, 1) - np.roll(h, 1, 1), np.roll(h, -1, 0) - np.roll(h, 1, 0)
+        n = np.stack([-gx * strength, -gy * strength, np.ones_like(gx)], -1)
+        n /= np.linalg.norm(n, axis=-1, keepdims=True)
+        return n * 0.5 + 0.5
+
+    def mr(color, metallic, roughness, **extra):
+        m = {"pbrMetallicRoughness": {"baseColorFactor": [*[float(c) for c in color], 1.0], "metallicFactor": float(metallic), "roughnessFactor": float(roughness)}}
+        m.update(extra)
+        return m
+
+    if group == "clearcoat":
+        return [
+            mr((0.8, 0.1, 0.1), 0.0, 0.6, extensions={"KHR_materials_clearcoat": {"clearcoatFactor": 1.0, "clearcoatRoughnessFactor": 0.05}}),
+            mr((0.1, 0.3, 0.8), 1.0, 0.4, extensions={"KHR_materials_clearcoat": {"clearcoatFactor": 0.7, "clearcoatRoughnessFactor": 0.3}}),
+            mr((0.2, 0.7, 0.2), 0.0, 0.5, normalTexture={"index": tex(nmap()), "scale": 0.8},
+               extensions={"KHR_materials_clearcoat": {"clearcoatFactor": 1.0, "clearcoatRoughnessFactor": 0.6, "clearcoatTexture": {"index": tex(noise(3))},
+                                                       "clearcoatRoughnessTexture": {"index": tex(noise(3))}, "clearcoatNormalTexture": {"index": tex(nmap(3.0))}}}),
+        ]
+    if group == "sheen":
+        return [
+            mr((0.3, 0.05, 0.3), 0.0, 0.8, extensions={"KHR_materials_sheen": {"sheenColorFactor": [0.9, 0.8, 1.0], "sheenRoughnessFactor": 0.3}}),
+            mr((0.05, 0.2, 0.4), 0.0, 0.9, extensions={"KHR_materials_sheen": {"sheenColorFactor": [1.0, 1.0, 1.0], "sheenRoughnessFactor": 0.8,
+                                                                                "sheenColorTexture": {"index": tex(0.3 + 0.7 * noise(3))},
+                                                                                "sheenRoughnessTexture": {"index": tex(noise(3), 0.2 + 0.8 * noise(1))}}}),
+            mr((0.5, 0.5, 0.5), 0.6, 0.5, extensions={"KHR_materials_sheen": {"sheenColorFactor": [0.2, 0.9, 0.4], "sheenRoughnessFactor": 0.05}}),
+        ]
+    if group == "iridescence":
+        return [
+            mr((0.05, 0.05, 0.05), 0.0, 0.2, extensions={"KHR_materials_iridescence": {"iridescenceFactor": 1.0, "iridescenceIor": 1.3, "iridescenceThicknessMaximum": 400.0}}),
+            mr((0.9, 0.8, 0.7), 1.0, 0.15, extensions={"KHR_materials_iridescence": {"iridescenceFactor": 0.8, "iridescenceIor": 1.8, "iridescenceThicknessMinimum": 150.0,
+                                                                                     "iridescenceThicknessMaximum": 900.0, "iridescenceTexture": {"index": tex(0.4 + 0.6 * noise(3))},
+                                                                                     "iridescenceThicknessTexture": {"index": tex(noise(3))}}}),
+            mr((0.6, 0.6, 0.9), 0.3, 0.4, extensions={"KHR_materials_iridescence": {"iridescenceFactor": 0.5, "iridescenceThicknessMaximum": 250.0},
+                                                       "KHR_materials_specular": {"specularColorFactor": [1.0, 0.6, 0.3]}}),
+        ]
+    if group == "anisotropy":
+        an = np.concatenate([0.5 + 0.5 * np.cos(noise(1)[..., None] * 6.28), 0.5 + 0.5 * np.sin(noise(1)[..., None] * 6.28), noise(1)[..., None]], -1)
+        return [
+            mr((0.9, 0.9, 0.9), 1.0, 0.35, extensions={"KHR_materials_anisotropy": {"anisotropyStrength": 0.9, "anisotropyRotation": 0.0}}),
+            mr((0.9, 0.6, 0.2), 1.0, 0.25, extensions={"KHR_materials_anisotropy": {"anisotropyStrength": 0.7, "anisotropyRotation": 1.1}}),
+            mr((0.2, 0.2, 0.8), 0.0, 0.3, normalTexture={"index": tex(nmap(3.0))},
+               extensions={"KHR_materials_anisotropy": {"anisotropyStrength": 1.0, "anisotropyRotation": 0.4, "anisotropyTexture": {"index": tex(an)}}}),
+        ]
+    if group == "specgloss":
+        return [
+            {"extensions": {"KHR_materials_pbrSpecularGlossiness": {"diffuseFactor": [0.7, 0.3, 0.1, 1.0], "specularFactor": [0.04, 0.04, 0.04], "glossinessFactor": 0.6}}},
+            {"extensions": {"KHR_materials_pbrSpecularGlossiness": {"diffuseFactor": [0.05, 0.05, 0.05, 1.0], "specularFactor": [0.9, 0.7, 0.3], "glossinessFactor": 0.8}}},
+            {"extensions": {"KHR_materials_pbrSpecularGlossiness": {"diffuseFactor": [1.0, 1.0, 1.0, 1.0], "specularFactor": [1.0, 1.0, 1.0], "glossinessFactor": 1.0,
+                                                                   "diffuseTexture": {"index": tex(0.2 + 0.8 * noise(3))},
+                                                                   "specularGlossinessTexture": {"index": tex(0.3 * noise(3), 0.3 + 0.7 * noise(1))}}}},
+        ]
+    if group == "specular":
+        return [
+            mr((0.7, 0.2, 0.2), 0.0, 0.3, extensions={"KHR_materials_specular": {"specularFactor": 0.3, "specularColorFactor": [0.2, 0.6, 1.0]}}),
+            mr((0.2, 0.2, 0.2), 0.0, 0.2, extensions={"KHR_materials_specular": {"specularFactor": 1.0, "specularColorFactor": [1.0, 1.0, 1.0],
+                                                                                  "specularTexture": {"index": tex(noise(3), noise(1))},
+                                                                                  "specularColorTexture": {"index": tex(0.2 + 0.8 * noise(3))}},
+                                                       "KHR_materials_ior": {"ior": 1.9}}),
+            mr((0.8, 0.8, 0.8), 0.0, 0.5, occlusionTexture={"index": tex(0.3 + 0.7 * noise(3)), "strength": 0.7},
+               emissiveFactor=[1.0, 1.0, 1.0], emissiveTexture={"index": tex(np.clip((noise(3) - 0.6) * 4.0, 0, 1))},
+               extensions={"KHR_materials_emissive_strength": {"emissiveStrength": 2.5}}),
+        ]
+    if group == "diffuse_transmission":
+        return [
+            mr((0.8, 0.7, 0.3), 0.0, 0.7, doubleSided=True, extensions={"KHR_materials_diffuse_transmission": {"diffuseTransmissionFactor": 0.7,
+                                                                                                              "diffuseTransmissionColorFactor": [0.9, 0.5, 0.2]}}),
+            mr((0.3, 0.7, 0.3), 0.0, 0.5, doubleSided=True,
+               extensions={"KHR_materials_diffuse_transmission": {"diffuseTransmissionFactor": 1.0, "diffuseTransmissionColorFactor": [1.0, 1.0, 1.0],
+                                                                  "diffuseTransmissionTexture": {"index": tex(noise(3), 0.2 + 0.8 * noise(1))},
+                                                                  "diffuseTransmissionColorTexture": {"index": tex(0.3 + 0.7 * noise(3))}}}),
+            mr((0.6, 0.6, 0.9), 0.0, 0.4, extensions={"KHR_materials_diffuse_transmission": {"diffuseTransmissionFactor": 0.4},
+                                                       "KHR_materials_volume": {"thicknessFactor": 0.5, "attenuationDistance": 0.8, "attenuationColor": [0.9, 0.4, 0.4]}}),
+        ]
+    if group == "retroreflection":
+        return [
+            mr((0.8, 0.8, 0.1), 0.0, 0.3, extensions={"KHR_materials_retroreflection": {"retroreflectionFactor": 1.0}}),
+            mr((0.9, 0.9, 0.9), 1.0, 0.25, extensions={"KHR_materials_retroreflection": {"retroreflectionFactor": 0.6, "retroreflectionTexture": {"index": tex(noise(3))}}}),
+            mr((0.2, 0.3, 0.8), 0.0, 0.5, extensions={"KHR_materials_retroreflection": {"retroreflectionFactor": 0.5},
+                                                       "KHR_materials_clearcoat": {"clearcoatFactor": 0.8, "clearcoatRoughnessFactor": 0.1},
+                                                       "KHR_materials_sheen": {"sheenColorFactor": [0.5, 0.5, 0.5], "sheenRoughnessFactor": 0.5}}),
+        ]
+    if group == "unlit_emissive":
+        return [
+            mr((0.2, 0.8, 0.9), 0.0, 0.5, extensions={"KHR_materials_unlit": {}}),
+            {"pbrMetallicRoughness": {"baseColorTexture": {"index": tex(0.2 + 0.8 * noise(3))}, "metallicFactor": 0.0}, "extensions": {"KHR_materials_unlit": {}}},
+            mr((0.1, 0.1, 0.1), 0.0, 0.6, emissiveFactor=[1.0, 0.5, 0.2], extensions={"KHR_materials_emissive_strength": {"emissiveStrength": 4.0}}),
+        ]
+    if group == "blend":
+        a = (noise(1, 3) > 0.45).astype(np.float64) * 0.8 + 0.1
+        return [
+            {"pbrMetallicRoughness": {"baseColorFactor": [0.9, 0.2, 0.2, 0.45], "metallicFactor": 0.0, "roughnessFactor": 0.6}, "alphaMode": "BLEND", "doubleSided": True},
+            {"pbrMetallicRoughness": {"baseColorFactor": [1.0, 1.0, 1.0, 0.9], "baseColorTexture": {"index": tex(0.3 + 0.7 * noise(3), a)}, "metallicFactor": 0.0,
+                                      "roughnessFactor": 0.4}, "alphaMode": "BLEND"},
+            {"pbrMetallicRoughness": {"baseColorFactor": [0.3, 0.8, 0.3, 1.0], "baseColorTexture": {"index": tex(np.ones((tex_size, tex_size, 3)), noise(1, 3))},
+                                      "metallicFactor": 0.0, "roughnessFactor": 0.7}, "alphaMode": "MASK", "alphaCutoff": 0.55, "doubleSided": True},
+        ]
+    if group == "texture_transform":
+        chk = ((np.indices((tex_size, tex_size)).sum(0) // max(1, tex_size // 8)) % 2).astype(np.float64)
+        base = np.stack([0.2 + 0.7 * chk, 0.3 + 0.5 * noise(1), 0.9 - 0.6 * chk], -1)
+        t0, t1 = tex(base), tex(base, sampler=smp_clamp)
+        return [
+            {"pbrMetallicRoughness": {"baseColorTexture": {"index": t0, "extensions": {"KHR_texture_transform": {"offset": [0.25, 0.1], "scale": [3.0, 2.0], "rotation": 0.5}}},
+                                      "metallicFactor": 0.0, "roughnessFactor": 0.6}},
+            {"pbrMetallicRoughness": {"baseColorTexture": {"index": t1, "extensions": {"KHR_texture_transform": {"offset": [-0.4, 0.3], "scale": [2.5, 2.5]}}},
+                                      "metallicFactor": 0.0, "roughnessFactor": 0.6}},
+            {"pbrMetallicRoughness": {"baseColorTexture": {"index": t0, "texCoord": 0, "extensions": {"KHR_texture_transform": {"texCoord": 1, "rotation": -0.8, "scale": [1.5, 4.0]}}},
+                                      "metallicRoughnessTexture": {"index": tex(noise(3)), "extensions": {"KHR_texture_transform": {"scale": [4.0, 4.0]}}}, "metallicFactor": 1.0}},
+        ]
+    if group == "vertex_streams":
+        return [
+            mr((1.0, 1.0, 1.0), 0.0, 0.6),  # COLOR_0 (u8 normalised) modulates base colour
+            {"pbrMetallicRoughness": {"baseColorTexture": {"index": tex(0.2 + 0.8 * noise(3)), "texCoord": 1}, "metallicFactor": 0.0, "roughnessFactor": 0.5},
+             "occlusionTexture": {"index": tex(0.3 + 0.7 * noise(3)), "texCoord": 1}},
+            {"pbrMetallicRoughness": {"baseColorFactor": [1.0, 1.0, 1.0, 1.0], "metallicFactor": 0.0, "roughnessFactor": 0.5}, "alphaMode": "BLEND"},  # COLOR_0 alpha (float)
+        ]
+    raise KeyError(group)
+
+
+def scene_material_zoo(path, group, seed=21, tess=32, tex_size=64, lights="point", camera="perspective"):
+    """Three spheres carrying the materials of `group` over a Lambert floor + a back wall.  lights: "point" (sphere light + spot), "none"
+    (environment only).  camera: "perspective" | "ortho"."""
+    rng = np.random.default_rng(seed)
+    b = GlbBuilder()
+    mats = [b.material(m) for m in zoo_materials(b, group, rng, tex_size)]
+    floor = b.material(lambert_material((0.5, 0.5, 0.5)))
+    pos, nrm, uv, idx = grid(4, 4, (12, 12), "y")
+    b.node(mesh=b.mesh([b.primitive(pos, idx, nrm, uv, material=floor)]))
+    wall = b.material(lambert_material((0.7, 0.6, 0.5)))
+    pos, nrm, uv, idx = grid(4, 4, (12, 6), "z")
+    b.node(mesh=b.mesh([b.primitive(pos, idx, nrm, uv, material=wall)]), translation=[0, 3.0, -2.2])
+    sp_pos, sp_nrm, sp_uv, sp_idx = uv_sphere(tess, tess // 2, 0.8)
+    tan = _sphere_tangents(sp_pos)
+    for k, m in enumerate(mats):
+        kw = {}
+        if group == "vertex_streams":
+            d = sp_pos / 0.8
+            if k == 0:
+                kw["colors"] = (np.clip(np.concatenate([0.5 + 0.5 * d, np.ones((len(d), 1))], 1), 0, 1) * 255 + 0.5).astype(np.uint8)
+            if k == 1:
+                kw["uv1"] = np.stack([sp_uv[:, 1] * 2.0, sp_uv[:, 0] * 3.0], 1).astype(np.float32)
+            if k == 2:
+                kw["colors"] = np.concatenate([np.full((len(d), 3), 0.8), 0.15 + 0.85 * np.clip(0.5 + 0.5 * d[:, 1:2], 0, 1)], 1).astype(np.float32)
+        elif group == "texture_transform":
+            kw["uv1"] = np.stack([sp_uv[:, 1], sp_uv[:, 0]], 1).astype(np.float32)
+        b.node(mesh=b.mesh([b.primitive(sp_pos, sp_idx, sp_nrm, sp_uv, tangents=tan, material=m, **kw)]), translation=[-1.9 + 1.9 * k, 0.81, 0.0],
+               rotation=[0.0, float(np.sin(0.3 * k)), 0.0, float(np.cos(0.3 * k))])
+    if lights == "point":
+        li = b.light({"type": "point", "intensity": 260.0, "color": [1.0, 0.95, 0.9], "extras": {"radius": 0.3}})
+        b.node(extensions={"KHR_lights_punctual": {"light": li}}, translation=[1.5, 4.5, 3.0])
+        ls = b.light({"type": "spot", "intensity": 500.0, "color": [0.8, 0.9, 1.0], "spot": {"innerConeAngle": 0.25, "outerConeAngle": 0.5}})
+        # light direction = -Z of the node: aim at the middle sphere from the upper left
+        f = np.array([0.0, 0.8, 0.0]) - np.array([-3.0, 4.0, 2.5])
+        f /= np.linalg.norm(f)
+        zaxis = -f
+        xaxis = np.cross([0, 1, 0], zaxis)
+        xaxis /= np.linalg.norm(xaxis)
+        yaxis = np.cross(zaxis, xaxis)
+        m = np.eye(4)
+        m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = xaxis, yaxis, zaxis, [-3.0, 4.0, 2.5]
+        b.node(extensions={"KHR_lights_punctual": {"light": ls}}, matrix=[float(v) for v in m.T.reshape(-1)])
+    if camera == "ortho":
+        b.camera_node((0.0, 2.6, 6.0), (0, 0.7, 0), ortho=(3.4, 2.55))
+    else:
+        b.camera_node((0.0, 2.6, 6.0), (0, 0.7, 0), yfov=0.62)
     return b.save(path)
