@@ -125,7 +125,10 @@ def test_converged_image_within_north_star_tolerance(built, tmp_path):
     o, g = pu.render_oracle(s, 8), pu.render_gpu(s, 8)
     m = _check(o, g, rel_l2=1e-3)
     print("converged parity:", m)
+    # Refractive spheres are chaotic: a last-bit difference grows by the curvature at every bounce, so a few paths per thousand take
+    # another way on the two sides; both sides stay unbiased estimates of the same pixel, and the difference falls like Monte-Carlo
+    # noise (measured on the MI355X box: rel-L2 2.8e-3 at 384 spp, 4.6e-4 at 3072 spp).  Hence 3072 spp here.
     path = scenegen.scene_glass_class(str(tmp_path / "glass.glb"), seed=3, tess=16)
     s = pu.Setup(path, 96, 64, max_depth=12, hdr_path=HDR, spp_per_frame=64)
-    m = _check(pu.render_oracle(s, 6), pu.render_gpu(s, 6), rel_l2=1e-3, within_1e4=0.9)
+    m = _check(pu.render_oracle(s, 48), pu.render_gpu(s, 48, in_flight=8), rel_l2=1e-3, within_1e4=0.9, alpha_tol=5e-3)
     print("converged parity (transmission/volume):", m)

@@ -20,13 +20,15 @@ pytestmark = pytest.mark.gpu
 COUNTERS = ("cameraPaths", "segments", "shadowRays", "textureTaps")
 
 
-def _check(o, g, rel_l2=2e-3, within_1e2=0.99, within_1e4=0.97, counters=True, counter_rel=2e-3, depth_tol=2e-6):
+def _check(o, g, rel_l2=2e-3, within_1e2=0.99, within_1e4=0.97, counters=True, counter_rel=2e-3, depth_tol=2e-6, alpha_tol=5e-4):
     m = pu.compare_images(o["accum"], g["accum"])
     assert np.isfinite(g["accum"]).all()
     assert m["rel_l2"] <= rel_l2, m
     assert m["frac_within_1e-2"] >= within_1e2, m
     assert m["frac_within_1e-4"] >= within_1e4, m
-    assert m["alpha_max_abs"] <= 1e-4, m  # alpha is scaled by the firefly clamp factor (gltf_pathtrace.slang:535-538)
+    # alpha is 0/1 per sample times the firefly clamp factor threshold / luminance (gltf_pathtrace.slang:535-538): on a clamped sample
+    # it carries the relative error of that sample's luminance, so it gets the per-pixel colour tolerance of a bright sample
+    assert m["alpha_max_abs"] <= alpha_tol, m
     assert (o["selection"] == g["selection"]).mean() >= 0.9999
     assert np.abs(o["depth"] - g["depth"]).max() <= depth_tol
     if counters:

@@ -819,7 +819,9 @@ def scene_material_zoo(path, group, seed=21, tess=32, tex_size=64, lights="point
         m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = xaxis, yaxis, zaxis, [-3.0, 4.0, 2.5]
         b.node(extensions={"KHR_lights_punctual": {"light": ls}}, matrix=[float(v) for v in m.T.reshape(-1)])
     if camera == "ortho":
-        b.camera_node((0.0, 2.6, 6.0), (0, 0.7, 0), ortho=(3.4, 2.55))
+        # zfar kept small: the reference's getRay puts an orthographic ray's origin on the clip-space z = -1 plane, i.e. (zfar - 2 znear)
+        # BEHIND the eye under Vulkan's [0, 1] depth range, and every hit inherits |origin| * 2^-24 of rounding from that distance
+        b.camera_node((0.0, 2.6, 6.0), (0, 0.7, 0), ortho=(3.4, 2.55), znear=0.05, zfar=24.0)
     else:
         b.camera_node((0.0, 2.6, 6.0), (0, 0.7, 0), yfov=0.62)
     return b.save(path)
