@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the path-trace hot path on N MI355X GPUs of one node.
 
-A "step" is one pass of the hot path over one batch of synthetic input: a batch of `--in-flight` (default 32) consecutive
-frames per GPU, each ptSamples = 1 sample per pixel like the reference's headless run `--frames K --ptSamples 1`
-(docs/benchmarking.md:16-23), issued through mi_pt_render_frames so that the frames share every wavefront launch
-(bit-identical to rendering them one after the other; --in-flight 1 gives exactly that), of the workload BASELINE.json's
-metric is quoted on and that fits one GPU: configs[1], DamagedHelmet-class + std_env.hdr, 1920x1080, depth 8 (the asset
-itself is not available offline; vk_gltf_renderer_amd.scenegen writes a seeded stand-in of the same class as a .glb).
-Metric = the reference's throughput_MSps (src/benchmarking.cpp:272-279): W*H*spp / wall_s / 1e6 with spp = all samples
-of the timed region, inputs resident in HBM before the timed region.
+A "step" is one pass of the hot path over one batch of synthetic input: `--frames-per-step` (default 192) consecutive frames
+per GPU, each ptSamples = 1 sample per pixel like the reference's headless run `--frames K --ptSamples 1`
+(docs/benchmarking.md:16-23), of the workload BASELINE.json's metric is quoted on and that fits one GPU: configs[1],
+DamagedHelmet-class + std_env.hdr, 1920x1080, depth 8 (the asset itself is not available offline;
+vk_gltf_renderer_amd.scenegen writes a seeded stand-in of the same class as a .glb).  The frames of a step are issued through
+mi_pt_render_frames in groups of `--in-flight` (default 32) that share every wavefront launch (bit-identical to rendering them
+one after the other; --in-flight 1 gives exactly that).  Metric = the reference's throughput_MSps (src/benchmarking.cpp:272-279):
+W*H*spp / wall_s / 1e6 with spp = all samples of the timed region, inputs resident in HBM before the timed region.
 
 N > 1: the image is split into interleaved 32x32 tiles (--tile; tile % N == rank), every rank renders its tiles with no data-path
-collective, and ONE RCCL reduce(sum) of the RGBA32F accumulator over xGMI closes the frame set (inside the timed
-region).  The batch is in_flight * N frames, i.e. the work per GPU is fixed as N grows -> "weak" scaling.
+collective, and ONE RCCL reduce(sum) of the RGBA32F accumulator over xGMI closes every step (inside the timed region).  A rank
+owns 1/N of every frame, so a step renders frames_per_step * N frames: the work per GPU is fixed as N grows -> "weak" scaling.
 
-Prints ONE JSON line on rank 0.
+Rank 0 prints ONE JSON line.  Besides the driver's fields it carries
+  roofline      the dominant kernel against the roof that bounds it ("hbm": algorithmic bytes per launch over the launch time vs
+                8 TB/s; "valu": useful vector-lane operations per launch over the launch time vs 78.6 Tlaneop/s), and under
+                "kernels" the same for every kernel of the step (DESIGN.md §4 states the byte / operation model);
+  cpu_baseline  the CPU oracle timed on the host cores on a bounded sample of the same frames;
+  parity        the GPU accumulator against the oracle's on exactly those sample tiles (same frames, same seeds).
 """
 import argparse
 import ctypes as C
@@ -41,7 +46,16 @@ WORKLOADS = {
                   kw=dict(seed=99, tess=96), width=1920, height=1080, depth=24, hdr=True),
     "box": dict(config="configs[0]: resources/Box.glb, 256x256, depth 4", gen=None, kw={}, width=256, height=256, depth=4, hdr=True),
 }
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+# /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy); 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T
+# vector-lane operations per second (a wave64 instruction issues over 2 cycles; x2 flops per fma = the 157.3 TFLOP/s fp32 peak)
+HBM_PEAK_GBS = 8000.0
+VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+# Vector-ALU instructions of the two inner operations of the BVH walk, counted in the compiled code (tools/count_valu.sh):
+# one 8-wide node visit (decode + 8 slab tests + child order) and one triangle test (Moeller-Trumbore + candidate update).
+VALU_PER_NODE, VALU_PER_TRI = 235, 56
+# SURVEY §8(d) algorithmic bytes, per unit: ray + hit record, path state read + write, hit-attribute gather, instance +
+# primitive + material records, shadow-ray record, one texture tap, pixel accumulate
+B_RAYHIT, B_STATE, B_ATTR, B_RECORDS, B_SHADOW, B_TAP, B_PIXEL = 60, 192, 192, 480, 76, 48, 32
 
 
 def scene_path(name, rank):
@@ -60,19 +74,52 @@ def scene_path(name, rank):
     return path
 
 
-def algorithmic_bytes(stats, kernel):
-    """SURVEY §8(d) per-launch algorithmic bytes from exported counters (no cache effects, by definition)."""
-    s_node, s_tri = stats["bvhNodeBytes"], stats["bvhTriangleBytes"]
-    if kernel == "trace_closest":
-        # per ray: ray read (origin+tmax, dir+cone: 32 B) + hit write (16 B) + nodes * S_node + triangles * S_tri
-        return stats["segments"] * (32 + 16) + stats["nodesClosest"] * s_node + stats["trisClosest"] * s_tri
-    if kernel == "trace_shadow":
-        return stats["shadowRays"] * (3 * 16 + 2 * 16) + stats["nodesShadow"] * s_node + stats["trisShadow"] * s_tri
-    if kernel == "shade":
-        # hit + ray + throughput + radiance + misc read (5 x 16) and write-back of ray/throughput/radiance/misc (5 x 16),
-        # hit attribute gather 192 B, instance+primitive+material records 136+56+288, shadow record 48, 48 B per texture tap
-        return stats["segments"] * (80 + 80 + 192 + 480 + 48) + stats["textureTaps"] * 48
-    raise KeyError(kernel)
+def kernel_table(all_b, first_b, timing, frames):
+    """Per-kernel roofline entries.  all_b / first_b: counters PER FRAME of the whole path loop and of bounce 0 alone (a second
+    counter pass with maxDepth = 1); timing: MiPtFrameTiming totals over `frames` frames.  A kernel's algorithmic work per launch
+    is (work per frame) x (frames per launch); SURVEY §8(d) defines the bytes, hit/miss aware: a segment that leaves the scene
+    carries its ray and path state only, the attribute / record / texture / shadow terms belong to the surface hits."""
+    rest = {k: all_b[k] - first_b.get(k, 0) for k in all_b}
+    fused = timing["tracePrimaryLaunches"] > 0
+
+    def shade_bytes(c, shaded):
+        return shaded * (B_RAYHIT + B_STATE) + c["surfaceHits"] * (B_ATTR + B_RECORDS + B_SHADOW) + c["textureTaps"] * B_TAP
+
+    def walk_ops(nodes, tris, per_wave):
+        return (nodes * VALU_PER_NODE + tris * VALU_PER_TRI) * (64 if per_wave else 1)
+
+    rows = {}
+
+    def add(name, ms, launches, bound, work_per_frame, note):
+        if launches <= 0 or ms <= 0:
+            return
+        per_launch = work_per_frame * frames / launches
+        avg_ms = ms / launches
+        if bound == "hbm":
+            achieved, peak, unit = per_launch / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+        else:
+            achieved, peak, unit = per_launch / (avg_ms * 1e-3) / 1e12, VALU_PEAK_TLANEOPS, "Tlaneop/s"
+        rows[name] = {"bound": bound, "achieved": round(achieved, 3), "peak": round(peak, 2), "unit": unit, "frac": round(achieved / peak, 4),
+                      "avg_launch_ms": round(avg_ms, 5), "launches": launches, "ms_per_frame": round(ms / frames, 5),
+                      "work_per_launch": round(per_launch), "model": note}
+
+    if fused:
+        add("trace_primary", timing["tracePrimaryMs"], timing["tracePrimaryLaunches"], "valu", walk_ops(all_b["nodesPrimary"], all_b["trisPrimary"], True),
+            "64 x (nodesPrimary x 235 + trisPrimary x 56) lane-ops (every lane of the wave tests every record the wave fetches)")
+        add("shade_first", timing["shadeFirstMs"], timing["shadeFirstLaunches"], "hbm", shade_bytes(first_b, first_b["surfaceHits"]),
+            "bounce 0: surfaceHits x (60 + 192 + 192 + 480 + 76) + textureTaps x 48 B (camera rays that leave the scene end in k_trace_primary)")
+        add("trace_closest", timing["traceClosestMs"] - timing["tracePrimaryMs"], timing["traceClosestLaunches"] - timing["tracePrimaryLaunches"], "valu",
+            walk_ops(all_b["nodesClosest"], all_b["trisClosest"], False), "nodesClosest x 235 + trisClosest x 56 lane-ops (bounces >= 1)")
+        add("shade", timing["shadeMs"] - timing["shadeFirstMs"], timing["shadeLaunches"] - timing["shadeFirstLaunches"], "hbm", shade_bytes(rest, rest["segments"]),
+            "bounces >= 1: segments x (60 + 192) + surfaceHits x (192 + 480 + 76) + textureTaps x 48 B")
+    else:
+        add("trace_closest", timing["traceClosestMs"], timing["traceClosestLaunches"], "valu", walk_ops(all_b["nodesClosest"], all_b["trisClosest"], False),
+            "nodesClosest x 235 + trisClosest x 56 lane-ops")
+        add("shade", timing["shadeMs"], timing["shadeLaunches"], "hbm", shade_bytes(all_b, all_b["segments"]),
+            "segments x (60 + 192) + surfaceHits x (192 + 480 + 76) + textureTaps x 48 B")
+    add("trace_shadow", timing["traceShadowMs"], timing["traceShadowLaunches"], "valu", walk_ops(all_b["nodesShadow"], all_b["trisShadow"], False),
+        "nodesShadow x 235 + trisShadow x 56 lane-ops")
+    return rows
 
 
 def main():
@@ -89,8 +136,11 @@ def main():
                          "helmet workload to 4 %% (64: 19 %%, tools/check_rank_of_8.py)")
     ap.add_argument("--bvh", type=int, default=0, help="bit0: 0 = 8-wide compressed BVH (default), 1 = plain BVH2; bit1: 0 = PLOC topology (default), 1 = LBVH")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--frames-per-step", type=int, default=192,
+                    help="frames (1 spp each) per GPU and step; a step renders frames_per_step * n_gpus frames")
     ap.add_argument("--in-flight", type=int, default=32,
-                    help="frames in flight per GPU and step (mi_pt_render_frames, bit-identical to sequential frames); a step renders in_flight * n_gpus frames")
+                    help="frames in flight per GPU (mi_pt_render_frames, bit-identical to sequential frames): the frames of a step are issued "
+                         "in groups of in_flight * n_gpus (capped at 256)")
     args = ap.parse_args()
 
     import torch
@@ -119,6 +169,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == world
 
     w = WORKLOADS[args.workload]
     W, H = args.width or w["width"], args.height or w["height"]
@@ -131,18 +182,23 @@ def main():
     params = ptmod.default_params()
     params.maxDepth, params.numSamples, params.pixelAngle, params.focalDistance = w["depth"], 1, pixel_angle, focal
 
-    def make_tracer(counters):
+    def make_tracer(counters, partition=True):
         t = ptmod.PathTracer(scene, device=local_rank, collect_counters=counters, bvh=args.bvh)
         if hdr is not None:
             t.set_environment(hdr)
-        t.set_tile_partition(rank, world, args.tile)
+        if partition:
+            t.set_tile_partition(rank, world, args.tile)
         t.resize(W, H)
         t.set_frame_info(frame_info)
         t.set_sky(ptmod.default_sky())
         return t
 
+    t_create0 = time.perf_counter()
     tracer = make_tracer(False)
+    tracer.synchronize()
+    create_s = time.perf_counter() - t_create0
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    reduced = torch.zeros_like(accum) if dist is not None else None
     tracer.bind_accum(accum.data_ptr())
     stream = torch.cuda.current_stream()
     runner = ptmod.HeadlessRenderer(tracer, params)
@@ -152,20 +208,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # a step = one batch of F frames (1 spp each) sharing every wavefront launch.  Every rank owns 1/world of the tiles of each
-    # frame, so the batch grows with the world size to keep the rays in flight per GPU constant (weak scaling).
+    # Every rank owns 1/world of the tiles of each frame, so the frames per step and the frames in flight grow with the world size
+    # to keep the rays in flight per GPU constant (weak scaling).
     F = min(256, max(1, args.in_flight) * world)
-    runner.render(args.warmup * F, stream.cuda_stream, in_flight=F)
-    if dist is not None:  # warm the RCCL path too
+    frames_step = max(1, args.frames_per_step) * world
+
+    def step():
+        runner.render(frames_step, stream.cuda_stream, in_flight=F)
+        if dist is not None:  # one reduce of the accumulator per step: disjoint tiles, so sum == gather
+            reduced.copy_(accum)
+            dist.reduce(reduced, dst=0, op=dist.ReduceOp.SUM)
+
+    for _ in range(args.warmup):
+        step()
+    if dist is not None and args.warmup == 0:  # warm the RCCL path
         dist.reduce(accum.clone(), dst=0)
     sync_all()
     runner.reset_frame()
     tracer.enable_timing(True)
     sync_all()
     t0 = time.perf_counter()
-    runner.render(args.steps * F, stream.cuda_stream, in_flight=F)
-    if dist is not None:
-        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # disjoint tiles: sum == gather
+    for _ in range(args.steps):
+        step()
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -174,60 +238,67 @@ def main():
         elapsed = float(t.item())
     timing = tracer.frame_timing()
     tracer.enable_timing(False)
-    samples = float(W) * float(H) * float(args.steps) * F
+    frames_timed = args.steps * frames_step
+    samples = float(W) * float(H) * float(frames_timed)
     value = samples / elapsed / 1e6
 
     result = None
     if rank == 0:
-        img = accum.cpu().numpy()
+        img = (reduced if dist is not None else accum).cpu().numpy()
         assert np.isfinite(img).all()
-        # counter pass (deterministic: same frames -> same counts) for the algorithmic-bytes model
-        ctr = make_tracer(True)
-        ctr_runner = ptmod.HeadlessRenderer(ctr, params)
-        n_ctr = min(args.steps * F, 4)
-        ctr_runner.render(n_ctr)
-        stats = ctr.stats()
-        ctr.close()
-        per_frame = {k: (v / n_ctr if k not in ("bvhNodeCount", "bvhTriangleCount", "bvhNodeBytes", "bvhTriangleBytes") else v) for k, v in stats.items()}
-        kernels = {"trace_closest": ("traceClosestMs", "traceClosestLaunches"), "shade": ("shadeMs", "shadeLaunches"),
-                   "trace_shadow": ("traceShadowMs", "traceShadowLaunches")}
-        dominant = max(kernels, key=lambda k: timing[kernels[k][0]])
-        ms_key, n_key = kernels[dominant]
-        launches = max(timing[n_key], 1)
-        avg_launch_ms = timing[ms_key] / launches
-        # counters were taken on rank 0's tiles; bytes per launch = bytes per frame / launches per frame
-        launches_per_frame = launches / (args.steps * F)
-        bytes_per_launch = algorithmic_bytes(per_frame, dominant) / launches_per_frame
-        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
-        traffic = None
+        static = ("bvhNodeCount", "bvhTriangleCount", "bvhNodeBytes", "bvhTriangleBytes")
+
+        def counter_pass(depth):
+            # deterministic: same frames -> same counts; rank 0's tiles; 4 sequential frames
+            ctr = make_tracer(True)
+            p = ptmod.default_params()
+            p.maxDepth, p.numSamples, p.pixelAngle, p.focalDistance = depth, 1, pixel_angle, focal
+            n = min(frames_timed, 4)
+            ptmod.HeadlessRenderer(ctr, p).render(n)
+            st = ctr.stats()
+            ctr.close()
+            return {k: (v if k in static else v / n) for k, v in st.items()}
+
+        per_frame = counter_pass(w["depth"])
+        first = counter_pass(1) if w["depth"] >= 1 else dict(per_frame)  # bounce 0 alone: paths end after their first shade
+        # the timed frames belong to this rank's tiles: timing and counters are both rank 0's
+        kernels = kernel_table(per_frame, first, timing, frames_timed)
+        dominant = max(kernels, key=lambda k: kernels[k]["avg_launch_ms"] * kernels[k]["launches"])
+        roof = dict(kernels[dominant])
+        traffic, traffic_src = None, None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_file):
             try:
                 pmc = json.load(open(pmc_file))
                 if pmc.get("workload") == args.workload and pmc.get("frames_in_flight") == F and pmc.get("resolution") == [W, H] and world == 1:
                     traffic = pmc.get("bench_kernel_traffic", {}).get(dominant)
+                    if traffic is not None:
+                        traffic_src = f"profiles/pmc_latest.json ({pmc.get('command', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes')}; round {pmc.get('round')}): not measured in this run"
             except Exception:
                 traffic = None
+        roof.update({"kernel": dominant, "traffic": traffic, "traffic_source": traffic_src,
+                     "traffic_GBps": (round(traffic / (roof["avg_launch_ms"] * 1e-3) / 1e9, 1) if traffic else None)})
+        keys = ("cameraPaths", "segments", "surfaceHits", "shadowRays", "nodesPrimary", "trisPrimary", "nodesClosest", "trisClosest", "nodesShadow", "trisShadow", "textureTaps")
         result = {
             "metric": "Msamples/s (and ms/frame @ fixed spp) 1080p & 4K, 1/2/4/8 MI355X", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": w["config"] + " (seeded synthetic stand-in)" if w["gen"] else w["config"], "scene_triangles": scene.num_triangles,
-                       "resolution": [W, H], "spp_per_step": F, "frames_in_flight": F, "max_depth": w["depth"], "tile": args.tile,
-                       "parallelism": f"tiles{world}" if world > 1 else "single"},
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_launch_ms": round(avg_launch_ms, 5),
-                         # measured HBM bytes (profiles/pmc_latest.json) over the same launch time: what actually crossed the memory
-                         # interface; `achieved` counts the records the algorithm touches whether or not a cache served them
-                         "traffic_GBps": (round(traffic / (avg_launch_ms * 1e-3) / 1e9, 1) if traffic else None),
-                         "algorithmic_bytes_per_launch": round(bytes_per_launch),
-                         "per_frame": {k: round(per_frame[k], 1) for k in ("segments", "shadowRays", "nodesClosest", "trisClosest", "nodesShadow", "trisShadow", "textureTaps")},
-                         "kernel_ms_per_frame": {k: round(timing[v[0]] / (args.steps * F), 4) for k, v in kernels.items()},
-                         "frame_ms_device": round(timing["totalMs"] / (args.steps * F), 4)},
+                       "resolution": [W, H], "spp_per_step": frames_step, "frames_in_flight": F, "max_depth": w["depth"], "tile": args.tile,
+                       "parallelism": f"tiles{world}" if world > 1 else "single", "world_size_reported_by_backend": (dist.get_world_size() if dist is not None else 1),
+                       "reduce": ("one RCCL reduce(sum) of the RGBA32F accumulator per step" if dist is not None else None),
+                       "library": capi.pt_lib().mi_pt_version().decode()},
+            "ms_per_frame": round(elapsed / frames_timed * 1e3, 5),
+            "timed_region_s": round(elapsed, 3), "scene_build_s": round(create_s, 3),
+            "roofline": roof,
+            "kernels": kernels,
+            "per_frame": {k: round(per_frame[k], 1) for k in keys},
+            "per_frame_bounce0": {k: round(first[k], 1) for k in keys},
+            "frame_ms_device": round(timing["totalMs"] / frames_timed, 4),
         }
         if not args.no_cpu_baseline and world == 1:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import parity_util as pu  # the oracle is used here only as the timed CPU baseline
+            import parity_util as pu  # the oracle is used here only as the timed CPU baseline and as the checker of the GPU image
             setup = pu.Setup(scene.path, W, H, hdr_path=os.path.join(ROOT, "assets", "std_env.hdr") if w["hdr"] else None, max_depth=w["depth"])
             import oracle_lib
             O = oracle_lib.lib()
@@ -236,27 +307,39 @@ def main():
             if setup.hdr is not None:
                 O.oracle_pt_set_environment(o, setup.hdr.env)
             cores = os.cpu_count() or 1
-            # bounded sample: every 16th 64x64 tile of the same frames (same scene bytes, seeds, depth), then more tiles if fast
+            # bounded sample: every 16th 64x64 tile of the same frames (same scene bytes, seeds, depth), as many frames as fit the budget
             O.oracle_pt_resize(o, W, H)
             O.oracle_pt_set_frame_info(o, C.byref(setup.frame_info))
             O.oracle_pt_set_sky(o, C.byref(setup.sky))
-            tiles_total = ((W + 63) // 64) * ((H + 63) // 64)
-            done_px, frames_done, t_cpu0 = 0, 0, time.perf_counter()
+            tx, ty = (W + 63) // 64, (H + 63) // 64
+            tiles_total = tx * ty
             part = 16
             O.oracle_pt_set_tile_partition(o, 0, part, 64)
-            owned = sum(1 for t in range(tiles_total) if t % part == 0)
-            # pixels in owned tiles (edge tiles are partial)
-            tx = (W + 63) // 64
-            px_owned = sum(min(64, W - (t % tx) * 64) * min(64, H - (t // tx) * 64) for t in range(tiles_total) if t % part == 0)
+            owned = [t for t in range(tiles_total) if t % part == 0]
+            px_owned = sum(min(64, W - (t % tx) * 64) * min(64, H - (t // tx) * 64) for t in owned)
+            done_px, frames_done, t_cpu0 = 0, 0, time.perf_counter()
             while time.perf_counter() - t_cpu0 < args.cpu_seconds and frames_done < 4096:
                 p = setup.frame_params(frames_done, frames_done)
                 O.oracle_pt_render_frame(o, C.byref(p), cores)
                 frames_done += 1
                 done_px += px_owned
             t_cpu = time.perf_counter() - t_cpu0
+            cpu_img = np.ctypeslib.as_array(O.oracle_pt_accum(o), shape=(H, W, 4)).copy()
             O.oracle_pt_destroy(o)
             result["cpu_baseline"] = {"value": round(done_px / t_cpu / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-                                      "sample": f"{frames_done} frame(s) x {owned}/{tiles_total} tiles (every {part}th 64x64 tile) of the same workload, {t_cpu:.1f} s"}
+                                      "sample": f"{frames_done} frame(s) x {len(owned)}/{tiles_total} tiles (every {part}th 64x64 tile) of the same workload, {t_cpu:.1f} s"}
+            # parity at the FULL configuration: the same frames on the GPU, compared on the tiles the oracle rendered
+            chk = make_tracer(False, partition=False)
+            ptmod.HeadlessRenderer(chk, params).render(frames_done, in_flight=min(F, frames_done))
+            gpu_img = chk.read_accum()
+            chk.close()
+            mask = np.zeros((H, W), bool)
+            for t in owned:
+                mask[(t // tx) * 64:(t // tx) * 64 + 64, (t % tx) * 64:(t % tx) * 64 + 64] = True
+            m = pu.compare_images(cpu_img[mask][None], gpu_img[mask][None])
+            result["parity"] = {"rel_l2": float(f"{m['rel_l2']:.3e}"), "frac_within_1e-2": round(m["frac_within_1e-2"], 5), "frac_within_1e-4": round(m["frac_within_1e-4"], 5),
+                                "frac_exact": round(m["frac_exact"], 5), "tiles": len(owned), "pixels": int(mask.sum()), "frames": frames_done,
+                                "resolution": [W, H], "reference": "CPU oracle (oracle/oracle_pt.cpp), same scene bytes, seeds and frame indices"}
         print(json.dumps(result), flush=True)
     tracer.close()
     if dist is not None:

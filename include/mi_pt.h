@@ -125,6 +125,10 @@ typedef struct MiPtStats
   uint64_t bvhTriangleCount;
   uint64_t bvhNodeBytes;    /* S_node */
   uint64_t bvhTriangleBytes;/* S_tri */
+  uint64_t surfaceHits;     /* segments that ended on a surface (mesh or infinite plane) and were shaded; segments - surfaceHits
+                             * left the scene (environment / backplate).  Needs collectCounters. */
+  uint64_t nodesPrimary;    /* node / triangle records fetched by the bounce-0 packet walk: ONE per wave (64 camera rays) and visit, */
+  uint64_t trisPrimary;     /* not contained in nodesClosest / trisClosest (which count one per ray and visit) */
 } MiPtStats;
 
 /* Per-kernel device time summed over every mi_pt_render_frame since mi_pt_enable_timing(pt, 1), measured with HIP events
@@ -142,6 +146,11 @@ typedef struct MiPtFrameTiming
   int   shadeLaunches;
   int   traceShadowLaunches;
   int   bounceIterations;
+  /* the bounce-0 launches on their own (they are also contained in traceClosestMs / shadeMs and the launch counts above) */
+  float tracePrimaryMs;   /* k_trace_primary: camera-ray generation + packet walk + end of the paths that leave the scene */
+  float shadeFirstMs;     /* k_shade<FIRST> */
+  int   tracePrimaryLaunches;
+  int   shadeFirstLaunches;
 } MiPtFrameTiming;
 
 typedef struct MiPt MiPt;

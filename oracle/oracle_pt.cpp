@@ -1512,7 +1512,7 @@ struct HitPayload  // raytracer_interface.h.slang:36-47
 };
 struct Counters
 {
-  uint64_t cameraPaths = 0, segments = 0, shadowRays = 0, nodesClosest = 0, trisClosest = 0, nodesShadow = 0, trisShadow = 0, textureTaps = 0;
+  uint64_t cameraPaths = 0, segments = 0, shadowRays = 0, nodesClosest = 0, trisClosest = 0, nodesShadow = 0, trisShadow = 0, textureTaps = 0, surfaceHits = 0;
 };
 struct Ctx
 {
@@ -2429,6 +2429,8 @@ PathStepResult pathTraceOneBounce(Ctx& cx, RayDesc& ray, uint32_t& seed, PathTra
   }
   bool firstRay         = (pt.surfaceDepth == 0);
   bool hitInfinitePlane = checkInfinitePlaneIntersection(sc, ray, payload, hit);
+  if(payload.hitT != INFINITE_F)
+    cx.cnt.surfaceHits++;
   if(payload.hitT == INFINITE_F)  // :129-156
   {
     if(firstRay && tryPrimaryMissBackplate(sc, ray, pt))
@@ -2840,6 +2842,7 @@ int oracle_pt_render_frame(OraclePt* o, const MiPathtraceParams* params, int thr
     o->counters.nodesShadow += c.nodesShadow;
     o->counters.trisShadow += c.trisShadow;
     o->counters.textureTaps += c.textureTaps;
+    o->counters.surfaceHits += c.surfaceHits;
   }
   return 0;
 }
@@ -2859,6 +2862,7 @@ int             oracle_pt_get_stats(OraclePt* o, MiPtStats* s)
   s->nodesShadow      = o->counters.nodesShadow;
   s->trisShadow       = o->counters.trisShadow;
   s->textureTaps      = o->counters.textureTaps;
+  s->surfaceHits      = o->counters.surfaceHits;
   s->bvhNodeCount     = o->accel.nodes.size();
   s->bvhTriangleCount = o->accel.tris.size();
   s->bvhNodeBytes     = sizeof(BvhNode);

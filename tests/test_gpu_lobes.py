@@ -130,5 +130,7 @@ def test_converged_image_within_north_star_tolerance(built, tmp_path):
     # noise (measured on the MI355X box: rel-L2 2.8e-3 at 384 spp, 4.6e-4 at 3072 spp).  Hence 3072 spp here.
     path = scenegen.scene_glass_class(str(tmp_path / "glass.glb"), seed=3, tess=16)
     s = pu.Setup(path, 96, 64, max_depth=12, hdr_path=HDR, spp_per_frame=64)
-    m = _check(pu.render_oracle(s, 48), pu.render_gpu(s, 48, in_flight=8), rel_l2=1e-3, within_1e4=0.9, alpha_tol=5e-3)
+    # (depth: the seed threads through the 64 samples of a pixel and frame, so a path that took another way also shifts the jitter of
+    #  the samples after it -- and the first-hit depth of frame 0 is the LAST sample's: no depth bound here)
+    m = _check(pu.render_oracle(s, 48), pu.render_gpu(s, 48, in_flight=8), rel_l2=1e-3, within_1e4=0.9, alpha_tol=5e-3, depth_tol=1.0)
     print("converged parity (transmission/volume):", m)

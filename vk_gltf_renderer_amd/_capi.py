@@ -109,13 +109,14 @@ class MiPtCreateOptions(C.Structure):
 class MiPtStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "cameraPaths", "segments", "shadowRays", "nodesClosest", "trisClosest", "nodesShadow", "trisShadow",
-        "textureTaps", "bvhNodeCount", "bvhTriangleCount", "bvhNodeBytes", "bvhTriangleBytes")]
+        "textureTaps", "bvhNodeCount", "bvhTriangleCount", "bvhNodeBytes", "bvhTriangleBytes", "surfaceHits", "nodesPrimary", "trisPrimary")]
 
 
 class MiPtFrameTiming(C.Structure):
     _fields_ = [("totalMs", f32), ("generateMs", f32), ("traceClosestMs", f32), ("sortMs", f32), ("shadeMs", f32),
                 ("traceShadowMs", f32), ("accumulateMs", f32), ("traceClosestLaunches", i32), ("shadeLaunches", i32),
-                ("traceShadowLaunches", i32), ("bounceIterations", i32)]
+                ("traceShadowLaunches", i32), ("bounceIterations", i32), ("tracePrimaryMs", f32), ("shadeFirstMs", f32),
+                ("tracePrimaryLaunches", i32), ("shadeFirstLaunches", i32)]
 
 
 class MiCamera(C.Structure):

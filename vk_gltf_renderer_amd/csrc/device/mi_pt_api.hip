@@ -66,7 +66,7 @@ struct DevBuf
   ~DevBuf() { release(); }
 };
 
-enum TimedKernel { TK_GENERATE, TK_TRACE, TK_SORT, TK_SHADE, TK_SHADOW, TK_ACCUM, TK_COUNT };
+enum TimedKernel { TK_GENERATE, TK_TRACE, TK_SORT, TK_SHADE, TK_SHADOW, TK_ACCUM, TK_PRIMARY, TK_SHADE_FIRST, TK_COUNT };
 
 }  // namespace
 
@@ -696,6 +696,14 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   c.simpleMaterials  = pt->simpleMaterials && getenv("MI_PT_GENERIC_SHADE") == nullptr;
   c.wide             = pt->wide;
   c.collectCounters  = pt->collectCounters;
+  {
+    // Per-bounce sort of the shade kernel (k_shade): grouping the hits by material pays where the materials take different ways
+    // through the BSDF (glass workload: generic shade kernel -11 %); where every material runs the same code (the SIMPLE
+    // kernel, which therefore has no sort at all) it only cost (helmet +4 %, atrium +12 %, street +4 % of the shade kernel).
+    // MI_PT_SORT = 0 | 1 | 2 is the A/B switch of the generic kernel.
+    static const char* sortEnv = getenv("MI_PT_SORT");
+    c.sortMode = sortEnv ? atoi(sortEnv) : 2;
+  }
   // descriptor copies for the kernels that read them through a pointer
   if(pt->sceneDevDirty)
   {
@@ -743,7 +751,17 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   for(int s = 0; s < params->numSamples; ++s)
   {
     pt::launchResetCounters(c.queues, stream);
-    timed(TK_GENERATE, [&] { pt::launchGenerate(c, s); });
+    // 8-wide BVH: ONE kernel generates the camera rays, walks them as packets, finishes the paths that leave the scene and queues
+    // the hits (k_trace_primary); BVH2 / MI_PT_NO_PACKET: k_generate writes the rays and the per-lane kernel walks them
+    const bool fusedPrimary = c.wide && usePacket && !debugSpans;
+    if(fusedPrimary)
+    {
+      timed(TK_PRIMARY, [&] { pt::launchTracePrimary(c, s); });
+      if(pt->timingEnabled)
+        ++pt->accTiming.tracePrimaryLaunches;
+    }
+    else
+      timed(TK_GENERATE, [&] { pt::launchGenerate(c, s); });
     int cur = 0;
     // Every iteration either ends a path or consumes one unit of surfaceDepth, except volume scatter events
     // (pathtrace_functions.h.slang:925-931), which are free for VOLUME_FREE_BUDGET bounces and then Russian-rouletted.
@@ -801,13 +819,11 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
       }
       else
       {
-        timed(TK_TRACE, [&] {
-          if(it == 0 && c.wide && usePacket)
-            pt::launchTracePrimary(c);
-          else
-            pt::launchTraceClosest(c, cur);
-        });
-        timed(TK_SHADE, [&] { pt::launchShade(c, cur, it == 0); });
+        if(!(it == 0 && fusedPrimary))
+          timed(TK_TRACE, [&] { pt::launchTraceClosest(c, cur); });
+        timed(it == 0 ? TK_SHADE_FIRST : TK_SHADE, [&] { pt::launchShade(c, cur, it == 0); });
+        if(it == 0 && pt->timingEnabled)
+          ++pt->accTiming.shadeFirstLaunches;
         timed(TK_SHADOW, [&] { pt::launchTraceShadow(c, cur ^ 1); });
       }
       ++iterations; ++traceLaunches; ++shadeLaunches; ++shadowLaunches;
@@ -931,6 +947,9 @@ int mi_pt_get_stats(MiPt* pt, MiPtStats* out)
   out->nodesShadow  = h.nodesShadow;
   out->trisShadow   = h.trisShadow;
   out->textureTaps  = h.textureTaps;
+  out->surfaceHits  = h.surfaceHits;
+  out->nodesPrimary = h.nodesPrimary;
+  out->trisPrimary  = h.trisPrimary;
   return MI_PT_OK;
 }
 int mi_pt_reset_stats(MiPt* pt)
@@ -973,6 +992,8 @@ int mi_pt_get_frame_timing(MiPt* pt, MiPtFrameTiming* out)
       case TK_TRACE: t.traceClosestMs += ms; break;
       case TK_SORT: t.sortMs += ms; break;
       case TK_SHADE: t.shadeMs += ms; break;
+      case TK_PRIMARY: t.traceClosestMs += ms; t.tracePrimaryMs += ms; break;
+      case TK_SHADE_FIRST: t.shadeMs += ms; t.shadeFirstMs += ms; break;
       case TK_SHADOW: t.traceShadowMs += ms; break;
       case TK_ACCUM: t.accumulateMs += ms; break;
       default: t.totalMs += ms; break;

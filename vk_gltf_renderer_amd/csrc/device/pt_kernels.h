@@ -23,6 +23,7 @@ struct LaunchCtx
   bool            simpleMaterials;  // no material needs the transmission / clearcoat / sheen / iridescence / anisotropy paths
   bool            wide;  // traverse the 8-wide compressed BVH (scene.bvh8Nodes) instead of the BVH2
   bool            collectCounters;
+  int             sortMode;  // per-bounce sort of the shade kernel: 0 off, 1 surface hits / others / dead, 2 hits grouped by material too
 };
 
 void launchBuildShadeRecords(const DevScene& scene, uint32_t numTris, DevShadeTri* out, hipStream_t s);
@@ -32,7 +33,7 @@ void launchResetCounters(const Queues& Q, hipStream_t s);
 void launchSkyPrecomp(const MiSkyPhysicalParameters& sky, SkyPrecomp* out, hipStream_t stream);
 void launchGenerate(const LaunchCtx& c, int sampleIndex);
 void launchTraceClosest(const LaunchCtx& c, int cur);
-void launchTracePrimary(const LaunchCtx& c);  // bounce 0 of an 8-wide-BVH scene: packet walk of k_generate's camera rays (queue 0)
+void launchTracePrimary(const LaunchCtx& c, int sampleIndex);  // bounce 0 of an 8-wide-BVH scene: camera rays generated, packet-walked, misses finished, hits into queue 0
 void launchShade(const LaunchCtx& c, int cur, bool first);  // first: bounce 0 (paths still carry k_generate's initial state)
 void launchTraceShadow(const LaunchCtx& c, int nxt);  // nxt: active queue the preceding shade launch appended to
 void launchFinishSample(const LaunchCtx& c, int sampleIndex, float4* accum, float* depth, float4* albedo, float4* normal);

@@ -27,6 +27,13 @@ constexpr int SEL_BLOCK   = 256;
 #define TRACE_MIN_WAVES 1
 #endif
 constexpr int SHADE_BLOCK = 256;
+// Per-bounce sort in the shade kernel (see k_shade): window of queue entries sorted in LDS, and its bins.
+constexpr uint32_t SORT_ROUNDS   = 4;
+constexpr uint32_t SORT_WINDOW   = SORT_ROUNDS * SHADE_BLOCK;  // 1024 entries
+constexpr uint32_t SORT_SEGMENTS = SORT_ROUNDS * (SHADE_BLOCK / 64);
+constexpr int      SORT_BINS     = 32;  // one lane of the scan per bin
+constexpr uint32_t SORT_BIN_MISS = 30;  // bins 0..29: surface hits, materialID mod 30; 30: no surface hit (environment, infinite plane)
+constexpr uint32_t SORT_BIN_DEAD = 31;  // dead queue entries: not laid out
 #ifndef SHADE_SIMPLE_WAVES
 #define SHADE_SIMPLE_WAVES 3
 #endif
@@ -166,65 +173,128 @@ PT_DEV void unpackMedium(uint4 m, f3& ext, f3& sc, float& g)
 }
 
 //================================================================================================================================
-// k_generate: seed, AA jitter, camera ray, thin-lens DoF, path-state reset  (gltf_pathtrace.slang:546-596, 502-529)
+// Camera paths: seed, AA jitter, camera ray, thin-lens DoF  (gltf_pathtrace.slang:546-596, 502-529)
+//================================================================================================================================
+struct CameraPath
+{
+  bool     valid;  // the slot maps to a pixel of the image
+  uint32_t seed;   // RNG state after the camera draws
+  f3       origin, direction;
+};
+// Start of sample `sampleIndex` of path slot `slot` (slot < batchSlots).  Resets the denoiser guides of the slot on sample 0; the
+// caller stores the seed (PathSoA::misc).  PathTracerState{} of gltf_pathtrace.slang:443 is implicit: throughput 1, lastSamplePdf
+// DIRAC, radiance 0, maxRoughness 0, not inside, depth 0 -- the bounce-0 shade launch knows it as constants (k_shade<FIRST>), the
+// medium is written when a path first enters one, firstHit by the first shade of the path, pixelSum by k_finish_sample.
+PT_DEV CameraPath generateCameraPath(const FrameConsts& fc, const PathSoA& P, const uint32_t* ownedTiles, uint32_t slot, int sampleIndex)
+{
+  CameraPath     cp;
+  const uint32_t frame = slot / uint32_t(fc.numSlots);
+  int            px = 0, py = 0;
+  cp.seed      = 0u;
+  cp.origin    = mk3(0.0f);
+  cp.direction = mk3(0.0f);
+  cp.valid     = slotToPixel(fc, ownedTiles, slot - frame * uint32_t(fc.numSlots), px, py);
+  if(!cp.valid)
+    return cp;
+  uint32_t seed;
+  f2       jitter;
+  if(sampleIndex == 0)
+  {
+    seed     = xxhash32(uint32_t(px), uint32_t(py), uint32_t(fc.pc.frameCount) + frame);
+    float u1 = rnd(seed), u2 = rnd(seed);
+    // sampleGaussian (Box-Muller), pathtrace_functions.h.slang:784-789
+    float r     = sqrtf(-2.0f * logf(fmaxf(1e-38f, u1)));
+    float theta = 2.0f * K_PI * u2;
+    jitter      = mk2(0.5f + ANTIALIASING_STANDARD_DEVIATION * (r * cosf(theta)), 0.5f + ANTIALIASING_STANDARD_DEVIATION * (r * sinf(theta)));
+    if(P.guideAlbedo)
+    {
+      P.guideAlbedo[slot] = make_float4(0, 0, 0, 0);
+      P.guideNormal[slot] = make_float4(0, 0, 0, 0);
+    }
+  }
+  else
+  {
+    seed     = __float_as_uint(P.misc[slot].z);
+    float u1 = rnd(seed), u2 = rnd(seed);
+    jitter   = mk2(u1, u2);
+  }
+  f3 origin, direction;
+  getRay(fc, mk2(float(px), float(py)), jitter, origin, direction);
+  if(!hasFlag(fc.frameInfo.flags, MI_SCENE_IS_ORTHOGRAPHIC))
+  {
+    const float* V          = fc.frameInfo.viewInv;
+    f3           focalPoint = direction * fc.pc.focalDistance;
+    float        cam_r1     = rnd(seed) * K_TWO_PI;
+    float        cam_r2     = rnd(seed) * fc.pc.aperture;
+    f3           cam_right  = mk3(V[0], V[4], V[8]);  // Slang mul(viewMatrixI, float4(1,0,0,0)) = M^T e0
+    f3           cam_up     = mk3(V[1], V[5], V[9]);
+    f3           aperturePos = (cam_right * cosf(cam_r1) + cam_up * sinf(cam_r1)) * sqrtf(cam_r2);
+    f3           finalDir    = normalize(focalPoint - aperturePos);
+    origin += aperturePos;
+    direction = finalDir;
+  }
+  cp.seed      = seed;
+  cp.origin    = origin;
+  cp.direction = normalize(direction);  // pathTrace loop head, gltf_pathtrace.slang:447
+  return cp;
+}
+
+// tryPrimaryMissBackplate (pathtrace_functions.h.slang:944-971): what a camera ray that leaves the scene shows instead of the
+// environment, if anything.
+// (not inlined, like missEnvironment below: the bounce-0 kernel and the shade kernel must get the same bits out of it, and two
+//  inlined copies may be contracted into fused multiply-adds differently)
+__device__ __noinline__ bool primaryMissBackplate(const DevScene& sc, const FrameConsts& fc, f3 rayDir, f3& radiance)
+{
+  if(hasFlag(fc.frameInfo.flags, MI_SCENE_USE_SOLID_BACKGROUND))
+  {
+    radiance = mk3(fc.frameInfo.backgroundColor);
+    return true;
+  }
+  if(hasFlag(fc.frameInfo.flags, MI_SCENE_USE_HDR_ENVIRONMENT) && fc.frameInfo.envBlur > 0.0f)
+  {
+    f3 dir   = rotateAxis(rayDir, mk3(0, 1, 0), -fc.frameInfo.envRotation);
+    radiance = smoothHDRBlur(sc, getSphericalUv(dir), fc.frameInfo.envBlur) * fc.frameInfo.envIntensity;
+    return true;
+  }
+  return false;
+}
+// Environment seen by a ray that leaves the scene and its MIS weight against next-event estimation (gltf_pathtrace.slang:139-156).
+__device__ __noinline__ void missEnvironment(const DevScene& sc, const FrameConsts& fc, f3 rayDir, float lastSamplePdf, f3& envColor, float& mis)
+{
+  float envPdf;
+  sampleEnvironment(sc, fc, rayDir, envColor, envPdf);
+  mis = computeEnvHitMisWeight(sc, fc, lastSamplePdf, envPdf);
+}
+// checkInfinitePlaneIntersection (pathtrace_functions.h.slang:556-585): distance along the ray, or a negative number.
+PT_DEV float infinitePlaneT(const FrameConsts& fc, f3 rayOrigin, f3 rayDir, float hitT)
+{
+  if(!hasFlag(fc.frameInfo.flags, MI_SCENE_USE_INFINITE_PLANE))
+    return -1.0f;
+  const float planeHeight = fc.frameInfo.infinitePlaneDistance, Dn = rayDir.y;
+  if(rayOrigin.y > planeHeight && fabsf(Dn) > 1e-6f)
+  {
+    const float t = (-rayOrigin.y + planeHeight) / Dn;
+    if(t > 0.0f && t < hitT)
+      return t;
+  }
+  return -1.0f;
+}
+
+//================================================================================================================================
+// k_generate: camera paths into queue 0 for the per-lane trace kernel (BVH2 scenes and the A/B switch MI_PT_NO_PACKET; 8-wide
+// BVH scenes generate their camera rays inside k_trace_primary)
 //================================================================================================================================
 __global__ void __launch_bounds__(256) k_generate(DevScene sc, FrameConsts fc, PathSoA P, Queues Q, const uint32_t* ownedTiles, int sampleIndex,
                                                    StatCounters* stats)
 {
   const uint32_t batchSlots = uint32_t(fc.numSlots) * uint32_t(fc.numFrames);
   uint32_t       slot       = blockIdx.x * blockDim.x + threadIdx.x;
-  bool           valid      = slot < batchSlots;
-  const uint32_t frame      = slot / uint32_t(fc.numSlots);  // uniform per block: numSlots is a multiple of the block size
-  int            px = 0, py = 0;
-  float4         genOrg = make_float4(0, 0, 0, 0), genDir = make_float4(0, 0, 0, 0);
-  if(valid)
-    valid = slotToPixel(fc, ownedTiles, slot - frame * uint32_t(fc.numSlots), px, py);
-  if(valid)
+  CameraPath     cp{};
+  if(slot < batchSlots)
+    cp = generateCameraPath(fc, P, ownedTiles, slot, sampleIndex);
+  if(cp.valid)
   {
-    uint32_t seed;
-    f2       jitter;
-    if(sampleIndex == 0)
-    {
-      seed     = xxhash32(uint32_t(px), uint32_t(py), uint32_t(fc.pc.frameCount) + frame);
-      float u1 = rnd(seed), u2 = rnd(seed);
-      // sampleGaussian (Box-Muller), pathtrace_functions.h.slang:784-789
-      float r     = sqrtf(-2.0f * logf(fmaxf(1e-38f, u1)));
-      float theta = 2.0f * K_PI * u2;
-      jitter      = mk2(0.5f + ANTIALIASING_STANDARD_DEVIATION * (r * cosf(theta)), 0.5f + ANTIALIASING_STANDARD_DEVIATION * (r * sinf(theta)));
-      if(P.guideAlbedo)
-      {
-        P.guideAlbedo[slot] = make_float4(0, 0, 0, 0);
-        P.guideNormal[slot] = make_float4(0, 0, 0, 0);
-      }
-    }
-    else
-    {
-      seed     = __float_as_uint(P.misc[slot].z);
-      float u1 = rnd(seed), u2 = rnd(seed);
-      jitter   = mk2(u1, u2);
-    }
-    f3 origin, direction;
-    getRay(fc, mk2(float(px), float(py)), jitter, origin, direction);
-    if(!hasFlag(fc.frameInfo.flags, MI_SCENE_IS_ORTHOGRAPHIC))
-    {
-      const float* V          = fc.frameInfo.viewInv;
-      f3           focalPoint = direction * fc.pc.focalDistance;
-      float        cam_r1     = rnd(seed) * K_TWO_PI;
-      float        cam_r2     = rnd(seed) * fc.pc.aperture;
-      f3           cam_right  = mk3(V[0], V[4], V[8]);  // Slang mul(viewMatrixI, float4(1,0,0,0)) = M^T e0
-      f3           cam_up     = mk3(V[1], V[5], V[9]);
-      f3           aperturePos = (cam_right * cosf(cam_r1) + cam_up * sinf(cam_r1)) * sqrtf(cam_r2);
-      f3           finalDir    = normalize(focalPoint - aperturePos);
-      origin += aperturePos;
-      direction = finalDir;
-    }
-    direction          = normalize(direction);  // pathTrace loop head, gltf_pathtrace.slang:447
-    genOrg = make_float4(origin.x, origin.y, origin.z, 0.0f);
-    genDir = make_float4(direction.x, direction.y, direction.z, 0.0f);
-    // PathTracerState{} of gltf_pathtrace.slang:443: throughput 1, lastSamplePdf DIRAC, radiance 0, maxRoughness 0, not inside, depth 0.
-    // Only the seed (and the flags word) is stored: the bounce-0 shade launch knows the rest as constants (k_shade<FIRST>), the
-    // medium is written when a path first enters one, firstHit by the first shade of the path, pixelSum by k_finish_sample.
-    P.misc[slot] = make_float4(0.0f, __uint_as_float(PF_ALIVE), __uint_as_float(seed), 0.0f);  // cone.width = 0
+    P.misc[slot] = make_float4(0.0f, __uint_as_float(PF_ALIVE), __uint_as_float(cp.seed), 0.0f);  // cone.width = 0
     if(stats)
       atomicAdd(&stats->cameraPaths, 1ull);
   }
@@ -233,11 +303,11 @@ __global__ void __launch_bounds__(256) k_generate(DevScene sc, FrameConsts fc, P
   {
     const uint32_t chunk = slot / QCHUNK;
     const uint32_t pos   = (chunk % NSUB) * Q.subCap + (chunk / NSUB) * QCHUNK + (slot % QCHUNK);
-    Q.active[0].slot[pos] = valid ? slot : QUEUE_DEAD;
-    if(valid)
+    Q.active[0].slot[pos] = cp.valid ? slot : QUEUE_DEAD;
+    if(cp.valid)
     {
-      Q.active[0].org[pos] = genOrg;
-      Q.active[0].dir[pos] = genDir;
+      Q.active[0].org[pos] = make_float4(cp.origin.x, cp.origin.y, cp.origin.z, 0.0f);
+      Q.active[0].dir[pos] = make_float4(cp.direction.x, cp.direction.y, cp.direction.z, 0.0f);
     }
   }
   if(blockIdx.x == 0 && threadIdx.x < NSUB)
@@ -247,6 +317,7 @@ __global__ void __launch_bounds__(256) k_generate(DevScene sc, FrameConsts fc, P
   }
   if(blockIdx.x == 0 && threadIdx.x < 8)
     Q.counters[QC_HEADS_TRACE + threadIdx.x] = 0;
+  (void)sc;
 }
 
 //================================================================================================================================
@@ -838,12 +909,22 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
 }
 
 //================================================================================================================================
-// k_trace_primary: the camera rays of a bounce-0 queue, one 8x8-pixel tile per wave, traversed as a PACKET.
-// k_generate lays the 64 rays of a micro-tile out contiguously, so a wave owns 64 nearly parallel rays that visit almost the
-// same nodes.  The walk is therefore wave-uniform: one traversal stack per wave, node and triangle records fetched ONCE
-// per wave through the scalar cache (s_load, no vector-memory gather at all), every lane slab-tests the node's children
-// with its own origin / tmax, and a child is entered when ANY lane hits it.  Per-lane closest hits, tie-breaks, culling and
-// alpha draws are those of k_trace_closest, and box tests only ever prune, so the hit records are bit-identical.
+// k_trace_primary: bounce 0 of an 8-wide-BVH scene in ONE kernel -- camera-ray generation, closest hit, and the end of every
+// path whose camera ray leaves the scene.
+//
+// One 8x8-pixel micro-tile per wave.  The 64 camera rays of a wave are nearly parallel and visit almost the same nodes, so the
+// walk is a PACKET walk: one traversal stack per wave, node and triangle records fetched ONCE per wave through the scalar cache
+// (s_load, no vector-memory gather at all), every lane slab-tests the node's children with its own origin / tmax, and a child
+// is entered when ANY lane hits it.  Per-lane closest hits, tie-breaks, culling and alpha draws are those of k_trace_closest,
+// and box tests only ever prune, so the hit records are bit-identical.
+//
+// Camera rays are a pure function of the path slot, so they are generated here instead of being written to HBM by one kernel
+// and read back by the next (1.8 GB + 4 GB per 32-frame 1080p batch in round 1).  A camera ray that hits nothing (and cannot hit
+// the infinite plane) ends its path on the spot -- environment or backplate at full weight, exactly what the shade kernel would
+// compute for it (gltf_pathtrace.slang:129-156 with the initial state lastSamplePdf = DIRAC) -- and is never queued.  The rays
+// that did hit something are packed WITHIN their 256-slot chunk: a workgroup owns the chunk, survivors go to the front of the
+// chunk's range of queue 0, the rest of the range is marked dead.  No atomics, the queue counts stay the static ones, and the
+// bounce-0 shade launch sees waves that are full of surface hits or empty (the hit/miss part of the per-bounce sort).
 //================================================================================================================================
 constexpr int PACKET_STACK = 96;  // node groups per wave (tree depth bound; an overflow falls back to per-lane results below)
 
@@ -879,39 +960,46 @@ PT_DEV DevTri scalarLoadTri(const DevTri* tris, uint32_t index)
 }
 
 template <bool HAS_ALPHA, bool COUNT>
-__global__ void __launch_bounds__(256) k_trace_primary(DevScene sc, PathSoA P, Queues Q, uint32_t batchSlots, StatCounters* stats)
+__global__ void __launch_bounds__(256) k_trace_primary(DevScene sc, FrameConsts fc, const DevScene* __restrict__ scp, const FrameConsts* __restrict__ fcp, PathSoA P,
+                                                        Queues Q, const uint32_t* ownedTiles, int sampleIndex, uint32_t batchSlots, StatCounters* stats)
 {
+  // `sc` / `fc` (kernel arguments, SGPRs) serve the inlined generation and walk; the non-inlined environment helpers of the miss
+  // path get the device-resident copies so that the arguments' addresses never escape (no scratch copy, cf. k_shade)
   __shared__ uint32_t s_wstack[4][PACKET_STACK][2];
+  __shared__ uint32_t s_cnt[4];
   if(blockIdx.x == 0 && threadIdx.x < NSUB)
   {
+    // queue 0 holds one (partly dead) chunk per workgroup: static counts, as k_generate writes them
+    const uint32_t numChunks = batchSlots / QCHUNK;
+    Q.counters[QC_PAIR0 + 2 * threadIdx.x] = QCHUNK * (numChunks / NSUB + (threadIdx.x < numChunks % NSUB ? 1u : 0u));
     // same hand-over as k_trace_closest(cur = 0): the shade kernel of this iteration appends to these
     Q.counters[QC_PAIR1 + 2 * threadIdx.x]     = 0;
     Q.counters[QC_PAIR1 + 2 * threadIdx.x + 1] = 0;
     if(threadIdx.x < 8)
+    {
+      Q.counters[QC_HEADS_TRACE + threadIdx.x]  = 0;
       Q.counters[QC_HEADS_SHADOW + threadIdx.x] = 0;
+    }
   }
-  const uint32_t wave  = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  const uint32_t slot0 = (blockIdx.x * 4u + wave) * 64u;  // first path slot of this wave's micro-tile
-  if(slot0 >= batchSlots)
-    return;
-  const RayQueue in    = Q.active[0];
-  const uint32_t chunk = slot0 / QCHUNK;
-  const uint32_t pos   = (chunk % NSUB) * Q.subCap + (chunk / NSUB) * QCHUNK + (slot0 % QCHUNK) + lane;  // k_generate's placement
-  const uint32_t slot  = in.slot[pos];
-  bool           active = slot != QUEUE_DEAD;
-  if(__ballot(active) == 0ull)
-    return;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const uint32_t chunk = blockIdx.x;                 // 256 consecutive path slots = 4 micro-tiles (batchSlots is a multiple of 256)
+  const uint32_t slot  = chunk * QCHUNK + threadIdx.x;
+  if(chunk * QCHUNK >= batchSlots)
+    return;  // (uniform per workgroup)
+  const CameraPath cp     = generateCameraPath(fc, P, ownedTiles, slot, sampleIndex);
+  const bool       active = cp.valid;
   RaySetup r{};
   if(active)
-    r = makeRaySetup(xyz(in.org[pos]), xyz(in.dir[pos]));
+    r = makeRaySetup(cp.origin, cp.direction);
   ClosestBest best{INFINITE_F, 0.0f, 0.0f, -1, 0xffffffffu, 0xffffffffu};
-  uint32_t    seed0 = 0;
-  bool        seedLoaded = false;
+  uint32_t    seed0 = cp.seed;  // the alpha draws of this ray (P.misc is written below, after the walk)
+  bool        seedLoaded = true;
   unsigned    nodes = 0, tris = 0;
-  if(sc.bvhRoot != BVH_EMPTY)
+  const unsigned long long activeMask = __ballot(active);
+  if(sc.bvhRoot != BVH_EMPTY && activeMask != 0ull)
   {
     // wave-uniform walk state (kept uniform with readfirstlane so that it lives in SGPRs)
-    const uint32_t firstLane = uint32_t(__ffsll((long long)__ballot(active)) - 1);
+    const uint32_t firstLane = uint32_t(__ffsll((long long)activeMask) - 1);
     const uint32_t octinv    = __builtin_amdgcn_readfirstlane(uint32_t(__shfl(int(rayOctInv(r.idir)), int(firstLane))));
     uint32_t       gBase = 0, gBits = ((1u << octinv) << 8) | 1u;  // rootGroup
     int            sp = 0;
@@ -986,13 +1074,63 @@ __global__ void __launch_bounds__(256) k_trace_primary(DevScene sc, PathSoA P, Q
     }
     (void)overflow;  // PACKET_STACK covers any tree the builder emits for < 2^31 triangles at branching >= 2 per pending group
   }
-  if(active)
-    in.aux[pos] = make_float4(best.t, __int_as_float(best.tri), best.u, best.v);
+  // ---- who goes on to the shade kernel: mesh hits, and rays that reach the infinite plane before anything else
+  const bool meshHit = active && best.tri >= 0;
+  const bool toShade = active && (meshHit || infinitePlaneT(fc, cp.origin, cp.direction, best.t) > 0.0f);
+  // Survivors are packed to the front of the chunk's range of queue 0 (k_generate's placement of the chunk), the rest of the range is
+  // marked dead: the bounce-0 shade launch then runs full waves (measured on the helmet workload: 6.8 ms against 7.5 ms with the
+  // dead entries left where they fall; the workgroup barrier costs this kernel nothing measurable).
+  const unsigned long long shadeMask = __ballot(toShade);
+  if(lane == 0)
+    s_cnt[wave] = uint32_t(__popcll(shadeMask));
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+#pragma unroll
+  for(uint32_t w = 0; w < 4; ++w)
+  {
+    const uint32_t c = s_cnt[w];
+    before += w < wave ? c : 0u;
+    total += c;
+  }
+  const uint32_t pos0 = (chunk % NSUB) * Q.subCap + (chunk / NSUB) * QCHUNK;
+  if(toShade)
+  {
+    const uint32_t pos   = pos0 + before + laneCountBelow(shadeMask);
+    Q.active[0].slot[pos] = slot;
+    Q.active[0].org[pos]  = make_float4(cp.origin.x, cp.origin.y, cp.origin.z, 0.0f);
+    Q.active[0].dir[pos]  = make_float4(cp.direction.x, cp.direction.y, cp.direction.z, 0.0f);
+    Q.active[0].aux[pos]  = make_float4(best.t, __int_as_float(best.tri), best.u, best.v);
+    P.misc[slot]          = make_float4(0.0f, __uint_as_float(PF_ALIVE), __uint_as_float(cp.seed), 0.0f);  // cone.width = 0
+  }
+  if(threadIdx.x >= total)
+    Q.active[0].slot[pos0 + threadIdx.x] = QUEUE_DEAD;
+  // ---- the others end here: k_shade's miss branch for a first ray (gltf_pathtrace.slang:129-156, throughput 1, lastSamplePdf DIRAC)
+  if(active && !toShade)
+  {
+    const DevScene&    scd = *scp;
+    const FrameConsts& fcd = *fcp;
+    if(hasFlag(fc.pc.flags, MI_PT_FIRST_FRAME) && slot < uint32_t(fc.numSlots))  // NDC depth input of a first frame (k_finish_sample)
+      P.firstHit[slot] = make_float4(cp.direction.x, cp.direction.y, cp.direction.z, 0.0f);
+    f3 radiance = mk3(0.0f);
+    if(!primaryMissBackplate(scd, fcd, cp.direction, radiance))
+    {
+      f3    envColor;
+      float mis;
+      missEnvironment(scd, fcd, cp.direction, DIRAC, envColor, mis);
+      radiance += mk3(1.0f) * mis * envColor;
+    }
+    P.radiance[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);                          // maxRoughness.x = 0
+    P.misc[slot]     = make_float4(0.0f, __uint_as_float(PF_NOT_SOLID), __uint_as_float(cp.seed), 0.0f);  // depth 0, not alive, cone.width 0
+  }
   if(COUNT)
   {
-    atomicAdd(&stats->segments, (unsigned long long)(active ? 1u : 0u));
-    atomicAdd(&stats->nodesClosest, (unsigned long long)nodes);
-    atomicAdd(&stats->trisClosest, (unsigned long long)tris);
+    if(lane == 0)
+    {
+      atomicAdd(&stats->cameraPaths, (unsigned long long)__popcll(activeMask));
+      atomicAdd(&stats->segments, (unsigned long long)__popcll(activeMask));
+    }
+    atomicAdd(&stats->nodesPrimary, (unsigned long long)nodes);
+    atomicAdd(&stats->trisPrimary, (unsigned long long)tris);
   }
 }
 
@@ -1074,7 +1212,7 @@ __global__ void __launch_bounds__(SEL_BLOCK) k_selection(DevScene sc, FrameConst
 //================================================================================================================================
 // FIRST: the launch shades bounce 0 (every queued path still has its initial state, see k_generate).
 template <bool COUNT, bool SIMPLE, bool FIRST>
-__global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) k_shade(const DevScene* __restrict__ scp, const FrameConsts* __restrict__ fcp, PathSoA P, Queues Q, int cur, StatCounters* stats)
+__global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) k_shade(const DevScene* __restrict__ scp, const FrameConsts* __restrict__ fcp, PathSoA P, Queues Q, int cur, int sortMode, StatCounters* stats)
 {
   // The scene / frame descriptors reach the non-inlined helpers (getTexture, sampleLights, the sky) by reference.  As
   // by-value kernel arguments they would be copied to scratch (their address escapes) and every field read would become a
@@ -1084,29 +1222,118 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
   __shared__ uint32_t s_prefix[NSUB + 1];
   __shared__ uint32_t s_push[4];
   __shared__ float    s_srgb[256];  // sRGB decode table next to the ALU: 3 lookups per texel, up to 8 texels per tap
+  __shared__ uint32_t s_order[SIMPLE ? 1 : SORT_WINDOW];                     // queue positions of the window's live entries, sorted by bin
+  __shared__ uint16_t s_segCount[SIMPLE ? 1 : SORT_SEGMENTS][SORT_BINS];     // entries of a bin in one (round, wave) segment -> exclusive prefix inside the bin
+  __shared__ uint32_t s_binBase[SORT_BINS + 1];                 // first sorted index of each bin; [SORT_BINS] = live entries of the window
   static_assert(SHADE_BLOCK == 256, "one table entry per thread");
   if(blockIdx.x == 0 && threadIdx.x < 8)
     Q.counters[QC_HEADS_TRACE + threadIdx.x] = 0;  // for the next iteration's k_trace_closest
   queuePrefix(&Q.counters[cur ? QC_PAIR1 : QC_PAIR0], s_prefix);
-  const uint32_t count     = s_prefix[NSUB];
-  const int      nxt       = cur ^ 1;
-  const uint32_t numChunks = (count + SHADE_BLOCK - 1) / SHADE_BLOCK;  // SHADE_BLOCK == QCHUNK
-  if(blockIdx.x >= numChunks)
+  const uint32_t count      = s_prefix[NSUB];
+  const int      nxt        = cur ^ 1;
+  // The per-bounce sort exists in the generic kernel only: where every material runs the same code (SIMPLE) grouping the hits
+  // buys nothing and the window bookkeeping costs registers (measured: +9 % on the helmet workload's bounce-0 launch), so that
+  // flavour walks the queue chunk by chunk as it is.
+  constexpr uint32_t ROUNDS = SIMPLE ? 1u : SORT_ROUNDS;
+  constexpr uint32_t WINDOW = ROUNDS * SHADE_BLOCK;
+  const uint32_t     numWindows = (count + WINDOW - 1) / WINDOW;
+  if(blockIdx.x >= numWindows)
     return;  // nothing for this block (late bounces launch the full grid on short or empty queues)
   s_srgb[threadIdx.x] = sc.srgbLut[threadIdx.x];
   __syncthreads();
-  for(uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x)
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  for(uint32_t win = blockIdx.x; win < numWindows; win += gridDim.x)
   {
-    const uint32_t i    = chunk * SHADE_BLOCK + threadIdx.x;
-    const uint32_t inPos = (i < count) ? queuePos(Q.subCap, s_prefix, i) : 0u;
-    uint32_t       slot  = (i < count) ? Q.active[cur].slot[inPos] : QUEUE_DEAD;
-    const bool     inRange = slot != QUEUE_DEAD;
+    // ---- Per-bounce sort of the queue, one SORT_WINDOW-entry window at a time, in LDS (no extra pass over HBM, no global atomics):
+    // key = dead entries last, paths that left the scene (or reach the infinite plane) before them, surface hits first and grouped
+    // by material -- so that a wave shades one kind of thing, the texture / material records it gathers are shared by its lanes,
+    // and the dead entries the bounce-0 kernel leaves behind cost nothing.  Stable counting sort: a lane's rank inside its
+    // (round, wave) segment comes from ballots over the distinct bins of the wave (usually one to three), the segments of a bin
+    // are laid out in queue order.  Paths are independent, so the processing order cannot change any result.
+    uint32_t live = min(WINDOW, count - win * WINDOW);  // no sort: the window as it is, dead entries and all
+    if(!SIMPLE && sortMode != 0)
+    {
+    uint32_t myPos[SORT_ROUNDS], myBin[SORT_ROUNDS], myRank[SORT_ROUNDS];
+    for(uint32_t t = threadIdx.x; t < SORT_SEGMENTS * SORT_BINS; t += SHADE_BLOCK)
+      (&s_segCount[0][0])[t] = 0;
+    __syncthreads();
+#pragma unroll
+    for(uint32_t k = 0; k < SORT_ROUNDS; ++k)
+    {
+      const uint32_t i = win * WINDOW + k * SHADE_BLOCK + threadIdx.x;
+      uint32_t       bin = SORT_BIN_DEAD;
+      myPos[k]           = 0u;
+      if(i < count)
+      {
+        myPos[k]            = queuePos(Q.subCap, s_prefix, i);
+        const uint32_t slot = Q.active[cur].slot[myPos[k]];
+        if(slot != QUEUE_DEAD)
+        {
+          const int tri = __float_as_int(Q.active[cur].aux[myPos[k]].y);
+          // sortMode 1: surface hits / the rest / dead; 2: surface hits grouped by material as well
+          bin           = tri >= 0 ? (sortMode >= 2 ? uint32_t(sc.shadeTris[tri].materialID) % SORT_BIN_MISS : 0u) : SORT_BIN_MISS;
+        }
+      }
+      myBin[k] = bin;
+      // rank among the lanes of this wave with the same bin, and the segment's count of that bin
+      uint32_t           rank = 0;
+      unsigned long long todo = __ballot(bin != SORT_BIN_DEAD);
+      while(todo != 0ull)
+      {
+        const uint32_t           b = uint32_t(__builtin_amdgcn_readlane(int(bin), __ffsll((long long)todo) - 1));
+        const unsigned long long m = __ballot(bin == b);
+        if(bin == b)
+          rank = laneCountBelow(m);
+        if(lane == 0)
+          s_segCount[k * 4 + wave][b] = uint16_t(__popcll(m));
+        todo &= ~m;
+      }
+      myRank[k] = rank;
+    }
+    __syncthreads();
+    if(threadIdx.x < SORT_BINS)  // exclusive prefix of the segments inside each bin (queue order), and the bin totals
+    {
+      uint32_t acc = 0;
+      for(uint32_t sgm = 0; sgm < SORT_SEGMENTS; ++sgm)
+      {
+        const uint32_t c = s_segCount[sgm][threadIdx.x];
+        s_segCount[sgm][threadIdx.x] = uint16_t(acc);
+        acc += c;
+      }
+      // bins are laid out in index order: surface hits by material, then misses; dead entries are not laid out at all
+      uint32_t incl = acc;
+#pragma unroll
+      for(int d = 1; d < SORT_BINS; d <<= 1)
+      {
+        const uint32_t t = uint32_t(__shfl_up(int(incl), d));
+        if(threadIdx.x >= uint32_t(d))
+          incl += t;
+      }
+      s_binBase[threadIdx.x] = incl - acc;
+      if(threadIdx.x == SORT_BINS - 1)
+        s_binBase[SORT_BINS] = incl;
+    }
+    __syncthreads();
+#pragma unroll
+    for(uint32_t k = 0; k < SORT_ROUNDS; ++k)
+      if(myBin[k] != SORT_BIN_DEAD)
+        s_order[s_binBase[myBin[k]] + s_segCount[k * 4 + wave][myBin[k]] + myRank[k]] = myPos[k];
+    __syncthreads();
+    live = s_binBase[SORT_BINS];
+    }
+   for(uint32_t round = 0; round * SHADE_BLOCK < live; ++round)
+   {
+    const uint32_t chunk   = win * ROUNDS + round;  // 256 processed entries append to sub-queue chunk % NSUB, like a chunk of the queue
+    const uint32_t e       = round * SHADE_BLOCK + threadIdx.x;
+    const bool     inRange = e < live;
+    const uint32_t inPos   = !inRange ? 0u : ((!SIMPLE && sortMode != 0) ? s_order[e] : queuePos(Q.subCap, s_prefix, win * WINDOW + e));
+    uint32_t       slot    = inRange ? Q.active[cur].slot[inPos] : QUEUE_DEAD;
     bool           alive = false, pushShadow = false;
     unsigned       taps = 0;
     float4         nextOrg = make_float4(0, 0, 0, 0), nextDir = make_float4(0, 0, 0, 0);
     float4         shOrg = make_float4(0, 0, 0, 0), shDir = make_float4(0, 0, 0, 0), shCon = make_float4(0, 0, 0, 0), shCon2 = make_float4(0, 0, 0, 0);
     bool           catcher = false;
-    if(inRange)
+    if(inRange && slot != QUEUE_DEAD)
     {
       const float4 hit4 = Q.active[cur].aux[inPos], o4 = Q.active[cur].org[inPos], d4 = Q.active[cur].dir[inPos];
       const float4 misc4 = P.misc[slot];
@@ -1150,24 +1377,18 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
 
       // checkInfinitePlaneIntersection, pathtrace_functions.h.slang:556-585
       bool hitInfinitePlane = false;
-      if(hasFlag(fc.frameInfo.flags, MI_SCENE_USE_INFINITE_PLANE))
       {
-        float planeHeight = fc.frameInfo.infinitePlaneDistance;
-        float Dn          = rayDir.y;
-        if(rayOrigin.y > planeHeight && fabsf(Dn) > 1e-6f)
+        const float t = infinitePlaneT(fc, rayOrigin, rayDir, hitT);
+        if(t > 0.0f)
         {
-          float t = (-rayOrigin.y + planeHeight) / Dn;
-          if(t > 0.0f && t < hitT)
-          {
-            hitT             = t;
-            hit.pos          = rayOrigin + rayDir * hitT;
-            hit.shadowPos    = hit.pos;
-            hit.nrm          = mk3(0, 1, 0);
-            hit.geonrm       = mk3(0, 1, 0);
-            hit.tangent      = mk3(1, 0, 0);
-            hit.bitangent    = mk3(0, 0, 1);
-            hitInfinitePlane = true;
-          }
+          hitT             = t;
+          hit.pos          = rayOrigin + rayDir * hitT;
+          hit.shadowPos    = hit.pos;
+          hit.nrm          = mk3(0, 1, 0);
+          hit.geonrm       = mk3(0, 1, 0);
+          hit.tangent      = mk3(1, 0, 0);
+          hit.bitangent    = mk3(0, 0, 1);
+          hitInfinitePlane = true;
         }
       }
 
@@ -1179,24 +1400,13 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
           solid             = false;
           if(needFirstHit)
             P.firstHit[slot] = make_float4(rayDir.x, rayDir.y, rayDir.z, 0.0f);
-          if(hasFlag(fc.frameInfo.flags, MI_SCENE_USE_SOLID_BACKGROUND))
-          {
-            radiance  = mk3(fc.frameInfo.backgroundColor);
-            backplate = true;
-          }
-          else if(hasFlag(fc.frameInfo.flags, MI_SCENE_USE_HDR_ENVIRONMENT) && fc.frameInfo.envBlur > 0.0f)
-          {
-            f3 dir    = rotateAxis(rayDir, mk3(0, 1, 0), -fc.frameInfo.envRotation);
-            radiance  = smoothHDRBlur(sc, getSphericalUv(dir), fc.frameInfo.envBlur) * fc.frameInfo.envIntensity;
-            backplate = true;
-          }
+          backplate = primaryMissBackplate(sc, fc, rayDir, radiance);
         }
         if(!backplate)
         {
           f3    envColor;
-          float envPdf;
-          sampleEnvironment(sc, fc, rayDir, envColor, envPdf);
-          float mis = computeEnvHitMisWeight(sc, fc, lastSamplePdf, envPdf);
+          float mis;
+          missEnvironment(sc, fc, rayDir, lastSamplePdf, envColor, mis);
           radiance += throughput * mis * envColor;
         }
         done = true;
@@ -1449,6 +1659,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
       }
       if(COUNT && taps)
         atomicAdd(&stats->textureTaps, (unsigned long long)taps);
+      if(COUNT && (meshHit || hitInfinitePlane))
+        atomicAdd(&stats->surfaceHits, 1ull);
     }
     const PushPos  pp      = queuePushBlock2(alive, pushShadow, Q.subCap, &Q.counters[(nxt ? QC_PAIR1 : QC_PAIR0) + 2 * (chunk % NSUB)], chunk % NSUB, s_push);
     const uint32_t posNext = pp.next, posShadow = pp.shadow;
@@ -1467,6 +1679,9 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
       if(catcher)
         Q.shadow.aux2[posShadow] = make_float4(shCon2.x, shCon2.y, shCon2.z, __uint_as_float(alive ? posNext : 0xffffffffu));
     }
+   }  // rounds of the window
+   if(!SIMPLE)
+     __syncthreads();  // s_order / s_segCount are rebuilt for the next window
   }
 }
 
@@ -2078,24 +2293,21 @@ void launchTraceShadowT(const LaunchCtx& c, int nxt)
 #undef MI_LAUNCH_SHADOW
 }
 }  // namespace
-void launchTracePrimary(const LaunchCtx& c)
+void launchTracePrimary(const LaunchCtx& c, int sampleIndex)
 {
   const uint32_t batchSlots = uint32_t(c.fc.numSlots) * uint32_t(c.fc.numFrames);
-  dim3           grid((batchSlots / 64u + 3u) / 4u), block(256);
+  dim3           grid(batchSlots / 256u), block(256);  // one workgroup per 256-slot chunk (numSlots is a multiple of 256)
+#define MI_LAUNCH_PRIMARY(A, C) \
+  hipLaunchKernelGGL((k_trace_primary<A, C>), grid, block, 0, c.stream, c.scene, c.fc, c.sceneDev, c.fcDev, c.paths, c.queues, c.ownedTiles, sampleIndex, batchSlots, c.stats)
   if(c.hasAlpha)
   {
-    if(c.collectCounters)
-      hipLaunchKernelGGL((k_trace_primary<true, true>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, batchSlots, c.stats);
-    else
-      hipLaunchKernelGGL((k_trace_primary<true, false>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, batchSlots, c.stats);
+    if(c.collectCounters) MI_LAUNCH_PRIMARY(true, true); else MI_LAUNCH_PRIMARY(true, false);
   }
   else
   {
-    if(c.collectCounters)
-      hipLaunchKernelGGL((k_trace_primary<false, true>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, batchSlots, c.stats);
-    else
-      hipLaunchKernelGGL((k_trace_primary<false, false>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, batchSlots, c.stats);
+    if(c.collectCounters) MI_LAUNCH_PRIMARY(false, true); else MI_LAUNCH_PRIMARY(false, false);
   }
+#undef MI_LAUNCH_PRIMARY
 }
 void launchTraceClosest(const LaunchCtx& c, int cur)
 {
@@ -2108,7 +2320,7 @@ void launchShade(const LaunchCtx& c, int cur, bool first)
 {
   dim3 grid(c.persistentBlocks), block(SHADE_BLOCK);
 #define MI_LAUNCH_SHADE(C, S, F) \
-  hipLaunchKernelGGL((k_shade<C, S, F>), grid, block, 0, c.stream, c.sceneDev, c.fcDev, c.paths, c.queues, cur, c.stats)
+  hipLaunchKernelGGL((k_shade<C, S, F>), grid, block, 0, c.stream, c.sceneDev, c.fcDev, c.paths, c.queues, cur, c.sortMode, c.stats)
 #define MI_LAUNCH_SHADE_F(C, S) do { if(first) MI_LAUNCH_SHADE(C, S, true); else MI_LAUNCH_SHADE(C, S, false); } while(0)
   if(c.simpleMaterials)
   {

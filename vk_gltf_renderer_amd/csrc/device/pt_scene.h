@@ -219,7 +219,7 @@ enum : int
 
 struct StatCounters  // device mirror of MiPtStats' dynamic part
 {
-  unsigned long long cameraPaths, segments, shadowRays, nodesClosest, trisClosest, nodesShadow, trisShadow, textureTaps;
+  unsigned long long cameraPaths, segments, shadowRays, nodesClosest, trisClosest, nodesShadow, trisShadow, textureTaps, surfaceHits, nodesPrimary, trisPrimary;
 };
 
 }  // namespace pt
