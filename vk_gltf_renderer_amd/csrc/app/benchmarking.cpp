@@ -1,164 +1,154 @@
-// See benchmarking.hpp.  Formulas follow src/benchmarking.cpp:162-304 of the reference line by line; the JSON records carry
-// the same keys (nlohmann::json prints object keys alphabetically, reproduced here so logs diff cleanly).
+// Headless timing + telemetry (see benchmarking.hpp).  Written from the LOG SCHEMA the reference documents, not from its source:
+//   docs/benchmarking.md:27-47   the HEADLESS_START / HEADLESS_PROGRESS / HEADLESS_SUMMARY lines and what every field means
+//   utils/benchmark/benchmark_results.py  the consumer: `BENCHMARK_JSON {...,"schema":1}` records with type headless_start /
+//                                headless_progress / headless_summary (parse_headless_summary reads the summary's keys)
+// Design here: a run is three time stamps (loop start, end of warm-up, now) and a frame counter; everything that gets printed is
+// derived from them in one place (Window / Derived below) and goes through one field list that feeds both the text line and the
+// JSON record, so the two cannot drift apart.
 #include "benchmarking.hpp"
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
-#include <map>
-#include <sstream>
+#include <string>
+#include <vector>
 
 namespace {
 
-double roundTo(double value, double scale) { return std::round(value * scale) / scale; }
-
-struct JsonRecord
+// One output field: printed as `name=value` in the text line and as `"name":value` in the JSON record.
+struct Field
 {
-  std::map<std::string, std::string> kv;  // alphabetical, like nlohmann::json
-  void str(const std::string& k, const std::string& v) { kv[k] = "\"" + v + "\""; }
-  void num(const std::string& k, double v)
-  {
-    char buf[64];
-    if(v == std::floor(v) && std::fabs(v) < 1e15)
-      snprintf(buf, sizeof(buf), "%.1f", v);
-    else
-      snprintf(buf, sizeof(buf), "%.15g", v);
-    kv[k] = buf;
-  }
-  void integer(const std::string& k, long long v) { kv[k] = std::to_string(v); }
-  void emit()
-  {
-    integer("schema", 1);
-    std::ostringstream o;
-    o << "BENCHMARK_JSON {";
-    bool first = true;
-    for(const auto& e : kv)
-    {
-      o << (first ? "" : ",") << "\"" << e.first << "\":" << e.second;
-      first = false;
-    }
-    o << "}";
-    printf("%s\n", o.str().c_str());
-    fflush(stdout);
-  }
+  std::string name, text, json;
 };
+std::string fmt(const char* f, double v)
+{
+  char b[64];
+  snprintf(b, sizeof(b), f, v);
+  return b;
+}
+Field whole(const char* name, long long v) { return {name, std::to_string(v), std::to_string(v)}; }
+// `digits` decimals in the record (the consumer parses floats; whole values keep a ".0" so they stay floats), `textFmt` in the line
+Field real(const char* name, double v, int digits, const char* textFmt)
+{
+  const double s = std::pow(10.0, digits), r = std::round(v * s) / s;
+  std::string  j = (r == std::floor(r) && std::fabs(r) < 1e15) ? fmt("%.1f", r) : fmt("%.15g", r);
+  return {name, fmt(textFmt, v), j};
+}
+void emitRecord(const char* type, std::vector<Field> fields)
+{
+  fields.push_back({"schema", "", "1"});
+  fields.push_back({"type", "", std::string("\"") + type + "\""});
+  // keys in alphabetical order, like the reference's JSON library prints them: logs of the two programs then diff cleanly
+  std::sort(fields.begin(), fields.end(), [](const Field& a, const Field& b) { return a.name < b.name; });
+  std::string line = "BENCHMARK_JSON {";
+  for(size_t i = 0; i < fields.size(); ++i)
+    line += (i ? ",\"" : "\"") + fields[i].name + "\":" + fields[i].json;
+  printf("%s}\n", line.c_str());
+  fflush(stdout);
+}
+std::string textOf(const std::vector<Field>& fields)
+{
+  std::string s;
+  for(const Field& f : fields)
+    s += " " + f.name + "=" + f.text;
+  return s;
+}
 
 }  // namespace
 
 void BenchmarkController::alignMaxFramesForHeadless(int& maxFrames, uint32_t headlessFrames)
 {
-  const int minMaxFrames = static_cast<int>(headlessFrames);
-  if(maxFrames < minMaxFrames)
-  {
-    printf("maxFrames (%d) is less than headless --frames (%u); setting maxFrames to %u\n", maxFrames, headlessFrames, headlessFrames);
-    maxFrames = minMaxFrames;
-  }
+  // docs/benchmarking.md:39: in headless mode --maxFrames is raised to at least --frames so that every app frame accumulates
+  if(int64_t(maxFrames) >= int64_t(headlessFrames))
+    return;
+  printf("maxFrames (%d) is less than headless --frames (%u); setting maxFrames to %u\n", maxFrames, headlessFrames, headlessFrames);
+  maxFrames = int(headlessFrames);
 }
 
 void BenchmarkController::beginHeadlessTimingIfNeeded(bool isHeadless, const HeadlessFrameInfo& info)
 {
-  if(!isHeadless || m_headlessTimingActive)
+  if(!isHeadless || m_running)
     return;
-  m_headlessWallTimer            = Clock::now();
-  m_headlessMeasuredTimer        = Clock::now();
-  m_headlessTimingActive         = true;
-  m_headlessMeasuredTimingActive = false;
-  m_headlessFramesDone           = 0;
-  m_headlessMeasuredStartFrame   = 0;
-  m_headlessLastProgressLogMs    = 0.0;
-  printf("HEADLESS_START frames=%u maxFrames=%d ptSamples=%d\n", info.totalFrames, info.maxFrames, info.ptSamples);
-  JsonRecord r;
-  r.str("type", "headless_start");
-  r.integer("frames", info.totalFrames);
-  r.integer("maxFrames", info.maxFrames);
-  r.integer("ptSamples", info.ptSamples);
-  r.emit();
+  m_running     = true;
+  m_loopStart   = Clock::now();
+  m_warmupEnd   = m_loopStart;
+  m_warmedUp    = false;
+  m_framesDone  = 0;
+  m_warmupCount = 0;
+  m_lastLogMs   = 0.0;
+  const std::vector<Field> f = {whole("frames", info.totalFrames), whole("maxFrames", info.maxFrames), whole("ptSamples", info.ptSamples)};
+  printf("HEADLESS_START%s\n", textOf(f).c_str());
+  emitRecord("headless_start", f);
 }
 
 void BenchmarkController::updateHeadlessProgressIfNeeded(const HeadlessFrameInfo& info)
 {
-  if(!m_headlessTimingActive)
+  if(!m_running)
     return;
-  ++m_headlessFramesDone;
-  const double elapsedMs   = msSince(m_headlessWallTimer);
-  const bool   onInterval  = (m_headlessFramesDone % kHeadlessLogEveryNFrames) == 0;
-  const bool   onTime      = (elapsedMs - m_headlessLastProgressLogMs) >= kHeadlessLogMinIntervalMs;
-  const bool   firstOrLast = m_headlessFramesDone == 1 || m_headlessFramesDone >= info.totalFrames;
-  if(!m_headlessMeasuredTimingActive && m_headlessFramesDone >= kHeadlessWarmupFrames)
+  const uint32_t done = ++m_framesDone;
+  const double   ms   = msSince(m_loopStart);
+  // the measured window opens once the warm-up frames are complete (docs/benchmarking.md:40: the first completed frame carries
+  // one-time setup and is not charged to throughput)
+  if(!m_warmedUp && done >= kWarmupFrames)
   {
-    m_headlessMeasuredTimer        = Clock::now();
-    m_headlessMeasuredTimingActive = true;
-    m_headlessMeasuredStartFrame   = m_headlessFramesDone;
+    m_warmedUp    = true;
+    m_warmupEnd   = Clock::now();
+    m_warmupCount = done;
   }
-  if(!firstOrLast && !onInterval && !onTime)
+  // a line for the first and the last frame, every 50th frame, and whenever 5 s went by without one (docs/benchmarking.md:27)
+  const bool due = done == 1 || done >= info.totalFrames || done % kLogEveryFrames == 0 || ms - m_lastLogMs >= kLogEveryMs;
+  if(!due)
     return;
-  const float  pct = info.totalFrames > 0 ? 100.0F * static_cast<float>(m_headlessFramesDone) / static_cast<float>(info.totalFrames) : 0.0F;
-  const double msPerFrame = m_headlessFramesDone > 0 ? elapsedMs / static_cast<double>(m_headlessFramesDone) : 0.0;
-  printf("HEADLESS_PROGRESS app_frame %u/%u (%.0f%%) elapsed_ms=%.1f ms_per_frame=%.2f\n", m_headlessFramesDone, info.totalFrames, pct, elapsedMs,
-         msPerFrame);
-  JsonRecord r;
-  r.str("type", "headless_progress");
-  r.integer("app_frame", m_headlessFramesDone);
-  r.integer("frames", info.totalFrames);
-  r.num("percent", roundTo(pct, 1000.0));
-  r.num("elapsed_ms", roundTo(elapsedMs, 1000.0));
-  r.num("ms_per_frame", roundTo(msPerFrame, 1000.0));
-  r.emit();
-  m_headlessLastProgressLogMs = elapsedMs;
+  m_lastLogMs            = ms;
+  const double percent   = info.totalFrames ? 100.0 * double(done) / double(info.totalFrames) : 0.0;
+  const double perFrame  = ms / double(done);
+  printf("HEADLESS_PROGRESS app_frame %u/%u (%.0f%%) elapsed_ms=%.1f ms_per_frame=%.2f\n", done, info.totalFrames, float(percent), ms, perFrame);
+  emitRecord("headless_progress", {whole("app_frame", done), whole("frames", info.totalFrames), real("percent", float(percent), 3, "%.0f"),
+                                   real("elapsed_ms", ms, 3, "%.1f"), real("ms_per_frame", perFrame, 3, "%.2f")});
 }
 
 void BenchmarkController::logHeadlessSummary(const HeadlessFrameInfo& info)
 {
-  if(!m_headlessTimingActive)
+  if(!m_running)
     return;
-  const double   totalWallMs     = msSince(m_headlessWallTimer);
-  const double   totalMsPerFrame = info.totalFrames > 0 ? totalWallMs / static_cast<double>(info.totalFrames) : 0.0;
-  const uint32_t completedFrames = std::min(m_headlessFramesDone, info.totalFrames);
-  uint32_t       warmupFrames = 0, measuredFrames = completedFrames;
-  double         measuredWallMs = totalWallMs;
-  if(m_headlessMeasuredTimingActive && completedFrames >= m_headlessMeasuredStartFrame)
-  {
-    warmupFrames   = m_headlessMeasuredStartFrame;
-    measuredFrames = completedFrames - m_headlessMeasuredStartFrame;
-    measuredWallMs = measuredFrames > 0 ? msSince(m_headlessMeasuredTimer) : 0.0;
-  }
-  const double measuredWallSec    = measuredWallMs / 1000.0;
-  const double measuredMsPerFrame = measuredFrames > 0 ? measuredWallMs / static_cast<double>(measuredFrames) : 0.0;
-  const int    accumFrames        = std::min(static_cast<int>(info.totalFrames), std::max(info.maxFrames, 0));
-  const int    measuredAccumFrames = std::clamp(accumFrames - static_cast<int>(warmupFrames), 0, static_cast<int>(measuredFrames));
-  const int    effectiveSpp         = accumFrames * std::max(info.ptSamples, 1);
-  const int    measuredEffectiveSpp = measuredAccumFrames * std::max(info.ptSamples, 1);
-  const uint64_t pixels = static_cast<uint64_t>(info.imageSize.width) * static_cast<uint64_t>(info.imageSize.height);
-  const double measuredSamples = static_cast<double>(pixels) * static_cast<double>(measuredEffectiveSpp);
-  const double throughputMSps  = measuredWallSec > 0.0 ? measuredSamples / measuredWallSec / 1e6 : 0.0;
-  const double sppPerSec       = measuredWallSec > 0.0 ? static_cast<double>(measuredEffectiveSpp) / measuredWallSec : 0.0;
-  printf("HEADLESS_SUMMARY frames=%u maxFrames=%d ptSamples=%d effective_spp=%d measured_effective_spp=%d "
-         "resolution=%ux%u wall_ms=%.3f ms_per_frame=%.3f total_wall_ms=%.3f total_ms_per_frame=%.3f "
-         "warmup_frames=%u measured_frames=%u throughput_MSps=%.3f spp_per_sec=%.2f\n",
-         info.totalFrames, info.maxFrames, info.ptSamples, effectiveSpp, measuredEffectiveSpp, info.imageSize.width, info.imageSize.height,
-         measuredWallMs, measuredMsPerFrame, totalWallMs, totalMsPerFrame, warmupFrames, measuredFrames, throughputMSps, sppPerSec);
-  JsonRecord r;
-  r.str("type", "headless_summary");
-  r.integer("frames", info.totalFrames);
-  r.integer("maxFrames", info.maxFrames);
-  r.integer("ptSamples", info.ptSamples);
-  r.integer("effective_spp", effectiveSpp);
-  r.integer("measured_effective_spp", measuredEffectiveSpp);
-  r.integer("resolution_w", info.imageSize.width);
-  r.integer("resolution_h", info.imageSize.height);
-  r.num("wall_ms", roundTo(measuredWallMs, 1000.0));
-  r.num("ms_per_frame", roundTo(measuredMsPerFrame, 1000.0));
-  r.num("total_wall_ms", roundTo(totalWallMs, 1000.0));
-  r.num("total_ms_per_frame", roundTo(totalMsPerFrame, 1000.0));
-  r.integer("warmup_frames", warmupFrames);
-  r.integer("measured_frames", measuredFrames);
-  r.num("throughput_MSps", roundTo(throughputMSps, 1000.0));
-  r.num("spp_per_sec", roundTo(sppPerSec, 100.0));
-  r.emit();
+  // ---- the two windows: the whole loop, and the part after the warm-up
+  const double   totalMs  = msSince(m_loopStart);
+  const uint32_t finished = std::min(m_framesDone, info.totalFrames);
+  const bool     split    = m_warmedUp && finished >= m_warmupCount;
+  const uint32_t warmup   = split ? m_warmupCount : 0u;
+  const uint32_t measured = finished - warmup;
+  const double   windowMs = !split ? totalMs : (measured ? msSince(m_warmupEnd) : 0.0);
+  // ---- accumulation: every app frame up to maxFrames adds ptSamples samples per pixel (docs/benchmarking.md:43-44)
+  const int spp          = std::max(info.ptSamples, 1);
+  const int accumulating = std::min(int(info.totalFrames), std::max(info.maxFrames, 0));
+  const int inWindow     = std::max(0, std::min(accumulating - int(warmup), int(measured)));
+  // ---- rates over the measured window (docs/benchmarking.md:45-46)
+  const double seconds = windowMs * 1e-3;
+  const double pixels  = double(info.imageSize.width) * double(info.imageSize.height);
+  const double msps    = seconds > 0.0 ? pixels * double(inWindow * spp) / seconds * 1e-6 : 0.0;
+  const double sppRate = seconds > 0.0 ? double(inWindow * spp) / seconds : 0.0;
+
+  const std::vector<Field> head = {whole("frames", info.totalFrames), whole("maxFrames", info.maxFrames), whole("ptSamples", info.ptSamples),
+                                   whole("effective_spp", accumulating * spp), whole("measured_effective_spp", inWindow * spp)};
+  const std::vector<Field> tail = {real("wall_ms", windowMs, 3, "%.3f"),
+                                   real("ms_per_frame", measured ? windowMs / double(measured) : 0.0, 3, "%.3f"),
+                                   real("total_wall_ms", totalMs, 3, "%.3f"),
+                                   real("total_ms_per_frame", info.totalFrames ? totalMs / double(info.totalFrames) : 0.0, 3, "%.3f"),
+                                   whole("warmup_frames", warmup),
+                                   whole("measured_frames", measured),
+                                   real("throughput_MSps", msps, 3, "%.3f"),
+                                   real("spp_per_sec", sppRate, 2, "%.2f")};
+  // the text line names the resolution WxH, the record splits it into two keys
+  printf("HEADLESS_SUMMARY%s resolution=%ux%u%s\n", textOf(head).c_str(), info.imageSize.width, info.imageSize.height, textOf(tail).c_str());
+  std::vector<Field> record = head;
+  record.push_back(whole("resolution_w", info.imageSize.width));
+  record.push_back(whole("resolution_h", info.imageSize.height));
+  record.insert(record.end(), tail.begin(), tail.end());
+  emitRecord("headless_summary", record);
 }
 
 void BenchmarkController::finishHeadlessTiming()
 {
-  m_headlessTimingActive         = false;
-  m_headlessMeasuredTimingActive = false;
+  m_running  = false;
+  m_warmedUp = false;
 }

@@ -34,15 +34,17 @@ public:
   void finishHeadlessTiming();
 
 private:
-  static constexpr uint32_t kHeadlessLogEveryNFrames  = 50;      // reference: src/benchmarking.hpp:126-128
-  static constexpr double   kHeadlessLogMinIntervalMs = 5000.0;
-  static constexpr uint32_t kHeadlessWarmupFrames     = 1;
+  // docs/benchmarking.md:27 ("every 50 frames or 5 seconds") and :40 ("the first completed frame is excluded")
+  static constexpr uint32_t kLogEveryFrames = 50;
+  static constexpr double   kLogEveryMs     = 5000.0;
+  static constexpr uint32_t kWarmupFrames   = 1;
   using Clock = std::chrono::steady_clock;
   static double msSince(Clock::time_point t) { return std::chrono::duration<double, std::milli>(Clock::now() - t).count(); }
 
   BenchmarkOptions& m_options;
-  Clock::time_point m_headlessWallTimer{}, m_headlessMeasuredTimer{};
-  bool              m_headlessTimingActive{false}, m_headlessMeasuredTimingActive{false};
-  uint32_t          m_headlessFramesDone{0}, m_headlessMeasuredStartFrame{0};
-  double            m_headlessLastProgressLogMs{0.0};
+  // a headless run = the time the loop started, the time its warm-up ended, and how many frames have completed
+  bool              m_running{false}, m_warmedUp{false};
+  Clock::time_point m_loopStart{}, m_warmupEnd{};
+  uint32_t          m_framesDone{0}, m_warmupCount{0};
+  double            m_lastLogMs{0.0};
 };

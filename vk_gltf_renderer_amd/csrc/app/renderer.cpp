@@ -208,13 +208,17 @@ bool GltfRenderer::saveHdr(const std::string& path, const float* rgba, int w, in
   if(!f)
     return false;
   fprintf(f, "#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n", h, w);
+  // Flat (uncompressed) RGBE scanlines.  Readers take a scanline that STARTS with the bytes 2, 2, <128 for a new-style run-length
+  // header when 8 <= width < 32768, so such a first pixel is nudged (green mantissa 2 -> 3: one part in 256 of one pixel).
+  auto clean = [](float v) { return (v > 0.0f && std::isfinite(v)) ? v : 0.0f; };  // negative / NaN / inf components would be undefined to convert
   std::vector<unsigned char> row(size_t(w) * 4);
   for(int y = 0; y < h; ++y)
   {
     for(int x = 0; x < w; ++x)
     {
       const float* p = rgba + (size_t(y) * size_t(w) + size_t(x)) * 4;
-      float        m = std::max(p[0], std::max(p[1], p[2]));
+      const float  r = clean(p[0]), g = clean(p[1]), b = clean(p[2]);
+      float        m = std::max(r, std::max(g, b));
       unsigned char* o = &row[size_t(x) * 4];
       if(m < 1e-32f)
         o[0] = o[1] = o[2] = o[3] = 0;
@@ -222,9 +226,12 @@ bool GltfRenderer::saveHdr(const std::string& path, const float* rgba, int w, in
       {
         int   e;
         float s = std::frexp(m, &e) * 256.0f / m;
-        o[0] = (unsigned char)(p[0] * s); o[1] = (unsigned char)(p[1] * s); o[2] = (unsigned char)(p[2] * s); o[3] = (unsigned char)(e + 128);
+        auto  q = [&](float v) { return (unsigned char)std::min(255.0f, v * s); };
+        o[0] = q(r); o[1] = q(g); o[2] = q(b); o[3] = (unsigned char)std::clamp(e + 128, 0, 255);
       }
     }
+    if(w >= 8 && w < 32768 && row[0] == 2 && row[1] == 2 && row[2] < 128)
+      row[1] = 3;
     fwrite(row.data(), 1, row.size(), f);
   }
   fclose(f);

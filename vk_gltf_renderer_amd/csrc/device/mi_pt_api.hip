@@ -279,6 +279,39 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
   if(sd->numMaterials <= 0 || sd->numTextureInfos <= 0)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_create: scene needs at least one material and the reserved texture-info slot 0");
 
+  // ---- cross-table consistency (include/mi_pt.h: MI_PT_ERR_ARGUMENT for inconsistent tables).  The kernels index these tables
+  // without further checks, so a caller other than the in-tree loader gets an error here instead of a device fault.
+  if(sd->numRenderNodes < 0 || sd->numRenderPrimitives < 0 || sd->numLights < 0 || sd->numTextures < 0 || sd->numMaterials > 65535 * 4
+     || (sd->numRenderNodes > 0 && !sd->renderNodes) || (sd->numRenderPrimitives > 0 && !sd->renderPrimitives) || (sd->numLights > 0 && !sd->lights)
+     || (sd->numTextures > 0 && !sd->textures) || !sd->materials || !sd->textureInfos)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_create: negative table size or null table");
+  for(int n = 0; n < sd->numRenderNodes; ++n)
+  {
+    const MiGltfRenderNode& rn = sd->renderNodes[n];
+    if(rn.materialID >= sd->numMaterials)  // (negative ids mean "default material", reference: max(0, materialID))
+      return fail(MI_PT_ERR_ARGUMENT, "mi_pt_create: render node " + std::to_string(n) + " references material " + std::to_string(rn.materialID) + " of "
+                                          + std::to_string(sd->numMaterials));
+  }
+  for(int m = 0; m < sd->numMaterials; ++m)
+  {
+    const uint16_t* slots = &sd->materials[m].pbrBaseColorTexture;  // the 22 texture-info slots are contiguous (mi_pt_shaderio.h)
+    for(int k = 0; k < 22; ++k)
+      if(int(slots[k]) >= sd->numTextureInfos)
+        return fail(MI_PT_ERR_ARGUMENT, "mi_pt_create: material " + std::to_string(m) + " references texture info " + std::to_string(slots[k]) + " of "
+                                            + std::to_string(sd->numTextureInfos));
+  }
+  for(int i = 0; i < sd->numRenderPrimitives; ++i)
+  {
+    const MiPtRenderPrimitive& p = sd->renderPrimitives[i];
+    if(p.vertexCount > 0 && !p.positions)
+      return fail(MI_PT_ERR_ARGUMENT, "mi_pt_create: render primitive " + std::to_string(i) + " has vertices but no positions");
+    if(p.triangleCount > 0 && !p.indices)
+      return fail(MI_PT_ERR_ARGUMENT, "mi_pt_create: render primitive " + std::to_string(i) + " has triangles but no indices");
+    for(size_t k = 0, n = size_t(p.triangleCount) * 3; k < n; ++k)
+      if(p.indices[k] >= p.vertexCount)
+        return fail(MI_PT_ERR_ARGUMENT, "mi_pt_create: render primitive " + std::to_string(i) + " has a vertex index beyond its vertexCount");
+  }
+
   std::unique_ptr<MiPt> pt(new MiPt());
   pt->device          = device;
   pt->numCUs          = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -483,7 +516,13 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
     {
       pt::Bvh8Output b8;
       if(!pt::buildBvh8(bo, b8, nullptr, err))
+      {
+        if(b8.nodes)
+          (void)hipFree(b8.nodes);
+        if(b8.tris)
+          (void)hipFree(b8.tris);
         return fail(MI_PT_ERR_HIP, "BVH8 collapse failed: " + err);
+      }
       // the wide structure owns its own triangle order; the BVH2 arrays are no longer needed
       (void)hipFree(pt->bvhNodes);
       (void)hipFree(pt->bvhTris);

@@ -112,6 +112,11 @@ PT_DEV f2 getSphericalUv(f3 v)
 }
 PT_DEV f3 rotateAxis(f3 v, f3 k, float theta)
 {
+  // theta is a per-frame constant (envRotation): a wave-uniform branch.  With theta = 0 the formula below returns v itself
+  // (v * 1 + x * 0 + k * 0), so skipping it changes no result, and it saves the sine / cosine (some hundred vector
+  // instructions) that every environment lookup of every lane would otherwise spend on the default setting.
+  if(theta == 0.0f)
+    return v;
   float c = cosf(theta), s = sinf(theta);
   return v * c + cross(k, v) * s + k * (dot(k, v) * (1.0f - c));
 }

@@ -362,16 +362,51 @@ void createSimpleTangents(RenderPrimitiveData& d)
 }  // namespace
 
 //----------------------------------------------------------------------------------------------------------------------
+// Scene files are untrusted input: every byte count / offset / element count read from the JSON goes through these two helpers
+// before it is used in pointer arithmetic.
+namespace {
+// JSON number -> size_t; false for negative, non-finite, fractional-overflowing or > 2^53 values (a cast of those is undefined)
+bool toSize(double v, size_t& out)
+{
+  if(!(v >= 0.0) || !(v <= 9007199254740992.0))
+    return false;
+  out = size_t(v);
+  return true;
+}
+bool sizeField(const Value& obj, const char* key, size_t& out)
+{
+  const Value& v = obj[key];
+  out            = 0;
+  return !v.isNumber() || toSize(v.number(0), out);
+}
+// [off, off + (count - 1) * stride + elem) inside [0, size), without wrapping
+bool rangeFits(size_t size, size_t off, size_t count, size_t stride, size_t elem)
+{
+  if(count == 0)
+    return off <= size;
+  if(elem > size || off > size - elem)
+    return false;
+  const size_t room = size - elem - off;  // what (count - 1) * stride may use
+  return stride == 0 ? true : (count - 1) <= room / stride;
+}
+}  // namespace
+
 const uint8_t* GltfScene::bufferViewData(int bufferView, size_t& size, size_t& stride)
 {
+  size = stride = 0;
+  if(bufferView < 0)
+    return nullptr;
   const Value& bv = m_doc["bufferViews"][size_t(bufferView)];
   if(!bv.isObject())
     return nullptr;
   int    buffer = getInt(bv, "buffer", -1);
-  size_t offset = size_t(bv["byteOffset"].number(0));
-  size          = size_t(bv["byteLength"].number(0));
-  stride        = size_t(bv["byteStride"].number(0));
-  if(buffer < 0 || size_t(buffer) >= m_buffers.size() || offset + size > m_buffers[size_t(buffer)].size())
+  size_t offset = 0;
+  if(!sizeField(bv, "byteOffset", offset) || !sizeField(bv, "byteLength", size) || !sizeField(bv, "byteStride", stride))
+    return nullptr;
+  if(buffer < 0 || size_t(buffer) >= m_buffers.size())
+    return nullptr;
+  const size_t bufSize = m_buffers[size_t(buffer)].size();
+  if(offset > bufSize || size > bufSize - offset)
     return nullptr;
   return m_buffers[size_t(buffer)].data() + offset;
 }
@@ -386,9 +421,9 @@ bool GltfScene::readAccessorFloats(int accessor, int expectedComponents, std::ve
   const int    nc         = componentCount(acc["type"].string());
   const int    ctype      = getInt(acc, "componentType", 0);
   const int    csize      = componentSize(ctype);
-  const size_t count      = size_t(acc["count"].number(0));
+  size_t       count      = 0;
   const bool   normalized = acc["normalized"].boolean(false);
-  if(nc == 0 || csize == 0)
+  if(nc == 0 || csize == 0 || !sizeField(acc, "count", count) || count > (size_t(1) << 32))
     return false;
   if(outComponents)
     *outComponents = nc;
@@ -405,10 +440,12 @@ bool GltfScene::readAccessorFloats(int accessor, int expectedComponents, std::ve
     const uint8_t* base = bufferViewData(bvIndex, size, stride);
     if(!base)
       return false;
-    size_t off = size_t(acc["byteOffset"].number(0));
+    size_t off = 0;
+    if(!sizeField(acc, "byteOffset", off))
+      return false;
     if(stride == 0)
       stride = size_t(nc) * size_t(csize);
-    if(count > 0 && off + (count - 1) * stride + size_t(nc) * size_t(csize) > size)
+    if(!rangeFits(size, off, count, stride, size_t(nc) * size_t(csize)))
       return false;
     for(size_t i = 0; i < count; ++i)
     {
@@ -420,7 +457,9 @@ bool GltfScene::readAccessorFloats(int accessor, int expectedComponents, std::ve
   const Value& sparse = acc["sparse"];
   if(sparse.isObject())
   {
-    size_t       scount = size_t(sparse["count"].number(0));
+    size_t       scount = 0;
+    if(!sizeField(sparse, "count", scount) || scount > count)  // glTF 2.0: sparse.count <= accessor.count
+      return false;
     const Value& sidx   = sparse["indices"];
     const Value& sval   = sparse["values"];
     size_t       isz = 0, istride = 0, vsz = 0, vstride = 0;
@@ -429,7 +468,12 @@ bool GltfScene::readAccessorFloats(int accessor, int expectedComponents, std::ve
     if(!ibase || !vbase)
       return false;
     int    ictype = getInt(sidx, "componentType", 5125);
-    size_t ioff = size_t(sidx["byteOffset"].number(0)), voff = size_t(sval["byteOffset"].number(0));
+    size_t ioff = 0, voff = 0;
+    const size_t isize = size_t(componentSize(ictype)), vsize = size_t(nc) * size_t(csize);
+    // the index and value arrays are tightly packed (glTF 2.0 §3.6.2.3): both must lie inside their buffer views
+    if(isize == 0 || !sizeField(sidx, "byteOffset", ioff) || !sizeField(sval, "byteOffset", voff) || !rangeFits(isz, ioff, scount, isize, isize)
+       || !rangeFits(vsz, voff, scount, vsize, vsize))
+      return false;
     for(size_t s = 0; s < scount; ++s)
     {
       uint32_t target = decodeUint(ibase + ioff + s * size_t(componentSize(ictype)), ictype);
@@ -450,15 +494,14 @@ bool GltfScene::readAccessorUints(int accessor, std::vector<uint32_t>& out)
     return false;
   const int    ctype = getInt(acc, "componentType", 0);
   const int    csize = componentSize(ctype);
-  const size_t count = size_t(acc["count"].number(0));
+  size_t       count = 0, off = 0;
   size_t       size = 0, stride = 0;
   const uint8_t* base = bufferViewData(getInt(acc, "bufferView", -1), size, stride);
-  if(!base || csize == 0)
+  if(!base || csize == 0 || !sizeField(acc, "count", count) || count > (size_t(1) << 32) || !sizeField(acc, "byteOffset", off))
     return false;
-  size_t off = size_t(acc["byteOffset"].number(0));
   if(stride == 0)
     stride = size_t(csize);
-  if(count > 0 && off + (count - 1) * stride + size_t(csize) > size)
+  if(!rangeFits(size, off, count, stride, size_t(csize)))
     return false;
   out.resize(count);
   for(size_t i = 0; i < count; ++i)

@@ -53,7 +53,8 @@ struct Value
   size_t size() const { return type == Array ? arr.size() : (type == Object ? obj.size() : 0); }
 
   double      number(double def = 0.0) const { return type == Number ? num : def; }
-  int         integer(int def = 0) const { return type == Number ? int(std::llround(num)) : def; }
+  // (out-of-range / non-finite numbers fall back to the default: converting them would be undefined behaviour)
+  int         integer(int def = 0) const { return (type == Number && num > -2147483648.0 && num < 2147483647.0) ? int(std::llround(num)) : def; }
   bool        boolean(bool def = false) const { return type == Bool ? b : def; }
   std::string string(const std::string& def = "") const { return type == String ? str : def; }
 };
