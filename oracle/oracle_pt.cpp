@@ -2927,6 +2927,33 @@ void oracle_bsdf_sample(const float* m, const float* k1, const float* xi, float*
   out8[7] = float(d.event_type);
 }
 float oracle_round_to_half(float f) { return roundToHalf(f); }
+// ---- hooks for the closed-form pins of tests/test_oracle_pins.py (published formulas, tests/golden/pins_*.json)
+float oracle_fresnel_dielectric_unpolarized(float eta, float cosTheta) { return ior_fresnel(eta, cosTheta); }
+float oracle_fresnel_schlick(float ior, float cosTheta) { return schlickFresnelIor(ior, cosTheta); }
+void  oracle_fresnel_conductor(float n_a, float n_b, float k_b, float cosTheta, float* rs_rp)
+{
+  float2 ps, pc;
+  float2 r = fresnel_conductor(ps, pc, n_a, n_b, k_b, cosTheta, std::fmax(0.0f, 1.0f - cosTheta * cosTheta));
+  rs_rp[0] = r.x; rs_rp[1] = r.y;
+}
+void oracle_thin_film(float thickness, float coatingIor, float baseIor, float incomingIor, float cosTheta, float* rgb)
+{
+  float3 c = thin_film_factor(thickness, coatingIor, baseIor, incomingIor, cosTheta);
+  rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;
+}
+float oracle_ggx_ndf(float ax, float ay, const float* h) { return hvd_ggx_eval(float2(1.0f / ax, 1.0f / ay), float3(h)); }  // D(h) * cos(theta_h)
+float oracle_ggx_g1(float ax, float ay, const float* k) { return smith_shadow_mask(float3(k), float2(ax, ay)); }
+void  oracle_ggx_sample_vndf(float ax, float ay, const float* k, float u, float v, float* h)
+{
+  float3 r = hvd_ggx_sample_vndf(float3(k), float2(ax, ay), float2(u, v));
+  h[0] = r.x; h[1] = r.y; h[2] = r.z;
+}
+float oracle_hg_pdf(float cosTheta, float g) { return henyeyGreensteinPdf(cosTheta, g); }
+void  oracle_hg_sample(float u, float v, float g, const float* wi, float* wo)
+{
+  float3 r = sampleHenyeyGreenstein(float2(u, v), g, normalize(float3(wi)));
+  wo[0] = r.x; wo[1] = r.y; wo[2] = r.z;
+}
 void oracle_light_contribution(const MiGltfLight* light, const float* pos, const float* xi, float* out8)
 {
   LightContrib c = singleLightContribution(*light, float3(pos), float3(0, 0, 1), float2(xi[0], xi[1]));

@@ -38,6 +38,16 @@ void     oracle_sky_sample(const MiSkyPhysicalParameters* s, float u, float v, f
 void  oracle_bsdf_eval(const float* m, const float* k1, const float* k2, const float* xi, float* out7);
 void  oracle_bsdf_sample(const float* m, const float* k1, const float* xi, float* out8);
 float oracle_round_to_half(float f);
+/* closed-form pins (tests/test_oracle_pins.py) */
+float oracle_fresnel_dielectric_unpolarized(float eta, float cosTheta);
+float oracle_fresnel_schlick(float ior, float cosTheta);
+void  oracle_fresnel_conductor(float n_a, float n_b, float k_b, float cosTheta, float* rs_rp);
+void  oracle_thin_film(float thickness, float coatingIor, float baseIor, float incomingIor, float cosTheta, float* rgb);
+float oracle_ggx_ndf(float ax, float ay, const float* h);
+float oracle_ggx_g1(float ax, float ay, const float* k);
+void  oracle_ggx_sample_vndf(float ax, float ay, const float* k, float u, float v, float* h);
+float oracle_hg_pdf(float cosTheta, float g);
+void  oracle_hg_sample(float u, float v, float g, const float* wi, float* wo);
 /* out8 = incidentVector[3] distance intensity[3] pdf of singleLightContribution(light, pos, xi) */
 void  oracle_light_contribution(const MiGltfLight* light, const float* pos, const float* xi, float* out8);
 #ifdef __cplusplus

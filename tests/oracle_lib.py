@@ -46,6 +46,15 @@ def lib():
             "oracle_bsdf_eval": (None, [P(f32), P(f32), P(f32), P(f32), P(f32)]),
             "oracle_bsdf_sample": (None, [P(f32), P(f32), P(f32), P(f32)]),
             "oracle_round_to_half": (f32, [f32]),
+            "oracle_fresnel_dielectric_unpolarized": (f32, [f32, f32]),
+            "oracle_fresnel_schlick": (f32, [f32, f32]),
+            "oracle_fresnel_conductor": (None, [f32, f32, f32, f32, P(f32)]),
+            "oracle_thin_film": (None, [f32, f32, f32, f32, f32, P(f32)]),
+            "oracle_ggx_ndf": (f32, [f32, f32, P(f32)]),
+            "oracle_ggx_g1": (f32, [f32, f32, P(f32)]),
+            "oracle_ggx_sample_vndf": (None, [f32, f32, P(f32), f32, f32, P(f32)]),
+            "oracle_hg_pdf": (f32, [f32, f32]),
+            "oracle_hg_sample": (None, [f32, f32, f32, P(f32), P(f32)]),
             "oracle_light_contribution": (None, [P(capi.MiGltfLight), P(f32), P(f32), P(f32)]),
         }
         for name, (res, args) in sig.items():

@@ -1,0 +1,74 @@
+"""N > 1 path with the HIP renderer itself: two processes share the one GPU of the test box (torch.distributed gloo on the host
+side, the data path is the same tile partition + reduce(sum) of the RGBA32F accumulator that bench.py issues over RCCL).  The
+reduced frame must equal the single-rank frame bit for bit: the partition only decides who renders a pixel, never its value.
+Also runs bench.py --gpus 2 end to end in the same shared-GPU mode (rendezvous, per-step reduce, max-over-ranks timing, JSON line)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["MI_ROOT"]); sys.path.insert(0, os.path.join(os.environ["MI_ROOT"], "tests"))
+import parity_util as pu
+from vk_gltf_renderer_amd import scenegen
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+path = os.path.join(os.environ["MI_TMP"], f"zoo_{rank}.glb")
+scenegen.scene_material_zoo(path, "clearcoat")   # same seeded bytes on every rank
+s = pu.Setup(path, 200, 136, max_depth=5, hdr_path=os.path.join(os.environ["MI_ROOT"], "assets", "std_env.hdr"))
+part = pu.render_gpu(s, 5, collect_counters=False, tile=(rank, world, 32), in_flight=3)["accum"]
+t = torch.from_numpy(part.copy())
+dist.barrier()
+dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+if rank == 0:
+    full = pu.render_gpu(s, 5, collect_counters=False)["accum"]
+    assert (part != 0).any() and not (part == full).all()
+    assert (t.numpy() == full).all(), "reduced tiles differ from the single-rank frame"
+    np.save(os.environ["MI_OUT"], t.numpy())
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_ranks_of_the_hip_renderer_reduce_to_the_single_rank_frame(built, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    out = tmp_path / "reduced.npy"
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MI_ROOT=ROOT, MI_OUT=str(out), MI_TMP=str(tmp_path),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    img = np.load(out)
+    assert img.shape == (136, 200, 4) and np.isfinite(img).all() and img[..., :3].max() > 0
+
+
+def test_bench_two_ranks_on_one_gpu(built):
+    """bench.py's N = 2 code path (functional check; the numbers of a shared GPU mean nothing)."""
+    port = _free_port()
+    env = dict(os.environ, BENCH_SHARE_GPU="1", BENCH_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "box", "--frames-per-step", "8", "--in-flight", "4"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["config"]["world_size_reported_by_backend"] == 2 and j["config"]["spp_per_step"] == 16 and j["value"] > 0
+    assert j["config"]["reduce"].startswith("one RCCL reduce")
