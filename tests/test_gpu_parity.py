@@ -263,3 +263,25 @@ def test_full_size_properties_1080p(built, assets):
     f1 = tr.read_accum()
     tr.close()
     assert np.allclose((f0.astype(np.float64) + f1) / 2, a, rtol=1e-5, atol=1e-7)
+
+
+def test_device_bvh8_collapse_equals_host_collapse(built, tmp_path):
+    """The 8-wide BVH is collapsed on the device (bvh8.hip, level by level); the single-threaded host collapse it replaced stays behind
+    MI_PT_HOST_COLLAPSE=1 as the reference.  Same greedy collapse -> the same images bit for bit (any conservative structure gives
+    those) and the same tree up to floating-point ties of the greedy order: node count and traversal work within 0.5 %."""
+    import subprocess
+    import sys
+    path = scenegen.scene_atrium_class(str(tmp_path / "atrium.glb"), seed=5, detail=0.2, tex_size=64)
+    s = pu.Setup(path, 160, 96, max_depth=6)
+    dev = pu.render_gpu(s, 2)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import parity_util as pu; s = pu.Setup(%r, 160, 96, max_depth=6); "
+            "g = pu.render_gpu(s, 2); np.save(%r, g['accum']); print({k: g['stats'][k] for k in ('nodesClosest', 'trisClosest', 'nodesShadow', 'trisShadow', 'nodesPrimary', "
+            "'trisPrimary', 'bvhNodeCount')})") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), path,
+                                                   str(tmp_path / "host.npy"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MI_PT_HOST_COLLAPSE="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    host_stats = eval(r.stdout.strip().splitlines()[-1])
+    assert (np.load(tmp_path / "host.npy") == dev["accum"]).all()
+    print("device", {k: dev["stats"][k] for k in host_stats}, "host", host_stats)
+    for k, v in host_stats.items():
+        assert abs(dev["stats"][k] - v) <= 0.005 * v, (k, dev["stats"][k], v)

@@ -196,7 +196,7 @@ __global__ void k_hierarchy(int n, const uint64_t* keys, int2* children, int* pa
 }
 
 __global__ void k_fit(int n, const uint32_t* vals, const float4* boxLo, const float4* boxHi, const int2* children, const int* parentInternal,
-                      const int* parentLeaf, float4* nodeLo, float4* nodeHi, unsigned int* arrive)
+                      const int* parentLeaf, float4* nodeLo, float4* nodeHi, unsigned int* arrive, int* nodeCnt)
 {
   int leaf = blockIdx.x * blockDim.x + threadIdx.x;
   if(leaf >= n)
@@ -235,12 +235,13 @@ __global__ void k_fit(int n, const uint32_t* vals, const float4* boxLo, const fl
     }
     nodeLo[cur] = make_float4(fminf(lo0.x, lo1.x), fminf(lo0.y, lo1.y), fminf(lo0.z, lo1.z), 0.0f);
     nodeHi[cur] = make_float4(fmaxf(hi0.x, hi1.x), fmaxf(hi0.y, hi1.y), fmaxf(hi0.z, hi1.z), 0.0f);
+    nodeCnt[cur] = (ch.x >= 0 ? nodeCnt[ch.x] : 1) + (ch.y >= 0 ? nodeCnt[ch.y] : 1);  // triangles below (read by the 8-wide collapse)
     cur         = parentInternal[cur];
   }
 }
 
 __global__ void k_emit_nodes(int n, const uint32_t* vals, const float4* boxLo, const float4* boxHi, const int2* children, const float4* nodeLo,
-                             const float4* nodeHi, float4* outNodes)
+                             const float4* nodeHi, const int* nodeCnt, float4* outNodes)
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if(i >= n - 1)
@@ -253,7 +254,7 @@ __global__ void k_emit_nodes(int n, const uint32_t* vals, const float4* boxLo, c
   o[0]      = make_float4(lo0.x, hi0.x, lo0.y, hi0.y);
   o[1]      = make_float4(lo1.x, hi1.x, lo1.y, hi1.y);
   o[2]      = make_float4(lo0.z, hi0.z, lo1.z, hi1.z);
-  o[3]      = make_float4(__int_as_float(ch.x), __int_as_float(ch.y), 0.0f, 0.0f);
+  o[3]      = make_float4(__int_as_float(ch.x), __int_as_float(ch.y), __int_as_float(nodeCnt[i]), 0.0f);
 }
 
 // ---- PLOC: parallel locally-ordered clustering (Meister & Bittner 2018) ----------------------------------------------
@@ -267,6 +268,8 @@ __global__ void k_emit_nodes(int n, const uint32_t* vals, const float4* boxLo, c
 #define PLOC_RADIUS 16
 #endif
 
+// (the .w of a cluster's lower corner carries the number of triangles below it, as int bits: the 8-wide collapse reads it from
+//  the node record, n3.z)
 __global__ void k_ploc_init(int n, const uint32_t* vals, const float4* boxLo, const float4* boxHi, int* cid, float4* clo, float4* chi)
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -274,7 +277,9 @@ __global__ void k_ploc_init(int n, const uint32_t* vals, const float4* boxLo, co
     return;
   uint32_t t = vals[i];
   cid[i]     = ~i;
-  clo[i]     = boxLo[t];
+  float4 lo  = boxLo[t];
+  lo.w       = __int_as_float(1);
+  clo[i]     = lo;
   chi[i]     = boxHi[t];
 }
 
@@ -348,9 +353,10 @@ __global__ void k_ploc_emit(int m, const int* nn, const unsigned long long* flag
     o[0]           = make_float4(lo0.x, hi0.x, lo0.y, hi0.y);
     o[1]           = make_float4(lo1.x, hi1.x, lo1.y, hi1.y);
     o[2]           = make_float4(lo0.z, hi0.z, lo1.z, hi1.z);
-    o[3]           = make_float4(__int_as_float(cid[i]), __int_as_float(cid[j]), 0.0f, 0.0f);
+    const int      cnt = __float_as_int(lo0.w) + __float_as_int(lo1.w);
+    o[3]           = make_float4(__int_as_float(cid[i]), __int_as_float(cid[j]), __int_as_float(cnt), 0.0f);
     cid2[p]        = k;
-    clo2[p]        = make_float4(fminf(lo0.x, lo1.x), fminf(lo0.y, lo1.y), fminf(lo0.z, lo1.z), 0.0f);
+    clo2[p]        = make_float4(fminf(lo0.x, lo1.x), fminf(lo0.y, lo1.y), fminf(lo0.z, lo1.z), __int_as_float(cnt));
     chi2[p]        = make_float4(fmaxf(hi0.x, hi1.x), fmaxf(hi0.y, hi1.y), fmaxf(hi0.z, hi1.z), 0.0f);
   }
   else
@@ -398,6 +404,7 @@ bool buildBvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream, 
   int2*     children = nullptr;
   int *     parentInternal = nullptr, *parentLeaf = nullptr;
   unsigned* arrive         = nullptr;
+  int*      nodeCnt        = nullptr;
   void*     sortTemp       = nullptr;
   size_t    sortBytes      = 0;
   int *     cidA = nullptr, *cidB = nullptr, *nn = nullptr;
@@ -500,12 +507,13 @@ bool buildBvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream, 
     BUILD_CHECK(hipMalloc(&nodeLo, sizeof(float4) * (n - 1)));
     BUILD_CHECK(hipMalloc(&nodeHi, sizeof(float4) * (n - 1)));
     BUILD_CHECK(hipMalloc(&arrive, sizeof(unsigned) * (n - 1)));
+    BUILD_CHECK(hipMalloc(&nodeCnt, sizeof(int) * (n - 1)));
     BUILD_CHECK(hipMemsetAsync(arrive, 0, sizeof(unsigned) * (n - 1), stream));
     hipLaunchKernelGGL(k_hierarchy, dim3((n - 1 + B - 1) / B), dim3(B), 0, stream, int(n), keysB, children, parentInternal, parentLeaf);
     BUILD_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(k_fit, dim3(gridT), dim3(B), 0, stream, int(n), valsB, boxLo, boxHi, children, parentInternal, parentLeaf, nodeLo, nodeHi, arrive);
+    hipLaunchKernelGGL(k_fit, dim3(gridT), dim3(B), 0, stream, int(n), valsB, boxLo, boxHi, children, parentInternal, parentLeaf, nodeLo, nodeHi, arrive, nodeCnt);
     BUILD_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(k_emit_nodes, dim3((n - 1 + B - 1) / B), dim3(B), 0, stream, int(n), valsB, boxLo, boxHi, children, nodeLo, nodeHi, out.nodes);
+    hipLaunchKernelGGL(k_emit_nodes, dim3((n - 1 + B - 1) / B), dim3(B), 0, stream, int(n), valsB, boxLo, boxHi, children, nodeLo, nodeHi, nodeCnt, out.nodes);
     BUILD_CHECK(hipGetLastError());
     hipLaunchKernelGGL(k_emit_tris, dim3(gridT), dim3(B), 0, stream, int(n), valsB, trisTmp, out.tris);
     BUILD_CHECK(hipGetLastError());
@@ -540,7 +548,7 @@ bool buildBvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream, 
   {
     (void)hipFree(trisTmp); (void)hipFree(boxLo); (void)hipFree(boxHi); (void)hipFree(nodeLo); (void)hipFree(nodeHi);
     (void)hipFree(bounds); (void)hipFree(valsA); (void)hipFree(valsB); (void)hipFree(keysA); (void)hipFree(keysB);
-    (void)hipFree(children); (void)hipFree(parentInternal); (void)hipFree(parentLeaf); (void)hipFree(arrive); (void)hipFree(sortTemp);
+    (void)hipFree(children); (void)hipFree(parentInternal); (void)hipFree(parentLeaf); (void)hipFree(arrive); (void)hipFree(nodeCnt); (void)hipFree(sortTemp);
     (void)hipFree(cidA); (void)hipFree(cidB); (void)hipFree(nn); (void)hipFree(cloA); (void)hipFree(chiA); (void)hipFree(cloB); (void)hipFree(chiB);
     (void)hipFree(flags); (void)hipFree(pos); (void)hipFree(totals); (void)hipFree(scanTemp);
     return ok;

@@ -312,6 +312,18 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
         return fail(MI_PT_ERR_ARGUMENT, "mi_pt_create: render primitive " + std::to_string(i) + " has a vertex index beyond its vertexCount");
   }
 
+  // MI_PT_BUILD_TIMING=1: wall time of the phases of the scene build on stderr (diagnostics)
+  static const bool buildTiming = getenv("MI_PT_BUILD_TIMING") != nullptr;
+  auto              tPhase      = std::chrono::steady_clock::now();
+  auto              phase       = [&](const char* what) {
+    if(!buildTiming)
+      return;
+    (void)hipDeviceSynchronize();
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[mi_pt build] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tPhase).count());
+    tPhase = now;
+  };
+
   std::unique_ptr<MiPt> pt(new MiPt());
   pt->device          = device;
   pt->numCUs          = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -376,6 +388,7 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
     HIP_TRY(hipMemcpy(pt->geometry.ptr, staging.data(), staging.size(), hipMemcpyHostToDevice));
   }
   HIP_TRY(pt->prims.upload(devPrims.data(), devPrims.size()));
+  phase("tables + geometry upload");
 
   // ---- per-instance flags (reference: getInstanceFlag, src/gltf_scene_rtx.cpp:271-295) + triangle offsets -------------
   std::vector<uint8_t>  flags(size_t(std::max(sd->numRenderNodes, 1)), 0);
@@ -487,6 +500,7 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
     }
     HIP_TRY(pt->srgbLut.upload(lut, 256));
   }
+  phase("textures upload");
 
   // ---- BVH ----------------------------------------------------------------------------------------------------------
   {
@@ -500,6 +514,7 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
     std::string        err;
     if(!pt::buildBvh(in, bo, nullptr, err))
       return fail(MI_PT_ERR_HIP, "BVH build failed: " + err);
+    phase("BVH2 (Morton sort + PLOC)");
     pt->bvhNodes = bo.nodes;
     pt->bvhTris  = bo.tris;
     pt->scene.bvhRoot = bo.root;
@@ -523,6 +538,7 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
           (void)hipFree(b8.tris);
         return fail(MI_PT_ERR_HIP, "BVH8 collapse failed: " + err);
       }
+      phase("BVH8 collapse");
       // the wide structure owns its own triangle order; the BVH2 arrays are no longer needed
       (void)hipFree(pt->bvhNodes);
       (void)hipFree(pt->bvhTris);
@@ -559,6 +575,7 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
     HIP_TRY(hipDeviceSynchronize());
     S.alphaTris = pt->alphaTris.ptr;
   }
+  phase("shade / alpha records");
   HIP_TRY(pt->stats.alloc(1));
   HIP_TRY(hipMemset(pt->stats.ptr, 0, sizeof(pt::StatCounters)));
   // SkyPhysicalParameters{} defaults, so a caller that never calls mi_pt_set_sky still renders the default sky
