@@ -180,6 +180,7 @@ PT_SYMBOLS = {
     "mi_pt_get_frame_timing": (i32, [VP, P(MiPtFrameTiming)]),
     "mi_pt_last_error": (C.c_char_p, []),
     "mi_pt_version": (C.c_char_p, []),
+    "mi_pt_update_render_nodes": (i32, [VP, P(MiGltfRenderNode), i32, P(C.c_uint8)]),
 }
 
 

@@ -109,6 +109,13 @@ struct MiPt
   hipEvent_t                  fcDone[FC_RING] = {};
   unsigned                    fcCursor = 0;
   MiPtStats                   staticStats{};
+  // host copies of what the acceleration structure is built from, kept so that mi_pt_update_render_nodes can rebuild it
+  std::vector<MiGltfRenderNode> hostNodes;
+  std::vector<uint8_t>          hostVisible;    // empty = all visible
+  std::vector<uint8_t>          matInstFlags;   // per material: INST_FORCE_OPAQUE | INST_CULL_DISABLE | INST_TRANSMISSIVE
+  std::vector<uint8_t>          matFeatures;    // per material: bit0 volume scatter, bit1 needs the generic shade kernel
+  std::vector<uint32_t>         primTriangles;  // per render primitive: triangle count, 0 when it has no usable geometry
+  int                           bvhBuilder = 0;
   // frame state
   int                     width = 0, height = 0;
   int                     tileRank = 0, tileWorld = 1, tileSize = 64;
@@ -241,6 +248,130 @@ hipEvent_t getEvent(MiPt* pt, size_t& cursor)
     pt->eventPool.push_back(e);
   }
   return pt->eventPool[cursor++];
+}
+
+
+// Flattens the visible render-node instances to world-space triangles and builds the acceleration structure over them on the
+// device: Morton sort + PLOC -> BVH2 -> (default) 8-wide collapse, then the per-triangle shading / alpha records.  Everything it
+// needs is resident (geometry pool, materials) or kept on the host in MiPt (node matrices, visibility), so it serves the scene
+// build (mi_pt_create; reference: SceneRtx BLAS + TLAS build, src/gltf_scene_rtx.cpp:173-385) and the transform / visibility
+// updates of animated scenes (mi_pt_update_render_nodes; reference: TLAS update, src/gltf_scene_transform_vk.cpp:534-639) alike.
+int buildAcceleration(MiPt* pt)
+{
+  const int numNodes = int(pt->hostNodes.size()), numMaterials = int(pt->matInstFlags.size()), numPrims = int(pt->primTriangles.size());
+  std::vector<uint8_t>  flags(size_t(std::max(numNodes, 1)), 0);
+  std::vector<uint32_t> triOffset;
+  std::vector<int32_t>  entryNode;
+  uint64_t              totalTris = 0;
+  triOffset.push_back(0);
+  pt->hasAlpha = pt->hasTransmissive = pt->hasVolumeScatter = false;
+  pt->simpleMaterials = true;
+  for(int n = 0; n < numNodes; ++n)
+  {
+    const MiGltfRenderNode& rn = pt->hostNodes[size_t(n)];
+    const int               m  = std::max(0, std::min(rn.materialID, numMaterials - 1));
+    uint32_t                f  = pt->matInstFlags[size_t(m)];
+    if(!(f & pt::INST_FORCE_OPAQUE))
+      pt->hasAlpha = true;
+    if(f & pt::INST_TRANSMISSIVE)
+      pt->hasTransmissive = true;
+    if(pt->matFeatures[size_t(m)] & 1u)
+      pt->hasVolumeScatter = true;
+    if(pt->matFeatures[size_t(m)] & 2u)
+      pt->simpleMaterials = false;
+    const float* M   = rn.objectToWorld;
+    float        det = M[0] * (M[5] * M[10] - M[9] * M[6]) - M[4] * (M[1] * M[10] - M[9] * M[2]) + M[8] * (M[1] * M[6] - M[5] * M[2]);
+    if(det < 0.0f)
+      f |= pt::INST_FLIP_FACING;
+    flags[size_t(n)] = uint8_t(f);
+    if(!pt->hostVisible.empty() && !pt->hostVisible[size_t(n)])
+      continue;  // invisible nodes get no geometry (reference: src/gltf_scene_rtx.cpp:319-323)
+    if(rn.renderPrimID < 0 || rn.renderPrimID >= numPrims || pt->primTriangles[size_t(rn.renderPrimID)] == 0)
+      continue;
+    totalTris += pt->primTriangles[size_t(rn.renderPrimID)];
+    if(totalTris > 0x7fffffffull)
+      return fail(MI_PT_ERR_ARGUMENT, "more than 2^31 flattened triangles");
+    entryNode.push_back(n);
+    triOffset.push_back(uint32_t(totalTris));
+  }
+  HIP_TRY(pt->nodes.upload(pt->hostNodes.data(), pt->hostNodes.size()));
+  HIP_TRY(pt->instFlags.upload(flags.data(), flags.size()));
+  pt->scene.nodes = pt->nodes.ptr;
+
+  // release the previous structure (an update), then build
+  if(pt->bvhNodes) (void)hipFree(pt->bvhNodes);
+  if(pt->bvhTris) (void)hipFree(pt->bvhTris);
+  if(pt->bvh8Nodes) (void)hipFree(pt->bvh8Nodes);
+  pt->bvhNodes = nullptr; pt->bvhTris = nullptr; pt->bvh8Nodes = nullptr;
+  {
+    DevBuf<uint32_t> dOffset;
+    DevBuf<int32_t>  dEntry;
+    HIP_TRY(dOffset.upload(triOffset.data(), triOffset.size()));
+    HIP_TRY(dEntry.upload(entryNode.data(), entryNode.size()));
+    pt::BvhBuildInput in{pt->nodes.ptr, pt->prims.ptr, pt->instFlags.ptr, dOffset.ptr, dEntry.ptr, int(entryNode.size()), uint32_t(totalTris)};
+    in.karrasTopology = (pt->bvhBuilder & 2) != 0;
+    pt::BvhBuildOutput bo;
+    std::string        err;
+    if(!pt::buildBvh(in, bo, nullptr, err))
+      return fail(MI_PT_ERR_HIP, "BVH build failed: " + err);
+    pt->bvhNodes = bo.nodes;
+    pt->bvhTris  = bo.tris;
+    pt->scene.bvhRoot = bo.root;
+    pt->scene.numTris = int(bo.numTris);
+    pt->scene.bvh8NumNodes = 0;
+    pt->staticStats.bvhNodeCount     = bo.numNodes;
+    pt->staticStats.bvhTriangleCount = bo.numTris;
+    pt->staticStats.bvhNodeBytes     = 64;
+    pt->staticStats.bvhTriangleBytes = sizeof(pt::DevTri);
+    pt->wide = (pt->bvhBuilder & 1) == 0;
+    // the triangle rounds of the 8-wide walk pack (triangle index | owner lane << 26) into one word (pt_kernels.hip)
+    if(pt->wide && bo.numTris >= (1u << 26))
+      return fail(MI_PT_ERR_ARGUMENT, "scene has 2^26 or more triangles: beyond what the 8-wide BVH walk indexes (select the BVH2 walk, bvhBuilder bit 0)");
+    if(pt->wide && bo.numTris > 0)
+    {
+      pt::Bvh8Output b8;
+      if(!pt::buildBvh8(bo, b8, nullptr, err))
+      {
+        if(b8.nodes)
+          (void)hipFree(b8.nodes);
+        if(b8.tris)
+          (void)hipFree(b8.tris);
+        return fail(MI_PT_ERR_HIP, "BVH8 collapse failed: " + err);
+      }
+      // the wide structure owns its own triangle order; the BVH2 arrays are no longer needed
+      (void)hipFree(pt->bvhNodes);
+      (void)hipFree(pt->bvhTris);
+      pt->bvhNodes  = nullptr;
+      pt->bvhTris   = b8.tris;
+      pt->bvh8Nodes = b8.nodes;
+      pt->scene.bvhRoot = 0;
+      pt->scene.bvh8NumNodes = int(b8.numNodes);
+      pt->staticStats.bvhNodeCount = b8.numNodes;
+      pt->staticStats.bvhNodeBytes = 80;
+    }
+  }
+  pt::DevScene& S = pt->scene;
+  S.bvhNodes = pt->bvhNodes; S.bvh8Nodes = pt->bvh8Nodes; S.tris = pt->bvhTris;
+  S.shadeTris = nullptr;
+  S.alphaTris = nullptr;
+  if(S.numTris > 0)
+  {
+    HIP_TRY(pt->shadeTris.alloc(size_t(S.numTris)));
+    pt::launchBuildShadeRecords(S, uint32_t(S.numTris), pt->shadeTris.ptr, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    S.shadeTris = pt->shadeTris.ptr;
+  }
+  if(pt->hasAlpha && S.numTris > 0)
+  {
+    HIP_TRY(pt->alphaTris.alloc(size_t(S.numTris)));
+    pt::launchBuildAlphaRecords(S, uint32_t(S.numTris), pt->alphaTris.ptr, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    S.alphaTris = pt->alphaTris.ptr;
+  }
+  pt->sceneDevDirty = true;
+  return MI_PT_OK;
 }
 
 }  // namespace
@@ -390,54 +521,41 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
   HIP_TRY(pt->prims.upload(devPrims.data(), devPrims.size()));
   phase("tables + geometry upload");
 
-  // ---- per-instance flags (reference: getInstanceFlag, src/gltf_scene_rtx.cpp:271-295) + triangle offsets -------------
-  std::vector<uint8_t>  flags(size_t(std::max(sd->numRenderNodes, 1)), 0);
-  std::vector<uint32_t> triOffset;
-  std::vector<int32_t>  entryNode;
-  uint64_t              totalTris = 0;
-  triOffset.push_back(0);
-  for(int n = 0; n < sd->numRenderNodes; ++n)
+  // ---- what the acceleration structure is built from (see buildAcceleration) ------------------------------------------------
+  pt->hostNodes.assign(sd->renderNodes, sd->renderNodes + sd->numRenderNodes);
+  if(sd->renderNodeVisible)
+    pt->hostVisible.assign(sd->renderNodeVisible, sd->renderNodeVisible + sd->numRenderNodes);
+  pt->matInstFlags.resize(size_t(sd->numMaterials));
+  pt->matFeatures.resize(size_t(sd->numMaterials));
+  for(int m = 0; m < sd->numMaterials; ++m)
   {
-    const MiGltfRenderNode&    rn  = sd->renderNodes[n];
-    const MiGltfShadeMaterial& mat = sd->materials[std::max(0, std::min(rn.materialID, sd->numMaterials - 1))];
+    const MiGltfShadeMaterial& mat = sd->materials[m];
     uint32_t                   f   = 0;
+    // reference: getInstanceFlag, src/gltf_scene_rtx.cpp:271-295
     if(mat.transmissionFactor == 0.0f && mat.alphaMode == MI_ALPHA_OPAQUE && mat.diffuseTransmissionFactor == 0.0f)
       f |= pt::INST_FORCE_OPAQUE;
-    else
-      pt->hasAlpha = true;
     if(mat.doubleSided == 1 || mat.thicknessFactor > 0.0f || mat.transmissionFactor > 0.0f)
       f |= pt::INST_CULL_DISABLE;
     if(mat.transmissionFactor > 0.01f)  // MIN_TRANSMISSION, shaders/pathtrace_functions.h.slang:36,256
-    {
       f |= pt::INST_TRANSMISSIVE;
-      pt->hasTransmissive = true;
-    }
-    const float* M   = rn.objectToWorld;
-    float        det = M[0] * (M[5] * M[10] - M[9] * M[6]) - M[4] * (M[1] * M[10] - M[9] * M[2]) + M[8] * (M[1] * M[6] - M[5] * M[2]);
-    if(det < 0.0f)
-      f |= pt::INST_FLIP_FACING;
-    flags[size_t(n)] = uint8_t(f);
+    pt->matInstFlags[size_t(m)] = uint8_t(f);
+    uint32_t g = 0;
     if(mat.multiscatterColorFactor[0] > 0.0f || mat.multiscatterColorFactor[1] > 0.0f || mat.multiscatterColorFactor[2] > 0.0f)
-      pt->hasVolumeScatter = true;
+      g |= 1u;
     // the materials the specialised shade kernel cannot serve (see evaluateMaterial<SIMPLE>, pt_shading.h)
     if(mat.transmissionFactor != 0.0f || mat.diffuseTransmissionFactor != 0.0f || mat.clearcoatFactor != 0.0f || mat.iridescenceFactor != 0.0f
        || mat.anisotropyStrength > 0.0f || mat.retroreflectionFactor != 0.0f || mat.sheenColorFactor[0] != 0.0f || mat.sheenColorFactor[1] != 0.0f
        || mat.sheenColorFactor[2] != 0.0f)
-      pt->simpleMaterials = false;
-    if(sd->renderNodeVisible && !sd->renderNodeVisible[n])
-      continue;  // invisible nodes get no geometry (reference: src/gltf_scene_rtx.cpp:319-323)
-    if(rn.renderPrimID < 0 || rn.renderPrimID >= sd->numRenderPrimitives)
-      continue;
-    const MiPtRenderPrimitive& rp = sd->renderPrimitives[rn.renderPrimID];
-    if(!rp.positions || !rp.indices || rp.triangleCount == 0)
-      continue;
-    totalTris += rp.triangleCount;
-    if(totalTris > 0x7fffffffull)
-      return fail(MI_PT_ERR_ARGUMENT, "mi_pt_create: more than 2^31 flattened triangles");
-    entryNode.push_back(n);
-    triOffset.push_back(uint32_t(totalTris));
+      g |= 2u;
+    pt->matFeatures[size_t(m)] = uint8_t(g);
   }
-  HIP_TRY(pt->instFlags.upload(flags.data(), flags.size()));
+  pt->primTriangles.resize(size_t(sd->numRenderPrimitives));
+  for(int i = 0; i < sd->numRenderPrimitives; ++i)
+  {
+    const MiPtRenderPrimitive& rp = sd->renderPrimitives[i];
+    pt->primTriangles[size_t(i)]  = (rp.positions && rp.indices) ? rp.triangleCount : 0u;
+  }
+  pt->bvhBuilder = options ? options->bvhBuilder : 0;
 
   // ---- textures: one RGBA8 pool with all mip chains -----------------------------------------------------------------------
   {
@@ -502,79 +620,14 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
   }
   phase("textures upload");
 
-  // ---- BVH ----------------------------------------------------------------------------------------------------------
-  {
-    DevBuf<uint32_t> dOffset;
-    DevBuf<int32_t>  dEntry;
-    HIP_TRY(dOffset.upload(triOffset.data(), triOffset.size()));
-    HIP_TRY(dEntry.upload(entryNode.data(), entryNode.size()));
-    pt::BvhBuildInput in{pt->nodes.ptr, pt->prims.ptr, pt->instFlags.ptr, dOffset.ptr, dEntry.ptr, int(entryNode.size()), uint32_t(totalTris)};
-    in.karrasTopology = options && (options->bvhBuilder & 2) != 0;
-    pt::BvhBuildOutput bo;
-    std::string        err;
-    if(!pt::buildBvh(in, bo, nullptr, err))
-      return fail(MI_PT_ERR_HIP, "BVH build failed: " + err);
-    phase("BVH2 (Morton sort + PLOC)");
-    pt->bvhNodes = bo.nodes;
-    pt->bvhTris  = bo.tris;
-    pt->scene.bvhRoot = bo.root;
-    pt->scene.numTris = int(bo.numTris);
-    pt->staticStats.bvhNodeCount     = bo.numNodes;
-    pt->staticStats.bvhTriangleCount = bo.numTris;
-    pt->staticStats.bvhNodeBytes     = 64;
-    pt->staticStats.bvhTriangleBytes = sizeof(pt::DevTri);
-    pt->wide = !(options && (options->bvhBuilder & 1) != 0);
-    // the triangle rounds of the 8-wide walk pack (triangle index | owner lane << 26) into one word (pt_kernels.hip)
-    if(pt->wide && bo.numTris >= (1u << 26))
-      return fail(MI_PT_ERR_ARGUMENT, "scene has 2^26 or more triangles: beyond what the 8-wide BVH walk indexes (select the BVH2 walk, bvhBuilder bit 0)");
-    if(pt->wide && bo.numTris > 0)
-    {
-      pt::Bvh8Output b8;
-      if(!pt::buildBvh8(bo, b8, nullptr, err))
-      {
-        if(b8.nodes)
-          (void)hipFree(b8.nodes);
-        if(b8.tris)
-          (void)hipFree(b8.tris);
-        return fail(MI_PT_ERR_HIP, "BVH8 collapse failed: " + err);
-      }
-      phase("BVH8 collapse");
-      // the wide structure owns its own triangle order; the BVH2 arrays are no longer needed
-      (void)hipFree(pt->bvhNodes);
-      (void)hipFree(pt->bvhTris);
-      pt->bvhNodes  = nullptr;
-      pt->bvhTris   = b8.tris;
-      pt->bvh8Nodes = b8.nodes;
-      pt->scene.bvhRoot = 0;
-      pt->scene.bvh8NumNodes = int(b8.numNodes);
-      pt->staticStats.bvhNodeCount = b8.numNodes;
-      pt->staticStats.bvhNodeBytes = 80;
-    }
-  }
-
   pt::DevScene& S = pt->scene;
   S.materials = pt->materials.ptr; S.texInfos = pt->texInfos.ptr; S.nodes = pt->nodes.ptr; S.prims = pt->prims.ptr; S.lights = pt->lights.ptr;
-  S.textures = pt->textures.ptr; S.texels = pt->texels.ptr; S.envPixels = nullptr; S.envAccel = nullptr; S.bvhNodes = pt->bvhNodes; S.bvh8Nodes = pt->bvh8Nodes; S.tris = pt->bvhTris;
-  S.texRefs = pt->texRefs.ptr; S.alphaTris = nullptr; S.srgbLut = pt->srgbLut.ptr; S.numMaterials = sd->numMaterials; S.numTextures = sd->numTextures; S.numLights = sd->numLights; S.numNodes = sd->numRenderNodes;
+  S.textures = pt->textures.ptr; S.texels = pt->texels.ptr; S.envPixels = nullptr; S.envAccel = nullptr; S.bvhNodes = nullptr; S.bvh8Nodes = nullptr; S.tris = nullptr;
+  S.texRefs = pt->texRefs.ptr; S.alphaTris = nullptr; S.shadeTris = nullptr; S.srgbLut = pt->srgbLut.ptr; S.numMaterials = sd->numMaterials; S.numTextures = sd->numTextures;
+  S.numLights = sd->numLights; S.numNodes = sd->numRenderNodes;
   S.envWidth = 0; S.envHeight = 0;
-
-  S.shadeTris = nullptr;
-  if(S.numTris > 0)
-  {
-    HIP_TRY(pt->shadeTris.alloc(size_t(S.numTris)));
-    pt::launchBuildShadeRecords(S, uint32_t(S.numTris), pt->shadeTris.ptr, nullptr);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
-    S.shadeTris = pt->shadeTris.ptr;
-  }
-  if(pt->hasAlpha && S.numTris > 0)
-  {
-    HIP_TRY(pt->alphaTris.alloc(size_t(S.numTris)));
-    pt::launchBuildAlphaRecords(S, uint32_t(S.numTris), pt->alphaTris.ptr, nullptr);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
-    S.alphaTris = pt->alphaTris.ptr;
-  }
+  if(int rc = buildAcceleration(pt.get()))
+    return rc;
   phase("shade / alpha records");
   HIP_TRY(pt->stats.alloc(1));
   HIP_TRY(hipMemset(pt->stats.ptr, 0, sizeof(pt::StatCounters)));
@@ -587,6 +640,23 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
   pt->sky = s;
   *out    = pt.release();
   return MI_PT_OK;
+}
+
+int mi_pt_update_render_nodes(MiPt* pt, const MiGltfRenderNode* renderNodes, int numRenderNodes, const uint8_t* renderNodeVisible)
+{
+  if(!pt || !renderNodes || numRenderNodes != int(pt->hostNodes.size()))
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_update_render_nodes: the render-node count must be the one the instance was created with");
+  for(int n = 0; n < numRenderNodes; ++n)
+    if(renderNodes[n].materialID >= int(pt->matInstFlags.size()))
+      return fail(MI_PT_ERR_ARGUMENT, "mi_pt_update_render_nodes: render node references a material beyond the table");
+  HIP_TRY(hipSetDevice(pt->device));
+  HIP_TRY(hipDeviceSynchronize());  // nothing in flight may still walk the old structure
+  pt->hostNodes.assign(renderNodes, renderNodes + numRenderNodes);
+  if(renderNodeVisible)
+    pt->hostVisible.assign(renderNodeVisible, renderNodeVisible + numRenderNodes);
+  else
+    pt->hostVisible.clear();
+  return buildAcceleration(pt);
 }
 
 int mi_pt_destroy(MiPt* pt)

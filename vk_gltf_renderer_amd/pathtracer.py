@@ -129,6 +129,10 @@ class PathTracer:
         _check_pt(self._l.mi_pt_create(scene.desc, C.byref(opts), C.byref(self._p)))
         self.width = self.height = 0
 
+    def update_render_nodes(self, render_nodes, count, visible=None):
+        """New transforms / materials / visibility for the instances: rebuilds the acceleration structure on the device."""
+        _check_pt(self._l.mi_pt_update_render_nodes(self._p, render_nodes, count, visible))
+
     def set_environment(self, hdr):
         _check_pt(self._l.mi_pt_set_environment(self._p, hdr.env if hdr is not None else None))
 
