@@ -73,3 +73,20 @@ def test_headless_benchmark_command_line(tmp_path, assets):
     e = hdr.env.contents
     saved = np.ctypeslib.as_array(e.rgba, shape=(e.height, e.width, 4))[..., :3]
     assert np.abs(saved - img[..., :3]).max() <= img[..., :3].max() / 128 + 1e-3  # RGBE has an 8-bit mantissa
+
+
+@pytest.mark.gpu
+def test_adaptive_sampling_controller(assets):
+    """Auto SPP (reference: PathTracer::updateAdaptiveSampling, src/renderer_pathtracer.cpp:1326-1374): with the slowest target
+    (10 frames per second) a 64x64 frame leaves headroom every frame, so the samples per frame climb by one per frame from frame 5 on;
+    an explicit --ptSamples switches the controller off."""
+    base = ["--headless", "--size", "64", "64", "--scenefile", os.path.join(assets, "Box.glb"), "--hdrfile", os.path.join(assets, "std_env.hdr"), "--envSystem", "1",
+            "--frames", "20", "--maxFrames", "20", "--output", "/tmp/adaptive_test.hdr"]
+    r = _run(base + ["--ptAdaptiveSampling", "1", "--ptPerformanceTarget", "3"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"ADAPTIVE_SAMPLING samples_per_frame_at_end=(\d+) total_samples=(\d+)", r.stdout)
+    # frames 0..4 run 1 spp; frames 5..19 see headroom and add one sample each: 2, 3, ... 16
+    assert m and int(m.group(1)) == 16 and int(m.group(2)) == 5 + sum(range(2, 17)), r.stdout[-800:]
+    r = _run(base + ["--ptSamples", "2"])
+    assert r.returncode == 0 and "ADAPTIVE_SAMPLING" not in r.stdout
+    assert _records(r.stdout)[-1]["effective_spp"] == 40

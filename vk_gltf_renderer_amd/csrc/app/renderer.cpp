@@ -138,6 +138,8 @@ void GltfRenderer::onRender(StreamHandle cmd, bool headless, uint32_t headlessFr
 void GltfRenderer::onLastHeadlessFrame(uint32_t headlessFrames)
 {
   m_benchmark.logHeadlessSummary(benchmarkFrameInfo(headlessFrames));
+  if(m_pathTracer.adaptiveSampling())  // (our own line: the summary's effective_spp assumes a fixed --ptSamples, like the reference's)
+    printf("ADAPTIVE_SAMPLING samples_per_frame_at_end=%d total_samples=%d\n", m_pathTracer.m_pushConst.numSamples, m_pathTracer.totalSamples());
   m_benchmark.finishHeadlessTiming();
   saveHeadlessOutputImage();
 }

@@ -1,7 +1,9 @@
 #include "renderer_pathtracer.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 
 PathTracer::PathTracer()
 {
@@ -28,13 +30,18 @@ PathTracer::~PathTracer()
 void PathTracer::registerParameters(ParameterRegistry* r)
 {
   r->add("ptMaxDepth", "Maximum depth of the ray", &m_pushConst.maxDepth);
-  r->add("ptSamples", "Number of samples per pixel per frame (disables adaptive sampling)", &m_pushConst.numSamples);
+  // an explicit sample count switches the adaptive controller off (reference: src/renderer_pathtracer.cpp:120-123)
+  r->addCallback("ptSamples", "Number of samples per pixel per frame (disables adaptive sampling)", 1, [this](const std::vector<std::string>& a) {
+    m_pushConst.numSamples = std::atoi(a[0].c_str());
+    m_adaptiveSampling     = false;
+  });
   r->add("ptFireflyClamp", "Firefly clamp threshold", &m_pushConst.fireflyClampThreshold);
   r->add("ptTexGradScale", "Ray-footprint gradient scale", &m_pushConst.texGradScale);
   r->add("ptAperture", "Aperture for depth of field", &m_pushConst.aperture);
   r->add("ptFocalDistance", "Focal distance (disables auto focus)", &m_pushConst.focalDistance);
   r->add("ptAutoFocus", "Focus on the camera's interest point", &m_autoFocus);
-  r->add("ptAdaptiveSampling", "Accepted for CLI compatibility; adaptive sampling is not implemented (always off)", &m_adaptiveSampling);
+  r->add("ptAdaptiveSampling", "Adjust the samples per pixel and frame to the performance target", &m_adaptiveSampling);
+  r->add("ptPerformanceTarget", "Performance target [Interactive:0, Balanced:1, Quality:2, MaxQuality:3]", &m_performanceTarget);
 }
 
 void PathTracer::onAttach(Resources& res, void* profiler)
@@ -96,6 +103,28 @@ void PathTracer::setupPushConstant(Resources& res, const Extent2D& renderingSize
   m_pushConst.pixelAngle = 2.0f * std::fabs(res.frameInfo.projInv[5]) / std::max(float(renderingSize.height), 1.0f);
 }
 
+// Adaptive sampling (reference: PathTracer::updateAdaptiveSampling, src/renderer_pathtracer.cpp:1326-1374): a one-step controller
+// on the device time of the previous frame's path-trace pass -- more samples per frame while there is 20 % of headroom under the
+// target, fewer when 10 % over it; 1 sample again whenever accumulation restarts; hands off for the first frames after a restart.
+void PathTracer::updateAdaptiveSampling(Resources& res)
+{
+  if(!m_adaptiveSampling || !m_pt)
+    return;
+  if(res.frameCount == 0)
+  {
+    m_pushConst.numSamples = kMinSamplesPerPixel;
+    return;
+  }
+  if(res.frameCount < 5 || m_lastFrameDeviceMs <= 0.0)
+    return;
+  const double target = targetFrameTimeMs();
+  if(m_lastFrameDeviceMs < target * 0.8 && m_pushConst.numSamples < kMaxSamplesPerPixel)
+    ++m_pushConst.numSamples;
+  else if(m_lastFrameDeviceMs > target * 1.1 && m_pushConst.numSamples > kMinSamplesPerPixel)
+    --m_pushConst.numSamples;
+  m_pushConst.numSamples = std::min(std::max(m_pushConst.numSamples, kMinSamplesPerPixel), kMaxSamplesPerPixel);
+}
+
 void PathTracer::updateStatistics()
 {
   m_totalSamplesAccumulated += m_pushConst.numSamples;
@@ -105,14 +134,23 @@ void PathTracer::onRender(StreamHandle cmd, Resources& res)
 {
   if(!m_pt)
     return;
+  updateAdaptiveSampling(res);  // reference order: src/renderer_pathtracer.cpp:552-553, before the push constants are set up
   setupPushConstant(res, res.renderSize);
   mi_pt_set_frame_info(m_pt, &res.frameInfo);
   mi_pt_set_sky(m_pt, &res.skyParams);
+  if(m_adaptiveSampling)
+    mi_pt_enable_timing(m_pt, 1);  // (re)starts the per-kernel event timers: the controller needs this frame's device time
   if(mi_pt_render_frame(m_pt, &m_pushConst, cmd) != MI_PT_OK)
   {
     m_error = mi_pt_last_error();
     fprintf(stderr, "PathTracer::onRender: %s\n", m_error.c_str());
     return;
+  }
+  if(m_adaptiveSampling)
+  {
+    MiPtFrameTiming t{};
+    if(mi_pt_get_frame_timing(m_pt, &t) == MI_PT_OK)  // (synchronises: the reference reads its GPU timer one frame late instead)
+      m_lastFrameDeviceMs = t.totalMs;
   }
   updateStatistics();
 }

@@ -29,16 +29,28 @@ public:
   bool readSelection(uint32_t* ids) const;
   const std::string& lastError() const { return m_error; }
   MiPt* handle() const { return m_pt; }
+  bool  adaptiveSampling() const { return m_adaptiveSampling; }
+  int   totalSamples() const { return m_totalSamplesAccumulated; }
 
   MiPathtraceParams m_pushConst{};  // read by benchmarkFrameInfo() in the reference (src/renderer.cpp:526)
 
 private:
   void setupPushConstant(Resources& resources, const Extent2D& renderingSize);  // reference: :1496-1574
   void updateStatistics();                                                      // reference: :1377-1402
+  void updateAdaptiveSampling(Resources& resources);                            // reference: :1326-1374
+  // reference: src/renderer_pathtracer.hpp:167-195 (Interactive 60 / Balanced 30 / Quality 15 / MaxQuality 10 frames per second)
+  double targetFrameTimeMs() const
+  {
+    static const double fps[4] = {60.0, 30.0, 15.0, 10.0};
+    return 1000.0 / fps[(m_performanceTarget >= 0 && m_performanceTarget < 4) ? m_performanceTarget : 1];
+  }
+  static constexpr int kMinSamplesPerPixel = 1, kMaxSamplesPerPixel = 100;
 
   MiPt*       m_pt{nullptr};
   bool        m_autoFocus{true};           // reference: src/renderer_pathtracer.hpp:89
-  bool        m_adaptiveSampling{false};   // the reference default is ON unless --ptSamples is given; always off here
+  bool        m_adaptiveSampling{true};    // reference default: on, until --ptSamples is given (src/renderer_pathtracer.hpp:161)
+  int         m_performanceTarget{1};      // Balanced
+  double      m_lastFrameDeviceMs{0.0};
   int         m_totalSamplesAccumulated{0};
   std::string m_error;
 };
