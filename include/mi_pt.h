@@ -225,6 +225,17 @@ MI_PT_API void* mi_pt_accum_device_ptr(MiPt* pt);
 MI_PT_API int mi_pt_denoise(MiPt* pt, int iterations, float sigmaColor, float sigmaNormal, float sigmaAlbedo,
                             float* hostRGBA32F, void* hipStream);
 
+/* replaces GltfRenderer::tonemap -> nvshaders::Tonemapper::runCompute (reference: src/renderer.cpp:992-1056): the HDR image
+ * (source 0 = the accumulator eImgRendered, 1 = the denoised image of the last mi_pt_denoise, as the reference routes the OptiX
+ * output: src/renderer.cpp:1006-1016) -> display-referred RGBA8, the eImgTonemapped image the headless run saves
+ * (src/renderer.cpp:557-573).  Alpha passes through.  With tm->autoExposure the metering histogram and the exposure easing run on
+ * the device too; dtSeconds is the time since the previous call (< 0: jump to the target).  hostRGBA8 may be NULL (result kept in
+ * the internal image, mi_pt_tonemapped_device_ptr). */
+MI_PT_API int mi_pt_tonemap(MiPt* pt, const MiTonemapperData* tm, int source, float dtSeconds, uint8_t* hostRGBA8, void* hipStream);
+MI_PT_API void* mi_pt_tonemapped_device_ptr(MiPt* pt);
+/* the reference's defaults: Filmic, active, exposure / brightness / contrast / saturation 1, vignette 0, autoExposure as given */
+MI_PT_API void mi_pt_default_tonemapper(MiTonemapperData* tm, int autoExposure);
+
 MI_PT_API int mi_pt_get_stats(MiPt* pt, MiPtStats* stats);
 MI_PT_API int mi_pt_reset_stats(MiPt* pt);
 MI_PT_API int mi_pt_enable_timing(MiPt* pt, int enable);

@@ -234,6 +234,36 @@ typedef struct MiEnvAccel
   float    q;
 } MiEnvAccel;
 
+/* Tonemapper parameters (reference: nvshaders/tonemap_io.h.slang `TonemapperData`, external to the reference tree; held in
+ * Resources::tonemapperData with `.autoExposure = 1`, src/resources.hpp:212; set from the command line by tmMethod / tmExposure /
+ * tmGamma (-> brightness) / tmContrast / tmSaturation / tmWhitePoint (-> vignette), src/renderer.cpp:173-179; consumed by
+ * GltfRenderer::tonemap, src/renderer.cpp:1041-1050).  Field list restated from the public nvpro_core2 header. */
+enum MiTonemapMethod
+{
+  MI_TONEMAP_FILMIC      = 0,
+  MI_TONEMAP_UNCHARTED   = 1,
+  MI_TONEMAP_CLIP        = 2,
+  MI_TONEMAP_ACES        = 3,
+  MI_TONEMAP_AGX         = 4,
+  MI_TONEMAP_KHRONOS_PBR = 5
+};
+
+typedef struct MiTonemapperData
+{
+  int   method;     /* MiTonemapMethod */
+  int   isActive;   /* 0: the input is passed through (clamped to 8 bits), src/renderer.cpp:1042-1047 */
+  float exposure;   /* linear multiplier applied before the curve */
+  float brightness; /* display gamma applied after the curve: c^(1/brightness) */
+  float contrast;   /* about mid grey 0.5 */
+  float saturation; /* about Rec.601 luma */
+  float vignette;   /* radial darkening, 0 = off */
+  int   autoExposure;         /* 1: exposure is further scaled by key 0.18 / geometric-mean luminance of the image */
+  float autoExposureSpeed;    /* adaptation rate, 1/s (temporal easing 1 - exp(-dt * speed)) */
+  float evMinValue;           /* log2-luminance range of the metering histogram */
+  float evMaxValue;
+  int   enableCenterMetering; /* 1: the central disc of the image weighs four times */
+} MiTonemapperData;
+
 #ifdef __cplusplus
 }
 static_assert(sizeof(MiGltfRenderNode) == 136, "GltfRenderNode layout");
@@ -241,6 +271,7 @@ static_assert(sizeof(MiGltfLight) == 64, "GltfLight layout");
 static_assert(sizeof(MiGltfTextureInfo) == 32, "GltfTextureInfo layout");
 static_assert(sizeof(MiGltfShadeMaterial) == 288, "GltfShadeMaterial layout");
 static_assert(sizeof(MiSceneFrameInfo) == 396, "SceneFrameInfo layout");
+static_assert(sizeof(MiTonemapperData) == 48, "TonemapperData layout");
 #endif
 
 #endif /* MI_PT_SHADERIO_H */

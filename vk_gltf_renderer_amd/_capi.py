@@ -77,6 +77,14 @@ class MiEnvAccel(C.Structure):
     _fields_ = [("alias", u32), ("q", f32)]
 
 
+class MiTonemapperData(C.Structure):
+    _fields_ = [("method", i32), ("isActive", i32), ("exposure", f32), ("brightness", f32), ("contrast", f32), ("saturation", f32), ("vignette", f32),
+                ("autoExposure", i32), ("autoExposureSpeed", f32), ("evMinValue", f32), ("evMaxValue", f32), ("enableCenterMetering", i32)]
+
+
+TONEMAP_METHODS = ("filmic", "uncharted", "clip", "aces", "agx", "khronos_pbr")  # MiTonemapMethod 0..5 (src/renderer.cpp:173)
+
+
 class MiPtRenderPrimitive(C.Structure):
     _fields_ = [("indices", C.POINTER(u32)), ("triangleCount", u32), ("vertexCount", u32), ("positions", C.POINTER(f32)),
                 ("normals", C.POINTER(f32)), ("colors", C.POINTER(u32)), ("tangents", C.POINTER(f32)),
@@ -174,6 +182,9 @@ PT_SYMBOLS = {
     "mi_pt_read_depth": (i32, [VP, P(f32)]),
     "mi_pt_accum_device_ptr": (VP, [VP]),
     "mi_pt_denoise": (i32, [VP, i32, f32, f32, f32, P(f32), VP]),
+    "mi_pt_tonemap": (i32, [VP, P(MiTonemapperData), i32, f32, P(C.c_uint8), VP]),
+    "mi_pt_tonemapped_device_ptr": (VP, [VP]),
+    "mi_pt_default_tonemapper": (None, [P(MiTonemapperData), i32]),
     "mi_pt_get_stats": (i32, [VP, P(MiPtStats)]),
     "mi_pt_reset_stats": (i32, [VP]),
     "mi_pt_enable_timing": (i32, [VP, i32]),

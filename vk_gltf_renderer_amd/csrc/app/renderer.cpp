@@ -10,6 +10,7 @@
 GltfRenderer::GltfRenderer()
 {
   mi_default_sky(&m_resources.skyParams);  // reference: skyParams = {} at src/renderer.cpp:1328
+  mi_pt_default_tonemapper(&m_resources.tonemapperData, 1);  // reference: tonemapperData{.autoExposure = 1}, src/resources.hpp:212
 }
 
 GltfRenderer::~GltfRenderer()
@@ -34,6 +35,15 @@ void GltfRenderer::registerParameters(ParameterRegistry* r)
   r->add("isShadowCatcher", "Ground plane only catches shadows", &s.isShadowCatcher);
   r->add("infinitePlaneDistance", "Ground plane height", &s.infinitePlaneDistance);
   r->add("device", "HIP device ordinal", &m_resources.device);
+  // tonemapper (reference: src/renderer.cpp:173-179 -- same names, same members)
+  MiTonemapperData& tm = m_resources.tonemapperData;
+  r->add("tmMethod", "Tonemapper method: [Filmic:0, Uncharted:1, Clip:2, ACES:3, AgX:4, KhronosPBR:5]", &tm.method);
+  r->add("tmExposure", "Tonemapper exposure", &tm.exposure);
+  r->add("tmGamma", "Tonemapper brightness", &tm.brightness);
+  r->add("tmContrast", "Tonemapper contrast", &tm.contrast);
+  r->add("tmSaturation", "Tonemapper saturation", &tm.saturation);
+  r->add("tmWhitePoint", "Tonemapper vignette", &tm.vignette);
+  r->add("tmAutoExposure", "Tonemapper auto exposure [0, 1]", &tm.autoExposure);
   m_pathTracer.registerParameters(r);
 }
 
@@ -144,23 +154,6 @@ void GltfRenderer::onLastHeadlessFrame(uint32_t headlessFrames)
   saveHeadlessOutputImage();
 }
 
-// Filmic tone curve (Hejl / Burgess-Dawson) with a fixed exposure, then the curve's built-in ~sRGB response.
-// nvshaders::Tonemapper (external to the reference) offers Filmic as its method 0; exact parameter parity is a "next" row.
-void GltfRenderer::tonemap(const float* rgba, int w, int h, float exposure, std::vector<unsigned char>& ldr)
-{
-  ldr.resize(size_t(w) * size_t(h) * 4);
-  for(size_t i = 0; i < size_t(w) * size_t(h); ++i)
-  {
-    for(int c = 0; c < 3; ++c)
-    {
-      float x = std::max(0.0f, rgba[4 * i + size_t(c)] * exposure - 0.004f);
-      float y = (x * (6.2f * x + 0.5f)) / (x * (6.2f * x + 1.7f) + 0.06f);
-      ldr[4 * i + size_t(c)] = (unsigned char)(std::min(std::max(y, 0.0f), 1.0f) * 255.0f + 0.5f);
-    }
-    ldr[4 * i + 3] = 255;
-  }
-}
-
 bool GltfRenderer::savePng(const std::string& path, const unsigned char* rgba8, int w, int h)
 {
   std::vector<unsigned char> raw(size_t(h) * (size_t(w) * 4 + 1));
@@ -245,30 +238,25 @@ void GltfRenderer::saveHeadlessOutputImage()
   const int w = int(m_resources.renderSize.width), h = int(m_resources.renderSize.height);
   if(w <= 0 || !m_pathTracer.handle())
     return;
-  std::vector<float> rgba(size_t(w) * size_t(h) * 4);
-  if(!m_pathTracer.readRendered(rgba.data()))
-    return;
   std::string out = m_resources.headlessOutputPath.empty() ? std::string("mi_gltf_renderer.png") : m_resources.headlessOutputPath;
-  // auto exposure (the reference enables tonemapper auto-exposure: src/resources.hpp:206): key 0.18 over the log-average luminance
-  double logSum = 0.0;
-  size_t n      = 0;
-  for(size_t i = 0; i < size_t(w) * size_t(h); ++i)
-  {
-    float lum = 0.2126f * rgba[4 * i] + 0.7152f * rgba[4 * i + 1] + 0.0722f * rgba[4 * i + 2];
-    if(lum > 0.0f && std::isfinite(lum))
-    {
-      logSum += std::log(double(lum) + 1e-6);
-      ++n;
-    }
-  }
-  float exposure = n ? float(0.18 / std::exp(logSum / double(n))) : 1.0f;
   if(out.size() > 4 && out.substr(out.size() - 4) == ".hdr")
-    saveHdr(out, rgba.data(), w, h);
+  {  // eImgRendered as it is (reference: src/ui_renderer.cpp:1187-1195)
+    std::vector<float> rgba(size_t(w) * size_t(h) * 4);
+    if(!m_pathTracer.readRendered(rgba.data()) || !saveHdr(out, rgba.data(), w, h))
+      return;
+  }
   else
-  {
-    std::vector<unsigned char> ldr;
-    tonemap(rgba.data(), w, h, exposure, ldr);
-    savePng(out, ldr.data(), w, h);
+  {  // eImgTonemapped: GltfRenderer::tonemap on the device (reference: src/renderer.cpp:557-573, :992-1056)
+    std::vector<unsigned char> ldr(size_t(w) * size_t(h) * 4);
+    if(mi_pt_tonemap(m_pathTracer.handle(), &m_resources.tonemapperData, 0, -1.0f, ldr.data(), nullptr) != MI_PT_OK)
+    {
+      fprintf(stderr, "tonemap: %s\n", mi_pt_last_error());
+      return;
+    }
+    for(size_t i = 3; i < ldr.size(); i += 4)
+      ldr[i] = 255;  // saved opaque, like the reference's screenshot path
+    if(!savePng(out, ldr.data(), w, h))
+      return;
   }
   printf("Saved headless output image: %s\n", out.c_str());
 }

@@ -25,8 +25,7 @@ public:
   PathTracer&  pathTracer() { return m_pathTracer; }
   BenchmarkController& benchmark() { return m_benchmark; }
 
-  // tonemap + save helpers (also used by tests): Filmic curve + sRGB, PNG via zlib, Radiance .hdr dump
-  static void tonemap(const float* rgba, int w, int h, float exposure, std::vector<unsigned char>& ldr);
+  // save helpers: PNG via zlib, Radiance .hdr dump (the tonemapper itself runs on the device: mi_pt_tonemap)
   static bool savePng(const std::string& path, const unsigned char* rgba8, int w, int h);
   static bool saveHdr(const std::string& path, const float* rgba, int w, int h);
 

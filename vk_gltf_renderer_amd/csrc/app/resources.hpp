@@ -34,6 +34,7 @@ struct Resources
   MiScene*                scene{nullptr};  // nvvkgltf::Scene + SceneVk tables (libmi_host)
   MiHdr*                  hdrIbl{nullptr}; // nvvk::HdrIbl
   MiSkyPhysicalParameters skyParams{};
+  MiTonemapperData        tonemapperData{};  // reference: src/resources.hpp:212
   MiCamera                camera{};        // nvutils::CameraManipulator state
   MiSceneFrameInfo        frameInfo{};     // what GltfRenderer::onRender uploads into bFrameInfo each frame
   Extent2D                renderSize{};    // gBuffers.getSize()

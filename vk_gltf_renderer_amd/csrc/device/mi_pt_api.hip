@@ -131,6 +131,9 @@ struct MiPt
   DevBuf<float4>          queuePayload;
   pt::Queues              queues{};
   DevBuf<float4>          accumOwn, albedo, normal, denoiseA, denoiseB;
+  const float4*           denoised = nullptr;  // result of the last mi_pt_denoise (one of denoiseA / denoiseB)
+  DevBuf<uint32_t>        tonemapped, tmHistogram;
+  DevBuf<float>           tmAutoState;
   float4*                 accum = nullptr;  // accumOwn.ptr or caller-bound memory
   DevBuf<float>           depth;
   DevBuf<uint32_t>        selection;
@@ -236,6 +239,9 @@ int allocFrameResources(MiPt* pt)
   }
   pt->denoiseA.release();
   pt->denoiseB.release();
+  pt->tonemapped.release();
+  pt->tmHistogram.release();
+  pt->tmAutoState.release();
   return MI_PT_OK;
 }
 
@@ -382,18 +388,6 @@ const char* mi_pt_last_error(void)
 {
   return g_lastError.c_str();
 }
-const char* mi_pt_version(void)
-{
-#ifndef MI_PT_SRC_ID
-#define MI_PT_SRC_ID "unknown"
-#endif
-#ifndef MI_PT_GIT_ID
-#define MI_PT_GIT_ID "nogit"
-#endif
-  // src = sha1 of the device sources + public headers this binary was compiled from (csrc/Makefile), git = HEAD at build time
-  return "mi_pt 0.2 (gfx950 wavefront path tracer) src=" MI_PT_SRC_ID " git=" MI_PT_GIT_ID;
-}
-
 int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt** out)
 {
   if(!sd || !out)
@@ -1051,9 +1045,64 @@ int mi_pt_denoise(MiPt* pt, int iterations, float sigmaColor, float sigmaNormal,
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(stream));
+  pt->denoised = in;
   if(host)
     HIP_TRY(hipMemcpy(host, in, px * sizeof(float4), hipMemcpyDeviceToHost));
   return MI_PT_OK;
+}
+
+void mi_pt_default_tonemapper(MiTonemapperData* tm, int autoExposure)
+{
+  if(!tm)
+    return;
+  *tm                      = MiTonemapperData{};
+  tm->method               = MI_TONEMAP_FILMIC;
+  tm->isActive             = 1;
+  tm->exposure             = 1.0f;
+  tm->brightness           = 1.0f;
+  tm->contrast             = 1.0f;
+  tm->saturation           = 1.0f;
+  tm->vignette             = 0.0f;
+  tm->autoExposure         = autoExposure ? 1 : 0;
+  tm->autoExposureSpeed    = 1.0f;
+  tm->evMinValue           = -24.0f;
+  tm->evMaxValue           = 8.0f;
+  tm->enableCenterMetering = 0;
+}
+
+int mi_pt_tonemap(MiPt* pt, const MiTonemapperData* tm, int source, float dtSeconds, uint8_t* host, void* hipStream)
+{
+  if(!pt || !tm || pt->width <= 0 || source < 0 || source > 1)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_tonemap: bad arguments");
+  if(tm->method < MI_TONEMAP_FILMIC || tm->method > MI_TONEMAP_KHRONOS_PBR || !(tm->brightness > 0.0f) || !(tm->evMaxValue > tm->evMinValue))
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_tonemap: method outside [0, 5], brightness <= 0 or an empty EV range");
+  const size_t px = size_t(pt->width) * size_t(pt->height);
+  if(source == 1 && (!pt->denoised || pt->denoiseA.count != px))
+    return fail(MI_PT_ERR_STATE, "mi_pt_tonemap: source 1 needs a mi_pt_denoise result of the current size");
+  HIP_TRY(hipSetDevice(pt->device));
+  hipStream_t stream = reinterpret_cast<hipStream_t>(hipStream);
+  if(pt->tonemapped.count != px)
+    HIP_TRY(pt->tonemapped.alloc(px));
+  if(!pt->tmHistogram.ptr)
+  {
+    HIP_TRY(pt->tmHistogram.alloc(256));
+    HIP_TRY(pt->tmAutoState.alloc(2));
+    HIP_TRY(hipMemset(pt->tmAutoState.ptr, 0, 2 * sizeof(float)));
+  }
+  pt::launchTonemap(source == 1 ? pt->denoised : pt->accum, pt->tonemapped.ptr, pt->width, pt->height, *tm, pt->tmHistogram.ptr, pt->tmAutoState.ptr,
+                    dtSeconds, stream);
+  HIP_TRY(hipGetLastError());
+  if(host)
+  {
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipMemcpy(host, pt->tonemapped.ptr, px * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  }
+  return MI_PT_OK;
+}
+
+void* mi_pt_tonemapped_device_ptr(MiPt* pt)
+{
+  return pt ? pt->tonemapped.ptr : nullptr;
 }
 
 int mi_pt_get_stats(MiPt* pt, MiPtStats* out)

@@ -43,4 +43,9 @@ void launchSelection(const LaunchCtx& c, uint32_t* selection);
 void launchAtrous(const float4* in, float4* out, const float4* albedo, const float4* normal, int width, int height, int step, float sigmaColor,
                   float sigmaNormal, float sigmaAlbedo, hipStream_t s);
 
+
+// tonemapper (tonemap.hip): optional auto-exposure metering (histogram: 256 u32, autoState: 2 floats) + the curve, RGBA32F -> RGBA8
+void launchTonemap(const float4* in, uint32_t* outRgba8, int width, int height, const MiTonemapperData& tm, uint32_t* histogram, float* autoState,
+                   float dtSeconds, hipStream_t s);
+
 }  // namespace pt

@@ -190,6 +190,18 @@ class PathTracer:
                                         out.ctypes.data_as(C.POINTER(C.c_float)), None))
         return out
 
+    def tonemap(self, tm=None, source=0, dt_seconds=-1.0, **fields):
+        """HDR -> display RGBA8 (H, W, 4 uint8) on the device; tm = MiTonemapperData (default: the reference's defaults with auto exposure
+        off), fields override members (method may be a name from capi.TONEMAP_METHODS); source 1 = the last denoise() result."""
+        if tm is None:
+            tm = capi.MiTonemapperData()
+            self._l.mi_pt_default_tonemapper(C.byref(tm), 0)
+        for k, v in fields.items():
+            setattr(tm, k, capi.TONEMAP_METHODS.index(v) if (k == "method" and isinstance(v, str)) else v)
+        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        _check_pt(self._l.mi_pt_tonemap(self._p, C.byref(tm), source, dt_seconds, out.ctypes.data_as(C.POINTER(C.c_uint8)), None))
+        return out
+
     def stats(self):
         st = capi.MiPtStats()
         _check_pt(self._l.mi_pt_get_stats(self._p, C.byref(st)))
