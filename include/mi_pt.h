@@ -211,6 +211,9 @@ MI_PT_API int mi_pt_synchronize(MiPt* pt);
 
 /* Read-backs (the reference reads gBuffers images back for screenshots: src/renderer.cpp:557-573). */
 MI_PT_API int mi_pt_read_accum(MiPt* pt, float* hostRGBA32F);          /* eImgRendered   */
+/* Upload an image INTO eImgRendered (width*height RGBA32F), e.g. to post-process (denoise / tonemap) a frame rendered elsewhere or
+ * an accumulation restored from disk; the next frame without MI_PT_FIRST_FRAME continues the running mean from it. */
+MI_PT_API int mi_pt_write_accum(MiPt* pt, const float* hostRGBA32F);
 /* Denoiser guide layers accumulated while MI_PT_USE_OPTIX_DENOISER is set in params->flags (first-hit albedo.rgb + hit
  * fraction, first-hit shading normal.xyz; reference capture points: shaders/gltf_pathtrace.slang:228-264, the OptiX guide
  * images of src/optix_denoiser.hpp:128-153).  Either pointer may be NULL. */

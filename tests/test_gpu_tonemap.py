@@ -88,15 +88,13 @@ def _reference(img, method, exposure=1.0, brightness=1.0, contrast=1.0, saturati
 
 
 def _tracer_with_image(assets, img):
-    """A PathTracer whose accumulator holds `img` (bound caller-owned device memory, like bench.py binds a torch tensor)."""
-    import torch
+    """A PathTracer whose accumulator holds `img` (mi_pt_write_accum)."""
     H, W, _ = img.shape
     scene = ptmod.Scene(os.path.join(assets, "Box.glb"))
     t = ptmod.PathTracer(scene)
     t.resize(W, H)
-    dev = torch.from_numpy(np.ascontiguousarray(img, np.float32)).cuda()
-    t.bind_accum(dev.data_ptr())
-    return t, dev
+    t.write_accum(img)
+    return t, None
 
 
 @pytest.mark.parametrize("method", capi.TONEMAP_METHODS)
@@ -163,8 +161,7 @@ def test_auto_exposure_meters_the_geometric_mean(built, assets):
     b = t2.tonemap(tm, dt_seconds=-1.0).astype(np.int32)
     assert np.abs(a - b).max() <= 1  # 3 stops brighter = exactly 24 bins up: the same picture
     # easing: one step of dt = ln 2 / speed moves the exposure half way to the new target
-    keep2.mul_(0.25)
-    keep2[..., 3] = 1.0
+    t2.write_accum(img * np.array([2.0, 2.0, 2.0, 1.0], np.float32))
     c = t2.tonemap(tm, dt_seconds=float(np.log(2.0)) / tm.autoExposureSpeed).astype(np.int32)
     want_c = _reference(img * 2.0, "filmic", exposure=(expo / 8.0 + (expo / 2.0 - expo / 8.0) * 0.5))
     assert np.abs(c - np.floor(want_c + 0.5))[..., :3].max() <= 6

@@ -177,6 +177,7 @@ PT_SYMBOLS = {
     "mi_pt_render_frames": (i32, [VP, P(MiPathtraceParams), i32, VP]),
     "mi_pt_synchronize": (i32, [VP]),
     "mi_pt_read_accum": (i32, [VP, P(f32)]),
+    "mi_pt_write_accum": (i32, [VP, P(f32)]),
     "mi_pt_read_guides": (i32, [VP, P(f32), P(f32)]),
     "mi_pt_read_selection": (i32, [VP, P(u32)]),
     "mi_pt_read_depth": (i32, [VP, P(f32)]),

@@ -987,6 +987,15 @@ int mi_pt_read_accum(MiPt* pt, float* host)
   HIP_TRY(hipMemcpy(host, pt->accum, size_t(pt->width) * size_t(pt->height) * sizeof(float4), hipMemcpyDeviceToHost));
   return MI_PT_OK;
 }
+int mi_pt_write_accum(MiPt* pt, const float* host)
+{
+  if(!pt || !host || pt->width <= 0)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_write_accum: bad arguments");
+  HIP_TRY(hipSetDevice(pt->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(pt->accum, host, size_t(pt->width) * size_t(pt->height) * sizeof(float4), hipMemcpyHostToDevice));
+  return MI_PT_OK;
+}
 int mi_pt_read_guides(MiPt* pt, float* albedo, float* normal)
 {
   if(!pt || pt->width <= 0)

@@ -167,6 +167,11 @@ class PathTracer:
         _check_pt(self._l.mi_pt_read_accum(self._p, out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
 
+    def write_accum(self, img):
+        img = np.ascontiguousarray(img, dtype=np.float32)
+        assert img.shape == (self.height, self.width, 4)
+        _check_pt(self._l.mi_pt_write_accum(self._p, img.ctypes.data_as(C.POINTER(C.c_float))))
+
     def read_guides(self):
         """(albedo RGBA, normal RGBA) guide layers of the denoiser (valid when MI_PT_USE_OPTIX_DENOISER was set)."""
         a = np.empty((self.height, self.width, 4), dtype=np.float32)
