@@ -228,6 +228,15 @@ MI_PT_API void* mi_pt_accum_device_ptr(MiPt* pt);
 MI_PT_API int mi_pt_denoise(MiPt* pt, int iterations, float sigmaColor, float sigmaNormal, float sigmaAlbedo,
                             float* hostRGBA32F, void* hipStream);
 
+/* Variance-guided (SVGF-style) denoise of the accumulator: the same I/O contract as mi_pt_denoise, guided in addition by the
+ * per-pixel variance of the mean -- from the second moment of the per-frame pixel luminance that the frames accumulate next to
+ * the guides while MI_PT_USE_OPTIX_DENOISER is set (spatial estimate below 4 frames) -- and by the frame-0 depth; albedo is
+ * demodulated before and re-applied after filtering.  The temporal half of SVGF is the running mean itself (the camera of a
+ * progressive accumulation stands still), so there is no reprojection.  Asynchronous on hipStream unless hostRGBA32F is given. */
+MI_PT_API int mi_pt_denoise_svgf(MiPt* pt, int iterations, float sigmaLuminance, float sigmaNormal, float sigmaDepth, float* hostRGBA32F, void* hipStream);
+/* device address of the last denoise result (NULL before the first), valid until the next denoise / resize */
+MI_PT_API const void* mi_pt_denoised_device_ptr(MiPt* pt);
+
 /* replaces GltfRenderer::tonemap -> nvshaders::Tonemapper::runCompute (reference: src/renderer.cpp:992-1056): the HDR image
  * (source 0 = the accumulator eImgRendered, 1 = the denoised image of the last mi_pt_denoise, as the reference routes the OptiX
  * output: src/renderer.cpp:1006-1016) -> display-referred RGBA8, the eImgTonemapped image the headless run saves

@@ -2695,7 +2695,9 @@ void processPixel(Ctx& cx, int px, int py, int W, int H, const Outputs& out)  //
       out.depth[idx] = ndcDepth;
   }
   float* dst = out.accum + idx * 4;
-  float4 guideA(albedo / float(sc.pc.numSamples), hasSolidHit ? 1.0f : 0.0f), guideN(normal / float(sc.pc.numSamples), 0.0f);
+  // guideN.w: second moment of this frame's pixel luminance (our SVGF pass's temporal-variance input; no reference counterpart)
+  const float lumP = 0.2126f * pixel.x + 0.7152f * pixel.y + 0.0722f * pixel.z;
+  float4 guideA(albedo / float(sc.pc.numSamples), hasSolidHit ? 1.0f : 0.0f), guideN(normal / float(sc.pc.numSamples), lumP * lumP);
   if(firstFrame)
   {
     dst[0] = pixel.x; dst[1] = pixel.y; dst[2] = pixel.z; dst[3] = pixel.w;
@@ -2714,14 +2716,14 @@ void processPixel(Ctx& cx, int px, int py, int W, int H, const Outputs& out)  //
     if(firstFrame)
     {
       a[0] = guideA.x; a[1] = guideA.y; a[2] = guideA.z; a[3] = guideA.w;
-      n[0] = guideN.x; n[1] = guideN.y; n[2] = guideN.z; n[3] = 0.0f;
+      n[0] = guideN.x; n[1] = guideN.y; n[2] = guideN.z; n[3] = guideN.w;
     }
     else
     {
       float after = float(sc.pc.totalSamples + sc.pc.numSamples);
       float wOld = float(sc.pc.totalSamples) / after, wNew = float(sc.pc.numSamples) / after;
       a[0] = a[0] * wOld + guideA.x * wNew; a[1] = a[1] * wOld + guideA.y * wNew; a[2] = a[2] * wOld + guideA.z * wNew; a[3] = a[3] * wOld + guideA.w * wNew;
-      n[0] = n[0] * wOld + guideN.x * wNew; n[1] = n[1] * wOld + guideN.y * wNew; n[2] = n[2] * wOld + guideN.z * wNew; n[3] = 0.0f;
+      n[0] = n[0] * wOld + guideN.x * wNew; n[1] = n[1] * wOld + guideN.y * wNew; n[2] = n[2] * wOld + guideN.z * wNew; n[3] = n[3] * wOld + guideN.w * wNew;
     }
   }
 }

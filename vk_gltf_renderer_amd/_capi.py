@@ -183,6 +183,8 @@ PT_SYMBOLS = {
     "mi_pt_read_depth": (i32, [VP, P(f32)]),
     "mi_pt_accum_device_ptr": (VP, [VP]),
     "mi_pt_denoise": (i32, [VP, i32, f32, f32, f32, P(f32), VP]),
+    "mi_pt_denoise_svgf": (i32, [VP, i32, f32, f32, f32, P(f32), VP]),
+    "mi_pt_denoised_device_ptr": (VP, [VP]),
     "mi_pt_tonemap": (i32, [VP, P(MiTonemapperData), i32, f32, P(C.c_uint8), VP]),
     "mi_pt_tonemapped_device_ptr": (VP, [VP]),
     "mi_pt_default_tonemapper": (None, [P(MiTonemapperData), i32]),

@@ -131,6 +131,7 @@ struct MiPt
   DevBuf<float4>          queuePayload;
   pt::Queues              queues{};
   DevBuf<float4>          accumOwn, albedo, normal, denoiseA, denoiseB;
+  float                   accumFrames = 0.0f;  // frames folded into the accumulator (variance of the mean, SVGF pass)
   const float4*           denoised = nullptr;  // result of the last mi_pt_denoise (one of denoiseA / denoiseB)
   DevBuf<uint32_t>        tonemapped, tmHistogram;
   DevBuf<float>           tmAutoState;
@@ -697,8 +698,10 @@ int mi_pt_resize(MiPt* pt, int width, int height)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_resize: need 0 < width, height <= 32768");
   HIP_TRY(hipSetDevice(pt->device));
   HIP_TRY(hipDeviceSynchronize());
-  pt->width  = width;
-  pt->height = height;
+  pt->width       = width;
+  pt->height      = height;
+  pt->denoised    = nullptr;
+  pt->accumFrames = 0.0f;
   return allocFrameResources(pt);
 }
 
@@ -800,6 +803,7 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   c.fc.numSlots  = pt->numSlots;
   c.fc.numFrames = numFrames;
   c.paths        = pt->paths;
+  pt->accumFrames   = float(params->totalSamples) / float(params->numSamples) + float(numFrames);
   const bool guides = (params->flags & MI_PT_USE_OPTIX_DENOISER) != 0;
   if(!guides)
   {
@@ -1060,6 +1064,31 @@ int mi_pt_denoise(MiPt* pt, int iterations, float sigmaColor, float sigmaNormal,
   return MI_PT_OK;
 }
 
+int mi_pt_denoise_svgf(MiPt* pt, int iterations, float sigmaLuminance, float sigmaNormal, float sigmaDepth, float* host, void* hipStream)
+{
+  if(!pt || pt->width <= 0 || iterations < 1 || iterations > 8 || !(sigmaLuminance > 0.0f) || !(sigmaDepth > 0.0f) || !(sigmaNormal >= 0.0f))
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_denoise_svgf: bad arguments");
+  if(!(pt->accumFrames >= 1.0f))
+    return fail(MI_PT_ERR_STATE, "mi_pt_denoise_svgf: nothing rendered yet");
+  HIP_TRY(hipSetDevice(pt->device));
+  hipStream_t  stream = reinterpret_cast<hipStream_t>(hipStream);
+  const size_t px     = size_t(pt->width) * size_t(pt->height);
+  if(pt->denoiseA.count != px)
+  {
+    HIP_TRY(pt->denoiseA.alloc(px));
+    HIP_TRY(pt->denoiseB.alloc(px));
+  }
+  pt->denoised = pt::launchSvgf(pt->accum, pt->albedo.ptr, pt->normal.ptr, pt->depth.ptr, pt->denoiseA.ptr, pt->denoiseB.ptr, pt->width, pt->height, iterations,
+                                pt->accumFrames, sigmaLuminance, sigmaNormal, sigmaDepth, stream);
+  HIP_TRY(hipGetLastError());
+  if(host)
+  {
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipMemcpy(host, pt->denoised, px * sizeof(float4), hipMemcpyDeviceToHost));
+  }
+  return MI_PT_OK;
+}
+
 void mi_pt_default_tonemapper(MiTonemapperData* tm, int autoExposure)
 {
   if(!tm)
@@ -1107,6 +1136,11 @@ int mi_pt_tonemap(MiPt* pt, const MiTonemapperData* tm, int source, float dtSeco
     HIP_TRY(hipMemcpy(host, pt->tonemapped.ptr, px * sizeof(uint32_t), hipMemcpyDeviceToHost));
   }
   return MI_PT_OK;
+}
+
+const void* mi_pt_denoised_device_ptr(MiPt* pt)
+{
+  return pt ? pt->denoised : nullptr;
 }
 
 void* mi_pt_tonemapped_device_ptr(MiPt* pt)

@@ -43,6 +43,8 @@ void launchSelection(const LaunchCtx& c, uint32_t* selection);
 void launchAtrous(const float4* in, float4* out, const float4* albedo, const float4* normal, int width, int height, int step, float sigmaColor,
                   float sigmaNormal, float sigmaAlbedo, hipStream_t s);
 
+const float4* launchSvgf(const float4* color, const float4* albedo, const float4* normal, const float* depth, float4* bufA, float4* bufB, int width, int height,
+                         int iterations, float frames, float sigmaLuminance, float sigmaNormal, float sigmaDepth, hipStream_t s);
 
 // tonemapper (tonemap.hip): optional auto-exposure metering (histogram: 256 u32, autoState: 2 floats) + the curve, RGBA32F -> RGBA8
 void launchTonemap(const float4* in, uint32_t* outRgba8, int width, int height, const MiTonemapperData& tm, uint32_t* histogram, float* autoState,

@@ -2160,7 +2160,10 @@ __global__ void __launch_bounds__(256) k_finish_sample(FrameConsts fc, PathSoA P
     {
       const float4 ga = P.guideAlbedo[slot], gn = P.guideNormal[slot];
       const float4 a  = make_float4(ga.x / n, ga.y / n, ga.z / n, r.w > 0.0f ? 1.0f : 0.0f);
-      const float4 nn = make_float4(gn.x / n, gn.y / n, gn.z / n, 0.0f);
+      // .w: second moment of this frame's pixel luminance (Rec. 709) -- with luminance(accum) it gives the temporal variance the
+      // SVGF pass is guided by (denoise.hip), at no extra image
+      const float  lumP = 0.2126f * pixel.x + 0.7152f * pixel.y + 0.0722f * pixel.z;
+      const float4 nn   = make_float4(gn.x / n, gn.y / n, gn.z / n, lumP * lumP);
       if(firstFrame)
       {
         accA = a;
@@ -2170,7 +2173,7 @@ __global__ void __launch_bounds__(256) k_finish_sample(FrameConsts fc, PathSoA P
       {
         const float wOld = tot / after, wNew = n / after;
         accA = make_float4(accA.x * wOld + a.x * wNew, accA.y * wOld + a.y * wNew, accA.z * wOld + a.z * wNew, accA.w * wOld + a.w * wNew);
-        accN = make_float4(accN.x * wOld + nn.x * wNew, accN.y * wOld + nn.y * wNew, accN.z * wOld + nn.z * wNew, 0.0f);
+        accN = make_float4(accN.x * wOld + nn.x * wNew, accN.y * wOld + nn.y * wNew, accN.z * wOld + nn.z * wNew, accN.w * wOld + nn.w * wNew);
       }
     }
   }

@@ -195,6 +195,13 @@ class PathTracer:
                                         out.ctypes.data_as(C.POINTER(C.c_float)), None))
         return out
 
+    def denoise_svgf(self, iterations=5, sigma_luminance=4.0, sigma_normal=128.0, sigma_depth=1.0, read=True):
+        """Variance-guided denoise (mi_pt_denoise_svgf); read=False leaves the result on the device (tonemap(source=1) picks it up)."""
+        out = np.empty((self.height, self.width, 4), dtype=np.float32) if read else None
+        _check_pt(self._l.mi_pt_denoise_svgf(self._p, iterations, sigma_luminance, sigma_normal, sigma_depth,
+                                             out.ctypes.data_as(C.POINTER(C.c_float)) if read else None, None))
+        return out
+
     def tonemap(self, tm=None, source=0, dt_seconds=-1.0, **fields):
         """HDR -> display RGBA8 (H, W, 4 uint8) on the device; tm = MiTonemapperData (default: the reference's defaults with auto exposure
         off), fields override members (method may be a name from capi.TONEMAP_METHODS); source 1 = the last denoise() result."""
