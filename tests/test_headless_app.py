@@ -90,3 +90,59 @@ def test_adaptive_sampling_controller(assets):
     r = _run(base + ["--ptSamples", "2"])
     assert r.returncode == 0 and "ADAPTIVE_SAMPLING" not in r.stdout
     assert _records(r.stdout)[-1]["effective_spp"] == 40
+
+
+def _read_png_rgba8(path):
+    """Minimal PNG reader for what GltfRenderer::savePng writes (8-bit RGBA, filter 0 on every row)."""
+    import struct
+    import zlib
+    b = open(path, "rb").read()
+    assert b[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w, h = 8, b"", 0, 0
+    while pos < len(b):
+        n, tag = struct.unpack(">I4s", b[pos:pos + 8])
+        if tag == b"IHDR":
+            w, h, depth, ctype = struct.unpack(">IIBB", b[pos + 8:pos + 18])
+            assert (depth, ctype) == (8, 6)
+        if tag == b"IDAT":
+            idat += b[pos + 8:pos + 8 + n]
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, w * 4 + 1)
+    assert (raw[:, 0] == 0).all()
+    return raw[:, 1:].reshape(h, w, 4)
+
+
+@pytest.mark.gpu
+def test_tonemapped_output_and_denoiser_cadence(tmp_path, assets):
+    """--output x.png saves eImgTonemapped: the device tonemapper with the reference's tm* switches (src/renderer.cpp:173-179), fed
+    by the denoised image when the denoiser is on (src/renderer.cpp:1006-1016).  The denoiser keeps the OptiX adapter's switches:
+    auto-denoise every optixAutoDenoiseInterval frames (src/optix_denoiser.cpp:773-800), plus the final frame of a headless run."""
+    from vk_gltf_renderer_amd import pathtracer as ptmod
+    import parity_util as pu
+    out = tmp_path / "box.png"
+    base = ["--headless", "--size", "96", "64", "--scenefile", os.path.join(assets, "Box.glb"), "--hdrfile", os.path.join(assets, "std_env.hdr"), "--envSystem", "1",
+            "--frames", "12", "--maxFrames", "12", "--ptSamples", "1", "--ptMaxDepth", "3", "--output", str(out)]
+    r = _run(base + ["--tmMethod", "3", "--tmExposure", "1.5", "--tmAutoExposure", "0", "--tmSaturation", "0.9"])
+    assert r.returncode == 0 and "DENOISER" not in r.stdout, r.stdout + r.stderr
+    png = _read_png_rgba8(out)
+    assert png.shape == (64, 96, 4) and (png[..., 3] == 255).all()
+    # the same frames through the C-ABI, tonemapped by the library with the same parameters
+    setup = pu.Setup(os.path.join(assets, "Box.glb"), 96, 64, hdr_path=os.path.join(assets, "std_env.hdr"), max_depth=3)
+    t = ptmod.PathTracer(setup.scene)
+    try:
+        t.set_environment(setup.hdr)
+        t.resize(96, 64)
+        t.set_frame_info(setup.frame_info)
+        t.set_sky(setup.sky)
+        for f in range(12):
+            t.render_frame(setup.frame_params(f, f))
+        want = t.tonemap(method="aces", exposure=1.5, saturation=0.9)
+    finally:
+        t.close()
+    assert np.abs(png[..., :3].astype(int) - want[..., :3].astype(int)).max() <= 1
+    r = _run(base + ["--optixEnable", "1", "--optixAutoDenoiseInterval", "5"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    # frames 5 and 10 by the cadence, the final (12th) frame by the headless save
+    assert "DENOISER passes=3 final_image=denoised" in r.stdout, r.stdout[-600:]
+    den = _read_png_rgba8(out)
+    assert den.shape == (64, 96, 4) and np.abs(den.astype(int) - png.astype(int)).max() > 0

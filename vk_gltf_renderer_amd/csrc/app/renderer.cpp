@@ -248,7 +248,14 @@ void GltfRenderer::saveHeadlessOutputImage()
   else
   {  // eImgTonemapped: GltfRenderer::tonemap on the device (reference: src/renderer.cpp:557-573, :992-1056)
     std::vector<unsigned char> ldr(size_t(w) * size_t(h) * 4);
-    if(mi_pt_tonemap(m_pathTracer.handle(), &m_resources.tonemapperData, 0, -1.0f, ldr.data(), nullptr) != MI_PT_OK)
+    // the denoised image is shown in place of the rendered one when there is one (reference: src/renderer.cpp:1006-1016); a
+    // headless run with the denoiser on denoises its final frame if the cadence did not land on it
+    if(m_pathTracer.isDenoiserEnabled() && !m_pathTracer.denoisedIsCurrent())
+      m_pathTracer.denoiseOneShot();
+    const int source = (m_pathTracer.isDenoiserEnabled() && m_pathTracer.hasValidDenoisedOutput()) ? 1 : 0;
+    if(source)
+      printf("DENOISER passes=%d final_image=denoised\n", m_pathTracer.denoiseCount());
+    if(mi_pt_tonemap(m_pathTracer.handle(), &m_resources.tonemapperData, source, -1.0f, ldr.data(), nullptr) != MI_PT_OK)
     {
       fprintf(stderr, "tonemap: %s\n", mi_pt_last_error());
       return;

@@ -41,6 +41,11 @@ void PathTracer::registerParameters(ParameterRegistry* r)
   r->add("ptFocalDistance", "Focal distance (disables auto focus)", &m_pushConst.focalDistance);
   r->add("ptAutoFocus", "Focus on the camera's interest point", &m_autoFocus);
   r->add("ptAdaptiveSampling", "Adjust the samples per pixel and frame to the performance target", &m_adaptiveSampling);
+  // the denoiser keeps the OptiX adapter's switches (reference: src/optix_denoiser.cpp:735-741)
+  r->add("optixEnable", "Denoiser: enable (HIP variance-guided a-trous in place of the OptiX denoiser)", &m_denoiser.enable);
+  r->add("optixAutoDenoiseEnabled", "Denoiser: auto-denoise every N frames", &m_denoiser.autoDenoiseEnabled);
+  r->add("optixAutoDenoiseInterval", "Denoiser: auto-denoise interval (frames)", &m_denoiser.autoDenoiseInterval);
+  r->add("denoiseMethod", "Denoiser: [a-trous:0, variance-guided:1]", &m_denoiser.method);
   r->add("ptPerformanceTarget", "Performance target [Interactive:0, Balanced:1, Quality:2, MaxQuality:3]", &m_performanceTarget);
 }
 
@@ -97,7 +102,10 @@ void PathTracer::setupPushConstant(Resources& res, const Extent2D& renderingSize
     m_pushConst.focalDistance = std::sqrt(dx * dx + dy * dy + dz * dz);
   }
   m_pushConst.frameCount   = res.frameCount;
-  m_pushConst.flags        = (res.frameCount == 0 ? MI_PT_FIRST_FRAME : 0);
+  // the guide layers are captured while the denoiser is enabled (reference: USE_OPTIX_DENOISER flag, src/renderer_pathtracer.cpp:1534-1550)
+  m_pushConst.flags        = (res.frameCount == 0 ? MI_PT_FIRST_FRAME : 0) | (m_denoiser.enable ? MI_PT_USE_OPTIX_DENOISER : 0);
+  if(res.frameCount == 0)
+    m_hasDenoisedOutput = false;
   m_pushConst.totalSamples = m_totalSamplesAccumulated;
   // pixelAngle = 2 |projInv[1][1]| / viewportHeight
   m_pushConst.pixelAngle = 2.0f * std::fabs(res.frameInfo.projInv[5]) / std::max(float(renderingSize.height), 1.0f);
@@ -123,6 +131,38 @@ void PathTracer::updateAdaptiveSampling(Resources& res)
   else if(m_lastFrameDeviceMs > target * 1.1 && m_pushConst.numSamples > kMinSamplesPerPixel)
     --m_pushConst.numSamples;
   m_pushConst.numSamples = std::min(std::max(m_pushConst.numSamples, kMinSamplesPerPixel), kMaxSamplesPerPixel);
+}
+
+bool PathTracer::denoiseOneShot()
+{
+  if(!m_pt)
+    return false;
+  const int rc = m_denoiser.method == 0 ? mi_pt_denoise(m_pt, 5, 0.6f, 64.0f, 0.2f, nullptr, nullptr) : mi_pt_denoise_svgf(m_pt, 5, 4.0f, 128.0f, 1.0f, nullptr, nullptr);
+  if(rc != MI_PT_OK)
+  {
+    m_error = mi_pt_last_error();
+    fprintf(stderr, "PathTracer::denoiseOneShot: %s\n", m_error.c_str());
+    return false;
+  }
+  m_hasDenoisedOutput = true;
+  m_denoisedAtSamples = m_totalSamplesAccumulated;
+  ++m_denoiseCount;
+  return true;
+}
+
+// Auto-denoise cadence: once per crossed multiple of the interval (every frame when the interval is 1); the tracking restarts
+// with the accumulation.  Unlike the reference's (src/optix_denoiser.hpp:78-97) there is no one-frame lag: the pass is enqueued on
+// the frame's stream behind the frame it denoises.
+void PathTracer::updateDenoiser(Resources& res)
+{
+  if(!m_denoiser.enable || !m_denoiser.autoDenoiseEnabled || m_denoiser.autoDenoiseInterval <= 0)
+    return;
+  const int frame = res.frameCount + 1;  // frames accumulated so far
+  if(frame < m_lastAutoDenoiseFrame)
+    m_lastAutoDenoiseFrame = 0;
+  const bool crossed = frame / m_denoiser.autoDenoiseInterval > m_lastAutoDenoiseFrame / m_denoiser.autoDenoiseInterval && frame % m_denoiser.autoDenoiseInterval == 0;
+  if((crossed || m_denoiser.autoDenoiseInterval == 1) && denoiseOneShot())
+    m_lastAutoDenoiseFrame = frame;
 }
 
 void PathTracer::updateStatistics()
@@ -153,6 +193,7 @@ void PathTracer::onRender(StreamHandle cmd, Resources& res)
       m_lastFrameDeviceMs = t.totalMs;
   }
   updateStatistics();
+  updateDenoiser(res);
 }
 
 bool PathTracer::readRendered(float* rgba) const

@@ -32,12 +32,28 @@ public:
   bool  adaptiveSampling() const { return m_adaptiveSampling; }
   int   totalSamples() const { return m_totalSamplesAccumulated; }
 
+  // The denoiser that takes the OptiX adapter's place (reference: OptiXDenoiser::Settings, src/optix_denoiser.hpp:134-140; same
+  // parameter names): off by default, auto-denoise at frames 50, 100, 150, ... once enabled.
+  struct DenoiserSettings
+  {
+    bool enable{false};
+    bool autoDenoiseEnabled{true};
+    int  autoDenoiseInterval{50};
+    int  method{1};  // ours: 0 = plain a-trous (mi_pt_denoise), 1 = variance-guided (mi_pt_denoise_svgf)
+  };
+  bool isDenoiserEnabled() const { return m_denoiser.enable; }
+  bool hasValidDenoisedOutput() const { return m_hasDenoisedOutput; }  // reference: src/optix_denoiser.hpp:196
+  bool denoiseOneShot();                                               // reference: OptiXDenoiser::denoiseOneShot
+  int  denoiseCount() const { return m_denoiseCount; }
+  bool denoisedIsCurrent() const { return m_hasDenoisedOutput && m_denoisedAtSamples == m_totalSamplesAccumulated; }
+
   MiPathtraceParams m_pushConst{};  // read by benchmarkFrameInfo() in the reference (src/renderer.cpp:526)
 
 private:
   void setupPushConstant(Resources& resources, const Extent2D& renderingSize);  // reference: :1496-1574
   void updateStatistics();                                                      // reference: :1377-1402
   void updateAdaptiveSampling(Resources& resources);                            // reference: :1326-1374
+  void updateDenoiser(Resources& resources);                                    // reference: src/optix_denoiser.cpp:751-805
   // reference: src/renderer_pathtracer.hpp:167-195 (Interactive 60 / Balanced 30 / Quality 15 / MaxQuality 10 frames per second)
   double targetFrameTimeMs() const
   {
@@ -52,5 +68,10 @@ private:
   int         m_performanceTarget{1};      // Balanced
   double      m_lastFrameDeviceMs{0.0};
   int         m_totalSamplesAccumulated{0};
+  DenoiserSettings m_denoiser;
+  int         m_lastAutoDenoiseFrame{0};
+  int         m_denoiseCount{0};
+  int         m_denoisedAtSamples{-1};
+  bool        m_hasDenoisedOutput{false};
   std::string m_error;
 };
