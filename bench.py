@@ -136,6 +136,9 @@ def main():
                          "helmet workload to 4 %% (64: 19 %%, tools/check_rank_of_8.py)")
     ap.add_argument("--bvh", type=int, default=0, help="bit0: 0 = 8-wide compressed BVH (default), 1 = plain BVH2; bit1: 0 = PLOC topology (default), 1 = LBVH")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--denoise", action="store_true",
+                    help="configs[4]'s denoise pass: the guide layers are captured with every frame and one variance-guided a-trous pass (mi_pt_denoise_svgf, "
+                         "5 iterations) closes every step inside the timed region -- on rank 0, after the reduce, when N > 1")
     ap.add_argument("--frames-per-step", type=int, default=192,
                     help="frames (1 spp each) per GPU and step; a step renders frames_per_step * n_gpus frames")
     ap.add_argument("--in-flight", type=int, default=32,
@@ -181,6 +184,8 @@ def main():
         frame_info.flags |= capi.MI_SCENE_USE_HDR_ENVIRONMENT
     params = ptmod.default_params()
     params.maxDepth, params.numSamples, params.pixelAngle, params.focalDistance = w["depth"], 1, pixel_angle, focal
+    if args.denoise:
+        params.flags |= capi.MI_PT_USE_OPTIX_DENOISER
 
     def make_tracer(counters, partition=True):
         t = ptmod.PathTracer(scene, device=local_rank, collect_counters=counters, bvh=args.bvh)
@@ -197,9 +202,26 @@ def main():
     tracer = make_tracer(False)
     tracer.synchronize()
     create_s = time.perf_counter() - t_create0
-    accum = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
-    reduced = torch.zeros_like(accum) if dist is not None else None
-    tracer.bind_accum(accum.data_ptr())
+    # accumulator (+ with --denoise the albedo / normal guides and the frame-0 depth) in ONE caller-owned allocation, so that a
+    # multi-GPU step closes with one reduce of one buffer
+    px = H * W
+    frame_buf = torch.zeros(px * (13 if args.denoise else 4), dtype=torch.float32, device="cuda")
+    reduced_buf = torch.zeros_like(frame_buf) if dist is not None else None
+
+    def views(buf):
+        v = {"accum": buf[:px * 4].view(H, W, 4)}
+        if args.denoise:
+            v.update(albedo=buf[px * 4:px * 8].view(H, W, 4), normal=buf[px * 8:px * 12].view(H, W, 4), depth=buf[px * 12:px * 13].view(H, W))
+        return v
+
+    def bind(v):
+        tracer.bind_accum(v["accum"].data_ptr())
+        if args.denoise:
+            tracer.bind_guides(v["albedo"].data_ptr(), v["normal"].data_ptr(), v["depth"].data_ptr())
+
+    local, total = views(frame_buf), (views(reduced_buf) if dist is not None else None)
+    accum, reduced = local["accum"], (total["accum"] if total is not None else None)
+    bind(local)
     stream = torch.cuda.current_stream()
     runner = ptmod.HeadlessRenderer(tracer, params)
 
@@ -215,14 +237,20 @@ def main():
 
     def step():
         runner.render(frames_step, stream.cuda_stream, in_flight=F)
-        if dist is not None:  # one reduce of the accumulator per step: disjoint tiles, so sum == gather
-            reduced.copy_(accum)
-            dist.reduce(reduced, dst=0, op=dist.ReduceOp.SUM)
+        if dist is not None:  # one reduce of the accumulator (+ guides) per step: disjoint tiles, so sum == gather
+            reduced_buf.copy_(frame_buf)
+            dist.reduce(reduced_buf, dst=0, op=dist.ReduceOp.SUM)
+        if args.denoise and rank == 0:
+            if dist is not None:  # denoise the reduced frame: point the library at it for the pass
+                bind(total)
+            tracer.denoise_svgf(iterations=5, read=False, stream=stream.cuda_stream)
+            if dist is not None:
+                bind(local)
 
     for _ in range(args.warmup):
         step()
     if dist is not None and args.warmup == 0:  # warm the RCCL path
-        dist.reduce(accum.clone(), dst=0)
+        dist.reduce(frame_buf.clone(), dst=0)
     sync_all()
     runner.reset_frame()
     tracer.enable_timing(True)
@@ -246,6 +274,13 @@ def main():
     if rank == 0:
         img = (reduced if dist is not None else accum).cpu().numpy()
         assert np.isfinite(img).all()
+        if os.environ.get("BENCH_DUMP"):  # test hook: the final frame (and its denoised version) of this run
+            dump = {"accum": img}
+            if args.denoise:
+                bind(total if dist is not None else local)
+                dump["denoised"] = tracer.denoise_svgf(iterations=5, read=True)
+                bind(local)
+            np.savez(os.environ["BENCH_DUMP"], **dump)
         static = ("bvhNodeCount", "bvhTriangleCount", "bvhNodeBytes", "bvhTriangleBytes")
 
         def counter_pass(depth):
@@ -286,7 +321,8 @@ def main():
             "config": {"workload": w["config"] + " (seeded synthetic stand-in)" if w["gen"] else w["config"], "scene_triangles": scene.num_triangles,
                        "resolution": [W, H], "spp_per_step": frames_step, "frames_in_flight": F, "max_depth": w["depth"], "tile": args.tile,
                        "parallelism": f"tiles{world}" if world > 1 else "single", "world_size_reported_by_backend": (dist.get_world_size() if dist is not None else 1),
-                       "reduce": ("one RCCL reduce(sum) of the RGBA32F accumulator per step" if dist is not None else None),
+                       "reduce": ((f"one RCCL reduce(sum) of {frame_buf.numel() * 4 / 1e6:.1f} MB (RGBA32F accumulator" + (" + albedo / normal guides + depth" if args.denoise else "") + ") per step") if dist is not None else None),
+                       "denoise": ("variance-guided a-trous (mi_pt_denoise_svgf, 5 iterations) once per step, inside the timed region" if args.denoise else None),
                        "library": capi.pt_lib().mi_pt_version().decode()},
             "ms_per_frame": round(elapsed / frames_timed * 1e3, 5),
             "timed_region_s": round(elapsed, 3), "scene_build_s": round(create_s, 3),

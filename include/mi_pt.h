@@ -190,6 +190,11 @@ MI_PT_API int mi_pt_set_tile_partition(MiPt* pt, int rank, int world, int tileSi
 
 /* Render into caller-owned device memory (width*height float4, e.g. a torch tensor) instead of the internal image. */
 MI_PT_API int mi_pt_bind_accum(MiPt* pt, void* deviceRGBA32F);
+/* The same for the images the denoiser reads next to the accumulator: first-hit albedo and normal guides (width*height float4
+ * each) and the frame-0 NDC depth (width*height float).  NULL = the internal image.  A multi-GPU run binds zero-initialised
+ * caller memory on every rank, sum-reduces it together with the accumulator (disjoint tiles: sum == gather) and denoises on the
+ * rank that holds the sum. */
+MI_PT_API int mi_pt_bind_guides(MiPt* pt, void* deviceAlbedoRGBA32F, void* deviceNormalRGBA32F, void* deviceDepthR32F);
 
 /* replaces PathTracer::onRender = setupPushConstant + renderRayQuery (reference: src/renderer_pathtracer.cpp:500-614,
  * :1496-1574, :1404-1431): enqueues ONE frame (params->numSamples spp for every owned pixel, running-mean

@@ -72,3 +72,26 @@ def test_bench_two_ranks_on_one_gpu(built):
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["config"]["world_size_reported_by_backend"] == 2 and j["config"]["spp_per_step"] == 16 and j["value"] > 0
     assert j["config"]["reduce"].startswith("one RCCL reduce")
+
+
+def test_bench_denoise_two_ranks_equals_one_rank(built, tmp_path):
+    """configs[4]'s denoise pass in bench.py: with 2 ranks the guides and the depth travel with the accumulator in the one reduce and
+    rank 0 denoises the reduced frame -- the same accumulator and the same denoised image, bit for bit, as the single-rank run of
+    the same frames (tiles are disjoint: sum == gather)."""
+    outs = []
+    for world in (1, 2):
+        port = _free_port()
+        out = tmp_path / f"dump{world}.npz"
+        env = dict(os.environ, BENCH_SHARE_GPU="1", BENCH_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BENCH_DUMP=str(out))
+        args = [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0", "--workload", "box", "--frames-per-step", str(8 // world),
+                "--in-flight", str(4 // world), "--denoise", "--no-cpu-baseline"]
+        cmd = [sys.executable] + args if world == 1 else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                                          "--master-port", str(port)] + args
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert j["config"]["denoise"].startswith("variance-guided") and j["config"]["spp_per_step"] == 8
+        outs.append(np.load(out))
+    assert np.array_equal(outs[0]["accum"], outs[1]["accum"])
+    assert np.array_equal(outs[0]["denoised"], outs[1]["denoised"])
+    assert np.abs(outs[0]["denoised"][..., :3] - outs[0]["accum"][..., :3]).max() > 0

@@ -173,6 +173,7 @@ PT_SYMBOLS = {
     "mi_pt_set_sky": (i32, [VP, P(MiSkyPhysicalParameters)]),
     "mi_pt_set_tile_partition": (i32, [VP, i32, i32, i32]),
     "mi_pt_bind_accum": (i32, [VP, VP]),
+    "mi_pt_bind_guides": (i32, [VP, VP, VP, VP]),
     "mi_pt_render_frame": (i32, [VP, P(MiPathtraceParams), VP]),
     "mi_pt_render_frames": (i32, [VP, P(MiPathtraceParams), i32, VP]),
     "mi_pt_synchronize": (i32, [VP]),

@@ -131,6 +131,12 @@ struct MiPt
   DevBuf<float4>          queuePayload;
   pt::Queues              queues{};
   DevBuf<float4>          accumOwn, albedo, normal, denoiseA, denoiseB;
+  float4*                 albedoBound = nullptr;  // caller-owned guide / depth images (mi_pt_bind_guides), NULL = the internal ones
+  float4*                 normalBound = nullptr;
+  float*                  depthBound  = nullptr;
+  float4*                 albedoImg() { return albedoBound ? albedoBound : albedo.ptr; }
+  float4*                 normalImg() { return normalBound ? normalBound : normal.ptr; }
+  float*                  depthImg() { return depthBound ? depthBound : depth.ptr; }
   float                   accumFrames = 0.0f;  // frames folded into the accumulator (variance of the mean, SVGF pass)
   const float4*           denoised = nullptr;  // result of the last mi_pt_denoise (one of denoiseA / denoiseB)
   DevBuf<uint32_t>        tonemapped, tmHistogram;
@@ -749,6 +755,16 @@ int mi_pt_bind_accum(MiPt* pt, void* deviceRGBA32F)
   return MI_PT_OK;
 }
 
+int mi_pt_bind_guides(MiPt* pt, void* albedoRGBA32F, void* normalRGBA32F, void* depthR32F)
+{
+  if(!pt)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_bind_guides: null instance");
+  pt->albedoBound = reinterpret_cast<float4*>(albedoRGBA32F);
+  pt->normalBound = reinterpret_cast<float4*>(normalRGBA32F);
+  pt->depthBound  = reinterpret_cast<float*>(depthR32F);
+  return MI_PT_OK;
+}
+
 int mi_pt_render_frame(MiPt* pt, const MiPathtraceParams* params, void* hipStream)
 {
   return mi_pt_render_frames(pt, params, 1, hipStream);
@@ -954,7 +970,7 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
       cur ^= 1;
     }
     timed(TK_ACCUM, [&] {
-      pt::launchFinishSample(c, s, pt->accum, pt->depth.ptr, guides ? pt->albedo.ptr : nullptr, guides ? pt->normal.ptr : nullptr);
+      pt::launchFinishSample(c, s, pt->accum, pt->depthImg(), guides ? pt->albedoImg() : nullptr, guides ? pt->normalImg() : nullptr);
     });
   }
   if(params->flags & MI_PT_FIRST_FRAME)
@@ -1008,9 +1024,9 @@ int mi_pt_read_guides(MiPt* pt, float* albedo, float* normal)
   HIP_TRY(hipDeviceSynchronize());
   const size_t bytes = size_t(pt->width) * size_t(pt->height) * sizeof(float4);
   if(albedo)
-    HIP_TRY(hipMemcpy(albedo, pt->albedo.ptr, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(albedo, pt->albedoImg(), bytes, hipMemcpyDeviceToHost));
   if(normal)
-    HIP_TRY(hipMemcpy(normal, pt->normal.ptr, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(normal, pt->normalImg(), bytes, hipMemcpyDeviceToHost));
   return MI_PT_OK;
 }
 int mi_pt_read_selection(MiPt* pt, uint32_t* host)
@@ -1028,7 +1044,7 @@ int mi_pt_read_depth(MiPt* pt, float* host)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_read_depth: bad arguments");
   HIP_TRY(hipSetDevice(pt->device));
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(host, pt->depth.ptr, size_t(pt->width) * size_t(pt->height) * sizeof(float), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(host, pt->depthImg(), size_t(pt->width) * size_t(pt->height) * sizeof(float), hipMemcpyDeviceToHost));
   return MI_PT_OK;
 }
 void* mi_pt_accum_device_ptr(MiPt* pt)
@@ -1052,7 +1068,7 @@ int mi_pt_denoise(MiPt* pt, int iterations, float sigmaColor, float sigmaNormal,
   float4*       out = pt->denoiseA.ptr;
   for(int i = 0; i < iterations; ++i)
   {
-    pt::launchAtrous(in, out, pt->albedo.ptr, pt->normal.ptr, pt->width, pt->height, 1 << i, sigmaColor, sigmaNormal, sigmaAlbedo, stream);
+    pt::launchAtrous(in, out, pt->albedoImg(), pt->normalImg(), pt->width, pt->height, 1 << i, sigmaColor, sigmaNormal, sigmaAlbedo, stream);
     in  = out;
     out = (out == pt->denoiseA.ptr) ? pt->denoiseB.ptr : pt->denoiseA.ptr;
   }
@@ -1078,7 +1094,7 @@ int mi_pt_denoise_svgf(MiPt* pt, int iterations, float sigmaLuminance, float sig
     HIP_TRY(pt->denoiseA.alloc(px));
     HIP_TRY(pt->denoiseB.alloc(px));
   }
-  pt->denoised = pt::launchSvgf(pt->accum, pt->albedo.ptr, pt->normal.ptr, pt->depth.ptr, pt->denoiseA.ptr, pt->denoiseB.ptr, pt->width, pt->height, iterations,
+  pt->denoised = pt::launchSvgf(pt->accum, pt->albedoImg(), pt->normalImg(), pt->depthImg(), pt->denoiseA.ptr, pt->denoiseB.ptr, pt->width, pt->height, iterations,
                                 pt->accumFrames, sigmaLuminance, sigmaNormal, sigmaDepth, stream);
   HIP_TRY(hipGetLastError());
   if(host)

@@ -152,6 +152,10 @@ class PathTracer:
     def bind_accum(self, device_ptr):
         _check_pt(self._l.mi_pt_bind_accum(self._p, C.c_void_p(device_ptr)))
 
+    def bind_guides(self, albedo_ptr=0, normal_ptr=0, depth_ptr=0):
+        """Denoiser guide / depth images in caller-owned device memory (0 = the internal image)."""
+        _check_pt(self._l.mi_pt_bind_guides(self._p, C.c_void_p(albedo_ptr or None), C.c_void_p(normal_ptr or None), C.c_void_p(depth_ptr or None)))
+
     def render_frame(self, params, stream=None):
         _check_pt(self._l.mi_pt_render_frame(self._p, C.byref(params), C.c_void_p(stream or 0)))
 
@@ -195,11 +199,11 @@ class PathTracer:
                                         out.ctypes.data_as(C.POINTER(C.c_float)), None))
         return out
 
-    def denoise_svgf(self, iterations=5, sigma_luminance=4.0, sigma_normal=128.0, sigma_depth=1.0, read=True):
+    def denoise_svgf(self, iterations=5, sigma_luminance=4.0, sigma_normal=128.0, sigma_depth=1.0, read=True, stream=None):
         """Variance-guided denoise (mi_pt_denoise_svgf); read=False leaves the result on the device (tonemap(source=1) picks it up)."""
         out = np.empty((self.height, self.width, 4), dtype=np.float32) if read else None
         _check_pt(self._l.mi_pt_denoise_svgf(self._p, iterations, sigma_luminance, sigma_normal, sigma_depth,
-                                             out.ctypes.data_as(C.POINTER(C.c_float)) if read else None, None))
+                                             out.ctypes.data_as(C.POINTER(C.c_float)) if read else None, C.c_void_p(stream or 0)))
         return out
 
     def tonemap(self, tm=None, source=0, dt_seconds=-1.0, **fields):
