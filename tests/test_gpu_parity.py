@@ -160,6 +160,30 @@ def test_glass_class_transmission_volume(built, tmp_path):
     _check(pu.render_oracle(s, 3), pu.render_gpu(s, 3), rel_l2=1e-2, within_1e4=0.95)
 
 
+def test_transmissive_shadow_paths_agree_bit_for_bit(built, tmp_path):
+    """Shadow rays through transmissive instances (raytracer_interface.h.slang:139-187) have three implementations that must give the
+    same image bit for bit, because all of them take the candidates in the same (t, renderNode, primitive) order with the same
+    arithmetic: the recording walk + k_shadow_resolve (default on the 8-wide BVH), the ordered-search kernel (MI_PT_DIAG_CAND_POOL=0),
+    and the mix of both when the candidate pool overflows (a 200-entry pool)."""
+    import subprocess
+    import sys
+    path = scenegen.scene_glass_class(str(tmp_path / "glass.glb"), seed=3, tess=24)
+    hdr = os.path.join(os.path.dirname(os.path.dirname(__file__)), "assets", "std_env.hdr")
+    s = pu.Setup(path, 160, 96, max_depth=12, hdr_path=hdr)
+    ref = pu.render_gpu(s, 3)
+    assert ref["stats"]["shadowRays"] > 10000
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import parity_util as pu; s = pu.Setup(%r, 160, 96, max_depth=12, hdr_path=%r); "
+            "g = pu.render_gpu(s, 3); np.save(sys.argv[1], g['accum']); print(g['stats']['shadowRays'])") % (
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), path, hdr)
+    for pool in ("0", "200"):
+        out = str(tmp_path / f"pool{pool}.npy")
+        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, MI_PT_DIAG_CAND_POOL=pool), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        traced = int(r.stdout.strip().splitlines()[-1])  # (rays whose candidates overflowed the pool are walked, and counted, twice)
+        assert traced == ref["stats"]["shadowRays"] if pool == "0" else traced > ref["stats"]["shadowRays"], (pool, traced)
+        assert np.array_equal(np.load(out), ref["accum"]), pool
+
+
 def test_street_class_instancing(built, tmp_path):
     """BASELINE config 4 stand-in at test size: EXT_mesh_gpu_instancing (hundreds of render nodes from a few meshes), ~130
     materials, alpha-MASK trees, sun + sky."""

@@ -1,3 +1,10 @@
-timeout 800 python -m pytest tests/test_gpu_multirank.py -m gpu -q 2>&1 | tail -15
-timeout 300 python bench.py --workload glass --denoise --steps 4 --warmup 1 --no-cpu-baseline > gpurun_out/r02_bench_glass_denoise.json 2> gpurun_out/r02_bench_glass_denoise.err; tail -c 1500 gpurun_out/r02_bench_glass_denoise.json; tail -3 gpurun_out/r02_bench_glass_denoise.err
-timeout 300 python bench.py --workload glass --steps 4 --warmup 1 --no-cpu-baseline > gpurun_out/r02_bench_glass.json 2> gpurun_out/r02_bench_glass.err; cut -c1-300 gpurun_out/r02_bench_glass.json
+timeout 800 python -m pytest tests/test_gpu_parity.py tests/test_gpu_lobes.py -m gpu -q -x 2>&1 | tail -5
+for w in glass atrium helmet; do
+timeout 300 python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r02_bench_${w}_c.json 2> gpurun_out/r02_bench_${w}_c.err; python - <<PY
+import json
+d=json.load(open("gpurun_out/r02_bench_${w}_c.json"))
+print("$w", d["value"], d["frame_ms_device"], {k:v["ms_per_frame"] for k,v in d["kernels"].items()})
+PY
+done
+MI_PT_LIB=$PWD/vk_gltf_renderer_amd/lib/var_prof/libmi_pt.so timeout 300 python tools/diag_spans.py glass 32 2>&1 | grep profile
+MI_PT_LIB=$PWD/vk_gltf_renderer_amd/lib/var_prof/libmi_pt.so timeout 300 python tools/diag_spans.py atrium 32 2>&1 | grep profile

@@ -129,6 +129,8 @@ struct MiPt
   pt::PathSoA             paths{};
   DevBuf<uint32_t>        queueMem;
   DevBuf<float4>          queuePayload;
+  DevBuf<float4>          candPool;   // recorded transmissive shadow candidates (Queues::candPool)
+  DevBuf<uint32_t>        candLists;  // candNext + overflow list
   pt::Queues              queues{};
   DevBuf<float4>          accumOwn, albedo, normal, denoiseA, denoiseB;
   float4*                 albedoBound = nullptr;  // caller-owned guide / depth images (mi_pt_bind_guides), NULL = the internal ones
@@ -212,6 +214,23 @@ int allocPathResources(MiPt* pt, int frames)
   pt->queues.shadow.aux2    = pt->queuePayload.ptr + qsize * 9;
   pt->queues.counters = pt->queueMem.ptr + 3 * qsize;
   pt->queues.subCap   = uint32_t(subCap);
+  // recorded transmissive shadow candidates (pt_scene.h): two pool entries per shadow-queue entry, and an overflow list as long as
+  // the queue.  MI_PT_DIAG_CAND_POOL=<entries> shrinks the pool (tests of the overflow path); 0 disables recording.
+  pt->queues.candPool = nullptr; pt->queues.candNext = nullptr; pt->queues.overflow = nullptr;
+  pt->queues.candCap  = 0;
+  size_t candCap = qsize * 2;
+  if(const char* e = getenv("MI_PT_DIAG_CAND_POOL"))
+    candCap = size_t(strtoull(e, nullptr, 10));
+  if(pt->hasTransmissive && pt->wide && candCap > 0)
+  {
+    candCap = std::min(candCap, size_t(0x7fffffff));
+    HIP_TRY(pt->candPool.alloc(candCap));
+    HIP_TRY(pt->candLists.alloc(candCap + qsize));
+    pt->queues.candPool = pt->candPool.ptr;
+    pt->queues.candNext = pt->candLists.ptr;
+    pt->queues.overflow = pt->candLists.ptr + candCap;
+    pt->queues.candCap  = uint32_t(candCap);
+  }
   HIP_TRY(hipMemset(pt->queues.counters, 0, sizeof(uint32_t) * pt::QC_COUNT));
   return MI_PT_OK;
 }
@@ -953,9 +972,10 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
         uint32_t nSh    = count((cur ? pt::QC_PAIR0 : pt::QC_PAIR1) + 1);
         double   tShadow = span([&] { pt::launchTraceShadow(c, cur ^ 1); });
         const pt::StatCounters s2 = segs();
-        fprintf(stderr, "[mi_pt span] frame %d it %2d rays %8u (traced %8llu) trace %8.3f ms shade %8.3f ms | shadow rays %8u (traced %8llu) %8.3f ms\n",
-                params->frameCount, it, nIn, (unsigned long long)(s1.segments - s0.segments), tTrace, tShade, nSh,
-                (unsigned long long)(s2.shadowRays - s1.shadowRays), tShadow);
+        fprintf(stderr, "[mi_pt span] frame %d it %2d rays %8u (traced %8llu, nodes %9llu tris %9llu) trace %8.3f ms shade %8.3f ms | shadow rays %8u (traced %8llu, nodes %9llu tris %9llu) %8.3f ms\n",
+                params->frameCount, it, nIn, (unsigned long long)(s1.segments - s0.segments), (unsigned long long)(s1.nodesClosest - s0.nodesClosest),
+                (unsigned long long)(s1.trisClosest - s0.trisClosest), tTrace, tShade, nSh, (unsigned long long)(s2.shadowRays - s1.shadowRays),
+                (unsigned long long)(s2.nodesShadow - s1.nodesShadow), (unsigned long long)(s2.trisShadow - s1.trisShadow), tShadow);
       }
       else
       {

@@ -328,6 +328,7 @@ __global__ void __launch_bounds__(256) k_generate(DevScene sc, FrameConsts fc, P
 // [8..15]: lane occupancy -- node steps / lanes visiting / triangle rounds / lanes testing / refills / lanes idle at refill /
 // triangle phases / lanes blocked (both park records full) per node step
 __device__ unsigned long long g_traceProf[18];
+__device__ unsigned long long g_shadowProf[16];  // the same for k_trace_shadow (8-wide BVH, deferring modes)
 #define PROF_T() __builtin_amdgcn_s_memtime()
 #define PROF_ADD(i, t0) profAcc[i] += PROF_T() - (t0)
 #define PROF_CNT(i, n) profCnt[i] += (unsigned long long)(n)
@@ -489,9 +490,24 @@ PT_DEV void closestUpdate(const DevScene& sc, ClosestBest& best, float tk, float
     best.t = tk; best.u = uk; best.v = vk; best.tri = int(ik);
   }
 }
+// Where the shadow walk of a scene with transmissive instances (k_trace_shadow MODE 3) records the transmissive candidates it
+// meets: a device-wide pool of {t, u, v, triangle}, the entries of one ray chained through `next`; the list heads live in LDS,
+// one per lane (= per ray in flight), next to a flag for "some candidate of this ray did not fit the pool".
+struct CandRec
+{
+  float4*   pool;
+  uint32_t* next;
+  uint32_t* poolCounter;
+  uint32_t  cap;
+  uint32_t* waveHead;  // this wave's 64 list heads (LDS)
+  uint32_t* waveOvf;   // this wave's 64 overflow flags (LDS)
+};
 // SHADOW: any-hit semantics (an accepted candidate occludes, draw < opacity); otherwise closest-hit (draw <= opacity).
-template <bool SHADOW>
-PT_DEV void alphaRound(const DevScene& sc, uint32_t seed0, uint4* waveAlpha, uint32_t& aCount, bool& aPending, ClosestBest& best, bool& occluded)
+// REC (shadow only): candidates on transmissive instances are not decided here -- their effect depends on their order along
+// the ray (Beer segments, raytracer_interface.h.slang:160-178) -- but recorded for k_shadow_resolve.
+template <bool SHADOW, bool REC = false>
+PT_DEV void alphaRound(const DevScene& sc, uint32_t seed0, uint4* waveAlpha, uint32_t& aCount, bool& aPending, ClosestBest& best, bool& occluded,
+                       const CandRec* rec = nullptr)
 {
   const uint32_t lane = laneId();
   const bool     has  = lane < aCount;
@@ -499,13 +515,43 @@ PT_DEV void alphaRound(const DevScene& sc, uint32_t seed0, uint4* waveAlpha, uin
   __builtin_amdgcn_wave_barrier();
   const uint32_t owner = e.x >> 26, tri = e.x & 0x3ffffffu;
   const uint32_t seedSrc = laneRead(seed0, owner);
-  bool           accept  = false;
+  bool           accept  = false, record = false;
   if(has)
   {
     const float    u = __uint_as_float(e.z), v = __uint_as_float(e.w);
     const uint32_t rnode = __float_as_uint(sc.tris[tri].a.w), prim = __float_as_uint(sc.tris[tri].b.w);
-    const float    draw = candidateRand(seedSrc, int(rnode), int(prim)), opacity = getOpacityFast(sc, int(tri), mk3(1.0f - u - v, u, v));
-    accept = SHADOW ? draw < opacity : draw <= opacity;
+    if(REC && (__float_as_uint(sc.tris[tri].c.w) & INST_TRANSMISSIVE))
+      record = true;
+    else
+    {
+      const float draw = candidateRand(seedSrc, int(rnode), int(prim)), opacity = getOpacityFast(sc, int(tri), mk3(1.0f - u - v, u, v));
+      accept = SHADOW ? draw < opacity : draw <= opacity;
+    }
+  }
+  if(REC)
+  {
+    const unsigned long long m = __ballot(record);
+    if(m != 0ull)
+    {
+      // one device-scope atomic per round hands out the pool entries of all its transmissive candidates
+      const int first = __ffsll((long long)m) - 1;
+      uint32_t  base  = 0u;
+      if(int(lane) == first)
+        base = atomicAdd(rec->poolCounter, uint32_t(__popcll(m)));
+      base = uint32_t(__builtin_amdgcn_readlane(int(base), first));
+      const uint32_t idx = base + laneCountBelow(m);
+      if(record)
+      {
+        if(idx < rec->cap)
+        {
+          rec->pool[idx] = make_float4(__uint_as_float(e.y), __uint_as_float(e.z), __uint_as_float(e.w), __uint_as_float(tri));
+          rec->next[idx] = __hip_atomic_exchange(&rec->waveHead[owner], idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        else
+          rec->waveOvf[owner] = 1u;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
   }
   unsigned long long acc = __ballot(accept);
   while(acc != 0ull)
@@ -526,15 +572,15 @@ PT_DEV void alphaRound(const DevScene& sc, uint32_t seed0, uint4* waveAlpha, uin
   aPending = false;
 }
 // puts this round's alpha candidates on the list (flushing it first when they would not fit)
-template <bool SHADOW>
+template <bool SHADOW, bool REC = false>
 PT_DEV void alphaDefer(const DevScene& sc, bool needAlpha, uint32_t item, float t, float u, float v, uint32_t seed0, uint4* waveAlpha, uint32_t& aCount,
-                       bool& aPending, ClosestBest& best, bool& occluded)
+                       bool& aPending, ClosestBest& best, bool& occluded, const CandRec* rec = nullptr)
 {
   const unsigned long long m = __ballot(needAlpha);
   if(m == 0ull)
     return;
   if(aCount + uint32_t(__popcll(m)) > 64u)
-    alphaRound<SHADOW>(sc, seed0, waveAlpha, aCount, aPending, best, occluded);
+    alphaRound<SHADOW, REC>(sc, seed0, waveAlpha, aCount, aPending, best, occluded, rec);
   if(needAlpha)
     waveAlpha[aCount + laneCountBelow(m)] = make_uint4(item, __float_as_uint(t), __float_as_uint(u), __float_as_uint(v));
   aCount += uint32_t(__popcll(m));
@@ -620,16 +666,16 @@ PT_DEV void triRoundFinish(const DevScene& sc, const RaySetup& r, ClosestBest& b
 
 // Second half of a triangle round of the any-hit (shadow) walk without transmissive instances: a candidate that commits
 // decides its ray (raytracer_interface.h.slang:149-179), so the owners only need to know whether any of theirs did.
-template <bool HAS_ALPHA, bool COUNT>
+template <bool HAS_ALPHA, bool COUNT, bool REC = false>
 PT_DEV void triRoundFinishShadow(const DevScene& sc, const RaySetup& r, float tMax, uint32_t seed0, const TriRound& tr, bool& occluded, unsigned& tris,
-                                 uint4* waveAlpha, uint32_t& aCount, bool& aPending)
+                                 uint4* waveAlpha, uint32_t& aCount, bool& aPending, const CandRec* rec = nullptr)
 {
   const uint32_t src = tr.item >> 26;
   const f3       org = mk3(laneRead(r.org.x, src), laneRead(r.org.y, src), laneRead(r.org.z, src));
   const f3       dir = mk3(laneRead(r.dir.x, src), laneRead(r.dir.y, src), laneRead(r.dir.z, src));
   const float    tmaxSrc = laneRead(tMax, src);
   bool           commits = false, needAlpha = false;
-  float          hu = 0.0f, hv = 0.0f;
+  float          hu = 0.0f, hv = 0.0f, ht = 0.0f;
   if(tr.has)
   {
     const DevTri& T = tr.T;
@@ -644,6 +690,7 @@ PT_DEV void triRoundFinishShadow(const DevScene& sc, const RaySetup& r, float tM
       commits   = !needAlpha;
       hu        = h.u;
       hv        = h.v;
+      ht        = h.t;
     }
   }
   if(COUNT) tris += tr.has ? 1u : 0u;
@@ -651,7 +698,7 @@ PT_DEV void triRoundFinishShadow(const DevScene& sc, const RaySetup& r, float tM
   if(HAS_ALPHA)
   {
     ClosestBest none{};
-    alphaDefer<true>(sc, needAlpha, tr.item, 0.0f, hu, hv, seed0, waveAlpha, aCount, aPending, none, occluded);
+    alphaDefer<true, REC>(sc, needAlpha, tr.item, ht, hu, hv, seed0, waveAlpha, aCount, aPending, none, occluded, rec);
     if(__ballot(needAlpha) & mine)
       aPending = true;
   }
@@ -677,7 +724,12 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
     Q.counters[(cur ? QC_PAIR0 : QC_PAIR1) + 2 * threadIdx.x]     = 0;
     Q.counters[(cur ? QC_PAIR0 : QC_PAIR1) + 2 * threadIdx.x + 1] = 0;
     if(threadIdx.x < 8)
-      Q.counters[QC_HEADS_SHADOW + threadIdx.x] = 0;
+    {
+      Q.counters[QC_HEADS_SHADOW + threadIdx.x]   = 0;
+      Q.counters[QC_HEADS_OVERFLOW + threadIdx.x] = 0;
+    }
+    if(threadIdx.x == 0)
+      Q.counters[QC_CAND_POOL] = Q.counters[QC_RESOLVE] = Q.counters[QC_OVERFLOW] = 0;
   }
   const RayQueue in = Q.active[cur];
   queuePrefix(&Q.counters[cur ? QC_PAIR1 : QC_PAIR0], s_prefix);
@@ -979,7 +1031,10 @@ __global__ void __launch_bounds__(256) k_trace_primary(DevScene sc, FrameConsts 
     {
       Q.counters[QC_HEADS_TRACE + threadIdx.x]  = 0;
       Q.counters[QC_HEADS_SHADOW + threadIdx.x] = 0;
+      Q.counters[QC_HEADS_OVERFLOW + threadIdx.x] = 0;
     }
+    if(threadIdx.x == 0)
+      Q.counters[QC_CAND_POOL] = Q.counters[QC_RESOLVE] = Q.counters[QC_OVERFLOW] = 0;
   }
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const uint32_t chunk = blockIdx.x;                 // 256 consecutive path slots = 4 micro-tiles (batchSlots is a multiple of 256)
@@ -1692,29 +1747,77 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
 // fit the 128 VGPRs of a 1024-thread workgroup without spilling into its hot loop: it runs as three 256-thread workgroups per
 // CU with a smaller LDS node cache instead.
 // MODE 0: every instance is FORCE_OPAQUE; 1: alpha-tested materials but no transmissive instance (no ordered candidates at all);
-// 2: transmissive instances present (ordered accumulation of getShadowTransmission).
+// 2: transmissive instances present, ordered accumulation of getShadowTransmission inside the walk (BVH2 scenes, and the rays of
+//    MODE 3 whose candidates overflowed the pool: `overflowOnly`);
+// 3: transmissive instances present, 8-wide BVH: the walk of MODE 1 (triangle rounds, deferred alpha rounds, 128 VGPRs, 16 waves per
+//    CU) that RECORDS the transmissive candidates it meets instead of evaluating them; k_shadow_resolve orders and evaluates them
+//    as one dense pass.  The ordered state (candidate list, search state, material evaluation: 245 VGPRs, 2 waves per SIMD) no
+//    longer rides on every shadow ray, and no ray is walked more than once.
 template <int MODE>
 struct ShadowCfg
 {
   static constexpr int BLOCK = MODE == 2 ? 256 : TRACE_BLOCK;
-  static constexpr int CACHE = MODE == 2 ? 320 : (MODE == 1 ? NODE_CACHE_ALPHA : NODE_CACHE);
+  static constexpr int CACHE = MODE == 2 ? 320 : (MODE == 1 ? NODE_CACHE_ALPHA : (MODE == 3 ? NODE_CACHE_ALPHA - 104 : NODE_CACHE));
 };
+
+// end of a shadow ray: radiance += contribution * transmission (gltf_pathtrace.slang:462-471), or the two outcomes of
+// handleShadowCatcher (pathtrace_functions.h.slang:520-534) for rays the shade kernel flagged as catcher probes
+PT_DEV void shadowDeposit(const PathSoA& P, const Queues& Q, int nxt, uint32_t slot, uint32_t qpos, bool catcherRay, f3 contrib, f3 total, bool occ,
+                          float catcherDarken)
+{
+  if(!catcherRay)
+  {
+    if(!occ)
+    {
+      float4 rad = P.radiance[slot];
+      rad.x += contrib.x * total.x;
+      rad.y += contrib.y * total.y;
+      rad.z += contrib.z * total.z;
+      P.radiance[slot] = rad;
+    }
+    return;
+  }
+  const float4 a2  = Q.shadow.aux2[qpos];
+  const f3     sf  = occ ? mk3(0.0f) : total;
+  float4       rad = P.radiance[slot];
+  if(sf.x == 1.0f && sf.y == 1.0f && sf.z == 1.0f)
+  {
+    rad.x += a2.x; rad.y += a2.y; rad.z += a2.z;  // unshadowed: environment seen through the plane, path ends
+    const uint32_t posNext = __float_as_uint(a2.w);
+    if(posNext != 0xffffffffu)
+      Q.active[nxt].slot[posNext] = QUEUE_DEAD;
+  }
+  else
+  {
+    f3 r3 = mk3(rad.x, rad.y, rad.z);
+    r3 += contrib * sf;
+    r3 -= contrib * (mk3(1.0f) - sf) * catcherDarken;
+    rad.x = r3.x; rad.y = r3.y; rad.z = r3.z;
+  }
+  P.radiance[slot] = rad;
+}
+
 template <bool WIDE, int MODE, bool COUNT>
-__global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_trace_shadow(DevScene sc, const DevScene* __restrict__ scp, PathSoA P, Queues Q, int nxt, float catcherDarken, StatCounters* stats)
+__global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_trace_shadow(DevScene sc, const DevScene* __restrict__ scp, PathSoA P, Queues Q, int nxt, float catcherDarken, StatCounters* stats, int overflowOnly)
 {
   // `sc` (kernel argument, SGPRs) serves the inlined walk; the non-inlined material helpers of the transmissive path get the
   // device-resident copy `*scp` so that the argument's address never escapes (no scratch copy, cf. k_shade)
   constexpr int  SBLOCK    = ShadowCfg<MODE>::BLOCK;
-  constexpr bool HAS_ALPHA = MODE >= 1, HAS_TRANS = MODE == 2;
+  constexpr bool HAS_ALPHA = MODE >= 1, HAS_TRANS = MODE == 2, REC = MODE == 3;
+  constexpr bool DEFER = MODE == 1 || MODE == 3;  // candidates of non-opaque instances go through alpha rounds
+  static_assert(!REC || WIDE, "the recording walk exists for the 8-wide BVH only");
   __shared__ int      s_stack[BVH_STACK_LDS * SBLOCK];
   __shared__ uint32_t s_prefix[NSUB + 1];
   __shared__ uint4    s_nodes[WIDE ? ShadowCfg<MODE>::CACHE * 5 : 1];
   __shared__ uint32_t s_items[(WIDE && !HAS_TRANS) ? SBLOCK : 1];  // triangle rounds (see triRoundPublish)
-  __shared__ uint4    s_alpha[(WIDE && MODE == 1) ? SBLOCK : 1];   // deferred alpha tests (see alphaRound)
+  __shared__ uint4    s_alpha[(WIDE && DEFER) ? SBLOCK : 1];       // deferred alpha tests (see alphaRound)
+  __shared__ uint32_t s_head[REC ? SBLOCK : 1], s_ovf[REC ? SBLOCK : 1];  // per ray in flight: recorded-candidate list head, overflow flag
   queuePrefix(&Q.counters[(nxt ? QC_PAIR1 : QC_PAIR0) + 1], s_prefix);  // the shadow tails written next to active queue `nxt`
   const RayQueue in = Q.shadow;
+  const bool     subset = MODE == 2 && overflowOnly != 0;  // only the rays k_trace_shadow<MODE 3> listed in Q.overflow
+  uint32_t* const heads = &Q.counters[subset ? QC_HEADS_OVERFLOW : QC_HEADS_SHADOW];
   WaveFeed feed;
-  feedInit(feed, s_prefix[NSUB]);
+  feedInit(feed, subset ? Q.counters[QC_OVERFLOW] : s_prefix[NSUB]);
   if(!feedBlockHasWork(feed))
     return;
   const uint32_t cachedNodes = WIDE ? fillNodeCache(sc, s_nodes, uint32_t(ShadowCfg<MODE>::CACHE)) : 0u;
@@ -1751,44 +1854,23 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
   float4   pO = make_float4(0, 0, 0, 0), pD = make_float4(0, 0, 0, 0), pC = make_float4(0, 0, 0, 0);
   bool     catcherRay = false;
   uint32_t pBase = 0, pMask = 0, qBase = 0, qMask = 0;  // parked leaf hits of the 8-wide walk (see k_trace_closest)
-  uint32_t aCount   = 0;                                // deferred alpha tests of this wave / some of them this lane's (MODE 1)
+  uint32_t aCount   = 0;                                // deferred alpha tests of this wave / some of them this lane's (MODE 1, 3)
   bool     aPending = false;
-  uint4*   waveAlpha = s_alpha + ((WIDE && MODE == 1) ? (threadIdx.x & ~63u) : 0u);
+  bool     toOverflow = false;                          // MODE 3: this lane's ray just ended with candidates that did not fit the pool
+#ifdef TRACE_PROFILE
+  unsigned long long sp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long spStart = PROF_T();
+#define SPROF_ADD(i, t0) sp[i] += PROF_T() - (t0)
+#define SPROF_CNT(i, n) sp[i] += (unsigned long long)(n)
+#else
+#define SPROF_ADD(i, t0) (void)(t0)
+#define SPROF_CNT(i, n) (void)0
+#endif
+  uint4*   waveAlpha = s_alpha + ((WIDE && DEFER) ? (threadIdx.x & ~63u) : 0u);
+  CandRec  rec{Q.candPool, Q.candNext, &Q.counters[QC_CAND_POOL], Q.candCap, s_head + (REC ? (threadIdx.x & ~63u) : 0u), s_ovf + (REC ? (threadIdx.x & ~63u) : 0u)};
+  (void)rec;
 
-  // end of a shadow ray: radiance += contribution * transmission (gltf_pathtrace.slang:462-471), or the two outcomes of
-  // handleShadowCatcher (pathtrace_functions.h.slang:520-534) for rays the shade kernel flagged as catcher probes
-  auto deposit = [&](bool occ) {
-    if(!catcherRay)
-    {
-      if(!occ)
-      {
-        float4 rad = P.radiance[slot];
-        rad.x += contrib.x * total.x;
-        rad.y += contrib.y * total.y;
-        rad.z += contrib.z * total.z;
-        P.radiance[slot] = rad;
-      }
-      return;
-    }
-    const float4 a2  = Q.shadow.aux2[qpos];
-    const f3     sf  = occ ? mk3(0.0f) : total;
-    float4       rad = P.radiance[slot];
-    if(sf.x == 1.0f && sf.y == 1.0f && sf.z == 1.0f)
-    {
-      rad.x += a2.x; rad.y += a2.y; rad.z += a2.z;  // unshadowed: environment seen through the plane, path ends
-      const uint32_t posNext = __float_as_uint(a2.w);
-      if(posNext != 0xffffffffu)
-        Q.active[nxt].slot[posNext] = QUEUE_DEAD;
-    }
-    else
-    {
-      f3 r3 = mk3(rad.x, rad.y, rad.z);
-      r3 += contrib * sf;
-      r3 -= contrib * (mk3(1.0f) - sf) * catcherDarken;
-      rad.x = r3.x; rad.y = r3.y; rad.z = r3.z;
-    }
-    P.radiance[slot] = rad;
-  };
+  auto deposit = [&](bool occ) { shadowDeposit(P, Q, nxt, slot, qpos, catcherRay, contrib, total, occ, catcherDarken); };
 
   // Transmissive candidates met by the any-hit walk, kept so that the common case (a few glass surfaces on the way to the
   // light) is settled by ordering this list instead of one search walk per candidate.  Separate local arrays: scratch, only
@@ -1870,6 +1952,9 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
 
   for(;;)
   {
+    const unsigned long long tOuter = PROF_T();
+    SPROF_CNT(8, 1);
+    SPROF_CNT(9, 64 - __popcll(__ballot(active)));
     if(!active && pValid)
     {
       pValid = false;
@@ -1893,20 +1978,28 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
         octinv   = rayOctInv(r.idir);
         restartWalk();
         active = true;
+        if(REC)
+        {
+          s_head[threadIdx.x] = CAND_NIL;
+          s_ovf[threadIdx.x]  = 0u;
+        }
         if(COUNT) ++rays;
         if(sc.bvhRoot == BVH_EMPTY)  // nothing to hit: unoccluded
         {
-          deposit(false);
+          if(HAS_TRANS)
+            deposit(false);
+          else
+            reinterpret_cast<uint32_t*>(&Q.shadow.org[qpos])[3] = CAND_NIL;
           active = false;
         }
       }
     }
     if(!feed.exhausted)
     {
-      uint32_t flat = feedTake(feed, !pValid, &Q.counters[QC_HEADS_SHADOW]);
+      uint32_t flat = feedTake(feed, !pValid, heads);
       if(flat != 0xffffffffu)
       {
-        const uint32_t pPos = queuePos(Q.subCap, s_prefix, flat);
+        const uint32_t pPos = subset ? Q.overflow[flat] : queuePos(Q.subCap, s_prefix, flat);
         pQPos  = pPos;
         pSlot  = in.slot[pPos];
         pO     = in.org[pPos];
@@ -1916,6 +2009,7 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
       }
     }
     const bool moreWork = !feed.exhausted || __ballot(pValid) != 0ull;
+    SPROF_ADD(0, tOuter);
     if(__ballot(active) == 0ull)
     {
       if(!moreWork)
@@ -1925,11 +2019,14 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
     for(;;)
     {
       bool walkDone = false;
+      const unsigned long long tInner = PROF_T();
+      SPROF_CNT(10, 1);
+      SPROF_CNT(11, __popcll(__ballot(active)));
       if(WIDE)
       {
         // node step + dense triangle phase, as in k_trace_closest (any-hit and the phase-1 search are order independent)
         bool visited = false;
-        if(active && qMask == 0u && !(MODE == 1 && occluded))  // (an occluded MODE-1 ray may still wait for its deferred alpha tests)
+        if(active && qMask == 0u && !(DEFER && occluded))  // (an occluded ray may still wait for its deferred alpha tests)
         {
           const float walkTmax = (HAS_TRANS && phase == 1 && found) ? bT : tMax;
           if((G.bits >> 8) == 0u && st2.sp > 0)
@@ -1950,6 +2047,9 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
             }
           }
         }
+        SPROF_ADD(1, tInner);
+        SPROF_CNT(12, __popcll(__ballot(visited)));
+        const unsigned long long tTri = PROF_T();
         unsigned long long pend = __ballot(active && pMask != 0u);
         if(!HAS_TRANS)
         {
@@ -1965,23 +2065,28 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
               {
                 TriRound tr;
                 triRoundPublish(sc, active, pBase, pMask, qBase, qMask, s_items + (threadIdx.x & ~63u), tr);
-                triRoundFinishShadow<HAS_ALPHA, COUNT>(sc, r, tMax, seed0, tr, occluded, tris, waveAlpha, aCount, aPending);
+                triRoundFinishShadow<HAS_ALPHA, COUNT, REC>(sc, r, tMax, seed0, tr, occluded, tris, waveAlpha, aCount, aPending, &rec);
                 if(occluded) { pMask = 0u; qMask = 0u; }
                 pend = __ballot(active && pMask != 0u);
               } while(pend != 0ull && (drain || __popcll(pend) >= TRI_ROUND_LANES));
             }
           }
-          if(MODE == 1 && aCount != 0u)
+          SPROF_ADD(2, tTri);
+          const unsigned long long tAlpha = PROF_T();
+          if(DEFER && aCount != 0u)
           {
             const bool walked  = active && (occluded || ((G.bits >> 8) == 0u && st2.sp == 0 && pMask == 0u));
             const int  waiting = __popcll(__ballot(walked && aPending));
             if(aCount >= ALPHA_ROUND_MIN || __popcll(__ballot(visited)) < TRI_PHASE_LANES || waiting >= ALPHA_ROUND_WAITING)
             {
               ClosestBest none{};
-              alphaRound<true>(sc, seed0, waveAlpha, aCount, aPending, none, occluded);
+              SPROF_CNT(13, 1);
+              SPROF_CNT(14, aCount);
+              alphaRound<true, REC>(sc, seed0, waveAlpha, aCount, aPending, none, occluded, &rec);
               if(occluded) { pMask = 0u; qMask = 0u; }
             }
           }
+          SPROF_ADD(3, tAlpha);
         }
         else if(pend != 0ull)
         {
@@ -2011,7 +2116,7 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
             } while(pend != 0ull && (drain || __popcll(pend) >= TRI_PHASE_EXIT_LANES || __ballot(active && qMask != 0u) != 0ull));
           }
         }
-        walkDone = active && !(MODE == 1 && aPending) && (occluded || ((G.bits >> 8) == 0u && st2.sp == 0 && pMask == 0u));
+        walkDone = active && !(DEFER && aPending) && (occluded || ((G.bits >> 8) == 0u && st2.sp == 0 && pMask == 0u));
       }
       else if(active)
       {
@@ -2029,6 +2134,7 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
         }
         walkDone = occluded || node == BVH_EMPTY;
       }
+      const unsigned long long tFin = PROF_T();
       if(active)
       {
         if(walkDone)
@@ -2073,21 +2179,168 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
           }
           if(finished)
           {
-            deposit(occluded);
+            if(HAS_TRANS)
+              deposit(occluded);  // the ordered-search kernel settles its rays itself
+            else
+            {
+              // The outcome goes into the ray's queue entry (org.w, the walk is done with tmax): k_shadow_resolve adds the
+              // contributions as one streaming pass.  Doing it here -- a dependent read-modify-write of the path's radiance in
+              // the middle of a persistent wave -- stalled the whole wave for a memory round trip whenever one of its rays
+              // ended: a quarter of this kernel's time on the glass workload.
+              uint32_t code = occluded ? SHADOW_OCCLUDED : CAND_NIL;
+              if(REC && !occluded)
+              {
+                code       = s_head[threadIdx.x];
+                toOverflow = s_ovf[threadIdx.x] != 0u;
+              }
+              if(toOverflow)  // the entry keeps its tmax for the ordered-search kernel and is flagged in dir.w (bit 2)
+                reinterpret_cast<uint32_t*>(&Q.shadow.dir[qpos])[3] |= SHADOW_DIR_OVERFLOW;
+              else
+                reinterpret_cast<uint32_t*>(&Q.shadow.org[qpos])[3] = code;
+            }
             active = false;
           }
         }
       }
+      if(REC)
+      {
+        // rays whose candidates did not fit the pool are listed for the ordered-search kernel (rare: one device atomic per event)
+        const unsigned long long mO = __ballot(toOverflow);
+        if(mO != 0ull)
+        {
+          const int first = __ffsll((long long)mO) - 1;
+          uint32_t  base  = 0u;
+          if(int(laneId()) == first)
+            base = atomicAdd(&Q.counters[QC_OVERFLOW], uint32_t(__popcll(mO)));
+          base = uint32_t(__builtin_amdgcn_readlane(int(base), first));
+          if(toOverflow)
+            Q.overflow[base + laneCountBelow(mO)] = qpos;
+        }
+        toOverflow = false;
+      }
+      SPROF_ADD(4, tFin);
       const unsigned long long act = __ballot(active);
       if(act == 0ull || (moreWork && __popcll(act) <= 64 - REFILL_IDLE_LANES))
         break;
     }
   }
+#ifdef TRACE_PROFILE
+  if(laneId() == 0 && WIDE && DEFER)
+  {
+    sp[5] = PROF_T() - spStart;
+    sp[6] = 1;
+    for(int i = 0; i < 16; ++i)
+      atomicAdd(&g_shadowProf[i], sp[i]);
+  }
+#endif
+#undef SPROF_ADD
+#undef SPROF_CNT
   if(COUNT)
   {
     atomicAdd(&stats->shadowRays, (unsigned long long)rays);
     atomicAdd(&stats->nodesShadow, (unsigned long long)nodes);
     atomicAdd(&stats->trisShadow, (unsigned long long)tris);
+  }
+}
+
+//================================================================================================================================
+// k_shadow_resolve: the end of every shadow ray -- `radiance += contribution * transmission` (gltf_pathtrace.slang:462-471) -- and
+// the ordered half of TraceShadow for rays that met transmissive candidates (raytracer_interface.h.slang:160-178)
+//================================================================================================================================
+// One streaming pass over the shadow queue, one thread per entry, reading the outcome k_trace_shadow left in org.w.  Occluded rays
+// cost one word.  A ray with recorded candidates (a chain in Q.candPool, typically two to four: the shells of the glass between a
+// point and the light) takes them in increasing (t, renderNode, primitive) order by repeated selection over the chain -- no
+// per-thread array, the chain is L2 resident -- and each accepted one multiplies the transmission by getShadowTransmission() over
+// the segment since the previous accepted one, until the product drops to MIN_TRANSMISSION.  Nothing here walks the BVH.
+template <bool REC>
+__global__ void __launch_bounds__(256) k_shadow_resolve(const DevScene* __restrict__ scp, PathSoA P, Queues Q, int nxt, float catcherDarken)
+{
+  __shared__ uint32_t s_prefix[NSUB + 1];
+  queuePrefix(&Q.counters[(nxt ? QC_PAIR1 : QC_PAIR0) + 1], s_prefix);
+  const uint32_t count = s_prefix[NSUB];
+  for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
+  {
+    const uint32_t qpos = queuePos(Q.subCap, s_prefix, i);
+    const uint32_t slot = Q.shadow.slot[qpos];
+    if(slot == QUEUE_DEAD)
+      continue;
+    const float4 d4 = Q.shadow.dir[qpos];
+    if(REC && (__float_as_uint(d4.w) & SHADOW_DIR_OVERFLOW))
+      continue;  // settled by the ordered-search kernel
+    const uint32_t code       = reinterpret_cast<const uint32_t*>(&Q.shadow.org[qpos])[3];
+    const bool     catcherRay = (__float_as_uint(d4.w) & 2u) != 0u;
+    bool         occluded   = code == SHADOW_OCCLUDED;
+    if(occluded && !catcherRay)
+      continue;
+    const float4 c4 = Q.shadow.aux[qpos];
+    f3           total = mk3(1.0f);
+    if(REC && !occluded && code != CAND_NIL)
+    {
+      const DevScene& sc       = *scp;
+      const f3        dir      = xyz(d4);
+      const uint32_t  seed0    = __float_as_uint(c4.w);
+      bool            isInside = (__float_as_uint(d4.w) & 1u) != 0u, haveLast = false;
+      float           lastT = -1.0f, prevHitT = 0.0f;
+      uint32_t        lastRnode = 0u, lastPrim = 0u;
+      for(;;)
+      {
+        // next candidate in the order: the smallest (t, renderNode, primitive) after the last one taken
+        uint32_t best = CAND_NIL, bRnode = 0u, bPrim = 0u;
+        bool     bIds = false;
+        float4   bC   = make_float4(0, 0, 0, 0);
+        for(uint32_t k = code; k != CAND_NIL; k = Q.candNext[k])
+        {
+          const float4   c   = Q.candPool[k];
+          const uint32_t tri = __float_as_uint(c.w);
+          const bool     tieLast = haveLast && c.x == lastT, tieBest = best != CAND_NIL && c.x == bC.x;
+          uint32_t       rnode = 0u, prim = 0u;
+          if(tieLast || tieBest)  // exact ties only: coincident surfaces
+          {
+            rnode = __float_as_uint(sc.tris[tri].a.w);
+            prim  = __float_as_uint(sc.tris[tri].b.w);
+          }
+          const bool afterLast  = !haveLast || c.x > lastT || (tieLast && (rnode > lastRnode || (rnode == lastRnode && prim > lastPrim)));
+          bool       beforeBest = best == CAND_NIL || c.x < bC.x;
+          if(tieBest)
+          {
+            if(!bIds)  // the best so far was taken without its ids
+            {
+              const uint32_t bt = __float_as_uint(bC.w);
+              bRnode = __float_as_uint(sc.tris[bt].a.w);
+              bPrim  = __float_as_uint(sc.tris[bt].b.w);
+              bIds   = true;
+            }
+            beforeBest = rnode < bRnode || (rnode == bRnode && prim < bPrim);
+          }
+          if(afterLast && beforeBest)
+          {
+            best = k; bC = c; bRnode = rnode; bPrim = prim; bIds = tieLast || tieBest;
+          }
+        }
+        if(best == CAND_NIL)
+          break;
+        const uint32_t tri = __float_as_uint(bC.w);
+        const uint32_t rnode = __float_as_uint(sc.tris[tri].a.w), prim = __float_as_uint(sc.tris[tri].b.w);
+        haveLast = true; lastT = bC.x; lastRnode = rnode; lastPrim = prim;
+        const f3    bary    = mk3(1.0f - bC.y - bC.z, bC.y, bC.z);
+        const float opacity = getOpacityFast(sc, int(tri), bary);
+        if(candidateRand(seed0, int(rnode), int(prim)) < opacity)
+        {
+          const float segment = fmaxf(0.0f, bC.x - prevHitT);
+          const f3    curT    = getShadowTransmission(sc, int(rnode), int(prim), bary, segment, dir, isInside);
+          prevHitT            = bC.x;
+          total *= curT;
+          if(maxComp(total) <= MIN_TRANSMISSION)
+          {
+            occluded = true;
+            break;
+          }
+        }
+      }
+      if(occluded && !catcherRay)
+        continue;
+    }
+    shadowDeposit(P, Q, nxt, slot, qpos, catcherRay, xyz(c4), total, occluded, catcherDarken);
   }
 }
 
@@ -2229,6 +2482,14 @@ void dumpTraceProfile()
   fprintf(stderr, "[mi_pt trace profile] waves %llu total ticks %.4g: feed %.1f%% node %.1f%% tri %.1f%% other %.1f%%\n", h[4], tot, 100.0 * h[0] / tot,
           100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * (tot - h[0] - h[1] - h[2]) / tot);
   fprintf(stderr, "[mi_pt trace profile] triangle rounds: test (permutes, intersection, alpha) %.1f%% gather %.1f%% of total\n", 100.0 * h[16] / tot, 100.0 * h[17] / tot);
+  unsigned long long g[16] = {};
+  (void)hipMemcpyFromSymbol(g, HIP_SYMBOL(g_shadowProf), sizeof(g));
+  const double st = double(g[5]) > 0 ? double(g[5]) : 1.0;
+  const auto   pr = [](unsigned long long a, unsigned long long b) { return b ? double(a) / double(b) : 0.0; };
+  fprintf(stderr, "[mi_pt shadow profile] waves %llu total ticks %.4g: feed %.1f%% node %.1f%% tri %.1f%% alpha %.1f%% finish %.1f%% other %.1f%%\n", g[6], st,
+          100.0 * g[0] / st, 100.0 * g[1] / st, 100.0 * g[2] / st, 100.0 * g[3] / st, 100.0 * g[4] / st, 100.0 * (st - g[0] - g[1] - g[2] - g[3] - g[4]) / st);
+  fprintf(stderr, "[mi_pt shadow profile] outer iterations %llu (%.1f idle lanes each), inner iterations %llu (%.1f active lanes, %.1f visiting), alpha rounds %llu (%.1f entries)\n",
+          g[8], pr(g[9], g[8]), g[10], pr(g[11], g[10]), pr(g[12], g[10]), g[13], pr(g[14], g[13]));
   const auto per = [](unsigned long long a, unsigned long long b) { return b ? double(a) / double(b) : 0.0; };
   fprintf(stderr, "[mi_pt trace profile] lanes: %.1f of 64 visit per node step (%llu steps, %.1f blocked); %.1f test per triangle round (%llu rounds in %llu phases); "
                   "%.1f idle at each of %llu refills\n",
@@ -2285,14 +2546,38 @@ template <bool WIDE>
 void launchTraceShadowT(const LaunchCtx& c, int nxt)
 {
   const float darken = c.fc.frameInfo.shadowCatcherDarkenAmount;
-  const int   mode   = !c.hasAlpha ? 0 : (c.hasTransmissive ? 2 : 1);
+  const bool  record = WIDE && c.hasAlpha && c.hasTransmissive && c.queues.candPool != nullptr;
+  const int   mode   = !c.hasAlpha ? 0 : (c.hasTransmissive ? (record ? 3 : 2) : 1);
   const unsigned bs  = mode == 2 ? unsigned(ShadowCfg<2>::BLOCK) : unsigned(ShadowCfg<0>::BLOCK);
   dim3 grid(c.persistentBlocks * 256u / bs), block(bs);
-#define MI_LAUNCH_SHADOW(M, C) \
-  hipLaunchKernelGGL((k_trace_shadow<WIDE, M, C>), grid, block, 0, c.stream, c.scene, c.sceneDev, c.paths, c.queues, nxt, darken, c.stats)
-  if(mode == 0)      { if(c.collectCounters) MI_LAUNCH_SHADOW(0, true); else MI_LAUNCH_SHADOW(0, false); }
-  else if(mode == 1) { if(c.collectCounters) MI_LAUNCH_SHADOW(1, true); else MI_LAUNCH_SHADOW(1, false); }
-  else               { if(c.collectCounters) MI_LAUNCH_SHADOW(2, true); else MI_LAUNCH_SHADOW(2, false); }
+#define MI_LAUNCH_SHADOW(M, C, OVF) \
+  hipLaunchKernelGGL((k_trace_shadow<WIDE, M, C>), grid, block, 0, c.stream, c.scene, c.sceneDev, c.paths, c.queues, nxt, darken, c.stats, OVF)
+  // the walk leaves every ray's outcome in its queue entry; k_shadow_resolve adds the contributions (and, after the recording
+  // walk, evaluates the recorded transmissive candidates in order) as one streaming pass
+  const dim3 rgrid(c.persistentBlocks), rblock(256);
+  if(mode == 0)      { if(c.collectCounters) MI_LAUNCH_SHADOW(0, true, 0); else MI_LAUNCH_SHADOW(0, false, 0); }
+  else if(mode == 1) { if(c.collectCounters) MI_LAUNCH_SHADOW(1, true, 0); else MI_LAUNCH_SHADOW(1, false, 0); }
+  else if(mode == 2) { if(c.collectCounters) MI_LAUNCH_SHADOW(2, true, 0); else MI_LAUNCH_SHADOW(2, false, 0); }
+  else
+  {
+    if constexpr(WIDE)
+    {
+      if(c.collectCounters) MI_LAUNCH_SHADOW(3, true, 0); else MI_LAUNCH_SHADOW(3, false, 0);
+    }
+  }
+  if(mode == 3)
+  {
+    hipLaunchKernelGGL(k_shadow_resolve<true>, rgrid, rblock, 0, c.stream, c.sceneDev, c.paths, c.queues, nxt, darken);
+    if constexpr(WIDE)
+    {
+      // normally on an empty list: the rays whose candidates did not fit the pool, by ordered search
+      grid  = dim3(c.persistentBlocks * 256u / unsigned(ShadowCfg<2>::BLOCK));
+      block = dim3(unsigned(ShadowCfg<2>::BLOCK));
+      if(c.collectCounters) MI_LAUNCH_SHADOW(2, true, 1); else MI_LAUNCH_SHADOW(2, false, 1);
+    }
+  }
+  else if(mode != 2)
+    hipLaunchKernelGGL(k_shadow_resolve<false>, rgrid, rblock, 0, c.stream, c.sceneDev, c.paths, c.queues, nxt, darken);
 #undef MI_LAUNCH_SHADOW
 }
 }  // namespace

@@ -202,7 +202,20 @@ struct Queues
   RayQueue  shadow;     // pending shadow rays
   uint32_t* counters;   // see QC_* indices
   uint32_t  subCap;
+  // Shadow rays through transmissive instances (scenes with such instances on the 8-wide BVH, k_trace_shadow MODE 3): the any-hit
+  // walk records every transmissive candidate {t, u, v, triangle} in `candPool` -- entries of one ray chained through `candNext`
+  // -- and leaves the chain's head in the ray's queue entry; k_shadow_resolve then takes each ray's candidates in increasing
+  // (t, renderNode, primitive) order (raytracer_interface.h.slang:160-178).  A ray whose candidates did not fit the pool is listed
+  // in `overflow` and re-traced by the ordered-search kernel (MODE 2).  Null when unused.
+  float4*   candPool;
+  uint32_t* candNext;
+  uint32_t* overflow;
+  uint32_t  candCap;
 };
+// Outcome of a shadow ray's walk, left in org.w of its queue entry for k_shadow_resolve: the first recorded candidate, or
+constexpr uint32_t CAND_NIL        = 0xffffffffu;  // unoccluded, nothing recorded
+constexpr uint32_t SHADOW_OCCLUDED = 0xfffffffeu;
+constexpr uint32_t SHADOW_DIR_OVERFLOW = 4u;  // dir.w bit 2: candidates did not fit the pool, the ordered-search kernel re-traces the ray (org.w keeps tmax)
 enum : int
 {
   // Queue tails.  PAIR q holds, per sub-queue s, two adjacent words: [2s] = entries appended to active queue q, [2s+1] =
@@ -214,7 +227,11 @@ enum : int
   QC_PAIR1        = 32,   // 2 * NSUB words
   QC_HEADS_TRACE  = 96,   // 8 dynamic-fetch heads (one per XCD by convention) of k_trace_closest
   QC_HEADS_SHADOW = 128,  // 8 heads of k_trace_shadow
-  QC_COUNT        = 160
+  QC_HEADS_OVERFLOW = 160,  // 8 heads of the ordered-search kernel over the overflow list
+  QC_CAND_POOL      = 192,  // entries handed out of candPool
+  QC_RESOLVE        = 224,  // (unused)
+  QC_OVERFLOW       = 256,  // entries of the overflow list
+  QC_COUNT          = 288
 };
 
 struct StatCounters  // device mirror of MiPtStats' dynamic part
