@@ -1,10 +1,14 @@
-timeout 800 python -m pytest tests/test_gpu_parity.py tests/test_gpu_lobes.py -m gpu -q -x 2>&1 | tail -5
-for w in glass atrium helmet; do
-timeout 300 python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r02_bench_${w}_c.json 2> gpurun_out/r02_bench_${w}_c.err; python - <<PY
-import json
-d=json.load(open("gpurun_out/r02_bench_${w}_c.json"))
-print("$w", d["value"], d["frame_ms_device"], {k:v["ms_per_frame"] for k,v in d["kernels"].items()})
+run() { w=$1; shift; timeout 300 python bench.py --workload $w --no-cpu-baseline "$@" > gpurun_out/tmp_bench.json 2> gpurun_out/tmp_bench.err; python - "$w" "$*" <<PY
+import json,sys
+try:
+    d=json.load(open("gpurun_out/tmp_bench.json"))
+    print(sys.argv[1], sys.argv[2], d["value"], d["frame_ms_device"], {k:v["ms_per_frame"] for k,v in d["kernels"].items()})
+except Exception as e:
+    print(sys.argv[1], sys.argv[2], "FAILED", e, open("gpurun_out/tmp_bench.err").read()[-500:])
 PY
-done
-MI_PT_LIB=$PWD/vk_gltf_renderer_amd/lib/var_prof/libmi_pt.so timeout 300 python tools/diag_spans.py glass 32 2>&1 | grep profile
-MI_PT_LIB=$PWD/vk_gltf_renderer_amd/lib/var_prof/libmi_pt.so timeout 300 python tools/diag_spans.py atrium 32 2>&1 | grep profile
+}
+run glass --steps 2 --warmup 1 --in-flight 64 --frames-per-step 192
+run glass --steps 2 --warmup 1 --in-flight 128 --frames-per-step 256
+run helmet --steps 6 --warmup 1 --in-flight 64 --frames-per-step 192
+run helmet --steps 6 --warmup 1 --in-flight 96 --frames-per-step 192
+run atrium --steps 2 --warmup 1 --in-flight 64 --frames-per-step 192
