@@ -415,3 +415,110 @@ def test_untrusted_accessor_sizes_are_rejected_not_read(built, tmp_path, case):
         assert rp.vertexCount <= 16 and rp.triangleCount <= 18
         idx = np.ctypeslib.as_array(rp.indices, shape=(rp.triangleCount * 3,)) if rp.triangleCount else np.zeros(0, np.uint32)
         assert (idx < max(rp.vertexCount, 1)).all()
+
+
+def _scene_with_images(tmp_path, name, blobs, mime, ext=None):
+    """One texture per image blob (optionally referenced through a texture extension), all on linear material slots."""
+    b = scenegen.GlbBuilder()
+    if ext:
+        b.ext_used.add(ext)
+    for data in blobs:
+        img = b.image_bytes(data, mime)
+        b.doc.setdefault("textures", []).append({"extensions": {ext: {"source": img}}} if ext else {"source": img})
+    b.material({"pbrMetallicRoughness": {"metallicRoughnessTexture": {"index": 0}}})
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    b.node(mesh=b.mesh([b.primitive(pos, np.array([0, 1, 2]), material=0)]))
+    sc = ptmod.Scene(b.save(str(tmp_path / name)))
+    d = sc.desc.contents
+    out = []
+    for i in range(len(blobs)):
+        t = d.textures[i]
+        out.append(np.ctypeslib.as_array(t.levels[0], shape=(t.height, t.width, 4)).copy())
+    return out
+
+
+def test_bc7_decode(built, tmp_path):
+    """BC7 (DXGI 98 in a DDS container) against Pillow's decoder on random blocks: random bytes hit mode m with probability 2^-(m+1),
+    so 64 x 64 blocks see every mode (mode 7 about 16 times); plus blocks forced into the rarer modes and the reserved mode."""
+    PIL_Image = pytest.importorskip("PIL.Image")
+    import io
+    rng = np.random.default_rng(77)
+    n = 64
+    blocks = rng.integers(0, 256, (n * n, 16), dtype=np.uint8)
+    for m in range(8):  # force the mode of a slice of the blocks: low bits = 0...01 at bit m
+        sl = blocks[m * 256:(m + 1) * 256]
+        sl[:, 0] = (sl[:, 0] & ~np.uint8((1 << (m + 1)) - 1)) | np.uint8(1 << m)
+    blocks[-1] = 0  # reserved mode: all zeros out
+    modes = [int(np.argmax([(b[0] >> k) & 1 for k in range(8)])) if b[0] else 8 for b in blocks]
+    assert all(modes.count(m) >= 200 for m in range(8)) and modes.count(8) >= 1
+    dds = _dds(4 * n, 4 * n, blocks.tobytes(), dxgi=98)
+    want = np.asarray(PIL_Image.open(io.BytesIO(dds)).convert("RGBA")).astype(int)
+    got = _scene_with_images(tmp_path, "bc7.glb", [dds], "image/vnd-ms.dds", "MSFT_texture_dds")[0].astype(int)
+    assert got.shape == want.shape == (4 * n, 4 * n, 4)
+    # reserved mode (first byte zero): transparent black per the D3D specification (Pillow leaves alpha opaque there)
+    reserved = np.repeat(np.repeat(np.array(modes).reshape(n, n) == 8, 4, 0), 4, 1)
+    assert (got[reserved] == 0).all()
+    bad = np.nonzero((got != want).any(-1) & ~reserved)
+    assert bad[0].size == 0, (bad[0][:4], bad[1][:4], got[bad][:2], want[bad][:2], [modes[(y // 4) * n + x // 4] for y, x in zip(bad[0][:4], bad[1][:4])])
+
+
+def _ktx2(width, height, vk_format, payload, scheme=0, levels=1):
+    """A minimal KTX 2.0 file: header, one-level index, no DFD / key-value data, `payload` as level 0 (supercompressed per `scheme`)."""
+    import struct
+    import zlib
+    raw = bytes(payload)
+    if scheme == 3:
+        data = zlib.compress(raw)
+    elif scheme == 2:
+        pa = pytest.importorskip("pyarrow")
+        data = pa.Codec("zstd").compress(raw, asbytes=True)
+    else:
+        data = raw
+    off = 80 + 24 * levels
+    hdr = b"\xabKTX 20\xbb\r\n\x1a\n" + struct.pack("<IIIIIIIII", vk_format, 1, width, height, 0, 0, 1, levels, scheme) + struct.pack("<IIIIQQ", 0, 0, 0, 0, 0, 0)
+    assert len(hdr) == 80
+    index = struct.pack("<QQQ", off, len(data), len(raw)) + b"".join(struct.pack("<QQQ", 0, 0, 0) for _ in range(levels - 1))
+    return hdr + index + data
+
+
+def test_ktx_decode(built, tmp_path):
+    """KTX 2 (uncompressed 8-bit formats, BC1 / BC7 blocks; no / ZLIB / Zstandard supercompression) and KTX 1, as KHR_texture_basisu
+    sources and plain images: what the reference reads through nv_ktx (src/gltf_image_loader.cpp:123-160).  BasisLZ / UASTC payloads
+    are refused cleanly (the texture then falls back, see test_dds_decode_and_texture_extension_sources)."""
+    import struct
+    rng = np.random.default_rng(9)
+    rgba = rng.integers(0, 256, (5, 7, 4), dtype=np.uint8)
+    rgb = rng.integers(0, 256, (3, 6, 3), dtype=np.uint8)
+    rg = rng.integers(0, 256, (4, 4, 2), dtype=np.uint8)
+    red, blue = 0xF800, 0x001F
+    idx = sum(((i % 4) << (2 * i)) for i in range(16))
+    bc1 = struct.pack("<HHI", red, blue, idx)
+    bc7_blocks = rng.integers(0, 256, (4, 16), dtype=np.uint8)
+    files = {
+        "rgba": _ktx2(7, 5, 37, rgba.tobytes()), "rgba_srgb_zlib": _ktx2(7, 5, 43, rgba.tobytes(), scheme=3), "rgba_zstd": _ktx2(7, 5, 37, rgba.tobytes(), scheme=2),
+        "bgra": _ktx2(7, 5, 44, rgba.tobytes()), "rgb": _ktx2(6, 3, 23, rgb.tobytes()), "rg": _ktx2(4, 4, 16, rg.tobytes()),
+        "bc1": _ktx2(4, 4, 131, bc1), "bc7_zstd": _ktx2(8, 8, 145, bc7_blocks.tobytes(), scheme=2),
+    }
+    # KTX 1.1: GL_RGB8 rows are padded to 4 bytes
+    rows = b"".join(rgb[y].tobytes() + bytes((-6 * 3) % 4) for y in range(3))
+    files["ktx1_rgb"] = (b"\xabKTX 11\xbb\r\n\x1a\n" + struct.pack("<IIIIIIIIIIIII", 0x04030201, 0x1401, 1, 0x1907, 0x8051, 0x1907, 6, 3, 0, 0, 1, 1, 0)
+                         + struct.pack("<I", len(rows)) + rows)
+    names = list(files)
+    tex = dict(zip(names, _scene_with_images(tmp_path, "k.glb", [files[k] for k in names], "image/ktx2", "KHR_texture_basisu")))
+    assert (tex["rgba"] == rgba).all() and (tex["rgba_srgb_zlib"] == rgba).all() and (tex["rgba_zstd"] == rgba).all()
+    assert (tex["bgra"] == rgba[..., [2, 1, 0, 3]]).all()
+    assert (tex["rgb"][..., :3] == rgb).all() and (tex["rgb"][..., 3] == 255).all() and (tex["ktx1_rgb"] == tex["rgb"]).all()
+    assert (tex["rg"][..., :2] == rg).all() and (tex["rg"][..., 2] == 0).all() and (tex["rg"][..., 3] == 255).all()
+    pal = [(255, 0, 0, 255), (0, 0, 255, 255), (170, 0, 85, 255), (85, 0, 170, 255)]
+    assert [tuple(int(c) for c in v) for v in tex["bc1"].reshape(16, 4)] == [pal[i % 4] for i in range(16)]
+    # the BC7 payload decodes like the same blocks in a DDS container (test_bc7_decode pins that decoder to Pillow)
+    dds = _scene_with_images(tmp_path, "k7.glb", [_dds(8, 8, bc7_blocks.tobytes(), dxgi=98)], "image/vnd-ms.dds", "MSFT_texture_dds")[0]
+    assert (tex["bc7_zstd"] == dds).all()
+    # refused: BasisLZ supercompression, UASTC (vkFormat 0), cube maps, truncated level -> no effective image -> the 1x1 magenta
+    bad = [_ktx2(4, 4, 0, bytes(16), scheme=1), _ktx2(4, 4, 0, bytes(16)), _ktx2(64, 64, 37, bytes(16)),
+           _ktx2(4, 4, 37, bytes(64))[:60]]
+    cube = bytearray(_ktx2(4, 4, 37, bytes(64)))
+    cube[36:40] = struct.pack("<I", 6)
+    bad.append(bytes(cube))
+    for t in _scene_with_images(tmp_path, "bad.glb", bad, "image/ktx2", "KHR_texture_basisu"):
+        assert t.shape == (1, 1, 4) and tuple(t[0, 0]) == (255, 0, 255, 255)

@@ -1,4 +1,4 @@
-run() { w=$1; shift; timeout 300 python bench.py --workload $w --no-cpu-baseline "$@" > gpurun_out/tmp_bench.json 2> gpurun_out/tmp_bench.err; python - "$w" "$*" <<PY
+run() { tag=$1; w=$2; shift 2; timeout 300 python bench.py --workload $w --no-cpu-baseline "$@" > gpurun_out/tmp_bench.json 2> gpurun_out/tmp_bench.err; python - "$tag $w" "$*" <<PY
 import json,sys
 try:
     d=json.load(open("gpurun_out/tmp_bench.json"))
@@ -7,8 +7,8 @@ except Exception as e:
     print(sys.argv[1], sys.argv[2], "FAILED", e, open("gpurun_out/tmp_bench.err").read()[-500:])
 PY
 }
-run glass --steps 2 --warmup 1 --in-flight 64 --frames-per-step 192
-run glass --steps 2 --warmup 1 --in-flight 128 --frames-per-step 256
-run helmet --steps 6 --warmup 1 --in-flight 64 --frames-per-step 192
-run helmet --steps 6 --warmup 1 --in-flight 96 --frames-per-step 192
-run atrium --steps 2 --warmup 1 --in-flight 64 --frames-per-step 192
+for v in var_P5 var_P6; do
+  unset MI_PT_LIB; if [ -n "$v" ]; then export MI_PT_LIB=$PWD/vk_gltf_renderer_amd/lib/$v/libmi_pt.so; fi
+  run "${v:-product}" helmet --steps 4 --warmup 1
+
+done

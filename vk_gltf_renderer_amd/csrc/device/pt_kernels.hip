@@ -1011,8 +1011,11 @@ PT_DEV DevTri scalarLoadTri(const DevTri* tris, uint32_t index)
   return T;
 }
 
+#ifndef PRIMARY_MIN_WAVES
+#define PRIMARY_MIN_WAVES 4
+#endif
 template <bool HAS_ALPHA, bool COUNT>
-__global__ void __launch_bounds__(256) k_trace_primary(DevScene sc, FrameConsts fc, const DevScene* __restrict__ scp, const FrameConsts* __restrict__ fcp, PathSoA P,
+__global__ void __launch_bounds__(256, PRIMARY_MIN_WAVES) k_trace_primary(DevScene sc, FrameConsts fc, const DevScene* __restrict__ scp, const FrameConsts* __restrict__ fcp, PathSoA P,
                                                         Queues Q, const uint32_t* ownedTiles, int sampleIndex, uint32_t batchSlots, StatCounters* stats)
 {
   // `sc` / `fc` (kernel arguments, SGPRs) serve the inlined generation and walk; the non-inlined environment helpers of the miss

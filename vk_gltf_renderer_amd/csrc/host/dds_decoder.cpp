@@ -5,8 +5,8 @@
 // decoded on the host: BC1, BC2, BC3 (colour endpoints expanded to 8 bits, palette entries (2a+b+1)/3 and (a+b+1)/2),
 // BC4 / BC5 (eight-entry ramps, rounded to nearest) -- the arithmetic of the D3D functional specification, which GPUs
 // implement to within a unit of the last place -- plus the uncompressed 8-bit layouts (RGBA, BGRA, BGRX, RGB, BGR, L, LA,
-// R, RG).  BC6H (HDR), BC7, cube maps and volume textures are not decoded (the loader falls back to the texture's core
-// `source` image or to the reference's 1x1 magenta).  Mip levels stored in the file are ignored: the chain is rebuilt from
+// R, RG), and BC7 (bc7_decoder.cpp).  BC6H (HDR), cube maps and volume textures are not decoded (the loader falls back to the
+// texture's core `source` image or to the reference's 1x1 magenta).  The block decode is shared with the KTX reader (ktx_decoder.cpp).  Mip levels stored in the file are ignored: the chain is rebuilt from
 // level 0 like for every other image (image_loader.cpp buildMipChain).
 #include "image_loader.hpp"
 
@@ -30,6 +30,7 @@ enum class Layout
   BC3,
   BC4,
   BC5,
+  BC7,
   Masks,  // uncompressed, described by bit masks
 };
 
@@ -134,6 +135,66 @@ uint8_t extract(uint32_t v, uint32_t mask)
 
 }  // namespace
 
+// width x height texels of 4x4 blocks in row-major block order -> RGBA8 (blocks beyond the image edge are cropped)
+bool decodeBlocks(BlockFormat format, const uint8_t* s, size_t size, int width, int height, Image& out)
+{
+  const uint32_t bw = uint32_t(width + 3) / 4, bh = uint32_t(height + 3) / 4;
+  const size_t   blockBytes = (format == BlockFormat::BC1 || format == BlockFormat::BC4) ? 8 : 16;
+  if(width <= 0 || height <= 0 || size < size_t(bw) * bh * blockBytes)
+    return false;
+  out.width  = width;
+  out.height = height;
+  out.rgba.assign(size_t(width) * size_t(height) * 4, 255);
+  for(uint32_t by = 0; by < bh; ++by)
+    for(uint32_t bx = 0; bx < bw; ++bx, s += blockBytes)
+    {
+      uint8_t px[16][4];
+      uint8_t ramp[16], ramp2[16];
+      switch(format)
+      {
+        case BlockFormat::BC1:
+          decodeColorBlock(s, px, true);
+          break;
+        case BlockFormat::BC2:
+          decodeColorBlock(s + 8, px, false);
+          for(int i = 0; i < 16; ++i)
+          {
+            const int a = (s[i >> 1] >> (4 * (i & 1))) & 15;
+            px[i][3]    = uint8_t(a * 17);
+          }
+          break;
+        case BlockFormat::BC3:
+          decodeColorBlock(s + 8, px, false);
+          decodeRampBlock(s, ramp);
+          for(int i = 0; i < 16; ++i)
+            px[i][3] = ramp[i];
+          break;
+        case BlockFormat::BC4:
+          decodeRampBlock(s, ramp);
+          for(int i = 0; i < 16; ++i)
+          {
+            px[i][0] = ramp[i]; px[i][1] = 0; px[i][2] = 0; px[i][3] = 255;  // (r, 0, 0, 1) as the texture unit returns it
+          }
+          break;
+        case BlockFormat::BC5:
+          decodeRampBlock(s, ramp);
+          decodeRampBlock(s + 8, ramp2);
+          for(int i = 0; i < 16; ++i)
+          {
+            px[i][0] = ramp[i]; px[i][1] = ramp2[i]; px[i][2] = 0; px[i][3] = 255;
+          }
+          break;
+        default:
+          decodeBc7Block(s, px);
+          break;
+      }
+      for(uint32_t y = 0; y < 4 && by * 4 + y < uint32_t(height); ++y)
+        for(uint32_t x = 0; x < 4 && bx * 4 + x < uint32_t(width); ++x)
+          std::memcpy(out.rgba.data() + (size_t(by * 4 + y) * size_t(width) + bx * 4 + x) * 4, px[y * 4 + x], 4);
+    }
+  return true;
+}
+
 bool isDds(const uint8_t* data, size_t size)
 {
   return size >= 128 && data[0] == 'D' && data[1] == 'D' && data[2] == 'S' && data[3] == ' ';
@@ -186,12 +247,13 @@ bool decodeDds(const uint8_t* data, size_t size, Image& out, std::string* error)
         case 76: case 77: case 78: layout = Layout::BC3; break;
         case 79: case 80: layout = Layout::BC4; break;
         case 82: case 83: layout = Layout::BC5; break;
+        case 97: case 98: case 99: layout = Layout::BC7; break;
         case 27: case 28: case 29: layout = Layout::Masks; bytesPerPixel = 4; rMask = 0xffu; gMask = 0xff00u; bMask = 0xff0000u; aMask = 0xff000000u; break;
         case 87: case 90: case 91: layout = Layout::Masks; bytesPerPixel = 4; bMask = 0xffu; gMask = 0xff00u; rMask = 0xff0000u; aMask = 0xff000000u; break;
         case 88: case 92: case 93: layout = Layout::Masks; bytesPerPixel = 4; bMask = 0xffu; gMask = 0xff00u; rMask = 0xff0000u; aMask = 0; break;
         case 61: layout = Layout::Masks; bytesPerPixel = 1; rMask = 0xffu; gMask = bMask = aMask = 0; break;
         case 49: layout = Layout::Masks; bytesPerPixel = 2; rMask = 0xffu; gMask = 0xff00u; bMask = aMask = 0; break;
-        default: return fail("unsupported DXGI format (BC6H, BC7, float and >8-bit formats are not decoded)");
+        default: return fail("unsupported DXGI format (BC6H, float and >8-bit formats are not decoded)");
       }
     }
     else
@@ -233,55 +295,10 @@ bool decodeDds(const uint8_t* data, size_t size, Image& out, std::string* error)
     }
     return true;
   }
-  const uint32_t bw = (width + 3) / 4, bh = (height + 3) / 4;
-  const size_t   blockBytes = (layout == Layout::BC1 || layout == Layout::BC4) ? 8 : 16;
-  if(size < offset + size_t(bw) * bh * blockBytes)
+  const BlockFormat bf = layout == Layout::BC1 ? BlockFormat::BC1 : layout == Layout::BC2 ? BlockFormat::BC2 : layout == Layout::BC3 ? BlockFormat::BC3
+                         : layout == Layout::BC4 ? BlockFormat::BC4 : layout == Layout::BC5 ? BlockFormat::BC5 : BlockFormat::BC7;
+  if(!decodeBlocks(bf, data + offset, size - offset, int(width), int(height), out))
     return fail("truncated block data");
-  const uint8_t* s = data + offset;
-  for(uint32_t by = 0; by < bh; ++by)
-    for(uint32_t bx = 0; bx < bw; ++bx, s += blockBytes)
-    {
-      uint8_t px[16][4];
-      uint8_t ramp[16], ramp2[16];
-      switch(layout)
-      {
-        case Layout::BC1:
-          decodeColorBlock(s, px, true);
-          break;
-        case Layout::BC2:
-          decodeColorBlock(s + 8, px, false);
-          for(int i = 0; i < 16; ++i)
-          {
-            const int a = (s[i >> 1] >> (4 * (i & 1))) & 15;
-            px[i][3]    = uint8_t(a * 17);
-          }
-          break;
-        case Layout::BC3:
-          decodeColorBlock(s + 8, px, false);
-          decodeRampBlock(s, ramp);
-          for(int i = 0; i < 16; ++i)
-            px[i][3] = ramp[i];
-          break;
-        case Layout::BC4:
-          decodeRampBlock(s, ramp);
-          for(int i = 0; i < 16; ++i)
-          {
-            px[i][0] = ramp[i]; px[i][1] = 0; px[i][2] = 0; px[i][3] = 255;  // (r, 0, 0, 1) as the texture unit returns it
-          }
-          break;
-        default:  // BC5
-          decodeRampBlock(s, ramp);
-          decodeRampBlock(s + 8, ramp2);
-          for(int i = 0; i < 16; ++i)
-          {
-            px[i][0] = ramp[i]; px[i][1] = ramp2[i]; px[i][2] = 0; px[i][3] = 255;
-          }
-          break;
-      }
-      for(uint32_t y = 0; y < 4 && by * 4 + y < height; ++y)
-        for(uint32_t x = 0; x < 4 && bx * 4 + x < width; ++x)
-          std::memcpy(out.rgba.data() + (size_t(by * 4 + y) * width + bx * 4 + x) * 4, px[y * 4 + x], 4);
-    }
   return true;
 }
 

@@ -303,8 +303,10 @@ bool decodeImage(const uint8_t* data, size_t size, Image& out, std::string* erro
     return decodeJpeg(data, size, out, error);
   if(isDds(data, size))
     return decodeDds(data, size, out, error);
+  if(isKtx(data, size))
+    return decodeKtx(data, size, out, error);
   if(error)
-    *error = "unsupported image container (PNG, JPEG and DDS are decoded; KTX2 and WebP are not)";
+    *error = "unsupported image container (PNG, JPEG, DDS, KTX and KTX2 are decoded; WebP is not)";
   return false;
 }
 

@@ -18,6 +18,12 @@ bool    isJpeg(const uint8_t* data, size_t size);
 bool    decodeJpeg(const uint8_t* data, size_t size, Image& out, std::string* error);  // jpeg_decoder.cpp
 bool    isDds(const uint8_t* data, size_t size);
 bool    decodeDds(const uint8_t* data, size_t size, Image& out, std::string* error);  // dds_decoder.cpp
+// 4x4 block formats shared by the DDS and KTX containers (decoded on the host: there is no texture unit on this path)
+enum class BlockFormat { BC1, BC2, BC3, BC4, BC5, BC7 };
+bool    decodeBlocks(BlockFormat format, const uint8_t* blocks, size_t size, int width, int height, Image& out);  // dds_decoder.cpp
+void    decodeBc7Block(const uint8_t* block16, uint8_t out[16][4]);                                             // bc7_decoder.cpp
+bool    isKtx(const uint8_t* data, size_t size);
+bool    decodeKtx(const uint8_t* data, size_t size, Image& out, std::string* error);  // ktx_decoder.cpp (KTX 1 and KTX 2)
 bool    decodeImage(const uint8_t* data, size_t size, Image& out, std::string* error);
 Image   magentaImage();
 float   srgbToLinear(uint8_t v);
