@@ -253,6 +253,18 @@ MI_PT_API void* mi_pt_tonemapped_device_ptr(MiPt* pt);
 /* the reference's defaults: Filmic, active, exposure / brightness / contrast / saturation 1, vignette 0, autoExposure as given */
 MI_PT_API void mi_pt_default_tonemapper(MiTonemapperData* tm, int autoExposure);
 
+/* Device memory held by this instance, in bytes, split the way the reference's benchmark reports it (GltfRenderer::
+ * benchmarkMemorySamples, src/renderer.cpp:530-555): "Scene" = geometry, textures, materials, environment and the acceleration
+ * structure (SceneVk + SceneRtx trackers); "PathTracer" = everything the renderer owns (path state, queues, images). */
+typedef struct MiPtMemory
+{
+  uint64_t sceneBytes;
+  uint64_t rendererBytes;
+  uint64_t deviceUsedBytes;  /* whole device, all processes: total - free as the driver reports it */
+  uint64_t deviceTotalBytes;
+} MiPtMemory;
+MI_PT_API int mi_pt_get_memory(MiPt* pt, MiPtMemory* memory);
+
 MI_PT_API int mi_pt_get_stats(MiPt* pt, MiPtStats* stats);
 MI_PT_API int mi_pt_reset_stats(MiPt* pt);
 MI_PT_API int mi_pt_enable_timing(MiPt* pt, int enable);

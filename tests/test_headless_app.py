@@ -146,3 +146,57 @@ def test_tonemapped_output_and_denoiser_cadence(tmp_path, assets):
     assert "DENOISER passes=3 final_image=denoised" in r.stdout, r.stdout[-600:]
     den = _read_png_rgba8(out)
     assert den.shape == (64, 96, 4) and np.abs(den.astype(int) - png.astype(int)).max() > 0
+
+
+QUICK_CFG = os.path.join(ROOT, "tests", "golden", "quick_sequences.cfg")  # the reference's utils/benchmark/quick.cfg, shortened
+
+
+def test_sequencer_log_parses_with_the_reference_tooling():
+    """tests/golden/sequencer_log_mi355x.txt is the output of `mi_gltf_renderer --benchmark 1 --sequencefile quick_sequences.cfg` on an
+    MI355X (test_scripted_sequencer runs the same command on the GPU box): the reference's own parser must read it."""
+    log = open(os.path.join(ROOT, "tests", "golden", "sequencer_log_mi355x.txt")).read()
+    ref_parser = "/root/reference/utils/benchmark"
+    if not os.path.isdir(ref_parser):
+        pytest.skip("the reference's benchmark scripts are only present in the authoring container")
+    sys.path.insert(0, ref_parser)
+    import benchmark_results
+    parsed = benchmark_results.parse_benchmark(log, "shader_ball")
+    assert [(b["id"], b["name"]) for b in parsed] == [(0, "Warmup"), (1, "PT 1spp"), (2, "Rasterizer")]
+    assert parsed[1]["timers"]["PathTracer::onRender"]["VK"] == pytest.approx(1.331) and parsed[1]["timers"]["PathTracer::onRender"]["CPU"] > 0
+    assert parsed[1]["memory"]["Scene"]["Device Used"] == 28643577 and parsed[1]["memory"]["PathTracer"]["Device Allocated"] == 9172120
+    assert parsed[2]["timers"] == {}
+    assert benchmark_results.primary_timer_ms(parsed[1], "VK", ["GltfRenderer::onRender", "PathTracer::onRender"]) == pytest.approx(1.331)
+
+
+@pytest.mark.gpu
+def test_scripted_sequencer(tmp_path, assets):
+    """`--benchmark 1 --sequencefile quick.cfg` (docs/benchmarking.md "Scripted sequencer"): per sequence a ParameterSequence timer block
+    and the memory snapshot (BENCHMARK_ADV + BENCHMARK_JSON sequence_memory) in the shape utils/benchmark/benchmark_results.py parses."""
+    r = _run(["--benchmark", "1", "--sequencefile", QUICK_CFG, "--size", "160", "120", "--scenefile", os.path.join(assets, "shader_ball.gltf"),
+              "--hdrfile", os.path.join(assets, "std_env.hdr")])
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    # the consumer's own regular expressions (benchmark_results.py parse_benchmark / _parse_legacy_memory_records)
+    seqs = re.split(r'ParameterSequence\s+(\d+)\s+"([^"]+)"\s*=', r.stdout)[1:]
+    assert [(int(seqs[i]), seqs[i + 1]) for i in range(0, len(seqs), 3)] == [(0, "Warmup"), (1, "PT 1spp"), (2, "Rasterizer")]
+    timer = re.compile(r'Timer\s+"([^"]+)"\s*;\s*GPU;\s*avg\s+(\d+);.*?CPU;\s*avg\s+(\d+);')
+    t = [timer.findall(seqs[i + 2].split("BENCHMARK_ADV")[0]) for i in range(0, len(seqs), 3)]
+    assert [x[0][0] for x in t[:2]] == ["PathTracer::onRender"] * 2 and t[2] == []  # no rasterizer on this path: no timers
+    assert all(int(x[0][1]) > 0 and int(x[0][2]) > 0 for x in t[:2])
+    legacy = re.findall(r"Memory (\w+); Host used\s+(\d+); Device Used\s+(\d+); Device Allocated\s+(\d+);", r.stdout)
+    assert [m[0] for m in legacy] == ["Scene", "PathTracer"] * 3 and all(int(m[2]) > 0 for m in legacy[:4])
+    mem = [x for x in _records(r.stdout) if x["type"] == "sequence_memory"]
+    assert [x["id"] for x in mem] == [0, 1, 2] and all(x["schema"] == 1 for x in mem)
+    assert [s["category"] for s in mem[1]["memory"]] == ["Scene", "PathTracer"]
+    assert int(legacy[2][2]) == mem[1]["memory"][0]["device_used"] > 100000  # the shader ball's geometry + BVH
+    ref_parser = "/root/reference/utils/benchmark"
+    if os.path.isdir(ref_parser):  # authoring container only
+        sys.path.insert(0, ref_parser)
+        import benchmark_results
+        parsed = benchmark_results.parse_benchmark(r.stdout, "shader_ball")
+        assert [b["name"] for b in parsed] == ["Warmup", "PT 1spp", "Rasterizer"]
+        assert parsed[1]["timers"]["PathTracer::onRender"]["VK"] > 0 and parsed[1]["memory"]["Scene"]["Device Used"] > 100000
+
+
+def test_sequencer_argument_errors():
+    assert _run(["--benchmark", "1", "--scenefile", "x.glb"]).returncode == 2  # no script
+    assert _run(["--benchmark", "1", "--sequencestring", 'SEQUENCE "a" --sequenceframes 1']).returncode == 2  # no scene

@@ -120,6 +120,10 @@ class MiPtStats(C.Structure):
         "textureTaps", "bvhNodeCount", "bvhTriangleCount", "bvhNodeBytes", "bvhTriangleBytes", "surfaceHits", "nodesPrimary", "trisPrimary")]
 
 
+class MiPtMemory(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("sceneBytes", "rendererBytes", "deviceUsedBytes", "deviceTotalBytes")]
+
+
 class MiPtFrameTiming(C.Structure):
     _fields_ = [("totalMs", f32), ("generateMs", f32), ("traceClosestMs", f32), ("sortMs", f32), ("shadeMs", f32),
                 ("traceShadowMs", f32), ("accumulateMs", f32), ("traceClosestLaunches", i32), ("shadeLaunches", i32),
@@ -189,6 +193,7 @@ PT_SYMBOLS = {
     "mi_pt_tonemap": (i32, [VP, P(MiTonemapperData), i32, f32, P(C.c_uint8), VP]),
     "mi_pt_tonemapped_device_ptr": (VP, [VP]),
     "mi_pt_default_tonemapper": (None, [P(MiTonemapperData), i32]),
+    "mi_pt_get_memory": (i32, [VP, P(MiPtMemory)]),
     "mi_pt_get_stats": (i32, [VP, P(MiPtStats)]),
     "mi_pt_reset_stats": (i32, [VP]),
     "mi_pt_enable_timing": (i32, [VP, i32]),

@@ -152,3 +152,37 @@ void BenchmarkController::finishHeadlessTiming()
   m_running  = false;
   m_warmedUp = false;
 }
+
+
+// ---- scripted sequencer ------------------------------------------------------------------------------------------------------
+// `ParameterSequence N "name" = { Timer "stage"; GPU; avg a; min b; max c; last d; CPU; avg a; ... }`, times in whole
+// microseconds: the shape utils/benchmark/benchmark_results.py parse_benchmark() reads (its regular expressions are the contract).
+void BenchmarkController::emitParameterSequence(const std::string& name, const std::vector<TimerStat>& timers)
+{
+  printf("ParameterSequence %u \"%s\" = {\n", m_sequenceId, name.c_str());
+  for(const TimerStat& t : timers)
+    printf(" Timer \"%s\"; GPU; avg %lld; min %lld; max %lld; last %lld; CPU; avg %lld; min %lld; max %lld; last %lld;\n", t.name.c_str(),
+           (long long)std::llround(t.gpuAvg), (long long)std::llround(t.gpuMin), (long long)std::llround(t.gpuMax), (long long)std::llround(t.gpuLast),
+           (long long)std::llround(t.cpuAvg), (long long)std::llround(t.cpuMin), (long long)std::llround(t.cpuMax), (long long)std::llround(t.cpuLast));
+  printf("}\n");
+  fflush(stdout);
+}
+
+void BenchmarkController::emitSequenceMemory(const std::vector<MemorySample>& samples)
+{
+  printf("BENCHMARK_ADV %u {\n", m_sequenceId);
+  for(const MemorySample& m : samples)
+    printf(" Memory %s; Host used \t%llu; Device Used \t%llu; Device Allocated \t%llu; (bytes)\n", m.category.c_str(), (unsigned long long)m.hostUsed,
+           (unsigned long long)m.deviceUsed, (unsigned long long)m.deviceAllocated);
+  printf("}\n");
+  std::string list = "[";
+  for(size_t i = 0; i < samples.size(); ++i)
+  {
+    const MemorySample& m = samples[i];
+    list += std::string(i ? "," : "") + "{\"category\":\"" + m.category + "\",\"device_allocated\":" + std::to_string(m.deviceAllocated)
+            + ",\"device_used\":" + std::to_string(m.deviceUsed) + ",\"host_used\":" + std::to_string(m.hostUsed) + "}";
+  }
+  list += "]";
+  emitRecord("sequence_memory", {whole("id", (long long)m_sequenceId), Field{"memory", "", list}});
+  ++m_sequenceId;
+}

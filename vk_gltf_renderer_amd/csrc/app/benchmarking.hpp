@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cstdint>
 #include <string>
+#include <vector>
 
 #include "renderer_base.hpp"
 
@@ -33,6 +34,23 @@ public:
   void logHeadlessSummary(const HeadlessFrameInfo& info);
   void finishHeadlessTiming();
 
+  // Scripted-sequencer telemetry (docs/benchmarking.md "Log parsing"; consumer: utils/benchmark/benchmark_results.py parse_benchmark):
+  // the timer block of one sequence -- what the reference's ProfilerManager logs after each SEQUENCE -- and its memory snapshot
+  // (legacy BENCHMARK_ADV block + BENCHMARK_JSON sequence_memory record; ids count up so the two can be joined).
+  struct TimerStat  // microseconds
+  {
+    std::string name;
+    double      gpuAvg{0}, gpuMin{0}, gpuMax{0}, gpuLast{0}, cpuAvg{0}, cpuMin{0}, cpuMax{0}, cpuLast{0};
+  };
+  struct MemorySample  // reference: src/benchmarking.hpp MemorySample
+  {
+    std::string category;
+    uint64_t    hostUsed{0}, deviceUsed{0}, deviceAllocated{0};
+  };
+  void     emitParameterSequence(const std::string& name, const std::vector<TimerStat>& timers);
+  void     emitSequenceMemory(const std::vector<MemorySample>& samples);
+  uint32_t sequenceId() const { return m_sequenceId; }
+
 private:
   // docs/benchmarking.md:27 ("every 50 frames or 5 seconds") and :40 ("the first completed frame is excluded")
   static constexpr uint32_t kLogEveryFrames = 50;
@@ -47,4 +65,5 @@ private:
   Clock::time_point m_loopStart{}, m_warmupEnd{};
   uint32_t          m_framesDone{0}, m_warmupCount{0};
   double            m_lastLogMs{0.0};
+  uint32_t          m_sequenceId{0};
 };

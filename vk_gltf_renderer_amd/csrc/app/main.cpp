@@ -15,15 +15,18 @@ int main(int argc, char** argv)
   ParameterRegistry registry;
   std::string       sceneFile, hdrFile = "std_env.hdr", outputFile;
   int               size[2] = {1280, 720};
-  int               frames = 1, renderSystem = 0;
-  bool              headless = false, vvl = false, selftest = false;
+  std::string       sequenceFile, sequenceString;
+  int               frames = 1;
+  bool              headless = false, vvl = false, selftest = false, benchmark = false;
   registry.add("scenefile", "Input scene filename (.gltf / .glb)", &sceneFile);
   registry.add("hdrfile", "Input HDR filename", &hdrFile);
   registry.add("output", "Headless output image (.png or .hdr)", &outputFile);
   registry.addVec2("size", "Render size: width height", size);
   registry.add("frames", "Number of frames to render in headless mode", &frames);
   registry.add("headless", "Run without a window", &headless, true);
-  registry.add("renderSystem", "Renderer [Pathtracer:0]; only 0 exists here", &renderSystem);
+  registry.add("benchmark", "Benchmark mode: run the scripted sequences of --sequencefile / --sequencestring", &benchmark);
+  registry.add("sequencefile", "Benchmark script (.cfg) with SEQUENCE blocks", &sequenceFile);
+  registry.add("sequencestring", "Benchmark script given on the command line", &sequenceString);
   registry.add("vvl", "accepted and ignored (Vulkan validation layers)", &vvl, true);
   registry.add("benchmarkSelftest", "Print a fabricated headless log (format check, no GPU needed)", &selftest, true);
   app.registerParameters(&registry);
@@ -54,9 +57,38 @@ int main(int argc, char** argv)
     app.benchmark().logHeadlessSummary(info);
     return 0;
   }
-  if(!headless || renderSystem != 0)
+  if(benchmark)
   {
-    fprintf(stderr, "only `--headless --renderSystem 0` (path tracer) is implemented\n");
+    // scripted sequencer (reference: src/main.cpp:138-160; "Benchmark mode requires --sequencefile or --sequencestring")
+    std::string script = sequenceString;
+    if(!sequenceFile.empty())
+    {
+      FILE* f = fopen(sequenceFile.c_str(), "rb");
+      if(!f)
+      {
+        fprintf(stderr, "cannot read %s\n", sequenceFile.c_str());
+        return 2;
+      }
+      char   buf[4096];
+      size_t n;
+      while((n = fread(buf, 1, sizeof(buf), f)) > 0)
+        script.append(buf, n);
+      fclose(f);
+    }
+    if(script.empty() || sceneFile.empty())
+    {
+      fprintf(stderr, "Benchmark mode requires --scenefile and --sequencefile or --sequencestring\n");
+      return 2;
+    }
+    app.onAttach(Extent2D{uint32_t(size[0]), uint32_t(size[1])});
+    if(!app.createScene(sceneFile))
+      return 1;
+    app.createHDR(hdrFile);
+    return app.runSequences(script, &registry);
+  }
+  if(!headless || app.renderSystemIndex() != 0)
+  {
+    fprintf(stderr, "only `--headless --renderSystem 0` (path tracer) and `--benchmark 1` (scripted sequences) are implemented\n");
     return 2;
   }
   if(sceneFile.empty())

@@ -48,12 +48,14 @@ public:
     m_params[name] = {help, arity, std::move(f)};
   }
   // Parses argv; positional arguments are returned.
-  std::vector<std::string> parse(int argc, char** argv)
+  std::vector<std::string> parse(int argc, char** argv) { return parseTokens(std::vector<std::string>(argv + (argc > 0 ? 1 : 0), argv + argc)); }
+  // The same for a token list (a SEQUENCE block of a benchmark script).
+  std::vector<std::string> parseTokens(const std::vector<std::string>& tokens)
   {
     std::vector<std::string> positional;
-    for(int i = 1; i < argc; ++i)
+    for(size_t i = 0; i < tokens.size(); ++i)
     {
-      std::string a = argv[i];
+      const std::string& a = tokens[i];
       if(a.rfind("--", 0) != 0)
       {
         positional.push_back(a);
@@ -65,9 +67,9 @@ public:
       std::vector<std::string> args;
       for(int k = 0; k < it->second.arity; ++k)
       {
-        if(i + 1 >= argc)
+        if(i + 1 >= tokens.size())
           throw std::runtime_error("option " + a + " needs " + std::to_string(it->second.arity) + " value(s)");
-        args.push_back(argv[++i]);
+        args.push_back(tokens[++i]);
       }
       it->second.set(args);
     }

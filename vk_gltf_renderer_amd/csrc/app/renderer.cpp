@@ -3,7 +3,10 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
+#include <stdexcept>
 #include <cstdio>
 #include <cstring>
 
@@ -44,7 +47,123 @@ void GltfRenderer::registerParameters(ParameterRegistry* r)
   r->add("tmSaturation", "Tonemapper saturation", &tm.saturation);
   r->add("tmWhitePoint", "Tonemapper vignette", &tm.vignette);
   r->add("tmAutoExposure", "Tonemapper auto exposure [0, 1]", &tm.autoExposure);
+  // what the benchmark scripts set per sequence (utils/benchmark/*.cfg)
+  r->add("renderSystem", "Renderer [Pathtracer:0, Rasterizer:1]; only the path tracer exists on this path", &m_seqRenderSystem);
+  r->add("sequenceframes", "Sequencer: frames to run this step", &m_seqFrames);
+  r->add("sequenceaverages", "Sequencer: frames averaged for the timer report", &m_seqAverages);
+  r->add("sequenceresetframes", "Sequencer: warm-up frames after the parameter changes", &m_seqResetFrames);
+  r->addCallback("gltfCamera", "Select the scene camera", 1, [this](const std::vector<std::string>& a) { m_gltfCamera = std::atoi(a[0].c_str()); selectCamera(m_gltfCamera); });
+  r->addCallback("resetFrame", "Restart the accumulation", 0, [this](const std::vector<std::string>&) { resetFrame(); });
+  r->addCallback("updateData", "Re-upload scene data (here: restart the accumulation)", 0, [this](const std::vector<std::string>&) { resetFrame(); });
+  r->addCallback("fitScene", "Frame the scene (accepted; the scene camera is kept)", 0, [](const std::vector<std::string>&) {});
   m_pathTracer.registerParameters(r);
+}
+
+bool GltfRenderer::selectCamera(int index)
+{
+  if(!m_resources.scene || mi_scene_camera(m_resources.scene, index, &m_resources.camera) != MI_PT_OK)
+    return false;
+  resetFrame();
+  return true;
+}
+
+int GltfRenderer::runSequences(const std::string& script, ParameterRegistry* registry)
+{
+  // tokens: whitespace separated, "quoted strings" kept whole, '#' starts a comment
+  struct Sequence
+  {
+    std::string              name;
+    std::vector<std::string> tokens;
+  };
+  std::vector<Sequence> sequences;
+  {
+    std::vector<std::string> tok;
+    std::string              cur;
+    bool                     quoted = false, comment = false, have = false;
+    auto flush = [&] { if(have) tok.push_back(cur); cur.clear(); have = false; };
+    for(char ch : script)
+    {
+      if(comment) { if(ch == '\n') comment = false; continue; }
+      if(quoted) { if(ch == '"') quoted = false; else cur += ch; continue; }
+      if(ch == '"') { quoted = true; have = true; continue; }
+      if(ch == '#' && !have) { comment = true; continue; }
+      if(ch == ' ' || ch == '\t' || ch == '\n' || ch == '\r') { flush(); continue; }
+      cur += ch; have = true;
+    }
+    flush();
+    for(size_t i = 0; i < tok.size(); ++i)
+    {
+      if(tok[i] == "SEQUENCE" && i + 1 < tok.size())
+        sequences.push_back({tok[++i], {}});
+      else if(!sequences.empty())
+        sequences.back().tokens.push_back(tok[i]);
+    }
+  }
+  if(sequences.empty())
+  {
+    fprintf(stderr, "benchmark script holds no SEQUENCE block\n");
+    return 2;
+  }
+  for(const Sequence& sq : sequences)
+  {
+    m_seqFrames = 256; m_seqAverages = 64; m_seqResetFrames = 0;
+    try
+    {
+      registry->parseTokens(sq.tokens);
+    }
+    catch(const std::exception& e)
+    {
+      fprintf(stderr, "SEQUENCE \"%s\": %s\n", sq.name.c_str(), e.what());
+      return 2;
+    }
+    m_resources.settings.envSystem = m_envSystem == 1 ? EnvSystem::eHdr : EnvSystem::eSky;
+    std::vector<BenchmarkController::TimerStat> timers;
+    m_resources.settings.renderSystem = m_seqRenderSystem == 0 ? RenderingMode::ePathtracer : RenderingMode::eRasterizer;
+    if(m_resources.settings.renderSystem != RenderingMode::ePathtracer)
+      printf("SEQUENCE \"%s\": only the path tracer exists on this path, no timers\n", sq.name.c_str());
+    else
+    {
+      std::vector<double> gpu, cpu;
+      const int total = std::max(m_seqResetFrames, 0) + std::max(m_seqFrames, 1);
+      for(int f = 0; f < total; ++f)
+      {
+        // a converged accumulation (frameCount == maxFrames) renders nothing: restart it, the sequence measures frames
+        if(m_resources.frameCount + 1 >= m_resources.settings.maxFrames)
+          resetFrame();
+        mi_pt_enable_timing(m_pathTracer.handle(), 1);
+        const auto t0 = std::chrono::steady_clock::now();
+        onRender(nullptr, false, 0);
+        const double    cpuUs = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        MiPtFrameTiming t{};
+        mi_pt_get_frame_timing(m_pathTracer.handle(), &t);  // synchronises
+        if(f >= std::max(m_seqResetFrames, 0))
+        {
+          gpu.push_back(double(t.totalMs) * 1000.0);
+          cpu.push_back(cpuUs);
+        }
+      }
+      mi_pt_enable_timing(m_pathTracer.handle(), 0);
+      const size_t n = std::min(gpu.size(), size_t(std::max(m_seqAverages, 1)));
+      BenchmarkController::TimerStat st;
+      st.name = "PathTracer::onRender";  // the stage the benchmark scripts look for first (benchmark_results.py:274)
+      st.gpuMin = st.cpuMin = 1e30;
+      for(size_t i = gpu.size() - n; i < gpu.size(); ++i)
+      {
+        st.gpuAvg += gpu[i] / double(n); st.gpuMin = std::min(st.gpuMin, gpu[i]); st.gpuMax = std::max(st.gpuMax, gpu[i]);
+        st.cpuAvg += cpu[i] / double(n); st.cpuMin = std::min(st.cpuMin, cpu[i]); st.cpuMax = std::max(st.cpuMax, cpu[i]);
+      }
+      st.gpuLast = gpu.back();
+      st.cpuLast = cpu.back();
+      timers.push_back(st);
+    }
+    m_benchmark.emitParameterSequence(sq.name, timers);
+    // GltfRenderer::benchmarkMemorySamples (reference: src/renderer.cpp:530-555)
+    MiPtMemory mem{};
+    if(m_pathTracer.handle())
+      mi_pt_get_memory(m_pathTracer.handle(), &mem);
+    m_benchmark.emitSequenceMemory({{"Scene", 0, mem.sceneBytes, mem.sceneBytes}, {"PathTracer", 0, mem.rendererBytes, mem.rendererBytes}});
+  }
+  return 0;
 }
 
 bool GltfRenderer::createScene(const std::string& sceneFile)

@@ -21,6 +21,13 @@ public:
   void onRender(StreamHandle cmd, bool headless, uint32_t headlessFrames);  // reference: src/renderer.cpp:588-742
   void onLastHeadlessFrame(uint32_t headlessFrames);                        // reference: src/renderer.cpp:762-767
   void resetFrame() { m_resources.frameCount = -1; }                        // reference: :1939-1942
+  // Scripted benchmark sequences (reference: nvutils::ParameterSequencer driven from src/main.cpp:85-160 with --benchmark 1
+  // --sequencefile / --sequencestring; docs/benchmarking.md "Scripted sequencer"): every `SEQUENCE "name"` block sets parameters
+  // through the registry, renders --sequenceresetframes warm-up frames and --sequenceframes measured ones, and logs the timer
+  // block (averaged over the last --sequenceaverages frames) and the memory snapshot the benchmark scripts parse.
+  int  runSequences(const std::string& script, ParameterRegistry* registry);
+  bool selectCamera(int index);  // --gltfCamera
+  int  renderSystemIndex() const { return m_seqRenderSystem; }
   Resources&   resources() { return m_resources; }
   PathTracer&  pathTracer() { return m_pathTracer; }
   BenchmarkController& benchmark() { return m_benchmark; }
@@ -41,4 +48,7 @@ private:
   MiCamera            m_refCamera{};
   bool                m_haveRefCamera{false};
   int                 m_envSystem{0};
+  // sequencer state (set through the registry by the script)
+  int                 m_seqFrames{256}, m_seqAverages{64}, m_seqResetFrames{0}, m_seqRenderSystem{0}, m_gltfCamera{0};
+  bool                m_seqFlag{false};
 };

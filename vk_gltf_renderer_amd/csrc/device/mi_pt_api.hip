@@ -1184,6 +1184,30 @@ void* mi_pt_tonemapped_device_ptr(MiPt* pt)
   return pt ? pt->tonemapped.ptr : nullptr;
 }
 
+int mi_pt_get_memory(MiPt* pt, MiPtMemory* out)
+{
+  if(!pt || !out)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_get_memory: null argument");
+  HIP_TRY(hipSetDevice(pt->device));
+  auto bytes = [](const auto& b) { return uint64_t(b.count) * sizeof(*b.ptr); };
+  const pt::DevScene& sc = pt->scene;
+  uint64_t scene = bytes(pt->materials) + bytes(pt->texInfos) + bytes(pt->nodes) + bytes(pt->prims) + bytes(pt->lights) + bytes(pt->textures) + bytes(pt->texels)
+                   + bytes(pt->geometry) + bytes(pt->instFlags) + bytes(pt->srgbLut) + bytes(pt->envPixels) + bytes(pt->envAccel) + bytes(pt->alphaTris)
+                   + bytes(pt->shadeTris) + bytes(pt->texRefs);
+  // the acceleration structure is raw allocations: 64-B BVH2 nodes or 80-B BVH8 nodes + 48-B triangle records
+  scene += uint64_t(pt->staticStats.bvhNodeCount) * pt->staticStats.bvhNodeBytes + uint64_t(sc.numTris) * sizeof(pt::DevTri);
+  const uint64_t renderer = bytes(pt->pathArrays) + bytes(pt->queueMem) + bytes(pt->queuePayload) + bytes(pt->candPool) + bytes(pt->candLists) + bytes(pt->accumOwn)
+                            + bytes(pt->albedo) + bytes(pt->normal) + bytes(pt->denoiseA) + bytes(pt->denoiseB) + bytes(pt->tonemapped) + bytes(pt->depth)
+                            + bytes(pt->selection) + bytes(pt->ownedTiles) + bytes(pt->sceneDev) + bytes(pt->fcRing) + bytes(pt->stats);
+  size_t freeB = 0, totalB = 0;
+  HIP_TRY(hipMemGetInfo(&freeB, &totalB));
+  out->sceneBytes       = scene;
+  out->rendererBytes    = renderer;
+  out->deviceUsedBytes  = uint64_t(totalB - freeB);
+  out->deviceTotalBytes = uint64_t(totalB);
+  return MI_PT_OK;
+}
+
 int mi_pt_get_stats(MiPt* pt, MiPtStats* out)
 {
   if(!pt || !out)
