@@ -18,6 +18,8 @@ Rank 0 prints ONE JSON line.  Besides the driver's fields it carries
   roofline      the dominant kernel against the roof that bounds it ("hbm": algorithmic bytes per launch over the launch time vs
                 8 TB/s; "valu": useful vector-lane operations per launch over the launch time vs 78.6 Tlaneop/s), and under
                 "kernels" the same for every kernel of the step (DESIGN.md §4 states the byte / operation model);
+  also          the Sponza-class atrium workload (configs[2], the one the north-star target is stated on) measured right after the default
+                helmet workload on the same GPU: value, per-kernel table, counters;
   cpu_baseline  the CPU oracle timed on the host cores on a bounded sample of the same frames;
   parity        the GPU accumulator against the oracle's on exactly those sample tiles (same frames, same seeds).
 """
@@ -122,6 +124,68 @@ def kernel_table(all_b, first_b, timing, frames):
     return rows
 
 
+def secondary_line(name, args, device):
+    """Throughput + per-kernel roofline table of another workload on this GPU (same step definition, 64 frames x 2 steps timed)."""
+    import torch
+    from vk_gltf_renderer_amd import _capi as capi
+    from vk_gltf_renderer_amd import pathtracer as ptmod
+    w = WORKLOADS[name]
+    W, H = w["width"], w["height"]
+    scene = ptmod.Scene(scene_path(name, 0))
+    hdr = ptmod.HdrEnvironment(path=os.path.join(ROOT, "assets", "std_env.hdr")) if w["hdr"] else None
+    frame_info, pixel_angle, focal = ptmod.camera_frame_info(scene.camera(0), W, H)
+    if hdr is not None:
+        frame_info.flags |= capi.MI_SCENE_USE_HDR_ENVIRONMENT
+
+    def params(depth):
+        p = ptmod.default_params()
+        p.maxDepth, p.numSamples, p.pixelAngle, p.focalDistance = depth, 1, pixel_angle, focal
+        return p
+
+    def tracer(counters):
+        t = ptmod.PathTracer(scene, device=device, collect_counters=counters, bvh=args.bvh)
+        if hdr is not None:
+            t.set_environment(hdr)
+        t.resize(W, H)
+        t.set_frame_info(frame_info)
+        t.set_sky(ptmod.default_sky())
+        return t
+
+    F = w.get("in_flight", 32)
+    frames_step, steps = 2 * F, 2
+    t = tracer(False)
+    r = ptmod.HeadlessRenderer(t, params(w["depth"]))
+    r.render(F, in_flight=F)  # warm-up
+    t.synchronize()
+    r.reset_frame()
+    t.enable_timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r.render(frames_step, in_flight=F)
+    t.synchronize()
+    elapsed = time.perf_counter() - t0
+    timing = t.frame_timing()
+    t.close()
+
+    def counter_pass(depth):
+        c = tracer(True)
+        ptmod.HeadlessRenderer(c, params(depth)).render(4)
+        st = c.stats()
+        c.close()
+        return {k: (v if k.startswith("bvh") else v / 4) for k, v in st.items()}
+
+    per_frame, first = counter_pass(w["depth"]), counter_pass(1)
+    frames = steps * frames_step
+    kernels = kernel_table(per_frame, first, timing, frames)
+    dominant = max(kernels, key=lambda k: kernels[k]["avg_launch_ms"] * kernels[k]["launches"])
+    keys = ("cameraPaths", "segments", "surfaceHits", "shadowRays", "nodesPrimary", "trisPrimary", "nodesClosest", "trisClosest", "nodesShadow", "trisShadow", "textureTaps")
+    return {"value": round(float(W) * H * frames / elapsed / 1e6, 3), "unit": "Msamples/s", "ms_per_frame": round(elapsed / frames * 1e3, 5),
+            "config": {"workload": w["config"] + " (seeded synthetic stand-in)", "scene_triangles": scene.num_triangles, "resolution": [W, H],
+                       "frames_in_flight": F, "max_depth": w["depth"], "frames_timed": frames}, "timed_region_s": round(elapsed, 3),
+            "roofline": dict(kernels[dominant], kernel=dominant), "kernels": kernels, "per_frame": {k: round(per_frame[k], 1) for k in keys}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,6 +200,10 @@ def main():
                          "helmet workload to 4 %% (64: 19 %%, tools/check_rank_of_8.py)")
     ap.add_argument("--bvh", type=int, default=0, help="bit0: 0 = 8-wide compressed BVH (default), 1 = plain BVH2; bit1: 0 = PLOC topology (default), 1 = LBVH")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--also", default=None,
+                    help="a second workload measured after the main one on a single GPU (a shorter timed region, no CPU leg) and reported "
+                         "under \"also\": by default the Sponza-class atrium next to the helmet, because that is the workload the north-star "
+                         "target is stated on; `--also none` switches it off")
     ap.add_argument("--denoise", action="store_true",
                     help="configs[4]'s denoise pass: the guide layers are captured with every frame and one variance-guided a-trous pass (mi_pt_denoise_svgf, "
                          "5 iterations) closes every step inside the timed region -- on rank 0, after the reduce, when N > 1")
@@ -379,6 +447,9 @@ def main():
             result["parity"] = {"rel_l2": float(f"{m['rel_l2']:.3e}"), "frac_within_1e-2": round(m["frac_within_1e-2"], 5), "frac_within_1e-4": round(m["frac_within_1e-4"], 5),
                                 "frac_exact": round(m["frac_exact"], 5), "tiles": len(owned), "pixels": int(mask.sum()), "frames": frames_done,
                                 "resolution": [W, H], "reference": "CPU oracle (oracle/oracle_pt.cpp), same scene bytes, seeds and frame indices"}
+        also = args.also if args.also is not None else ("atrium" if args.workload == "helmet" and not (args.width or args.height) else "none")
+        if also != "none" and world == 1:
+            result["also"] = {also: secondary_line(also, args, local_rank)}
         print(json.dumps(result), flush=True)
     tracer.close()
     if dist is not None:
