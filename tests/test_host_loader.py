@@ -522,3 +522,25 @@ def test_ktx_decode(built, tmp_path):
     bad.append(bytes(cube))
     for t in _scene_with_images(tmp_path, "bad.glb", bad, "image/ktx2", "KHR_texture_basisu"):
         assert t.shape == (1, 1, 4) and tuple(t[0, 0]) == (255, 0, 255, 255)
+
+
+def test_webp_decode(built, tmp_path):
+    """EXT_texture_webp through libwebp, as the reference does it (webPLoadCallback, src/renderer.cpp:106-131): lossless WebP round
+    trips exactly, lossy WebP decodes to what Pillow (the same libwebp) decodes."""
+    PIL_Image = pytest.importorskip("PIL.Image")
+    import io
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (9, 14, 4), dtype=np.uint8)
+    yy, xx = np.mgrid[0:40, 0:56]
+    smooth = np.stack([127 + 100 * np.sin(xx / 6.0), 127 + 100 * np.cos(yy / 5.0), (xx * 4 + yy * 2) % 256], -1).astype(np.uint8)
+    blobs, refs = [], []
+    for arr, kw in ((img, dict(lossless=True)), (smooth, dict(quality=80))):
+        buf = io.BytesIO()
+        PIL_Image.fromarray(arr, "RGBA" if arr.shape[2] == 4 else "RGB").save(buf, "WEBP", **kw)
+        blobs.append(buf.getvalue())
+        refs.append(np.asarray(PIL_Image.open(io.BytesIO(buf.getvalue())).convert("RGBA")))
+    got = _scene_with_images(tmp_path, "w.glb", blobs, "image/webp", "EXT_texture_webp")
+    assert (refs[0] == img).all() and (got[0] == img).all()
+    assert got[1].shape == refs[1].shape and (got[1] == refs[1]).all()
+    bad = _scene_with_images(tmp_path, "wbad.glb", [b"RIFF\x10\x00\x00\x00WEBPVP8 " + bytes(8)], "image/webp", "EXT_texture_webp")[0]
+    assert bad.shape == (1, 1, 4) and tuple(bad[0, 0]) == (255, 0, 255, 255)

@@ -1170,6 +1170,7 @@ __global__ void __launch_bounds__(256, PRIMARY_MIN_WAVES) k_trace_primary(DevSce
     if(hasFlag(fc.pc.flags, MI_PT_FIRST_FRAME) && slot < uint32_t(fc.numSlots))  // NDC depth input of a first frame (k_finish_sample)
       P.firstHit[slot] = make_float4(cp.direction.x, cp.direction.y, cp.direction.z, 0.0f);
     f3 radiance = mk3(0.0f);
+#ifndef MI_PT_DIAG_NO_MISS  // cost-attribution build (tools/attribution.sh): wrong image, escaped camera paths stay black
     if(!primaryMissBackplate(scd, fcd, cp.direction, radiance))
     {
       f3    envColor;
@@ -1177,6 +1178,7 @@ __global__ void __launch_bounds__(256, PRIMARY_MIN_WAVES) k_trace_primary(DevSce
       missEnvironment(scd, fcd, cp.direction, DIRAC, envColor, mis);
       radiance += mk3(1.0f) * mis * envColor;
     }
+#endif
     P.radiance[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);                          // maxRoughness.x = 0
     P.misc[slot]     = make_float4(0.0f, __uint_as_float(PF_NOT_SOLID), __uint_as_float(cp.seed), 0.0f);  // depth 0, not alive, cone.width 0
   }

@@ -305,8 +305,10 @@ bool decodeImage(const uint8_t* data, size_t size, Image& out, std::string* erro
     return decodeDds(data, size, out, error);
   if(isKtx(data, size))
     return decodeKtx(data, size, out, error);
+  if(isWebp(data, size))
+    return decodeWebp(data, size, out, error);
   if(error)
-    *error = "unsupported image container (PNG, JPEG, DDS, KTX and KTX2 are decoded; WebP is not)";
+    *error = "unsupported image container (PNG, JPEG, DDS, KTX, KTX2 and WebP are decoded)";
   return false;
 }
 

@@ -24,6 +24,8 @@ bool    decodeBlocks(BlockFormat format, const uint8_t* blocks, size_t size, int
 void    decodeBc7Block(const uint8_t* block16, uint8_t out[16][4]);                                             // bc7_decoder.cpp
 bool    isKtx(const uint8_t* data, size_t size);
 bool    decodeKtx(const uint8_t* data, size_t size, Image& out, std::string* error);  // ktx_decoder.cpp (KTX 1 and KTX 2)
+bool    isWebp(const uint8_t* data, size_t size);
+bool    decodeWebp(const uint8_t* data, size_t size, Image& out, std::string* error);  // ktx_decoder.cpp (through libwebp, like the reference)
 bool    decodeImage(const uint8_t* data, size_t size, Image& out, std::string* error);
 Image   magentaImage();
 float   srgbToLinear(uint8_t v);

@@ -1,4 +1,4 @@
-// KTX 1 / KTX 2 containers (KHR_texture_basisu images and plain .ktx2 textures) -> RGBA8 of the top mip level.
+// KTX 1 / KTX 2 containers (KHR_texture_basisu images and plain .ktx2 textures) -> RGBA8 of the top mip level; WebP at the end.
 //
 // The reference reads both through nv_ktx (src/gltf_image_loader.cpp:123-160; external library) and uploads the payload in its
 // VkFormat for the texture unit to filter.  There is no texture unit on this path, so level 0 is decoded on the host:
@@ -212,6 +212,39 @@ bool decodeKtx(const uint8_t* data, size_t size, Image& out, std::string* error)
   const size_t rowStride = L.block ? 0 : ((size_t(width) * size_t(L.channels) + 3) & ~size_t(3));
   if(!decodeLevel(L, data + at + 4, imageSize, int(width), int(height), rowStride, out))
     return fail("truncated level data");
+  return true;
+}
+
+// ---- WebP (EXT_texture_webp) -----------------------------------------------------------------------------------------------
+// The reference decodes WebP with libwebp (webPLoadCallback, src/renderer.cpp:106-131: WebPGetInfo + WebPDecodeRGBAInto); so does
+// this front end, through the run-time library (libwebp.so.7; no header in this image, the two entry points are its stable ABI).
+bool isWebp(const uint8_t* data, size_t size)
+{
+  return size >= 12 && memcmp(data, "RIFF", 4) == 0 && memcmp(data + 8, "WEBP", 4) == 0;
+}
+
+bool decodeWebp(const uint8_t* data, size_t size, Image& out, std::string* error)
+{
+  typedef int (*GetInfoFn)(const uint8_t*, size_t, int*, int*);
+  typedef uint8_t* (*DecodeIntoFn)(const uint8_t*, size_t, uint8_t*, size_t, int);
+  static void*        lib        = [] { void* h = dlopen("libwebp.so.7", RTLD_NOW | RTLD_LOCAL); return h ? h : dlopen("libwebp.so", RTLD_NOW | RTLD_LOCAL); }();
+  static GetInfoFn    getInfo    = lib ? reinterpret_cast<GetInfoFn>(dlsym(lib, "WebPGetInfo")) : nullptr;
+  static DecodeIntoFn decodeInto = lib ? reinterpret_cast<DecodeIntoFn>(dlsym(lib, "WebPDecodeRGBAInto")) : nullptr;
+  auto fail = [&](const char* msg) {
+    if(error)
+      *error = std::string("WebP: ") + msg;
+    return false;
+  };
+  if(!getInfo || !decodeInto)
+    return fail("libwebp could not be loaded");
+  int w = 0, h = 0;
+  if(!getInfo(data, size, &w, &h) || w <= 0 || h <= 0 || w > 32768 || h > 32768)
+    return fail("bad header");
+  out.width  = w;
+  out.height = h;
+  out.rgba.assign(size_t(w) * size_t(h) * 4, 0);
+  if(!decodeInto(data, size, out.rgba.data(), out.rgba.size(), w * 4))
+    return fail("corrupt image data");
   return true;
 }
 
