@@ -184,6 +184,31 @@ def test_transmissive_shadow_paths_agree_bit_for_bit(built, tmp_path):
         assert np.array_equal(np.load(out), ref["accum"]), pool
 
 
+def test_texture_footprint_layout_is_bit_identical(built, tmp_path):
+    """Bilinear taps read their 2x2 footprint as one 16-byte record (DevScene::texQuads, neighbours resolved under the sampler's wrap
+    modes at upload) instead of four texels: same texels, same arithmetic -> the same image bit for bit as the four-gather path
+    (MI_PT_DIAG_NO_QUADS=1), on the textured helmet-class scene (REPEAT, trilinear) and on the texture-transform zoo scene, whose
+    samplers are CLAMP_TO_EDGE / MIRRORED_REPEAT with transformed uvs that leave [0, 1]."""
+    import subprocess
+    import sys
+    hdr = os.path.join(os.path.dirname(os.path.dirname(__file__)), "assets", "std_env.hdr")
+    scenes = [scenegen.scene_helmet_class(str(tmp_path / "helmet.glb"), seed=7, tess=48, tex_size=128),
+              scenegen.scene_material_zoo(str(tmp_path / "zoo.glb"), "texture_transform", tess=24),
+              scenegen.scene_atrium_class(str(tmp_path / "atrium.glb"), seed=5, detail=0.2, tex_size=64)]  # alpha-tested foliage: the walks' alpha test
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import parity_util as pu; s = pu.Setup(sys.argv[1], 160, 96, max_depth=4, hdr_path=%r); "
+            "g = pu.render_gpu(s, 3); np.save(sys.argv[2], g['accum']); print(g['stats']['textureTaps'])") % (
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), hdr)
+    for k, path in enumerate(scenes):
+        s = pu.Setup(path, 160, 96, max_depth=4, hdr_path=hdr)
+        ref = pu.render_gpu(s, 3)
+        assert ref["stats"]["textureTaps"] > 10000
+        out = str(tmp_path / f"noquads{k}.npy")
+        r = subprocess.run([sys.executable, "-c", code, path, out], env=dict(os.environ, MI_PT_DIAG_NO_QUADS="1"), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert int(r.stdout.strip().splitlines()[-1]) == ref["stats"]["textureTaps"]
+        assert np.array_equal(np.load(out), ref["accum"]), path
+
+
 def test_street_class_instancing(built, tmp_path):
     """BASELINE config 4 stand-in at test size: EXT_mesh_gpu_instancing (hundreds of render nodes from a few meshes), ~130
     materials, alpha-MASK trees, sun + sky."""

@@ -83,6 +83,7 @@ struct MiPt
   DevBuf<MiGltfLight>         lights;
   DevBuf<pt::DevTexture>      textures;
   DevBuf<uchar4>              texels;
+  DevBuf<uint4>               texQuads;  // bilinear footprints, one per texel of the pool (DevScene::texQuads)
   DevBuf<uint8_t>             geometry;  // all index / attribute streams, 16-byte aligned sub-allocations
   DevBuf<uint8_t>             instFlags;
   DevBuf<float>               srgbLut;
@@ -611,6 +612,16 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
     }
     HIP_TRY(pt->textures.upload(dt.data(), dt.size()));
     HIP_TRY(pt->texels.upload(pool.data(), pool.size()));
+    // bilinear footprints (pt_scene.h: texQuads), built on the device from the pool just uploaded; MI_PT_DIAG_NO_QUADS=1: A/B switch
+    if(totalTexels > 0 && getenv("MI_PT_DIAG_NO_QUADS") == nullptr)
+    {
+      HIP_TRY(pt->texQuads.alloc(pool.size()));
+      for(const pt::DevTexture& d : dt)
+        for(int l = 0; l < d.numLevels; ++l)
+          pt::launchTextureQuads(pt->texels.ptr, pt->texQuads.ptr, d.levelOffset[l], std::max(1, int(d.width) >> l), std::max(1, int(d.height) >> l), d.wrapS,
+                                 d.wrapT, nullptr);
+      HIP_TRY(hipGetLastError());
+    }
     // texture info + descriptor, flattened per texture slot (pt_scene.h: DevTexRef)
     std::vector<pt::DevTexRef> refs(size_t(std::max(sd->numTextureInfos, 1)));
     memset(refs.data(), 0, refs.size() * sizeof(pt::DevTexRef));
@@ -642,7 +653,7 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
 
   pt::DevScene& S = pt->scene;
   S.materials = pt->materials.ptr; S.texInfos = pt->texInfos.ptr; S.nodes = pt->nodes.ptr; S.prims = pt->prims.ptr; S.lights = pt->lights.ptr;
-  S.textures = pt->textures.ptr; S.texels = pt->texels.ptr; S.envPixels = nullptr; S.envAccel = nullptr; S.bvhNodes = nullptr; S.bvh8Nodes = nullptr; S.tris = nullptr;
+  S.textures = pt->textures.ptr; S.texels = pt->texels.ptr; S.texQuads = pt->texQuads.ptr; S.envPixels = nullptr; S.envAccel = nullptr; S.bvhNodes = nullptr; S.bvh8Nodes = nullptr; S.tris = nullptr;
   S.texRefs = pt->texRefs.ptr; S.alphaTris = nullptr; S.shadeTris = nullptr; S.srgbLut = pt->srgbLut.ptr; S.numMaterials = sd->numMaterials; S.numTextures = sd->numTextures;
   S.numLights = sd->numLights; S.numNodes = sd->numRenderNodes;
   S.envWidth = 0; S.envHeight = 0;
@@ -1191,7 +1202,7 @@ int mi_pt_get_memory(MiPt* pt, MiPtMemory* out)
   HIP_TRY(hipSetDevice(pt->device));
   auto bytes = [](const auto& b) { return uint64_t(b.count) * sizeof(*b.ptr); };
   const pt::DevScene& sc = pt->scene;
-  uint64_t scene = bytes(pt->materials) + bytes(pt->texInfos) + bytes(pt->nodes) + bytes(pt->prims) + bytes(pt->lights) + bytes(pt->textures) + bytes(pt->texels)
+  uint64_t scene = bytes(pt->materials) + bytes(pt->texInfos) + bytes(pt->nodes) + bytes(pt->prims) + bytes(pt->lights) + bytes(pt->textures) + bytes(pt->texels) + bytes(pt->texQuads)
                    + bytes(pt->geometry) + bytes(pt->instFlags) + bytes(pt->srgbLut) + bytes(pt->envPixels) + bytes(pt->envAccel) + bytes(pt->alphaTris)
                    + bytes(pt->shadeTris) + bytes(pt->texRefs);
   // the acceleration structure is raw allocations: 64-B BVH2 nodes or 80-B BVH8 nodes + 48-B triangle records

@@ -1543,7 +1543,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
           mesh.isInside           = isInside;
           mesh.texGrad            = worldFoot * hit.texelDensity * fc.pc.texGradScale;
           mesh.baseColorVertexMul = hit.color;
-          mesh.tex                = TexCtx{sc.texRefs, sc.texels, s_srgb};
+          mesh.tex                = TexCtx{sc.texRefs, sc.texels, s_srgb, sc.texQuads};
           pbrMat                  = evaluateMaterial<SIMPLE>(sc, mat, mesh, taps);
           unlit                   = mat.unlit > 0;
         }
@@ -2459,6 +2459,20 @@ __global__ void k_shade_records(DevScene sc, uint32_t n, DevShadeTri* out)
     out[i] = makeShadeRecord(sc, sc.tris[i]);
 }
 
+// bilinear footprints of one mip level (DevScene::texQuads): neighbours under the texture's wrap modes
+__global__ void __launch_bounds__(256) k_texture_quads(const uint32_t* __restrict__ texels, uint4* __restrict__ quads, uint32_t offset, int w, int h, int wrapS, int wrapT)
+{
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if(i >= uint32_t(w) * uint32_t(h))
+    return;
+  const int x = int(i % uint32_t(w)), y = int(i / uint32_t(w));
+  const int x1 = wrapS == MI_WRAP_CLAMP_TO_EDGE ? min(x + 1, w - 1) : (x + 1 == w ? 0 : x + 1);
+  const int y1 = wrapT == MI_WRAP_CLAMP_TO_EDGE ? min(y + 1, h - 1) : (y + 1 == h ? 0 : y + 1);
+  const uint32_t* L = texels + offset;
+  quads[offset + i] = make_uint4(L[uint32_t(y) * uint32_t(w) + uint32_t(x)], L[uint32_t(y) * uint32_t(w) + uint32_t(x1)],
+                                 L[uint32_t(y1) * uint32_t(w) + uint32_t(x)], L[uint32_t(y1) * uint32_t(w) + uint32_t(x1)]);
+}
+
 __global__ void k_reset_counters(uint32_t* counters)
 {
   for(int i = threadIdx.x; i < QC_COUNT; i += blockDim.x)
@@ -2505,6 +2519,11 @@ void launchBuildShadeRecords(const DevScene& scene, uint32_t numTris, DevShadeTr
 {
   if(numTris)
     hipLaunchKernelGGL(k_shade_records, dim3((numTris + 255) / 256), dim3(256), 0, s, scene, numTris, out);
+}
+void launchTextureQuads(const uchar4* texels, uint4* quads, uint32_t offset, int width, int height, int wrapS, int wrapT, hipStream_t s)
+{
+  const uint32_t n = uint32_t(width) * uint32_t(height);
+  hipLaunchKernelGGL(k_texture_quads, dim3((n + 255u) / 256u), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(texels), quads, offset, width, height, wrapS, wrapT);
 }
 void launchResetCounters(const Queues& Q, hipStream_t s)
 {

@@ -35,7 +35,8 @@ struct TexCtx  // what a texture fetch needs, passed BY VALUE (registers) into t
 {
   const DevTexRef* refs;
   const uchar4*    texels;
-  const float*     lut;  // sRGB decode table (global, or the shade kernel's LDS copy)
+  const float*     lut;    // sRGB decode table (global, or the shade kernel's LDS copy)
+  const uint4*     quads;  // bilinear footprints, one per texel (DevScene::texQuads), or null
 };
 
 // GltfRenderPrimitive with device pointers (reference: shaders/gltf_scene_io.h.slang:50-64)
@@ -110,6 +111,13 @@ struct DevScene
   const MiGltfLight*         lights;
   const DevTexture*          textures;
   const uchar4*              texels;
+  // Bilinear footprints: texQuads[i] = the four RGBA8 texels {(x, y), (x+1, y), (x, y+1), (x+1, y+1)} of the footprint whose first
+  // texel is texel i of the pool, the neighbours taken under the texture's own wrap modes at upload.  There is no texture unit:
+  // a bilinear tap is four gathers and two wrapCoordPair() evaluations, a trilinear one twice that, five maps per hit -- 40
+  // gathers.  With the footprint stored per texel it is ONE 16-byte gather and no neighbour arithmetic; 4x the texel pool in HBM,
+  // which is what the 288 GB are for.  REPEAT and CLAMP_TO_EDGE only (the neighbour under MIRRORED_REPEAT depends on the period
+  // the coordinate is in); null = not built.
+  const uint4*               texQuads;
   const float4*              envPixels;  // rgb + pdf
   const MiEnvAccel*          envAccel;
   const float4*              bvhNodes;  // BVH2: 4 x float4 per node (see pt_bvh.h); null when the wide BVH is active

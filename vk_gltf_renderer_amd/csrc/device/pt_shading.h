@@ -161,6 +161,13 @@ PT_DEV f4 fetchTexelRef(const TexCtx& tc, const DevTexRef& R, uint32_t levelOffs
     return mk4(tc.lut[p.x], tc.lut[p.y], tc.lut[p.z], float(p.w) * (1.0f / 255.0f));
   return mk4(float(p.x) * (1.0f / 255.0f), float(p.y) * (1.0f / 255.0f), float(p.z) * (1.0f / 255.0f), float(p.w) * (1.0f / 255.0f));
 }
+PT_DEV f4 decodeTexelRef(const TexCtx& tc, const DevTexRef& R, uint32_t p)  // fetchTexelRef's arithmetic on an already fetched texel
+{
+  const uint32_t r = p & 0xffu, g = (p >> 8) & 0xffu, b = (p >> 16) & 0xffu, a = p >> 24;
+  if(R.srgb)
+    return mk4(tc.lut[r], tc.lut[g], tc.lut[b], float(a) * (1.0f / 255.0f));
+  return mk4(float(r) * (1.0f / 255.0f), float(g) * (1.0f / 255.0f), float(b) * (1.0f / 255.0f), float(a) * (1.0f / 255.0f));
+}
 PT_DEV f4 sampleLevelRef(const TexCtx& tc, const DevTexRef& R, f2 uv, int level, int filter)
 {
   uint32_t off = R.level0;
@@ -174,6 +181,17 @@ PT_DEV f4 sampleLevelRef(const TexCtx& tc, const DevTexRef& R, f2 uv, int level,
   fy -= 0.5f;
   float flx = floorf(fx), fly = floorf(fy);
   float tx = fx - flx, ty = fy - fly;
+  if(tc.quads && R.wrapS != MI_WRAP_MIRRORED_REPEAT && R.wrapT != MI_WRAP_MIRRORED_REPEAT)
+  {
+    // the whole footprint in one 16-byte gather (DevScene::texQuads): same texels, same arithmetic, same result
+    const int   ix = int(flx), iy = int(fly);
+    const uint4 q  = tc.quads[texelIndex(off, w, wrapCoord(ix, w, R.wrapS), wrapCoord(iy, h, R.wrapT))];
+    // CLAMP_TO_EDGE left of / above the image: both coordinates of the pair clamp to texel 0 (wrapCoord(i) == wrapCoord(i + 1))
+    const bool dupX = R.wrapS == MI_WRAP_CLAMP_TO_EDGE && ix < 0, dupY = R.wrapT == MI_WRAP_CLAMP_TO_EDGE && iy < 0;
+    const f4   a = decodeTexelRef(tc, R, q.x), b = decodeTexelRef(tc, R, dupX ? q.x : q.y);
+    const f4   c = decodeTexelRef(tc, R, dupY ? q.x : q.z), d = decodeTexelRef(tc, R, dupY ? (dupX ? q.x : q.y) : (dupX ? q.z : q.w));
+    return (a * (1.0f - tx) + b * tx) * (1.0f - ty) + (c * (1.0f - tx) + d * tx) * ty;
+  }
   int   x0, x1, y0, y1;
   wrapCoordPair(int(flx), w, R.wrapS, x0, x1);
   wrapCoordPair(int(fly), h, R.wrapT, y0, y1);
@@ -451,12 +469,27 @@ PT_DEV float getOpacityFast(const DevScene& sc, int triIndex, f3 bary)
       fy -= 0.5f;
       float flx = floorf(fx), fly = floorf(fy);
       float tx = fx - flx, ty = fy - fly;
-      int   x0, x1, y0, y1;
-      wrapCoordPair(int(flx), w, wrapS, x0, x1);
-      wrapCoordPair(int(fly), h, wrapT, y0, y1);
-      float a = float(texels[texelIndex(0u, w, x0, y0)].w) * (1.0f / 255.0f), b = float(texels[texelIndex(0u, w, x1, y0)].w) * (1.0f / 255.0f);
-      float c = float(texels[texelIndex(0u, w, x0, y1)].w) * (1.0f / 255.0f), d = float(texels[texelIndex(0u, w, x1, y1)].w) * (1.0f / 255.0f);
-      ta      = (a * (1.0f - tx) + b * tx) * (1.0f - ty) + (c * (1.0f - tx) + d * tx) * ty;
+      float a, b, c, d;
+      if(sc.texQuads && wrapS != MI_WRAP_MIRRORED_REPEAT && wrapT != MI_WRAP_MIRRORED_REPEAT)
+      {
+        // the footprint in one gather (DevScene::texQuads; see sampleLevelRef)
+        const int   ix = int(flx), iy = int(fly);
+        const uint4 q  = sc.texQuads[rec.c.x + texelIndex(0u, w, wrapCoord(ix, w, wrapS), wrapCoord(iy, h, wrapT))];
+        const bool  dupX = wrapS == MI_WRAP_CLAMP_TO_EDGE && ix < 0, dupY = wrapT == MI_WRAP_CLAMP_TO_EDGE && iy < 0;
+        a = float(q.x >> 24) * (1.0f / 255.0f);
+        b = float((dupX ? q.x : q.y) >> 24) * (1.0f / 255.0f);
+        c = float((dupY ? q.x : q.z) >> 24) * (1.0f / 255.0f);
+        d = float((dupY ? (dupX ? q.x : q.y) : (dupX ? q.z : q.w)) >> 24) * (1.0f / 255.0f);
+      }
+      else
+      {
+        int x0, x1, y0, y1;
+        wrapCoordPair(int(flx), w, wrapS, x0, x1);
+        wrapCoordPair(int(fly), h, wrapT, y0, y1);
+        a = float(texels[texelIndex(0u, w, x0, y0)].w) * (1.0f / 255.0f); b = float(texels[texelIndex(0u, w, x1, y0)].w) * (1.0f / 255.0f);
+        c = float(texels[texelIndex(0u, w, x0, y1)].w) * (1.0f / 255.0f); d = float(texels[texelIndex(0u, w, x1, y1)].w) * (1.0f / 255.0f);
+      }
+      ta = (a * (1.0f - tx) + b * tx) * (1.0f - ty) + (c * (1.0f - tx) + d * tx) * ty;
     }
     alpha *= ta;
   }
