@@ -6,7 +6,7 @@ per GPU, each ptSamples = 1 sample per pixel like the reference's headless run `
 (docs/benchmarking.md:16-23), of the workload BASELINE.json's metric is quoted on and that fits one GPU: configs[1],
 DamagedHelmet-class + std_env.hdr, 1920x1080, depth 8 (the asset itself is not available offline;
 vk_gltf_renderer_amd.scenegen writes a seeded stand-in of the same class as a .glb).  The frames of a step are issued through
-mi_pt_render_frames in groups of `--in-flight` (default 32) that share every wavefront launch (bit-identical to rendering them
+mi_pt_render_frames in groups of `--in-flight` (default 64) that share every wavefront launch (bit-identical to rendering them
 one after the other; --in-flight 1 gives exactly that).  Metric = the reference's throughput_MSps (src/benchmarking.cpp:272-279):
 W*H*spp / wall_s / 1e6 with spp = all samples of the timed region, inputs resident in HBM before the timed region.
 
@@ -151,7 +151,7 @@ def secondary_line(name, args, device):
         t.set_sky(ptmod.default_sky())
         return t
 
-    F = w.get("in_flight", 32)
+    F = w.get("in_flight", 64)
     frames_step, steps = 2 * F, 2
     t = tracer(False)
     r = ptmod.HeadlessRenderer(t, params(w["depth"]))
@@ -211,7 +211,7 @@ def main():
                     help="frames (1 spp each) per GPU and step (default 192; glass 256); a step renders frames_per_step * n_gpus frames")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="frames in flight per GPU (mi_pt_render_frames, bit-identical to sequential frames): the frames of a step are issued in "
-                         "groups of in_flight * n_gpus (capped at 256).  Default 32; 128 for the glass workload, whose volume random walks leave a "
+                         "groups of in_flight * n_gpus (capped at 1024).  Default 64; 128 for the glass workload, whose volume random walks leave a "
                          "long tail of ~100 nearly empty bounce iterations per batch (238 -> 469 Msamples/s from 32 to 128 frames)")
     args = ap.parse_args()
 
@@ -244,7 +244,7 @@ def main():
         assert dist.get_world_size() == world
 
     w = WORKLOADS[args.workload]
-    args.in_flight = args.in_flight or w.get("in_flight", 32)
+    args.in_flight = args.in_flight or w.get("in_flight", 64)
     args.frames_per_step = args.frames_per_step or w.get("frames_per_step", 192)
     W, H = args.width or w["width"], args.height or w["height"]
     scene = ptmod.Scene(scene_path(args.workload, rank))
@@ -303,7 +303,9 @@ def main():
 
     # Every rank owns 1/world of the tiles of each frame, so the frames per step and the frames in flight grow with the world size
     # to keep the rays in flight per GPU constant (weak scaling).
-    F = min(256, max(1, args.in_flight) * world)
+    F = min(1024, max(1, args.in_flight) * world)
+    # ... within a budget of 2.8e8 path slots per GPU (~85 GB of path state and queues at ~0.3 KB per slot): 4K frames run 33 in flight
+    F = max(1, min(F, int(2.8e8 * world // (W * H))))
     frames_step = max(1, args.frames_per_step) * world
 
     def step():

@@ -207,7 +207,7 @@ MI_PT_API int mi_pt_render_frame(MiPt* pt, const MiPathtraceParams* params, void
  * on f = 0 -- i.e. the frames GltfRenderer::onRender / updateFrameCounter would issue one after the other
  * (reference: src/renderer.cpp:1939-1977, src/renderer_pathtracer.cpp:1401, :1502-1505) -- but their paths share every
  * wavefront launch, so the short late-bounce queues and the launch overheads are paid once per batch.  Frames only
- * couple through the running mean, which the finish kernel folds in frame order.  1 <= numFrames <= 256; the path-state
+ * couple through the running mean, which the finish kernel folds in frame order.  1 <= numFrames <= 1024 (and frames x owned pixels < 2^31); the path-state
  * arrays grow (one synchronising reallocation) the first time a larger batch is requested: ~0.3 KB per pixel per frame. */
 MI_PT_API int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames, void* hipStream);
 

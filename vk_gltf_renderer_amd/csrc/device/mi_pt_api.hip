@@ -804,8 +804,8 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
 {
   if(!pt || !params)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_render_frame: null argument");
-  if(numFrames < 1 || numFrames > 256)
-    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_render_frames: 1 <= numFrames <= 256 required");
+  if(numFrames < 1 || numFrames > 1024)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_render_frames: 1 <= numFrames <= 1024 required");
   if(pt->width <= 0 || !pt->haveFrameInfo)
     return fail(MI_PT_ERR_STATE, "mi_pt_render_frame: call mi_pt_resize and mi_pt_set_frame_info first");
   if(params->numSamples < 1 || params->maxDepth < 0 || params->maxDepth > 255)
