@@ -5,7 +5,7 @@ set -u
 tag=$1; shift
 repo=$PWD; out=$repo/gpurun_out/kstats_$tag
 mkdir -p "$out"; export TMPDIR=/tmp
-( cd /tmp && timeout 170 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -- python "$repo/bench.py" "$@" --no-cpu-baseline > "$out/run.log" 2>&1 )
+( cd /tmp && timeout 170 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -- python "$repo/bench.py" "$@" --no-cpu-baseline --also none > "$out/run.log" 2>&1 )
 f=$(find "$out" -name "*kernel_stats.csv" | head -1)
 cp "$f" "$out/kernel_stats.csv" 2>/dev/null
 python3 - "$out/kernel_stats.csv" <<'PY'

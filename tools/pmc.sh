@@ -7,7 +7,7 @@ out=$PWD/gpurun_out/pmc_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 repo=$PWD
-( cd /tmp && timeout 90 rocprofv3 --pmc $counters --output-format csv -d "$out" -- python "$repo/bench.py" "$@" --no-cpu-baseline > "$out/run.log" 2>&1 )
+( cd /tmp && timeout 90 rocprofv3 --pmc $counters --output-format csv -d "$out" -- python "$repo/bench.py" "$@" --no-cpu-baseline --also none > "$out/run.log" 2>&1 )
 python3 - "$out" <<'PY'
 import csv, glob, os, re, sys
 from collections import defaultdict

@@ -10,7 +10,7 @@ run() { # name, rocprof args...
   local name=$1; shift
   ( cd /tmp && timeout 90 rocprofv3 "$@" --output-format csv -d "$out/$name" -- python "$OLDPWD/bench.py" "${BENCH_ARGS[@]}" > "$out/$name.log" 2>&1 )
 }
-BENCH_ARGS=("$@" --no-cpu-baseline)
+BENCH_ARGS=("$@" --no-cpu-baseline --also none)
 run stats --kernel-trace --stats
 run pmc_sq --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
 run pmc_sq2 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM
