@@ -501,13 +501,17 @@ struct CandRec
   uint32_t  cap;
   uint32_t* waveHead;  // this wave's 64 list heads (LDS)
   uint32_t* waveOvf;   // this wave's 64 overflow flags (LDS)
+  // the wave's private piece of the pool [cur, end): a device-scope atomic costs microseconds and its result is needed at once, so a
+  // wave takes CAND_CHUNK entries at a time (one atomic per ~15 alpha rounds instead of one per round) and wastes what is left at its end
+  uint32_t  cur, end;
 };
+constexpr uint32_t CAND_CHUNK = 256;  // >= 64, the most one alpha round can record
 // SHADOW: any-hit semantics (an accepted candidate occludes, draw < opacity); otherwise closest-hit (draw <= opacity).
 // REC (shadow only): candidates on transmissive instances are not decided here -- their effect depends on their order along
 // the ray (Beer segments, raytracer_interface.h.slang:160-178) -- but recorded for k_shadow_resolve.
 template <bool SHADOW, bool REC = false>
 PT_DEV void alphaRound(const DevScene& sc, uint32_t seed0, uint4* waveAlpha, uint32_t& aCount, bool& aPending, ClosestBest& best, bool& occluded,
-                       const CandRec* rec = nullptr)
+                       CandRec* rec = nullptr)
 {
   const uint32_t lane = laneId();
   const bool     has  = lane < aCount;
@@ -533,13 +537,19 @@ PT_DEV void alphaRound(const DevScene& sc, uint32_t seed0, uint4* waveAlpha, uin
     const unsigned long long m = __ballot(record);
     if(m != 0ull)
     {
-      // one device-scope atomic per round hands out the pool entries of all its transmissive candidates
-      const int first = __ffsll((long long)m) - 1;
-      uint32_t  base  = 0u;
-      if(int(lane) == first)
-        base = atomicAdd(rec->poolCounter, uint32_t(__popcll(m)));
-      base = uint32_t(__builtin_amdgcn_readlane(int(base), first));
-      const uint32_t idx = base + laneCountBelow(m);
+      // pool entries of all the round's transmissive candidates, out of the wave's private piece
+      const uint32_t n = uint32_t(__popcll(m));
+      if(rec->cur + n > rec->end)
+      {
+        const int first = __ffsll((long long)m) - 1;
+        uint32_t  base  = 0u;
+        if(int(lane) == first)
+          base = atomicAdd(rec->poolCounter, CAND_CHUNK);
+        rec->cur = uint32_t(__builtin_amdgcn_readlane(int(base), first));
+        rec->end = rec->cur + CAND_CHUNK;
+      }
+      const uint32_t idx = rec->cur + laneCountBelow(m);
+      rec->cur += n;
       if(record)
       {
         if(idx < rec->cap)
@@ -574,7 +584,7 @@ PT_DEV void alphaRound(const DevScene& sc, uint32_t seed0, uint4* waveAlpha, uin
 // puts this round's alpha candidates on the list (flushing it first when they would not fit)
 template <bool SHADOW, bool REC = false>
 PT_DEV void alphaDefer(const DevScene& sc, bool needAlpha, uint32_t item, float t, float u, float v, uint32_t seed0, uint4* waveAlpha, uint32_t& aCount,
-                       bool& aPending, ClosestBest& best, bool& occluded, const CandRec* rec = nullptr)
+                       bool& aPending, ClosestBest& best, bool& occluded, CandRec* rec = nullptr)
 {
   const unsigned long long m = __ballot(needAlpha);
   if(m == 0ull)
@@ -668,7 +678,7 @@ PT_DEV void triRoundFinish(const DevScene& sc, const RaySetup& r, ClosestBest& b
 // decides its ray (raytracer_interface.h.slang:149-179), so the owners only need to know whether any of theirs did.
 template <bool HAS_ALPHA, bool COUNT, bool REC = false>
 PT_DEV void triRoundFinishShadow(const DevScene& sc, const RaySetup& r, float tMax, uint32_t seed0, const TriRound& tr, bool& occluded, unsigned& tris,
-                                 uint4* waveAlpha, uint32_t& aCount, bool& aPending, const CandRec* rec = nullptr)
+                                 uint4* waveAlpha, uint32_t& aCount, bool& aPending, CandRec* rec = nullptr)
 {
   const uint32_t src = tr.item >> 26;
   const f3       org = mk3(laneRead(r.org.x, src), laneRead(r.org.y, src), laneRead(r.org.z, src));
@@ -1872,7 +1882,7 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
 #define SPROF_CNT(i, n) (void)0
 #endif
   uint4*   waveAlpha = s_alpha + ((WIDE && DEFER) ? (threadIdx.x & ~63u) : 0u);
-  CandRec  rec{Q.candPool, Q.candNext, &Q.counters[QC_CAND_POOL], Q.candCap, s_head + (REC ? (threadIdx.x & ~63u) : 0u), s_ovf + (REC ? (threadIdx.x & ~63u) : 0u)};
+  CandRec  rec{Q.candPool, Q.candNext, &Q.counters[QC_CAND_POOL], Q.candCap, s_head + (REC ? (threadIdx.x & ~63u) : 0u), s_ovf + (REC ? (threadIdx.x & ~63u) : 0u), 0u, 0u};
   (void)rec;
 
   auto deposit = [&](bool occ) { shadowDeposit(P, Q, nxt, slot, qpos, catcherRay, contrib, total, occ, catcherDarken); };
