@@ -517,6 +517,9 @@ def test_ktx_decode(built, tmp_path):
     # refused: BasisLZ supercompression, UASTC (vkFormat 0), cube maps, truncated level -> no effective image -> the 1x1 magenta
     bad = [_ktx2(4, 4, 0, bytes(16), scheme=1), _ktx2(4, 4, 0, bytes(16)), _ktx2(64, 64, 37, bytes(16)),
            _ktx2(4, 4, 37, bytes(64))[:60]]
+    lying = bytearray(_ktx2(4, 4, 37, bytes(64), scheme=3))
+    lying[80 + 16:80 + 24] = struct.pack("<Q", 1 << 40)  # a level that claims to inflate to a terabyte
+    bad.append(bytes(lying))
     cube = bytearray(_ktx2(4, 4, 37, bytes(64)))
     cube[36:40] = struct.pack("<I", 6)
     bad.append(bytes(cube))

@@ -165,8 +165,11 @@ bool decodeKtx(const uint8_t* data, size_t size, Image& out, std::string* error)
     std::vector<uint8_t> inflated;
     if(scheme == 2 || scheme == 3)
     {
-      if(ulen == 0 || ulen > (size_t(1) << 32))
-        return fail("bad uncompressed length");
+      // the inflated size of a level is known from the header: anything else is a corrupt or hostile file (and would size a buffer)
+      const uint64_t expect = L.block ? uint64_t((width + 3) / 4) * ((height + 3) / 4) * ((L.blockFormat == BlockFormat::BC1 || L.blockFormat == BlockFormat::BC4) ? 8 : 16)
+                                      : uint64_t(width) * height * uint64_t(L.channels);
+      if(ulen != expect)
+        return fail("uncompressed length does not match the image size");
       if(scheme == 2)
       {
         std::string why;
