@@ -76,6 +76,23 @@ def test_headless_benchmark_command_line(tmp_path, assets):
 
 
 @pytest.mark.gpu
+def test_headless_frames_in_flight_same_image(tmp_path, assets):
+    """--framesInFlight batches the app frames of a headless run into shared wavefront launches (default 32): the saved accumulation
+    is the one of the frame-by-frame run (--framesInFlight 1, the reference's loop) bit for bit, and the summary counts the same frames."""
+    outs, recs = [], []
+    for n in (1, 5, 32):
+        out = tmp_path / f"f{n}.hdr"
+        r = _run(["--headless", "--size", "200", "120", "--scenefile", os.path.join(assets, "shader_ball.gltf"), "--hdrfile", os.path.join(assets, "std_env.hdr"),
+                  "--frames", "23", "--maxFrames", "23", "--ptSamples", "1", "--ptAdaptiveSampling", "0", "--envSystem", "1", "--framesInFlight", str(n),
+                  "--output", str(out)])
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(out.read_bytes())
+        recs.append(_records(r.stdout)[-1])
+    assert outs[0] == outs[1] == outs[2]
+    assert all((s["frames"], s["effective_spp"], s["warmup_frames"], s["measured_frames"]) == (23, 23, 1, 22) for s in recs)
+
+
+@pytest.mark.gpu
 def test_adaptive_sampling_controller(assets):
     """Auto SPP (reference: PathTracer::updateAdaptiveSampling, src/renderer_pathtracer.cpp:1326-1374): with the slowest target
     (10 frames per second) a 64x64 frame leaves headroom every frame, so the samples per frame climb by one per frame from frame 5 on;

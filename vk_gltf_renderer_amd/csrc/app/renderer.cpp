@@ -232,9 +232,15 @@ BenchmarkController::HeadlessFrameInfo GltfRenderer::benchmarkFrameInfo(uint32_t
   return info;
 }
 
-void GltfRenderer::onRender(StreamHandle cmd, bool headless, uint32_t headlessFrames)
+void GltfRenderer::onRender(StreamHandle cmd, bool headless, uint32_t headlessFrames, int batch)
 {
   m_benchmark.beginHeadlessTimingIfNeeded(headless, benchmarkFrameInfo(headlessFrames));
+  // `batch` app frames in one go (headless runs, --framesInFlight): the library traces them as one set of wavefront launches and
+  // folds them into the accumulator in frame order -- the image of `batch` successive onRender calls, bit for bit
+  // (mi_pt_render_frames).  Only frames that would all accumulate (below maxFrames) are batched.
+  batch = std::max(1, std::min(batch, m_resources.settings.maxFrames - (m_resources.frameCount + 1)));
+  m_pathTracer.setFramesThisCall(batch);
+  int done = 1;  // app frames this call stands for (a frame beyond maxFrames renders nothing but still counts as an app frame)
   if(updateFrameCounter())
   {
     // fill SceneFrameInfo (reference: src/renderer.cpp:675-705)
@@ -257,11 +263,14 @@ void GltfRenderer::onRender(StreamHandle cmd, bool headless, uint32_t headlessFr
     f.shadowCatcherDarkenAmount = std::max(s.shadowCatcherDarkness, 0.0f);
     m_resources.skyParams.yIsUp = m_resources.camera.up[1] > 0.5f;  // reference: src/renderer.cpp:707
     m_pathTracer.onRender(cmd, m_resources);
+    done = m_pathTracer.framesLastCall();
+    m_resources.frameCount += done - 1;
     if(headless)
       mi_pt_synchronize(m_pathTracer.handle());  // the reference's headless loop waits for each frame's submission
   }
   if(headless)
-    m_benchmark.updateHeadlessProgressIfNeeded(benchmarkFrameInfo(headlessFrames));
+    for(int i = 0; i < done; ++i)
+      m_benchmark.updateHeadlessProgressIfNeeded(benchmarkFrameInfo(headlessFrames));
 }
 
 void GltfRenderer::onLastHeadlessFrame(uint32_t headlessFrames)

@@ -18,7 +18,7 @@ public:
   bool createScene(const std::string& sceneFile);  // reference: src/renderer.cpp:1238
   bool createHDR(const std::string& hdrFile);      // reference: src/renderer.cpp:1982
   void onAttach(const Extent2D& size);
-  void onRender(StreamHandle cmd, bool headless, uint32_t headlessFrames);  // reference: src/renderer.cpp:588-742
+  void onRender(StreamHandle cmd, bool headless, uint32_t headlessFrames, int batch = 1);  // reference: src/renderer.cpp:588-742
   void onLastHeadlessFrame(uint32_t headlessFrames);                        // reference: src/renderer.cpp:762-767
   void resetFrame() { m_resources.frameCount = -1; }                        // reference: :1939-1942
   // Scripted benchmark sequences (reference: nvutils::ParameterSequencer driven from src/main.cpp:85-160 with --benchmark 1

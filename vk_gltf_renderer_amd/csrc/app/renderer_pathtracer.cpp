@@ -167,7 +167,7 @@ void PathTracer::updateDenoiser(Resources& res)
 
 void PathTracer::updateStatistics()
 {
-  m_totalSamplesAccumulated += m_pushConst.numSamples;
+  m_totalSamplesAccumulated += m_pushConst.numSamples * m_framesLastCall;
 }
 
 void PathTracer::onRender(StreamHandle cmd, Resources& res)
@@ -180,8 +180,10 @@ void PathTracer::onRender(StreamHandle cmd, Resources& res)
   mi_pt_set_sky(m_pt, &res.skyParams);
   if(m_adaptiveSampling)
     mi_pt_enable_timing(m_pt, 1);  // (re)starts the per-kernel event timers: the controller needs this frame's device time
-  if(mi_pt_render_frame(m_pt, &m_pushConst, cmd) != MI_PT_OK)
+  m_framesLastCall = (m_adaptiveSampling || m_denoiser.enable) ? 1 : m_framesThisCall;
+  if((m_framesLastCall == 1 ? mi_pt_render_frame(m_pt, &m_pushConst, cmd) : mi_pt_render_frames(m_pt, &m_pushConst, m_framesLastCall, cmd)) != MI_PT_OK)
   {
+    m_framesLastCall = 1;
     m_error = mi_pt_last_error();
     fprintf(stderr, "PathTracer::onRender: %s\n", m_error.c_str());
     return;

@@ -47,6 +47,11 @@ public:
   int  denoiseCount() const { return m_denoiseCount; }
   bool denoisedIsCurrent() const { return m_hasDenoisedOutput && m_denoisedAtSamples == m_totalSamplesAccumulated; }
 
+  // frames the next onRender traces in one go (1 = the reference's behaviour); what it actually did (1 whenever the adaptive
+  // controller or the denoiser cadence need every frame's boundary)
+  void setFramesThisCall(int n) { m_framesThisCall = n < 1 ? 1 : n; }
+  int  framesLastCall() const { return m_framesLastCall; }
+
   MiPathtraceParams m_pushConst{};  // read by benchmarkFrameInfo() in the reference (src/renderer.cpp:526)
 
 private:
@@ -68,6 +73,7 @@ private:
   int         m_performanceTarget{1};      // Balanced
   double      m_lastFrameDeviceMs{0.0};
   int         m_totalSamplesAccumulated{0};
+  int         m_framesThisCall{1}, m_framesLastCall{1};
   DenoiserSettings m_denoiser;
   int         m_lastAutoDenoiseFrame{0};
   int         m_denoiseCount{0};
