@@ -1,4 +1,5 @@
-run() { tag=$1; w=$2; shift 2; timeout -k 5 120 python bench.py --workload $w --no-cpu-baseline --also none "$@" > gpurun_out/tmp_bench.json 2> gpurun_out/tmp_bench.err; python - "$tag $w" "$*" <<PY
+timeout -k 5 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_lobes.py -m gpu -q -x 2>&1 | tail -3
+run() { tag=$1; w=$2; shift 2; timeout -k 5 150 python bench.py --workload $w --no-cpu-baseline --also none "$@" > gpurun_out/tmp_bench.json 2> gpurun_out/tmp_bench.err; python - "$tag $w" "$*" <<PY
 import json,sys
 try:
     d=json.load(open("gpurun_out/tmp_bench.json"))
@@ -7,7 +8,5 @@ except Exception as e:
     print(sys.argv[1], "FAILED", e, open("gpurun_out/tmp_bench.err").read()[-300:])
 PY
 }
-for v in "" var_L14 var_L28 var_L36B8; do
-  unset MI_PT_LIB; if [ -n "$v" ]; then export MI_PT_LIB=$PWD/vk_gltf_renderer_amd/lib/$v/libmi_pt.so; fi
-  run "${v:-product}" atrium --steps 1 --warmup 1
-done
+run missfinish helmet --steps 6 --warmup 1
+run missfinish atrium --steps 1 --warmup 1

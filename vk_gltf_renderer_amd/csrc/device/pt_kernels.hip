@@ -1172,25 +1172,17 @@ __global__ void __launch_bounds__(256, PRIMARY_MIN_WAVES) k_trace_primary(DevSce
   }
   if(threadIdx.x >= total)
     Q.active[0].slot[pos0 + threadIdx.x] = QUEUE_DEAD;
-  // ---- the others end here: k_shade's miss branch for a first ray (gltf_pathtrace.slang:129-156, throughput 1, lastSamplePdf DIRAC)
+  // ---- the others end here.  What the shade kernel's miss branch would add for a first ray (gltf_pathtrace.slang:129-156: the
+  // environment or the backplate at throughput 1, lastSamplePdf DIRAC) is a pure function of the direction, and evaluating it
+  // here -- an atan2 / acos pair and four dependent gathers for the lanes of a wave that happen to miss, in a kernel whose waves
+  // are serial scalar-load chains -- cost 1.08 ms of 5.16 per 32 helmet frames.  The path's record keeps the DIRECTION instead of a
+  // radiance and k_finish_sample, which reads that record anyway and runs one dense thread per pixel, evaluates it.
   if(active && !toShade)
   {
-    const DevScene&    scd = *scp;
-    const FrameConsts& fcd = *fcp;
     if(hasFlag(fc.pc.flags, MI_PT_FIRST_FRAME) && slot < uint32_t(fc.numSlots))  // NDC depth input of a first frame (k_finish_sample)
       P.firstHit[slot] = make_float4(cp.direction.x, cp.direction.y, cp.direction.z, 0.0f);
-    f3 radiance = mk3(0.0f);
-#ifndef MI_PT_DIAG_NO_MISS  // cost-attribution build (tools/attribution.sh): wrong image, escaped camera paths stay black
-    if(!primaryMissBackplate(scd, fcd, cp.direction, radiance))
-    {
-      f3    envColor;
-      float mis;
-      missEnvironment(scd, fcd, cp.direction, DIRAC, envColor, mis);
-      radiance += mk3(1.0f) * mis * envColor;
-    }
-#endif
-    P.radiance[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);                          // maxRoughness.x = 0
-    P.misc[slot]     = make_float4(0.0f, __uint_as_float(PF_NOT_SOLID), __uint_as_float(cp.seed), 0.0f);  // depth 0, not alive, cone.width 0
+    P.radiance[slot] = make_float4(cp.direction.x, cp.direction.y, cp.direction.z, 0.0f);                                    // maxRoughness.x = 0
+    P.misc[slot]     = make_float4(0.0f, __uint_as_float(PF_NOT_SOLID | PF_PRIMARY_MISS), __uint_as_float(cp.seed), 0.0f);  // depth 0, not alive
   }
   if(COUNT)
   {
@@ -2363,8 +2355,9 @@ __global__ void __launch_bounds__(256) k_shadow_resolve(const DevScene* __restri
 // k_finish_sample: firefly clamp + per-frame mean + running-mean accumulation + NDC depth
 // (gltf_pathtrace.slang:531-538, 596, 604-630)
 //================================================================================================================================
-__global__ void __launch_bounds__(256) k_finish_sample(FrameConsts fc, PathSoA P, const uint32_t* ownedTiles, int sampleIndex, float4* accum, float* depth,
-                                                       float4* albedoOut, float4* normalOut)
+__global__ void __launch_bounds__(256) k_finish_sample(FrameConsts fc, const DevScene* __restrict__ scp, const FrameConsts* __restrict__ fcp, PathSoA P,
+                                                       const uint32_t* ownedTiles, int sampleIndex, float4* accum, float* depth, float4* albedoOut,
+                                                       float4* normalOut)
 {
   // One thread per PIXEL slot; the frames in flight are folded into the running mean in frame order, with exactly the
   // arithmetic of numFrames successive single-frame dispatches.
@@ -2381,9 +2374,23 @@ __global__ void __launch_bounds__(256) k_finish_sample(FrameConsts fc, PathSoA P
   for(int f = 0; f < fc.numFrames; ++f)
   {
     const uint32_t slot  = uint32_t(f) * uint32_t(fc.numSlots) + pslot;
-    const float4   rad4  = P.radiance[slot];
+    float4         rad4  = P.radiance[slot];
     const uint32_t flags = __float_as_uint(P.misc[slot].y);
     const bool     solid = !(flags & PF_NOT_SOLID);
+    if(flags & PF_PRIMARY_MISS)
+    {
+      // a camera ray that left the scene: rad4 is its direction (k_trace_primary); the shade kernel's miss branch for a first ray
+      const f3 dir      = mk3(rad4.x, rad4.y, rad4.z);
+      f3       radiance = mk3(0.0f);
+      if(!primaryMissBackplate(*scp, *fcp, dir, radiance))
+      {
+        f3    envColor;
+        float mis;
+        missEnvironment(*scp, *fcp, dir, DIRAC, envColor, mis);
+        radiance += mk3(1.0f) * mis * envColor;
+      }
+      rad4 = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+    }
     f4             r     = mk4(rad4.x, rad4.y, rad4.z, solid ? 1.0f : 0.0f);
     float          lum   = dot(xyz(r), mk3(1.0f / 3.0f));
     if(lum > fc.pc.fireflyClampThreshold)
@@ -2665,7 +2672,7 @@ void launchTraceShadow(const LaunchCtx& c, int nxt)
 void launchFinishSample(const LaunchCtx& c, int sampleIndex, float4* accum, float* depth, float4* albedo, float4* normal)
 {
   unsigned grid = (unsigned(c.fc.numSlots) + 255u) / 256u;
-  hipLaunchKernelGGL(k_finish_sample, dim3(grid), dim3(256), 0, c.stream, c.fc, c.paths, c.ownedTiles, sampleIndex, accum, depth, albedo, normal);
+  hipLaunchKernelGGL(k_finish_sample, dim3(grid), dim3(256), 0, c.stream, c.fc, c.sceneDev, c.fcDev, c.paths, c.ownedTiles, sampleIndex, accum, depth, albedo, normal);
 }
 void launchSelection(const LaunchCtx& c, uint32_t* selection)
 {

@@ -168,6 +168,8 @@ enum : uint32_t
   PF_NOT_SOLID  = 1u << 1,   // !pt.solid
   PF_ALIVE      = 1u << 2,   // still in the bounce loop
   PF_PLANE_HIT  = 1u << 3,
+  PF_PRIMARY_MISS = 1u << 4, // the camera ray left the scene (k_trace_primary): `radiance` holds its DIRECTION, k_finish_sample evaluates
+                             // the environment / backplate for it
   PF_DEPTH_SHIFT   = 8,      // bits 8..15  surfaceDepth
   PF_SCATTER_SHIFT = 16,     // bits 16..23 scatterBounces (saturating)
 };
