@@ -35,6 +35,16 @@ MI_PT_API int                  mi_scene_num_cameras(const MiScene* scene);
 MI_PT_API int                  mi_scene_camera(const MiScene* scene, int index, MiCamera* out);
 MI_PT_API void                 mi_scene_bounds(const MiScene* scene, float bmin[3], float bmax[3]);
 MI_PT_API uint64_t             mi_scene_num_triangles(const MiScene* scene);
+/* recomputeTangents(model, forceCreation, mikktspace) (reference: src/gltf_create_tangent.hpp:28-40, the UI's "Recreate Tangents"
+ * items src/ui_renderer.cpp:855-875): simple UV-gradient tangents (mikktspace = 0) or Mikkelsen's tangent space with vertex
+ * splitting at UV seams / mirrored UVs.  Returns the number of vertices added by the splitting (>= 0) or a negative MiPtStatus;
+ * the MiPtSceneDesc of the scene changes (fetch mi_scene_desc again and re-create the renderer, as the reference re-creates
+ * SceneVk / SceneRtx after a split). */
+MI_PT_API int                  mi_scene_recompute_tangents(MiScene* scene, int forceCreation, int mikktspace);
+/* The raw per-corner output of the Mikkelsen tangent-space computation for a triangle list (4 floats per corner: unit tangent, +1 /
+ * -1 orientation), exposed so that tests can compare it with the reference's third_party/MikkTSpace on the same arrays. */
+MI_PT_API int                  mi_mikktspace(const float* positions, const float* normals, const float* texCoords, uint32_t numVertices,
+                                             const uint32_t* indices, uint32_t numTriangles, float* cornerTangents);
 
 MI_PT_API int                    mi_hdr_load(const char* path, MiHdr** out);
 MI_PT_API int                    mi_hdr_from_pixels(int width, int height, const float* rgb, MiHdr** out);

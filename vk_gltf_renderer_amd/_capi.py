@@ -159,6 +159,8 @@ HOST_SYMBOLS = {
     "mi_scene_bounds": (None, [VP, P(f32), P(f32)]),
     "mi_scene_num_triangles": (C.c_uint64, [VP]),
     "mi_hdr_load": (i32, [C.c_char_p, P(VP)]),
+    "mi_scene_recompute_tangents": (i32, [VP, i32, i32]),
+    "mi_mikktspace": (i32, [P(f32), P(f32), P(f32), u32, P(u32), u32, P(f32)]),
     "mi_hdr_from_pixels": (i32, [i32, i32, P(f32), P(VP)]),
     "mi_hdr_destroy": (None, [VP]),
     "mi_hdr_env": (P(MiPtEnvironment), [VP]),

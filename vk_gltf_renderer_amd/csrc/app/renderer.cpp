@@ -38,6 +38,7 @@ void GltfRenderer::registerParameters(ParameterRegistry* r)
   r->add("isShadowCatcher", "Ground plane only catches shadows", &s.isShadowCatcher);
   r->add("infinitePlaneDistance", "Ground plane height", &s.infinitePlaneDistance);
   r->add("device", "HIP device ordinal", &m_resources.device);
+  r->add("recomputeTangents", "Recreate all tangents after loading: [off:0, UV gradient:1, MikkTSpace:2]", &m_recomputeTangents);
   // tonemapper (reference: src/renderer.cpp:173-179 -- same names, same members)
   MiTonemapperData& tm = m_resources.tonemapperData;
   r->add("tmMethod", "Tonemapper method: [Filmic:0, Uncharted:1, Clip:2, ACES:3, AgX:4, KhronosPBR:5]", &tm.method);
@@ -175,6 +176,15 @@ bool GltfRenderer::createScene(const std::string& sceneFile)
   {
     fprintf(stderr, "createScene: %s\n", mi_host_last_error());
     return false;
+  }
+  // the UI's "Recreate Tangents" / "Recreate Tangents - MikkTSpace" items as a start-up option (reference: src/ui_renderer.cpp:855-875)
+  if(m_recomputeTangents == 1 || m_recomputeTangents == 2)
+  {
+    const int added = mi_scene_recompute_tangents(m_resources.scene, 1, m_recomputeTangents == 2 ? 1 : 0);
+    if(added < 0)
+      fprintf(stderr, "recomputeTangents: %s\n", mi_host_last_error());
+    else if(m_recomputeTangents == 2)
+      printf("MikkTSpace: %d vertices added for tangent discontinuities\n", added);
   }
   // addSceneCamerasToWidget: first glTF camera -> manipulator (reference: src/gltf_camera_utils.hpp:62-90)
   mi_scene_camera(m_resources.scene, 0, &m_resources.camera);

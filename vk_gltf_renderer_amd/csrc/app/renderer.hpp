@@ -48,6 +48,7 @@ private:
   MiCamera            m_refCamera{};
   bool                m_haveRefCamera{false};
   int                 m_envSystem{0};
+  int                 m_recomputeTangents{0};
   // sequencer state (set through the registry by the script)
   int                 m_seqFrames{256}, m_seqAverages{64}, m_seqResetFrames{0}, m_seqRenderSystem{0}, m_gltfCamera{0};
   bool                m_seqFlag{false};

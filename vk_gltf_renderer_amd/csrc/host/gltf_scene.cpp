@@ -1,5 +1,6 @@
 // See gltf_scene.hpp for scope and reference citations.
 #include "gltf_scene.hpp"
+#include "mikktspace_tangents.hpp"
 
 #include <algorithm>
 #include <cfloat>
@@ -359,7 +360,134 @@ void createSimpleTangents(RenderPrimitiveData& d)
   }
 }
 
+// recomputeTangents(model, force, mikktspace = true) for one primitive (reference: createTangentsMikkTSpace,
+// src/gltf_create_tangent.cpp:512-612).  Per-corner Mikkelsen tangents; a corner's tangent is kept when it is not nearly parallel
+// to the vertex normal (|t . n| < 0.9) with the handedness flipped for this renderer's bitangent convention, else the fast tangent
+// of the normal (:169-187); corners of a vertex whose tangents are compatible (within ~11 degrees, same handedness, or one of them
+// degenerate: :194-218) share the vertex, the others get copies of it (:353-399), in corner order.  Returns the number of
+// vertices added.
+uint32_t recomputeTangentsMikk(RenderPrimitiveData& d)
+{
+  if(d.positions.empty() || d.normals.empty() || d.texCoords0.empty() || d.indices.size() < 3)
+    return 0;
+  const size_t nv = d.vertexCount, nc = d.indices.size() - d.indices.size() % 3;
+  for(size_t c = 0; c < nc; ++c)
+    if(d.indices[c] >= nv)
+      return 0;
+  std::vector<float> raw;
+  mikkTangentSpaces(d.positions.data(), d.normals.data(), d.texCoords0.data(), d.indices.data(), nc / 3, raw);
+  std::vector<float> corner(nc * 4);
+  for(size_t c = 0; c < nc; ++c)
+  {
+    const float* n = &d.normals[size_t(d.indices[c]) * 3];
+    const float* t = &raw[c * 4];
+    float*       o = &corner[c * 4];
+    if(std::fabs(t[0] * n[0] + t[1] * n[1] + t[2] * n[2]) < 0.9f)
+    {
+      o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = -t[3];
+    }
+    else
+      makeFastTangent(n, o);
+  }
+  auto compatible = [](const float* a, const float* b) {
+    const float la = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), lb = std::sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+    if(la < 1e-6f || lb < 1e-6f)
+      return true;
+    if((a[0] / la) * (b[0] / lb) + (a[1] / la) * (b[1] / lb) + (a[2] / la) * (b[2] / lb) < 0.98f)
+      return false;
+    return !(a[3] * b[3] < 0.0f);
+  };
+  // corners per vertex, in corner order
+  std::vector<uint32_t> first(nv + 1, 0), list(nc);
+  for(size_t c = 0; c < nc; ++c)
+    ++first[size_t(d.indices[c]) + 1];
+  for(size_t v = 0; v < nv; ++v)
+    first[v + 1] += first[v];
+  {
+    std::vector<uint32_t> fill(first.begin(), first.end() - 1);
+    for(size_t c = 0; c < nc; ++c)
+      list[fill[d.indices[c]]++] = uint32_t(c);
+  }
+  // vertex v keeps the tangent of its first corner; every later corner joins the first group (the vertex itself, then its copies in
+  // creation order) whose tangent it is compatible with, or founds a new copy
+  d.tangents.assign(nv * 4, 0.0f);
+  std::vector<uint32_t> copyOf;  // original vertex of every added vertex
+  std::vector<float>    copyTangent;
+  for(size_t v = 0; v < nv; ++v)
+  {
+    std::vector<uint32_t> groupVertex;  // vertex index of each tangent group of v
+    for(uint32_t k = first[v]; k < first[v + 1]; ++k)
+    {
+      const uint32_t c  = list[k];
+      const float*   t  = &corner[size_t(c) * 4];
+      bool           ok = false;
+      for(uint32_t g : groupVertex)
+      {
+        const float* gt = g < nv ? &d.tangents[size_t(g) * 4] : &copyTangent[size_t(g - nv) * 4];
+        if(compatible(gt, t))
+        {
+          d.indices[c] = g;
+          ok           = true;
+          break;
+        }
+      }
+      if(ok)
+        continue;
+      if(groupVertex.empty())
+      {
+        std::memcpy(&d.tangents[v * 4], t, 16);
+        groupVertex.push_back(uint32_t(v));
+      }
+      else
+      {
+        const uint32_t g = uint32_t(nv + copyOf.size());
+        copyOf.push_back(uint32_t(v));
+        copyTangent.insert(copyTangent.end(), t, t + 4);
+        groupVertex.push_back(g);
+        d.indices[c] = g;
+      }
+    }
+  }
+  // append the copies to every attribute stream
+  auto grow = [&](auto& stream, size_t width) {
+    if(stream.empty())
+      return;
+    stream.reserve((nv + copyOf.size()) * width);
+    for(uint32_t src : copyOf)
+      for(size_t k = 0; k < width; ++k)
+        stream.push_back(stream[size_t(src) * width + k]);
+  };
+  grow(d.positions, 3);
+  grow(d.normals, 3);
+  grow(d.texCoords0, 2);
+  grow(d.texCoords1, 2);
+  grow(d.colors, 1);
+  d.tangents.insert(d.tangents.end(), copyTangent.begin(), copyTangent.end());
+  d.vertexCount = uint32_t(nv + copyOf.size());
+  return uint32_t(copyOf.size());
+}
+
 }  // namespace
+
+uint32_t GltfScene::recomputeTangents(bool forceCreation, bool mikktspace)
+{
+  // reference: recomputeTangents / collectPrimitivesForTangents (src/gltf_create_tangent.cpp:619-677): primitives with positions,
+  // normals and TEXCOORD_0; those without a TANGENT stream only when creation is forced
+  uint32_t added = 0;
+  for(RenderPrimitiveData& d : m_primData)
+  {
+    if(d.positions.empty() || d.normals.empty() || d.texCoords0.empty())
+      continue;
+    if(d.tangents.empty() && !forceCreation)
+      continue;
+    if(mikktspace)
+      added += recomputeTangentsMikk(d);
+    else
+      createSimpleTangents(d);
+  }
+  finalizeDesc();  // the streams may have been reallocated
+  return added;
+}
 
 //----------------------------------------------------------------------------------------------------------------------
 // Scene files are untrusted input: every byte count / offset / element count read from the JSON goes through these two helpers

@@ -62,6 +62,10 @@ public:
   const std::vector<RenderCamera>&        cameras() const { return m_cameras; }
   const std::vector<TextureData>&         textures() const { return m_textures; }
   uint64_t                                numTriangles() const { return m_numTriangles; }
+  // recomputeTangents (reference: src/gltf_create_tangent.hpp:40; the UI's "Recreate Tangents" items): UV-gradient tangents, or
+  // Mikkelsen's with vertex splitting at tangent discontinuities.  Returns the number of vertices the splitting added; desc() is
+  // rebuilt (its pointers change).
+  uint32_t recomputeTangents(bool forceCreation, bool mikktspace);
   void bounds(float bmin[3], float bmax[3]) const;
   float boundsRadius() const;
 

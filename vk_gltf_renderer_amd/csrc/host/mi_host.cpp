@@ -1,5 +1,6 @@
 // C-ABI wrapper of the host scene front end (see include/mi_host.h).
 #include "mi_host.h"
+#include "mikktspace_tangents.hpp"
 
 #include <cmath>
 #include <cstring>
@@ -56,6 +57,50 @@ int mi_scene_load(const char* path, MiScene** out)
 void mi_scene_destroy(MiScene* scene)
 {
   delete scene;
+}
+int mi_scene_recompute_tangents(MiScene* scene, int forceCreation, int mikktspace)
+{
+  if(!scene)
+  {
+    g_hostError = "mi_scene_recompute_tangents: null scene";
+    return MI_PT_ERR_ARGUMENT;
+  }
+  try
+  {
+    return int(scene->scene.recomputeTangents(forceCreation != 0, mikktspace != 0));
+  }
+  catch(const std::exception& e)
+  {
+    g_hostError = e.what();
+    return MI_PT_ERR_IO;
+  }
+}
+int mi_mikktspace(const float* positions, const float* normals, const float* texCoords, uint32_t numVertices, const uint32_t* indices,
+                  uint32_t numTriangles, float* cornerTangents)
+{
+  if(!positions || !normals || !texCoords || !indices || !cornerTangents)
+  {
+    g_hostError = "mi_mikktspace: null argument";
+    return MI_PT_ERR_ARGUMENT;
+  }
+  for(size_t c = 0; c < size_t(numTriangles) * 3; ++c)
+    if(indices[c] >= numVertices)
+    {
+      g_hostError = "mi_mikktspace: index out of range";
+      return MI_PT_ERR_ARGUMENT;
+    }
+  try
+  {
+    std::vector<float> out;
+    mihost::mikkTangentSpaces(positions, normals, texCoords, indices, numTriangles, out);
+    std::memcpy(cornerTangents, out.data(), out.size() * sizeof(float));
+  }
+  catch(const std::exception& e)
+  {
+    g_hostError = e.what();
+    return MI_PT_ERR_IO;
+  }
+  return MI_PT_OK;
 }
 const MiPtSceneDesc* mi_scene_desc(const MiScene* scene)
 {

@@ -52,6 +52,14 @@ class Scene:
         _check_host(self._h.mi_scene_camera(self._p, index, C.byref(cam)))
         return cam
 
+    def recompute_tangents(self, force_creation=True, mikktspace=True):
+        """recomputeTangents of the reference (src/gltf_create_tangent.hpp:40); returns the vertices added by the MikkTSpace splitting.
+        The scene's desc changes: create PathTracers after this call."""
+        n = self._h.mi_scene_recompute_tangents(self._p, int(force_creation), int(mikktspace))
+        if n < 0:
+            _check_host(n)
+        return n
+
     def bounds(self):
         lo, hi = (C.c_float * 3)(), (C.c_float * 3)()
         self._h.mi_scene_bounds(self._p, lo, hi)
