@@ -189,7 +189,7 @@ def secondary_line(name, args, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="helmet", choices=sorted(WORKLOADS))
     ap.add_argument("--width", type=int, default=0)
