@@ -217,3 +217,34 @@ def test_scripted_sequencer(tmp_path, assets):
 def test_sequencer_argument_errors():
     assert _run(["--benchmark", "1", "--scenefile", "x.glb"]).returncode == 2  # no script
     assert _run(["--benchmark", "1", "--sequencestring", 'SEQUENCE "a" --sequenceframes 1']).returncode == 2  # no scene
+
+
+def test_png_and_jpeg_writers(tmp_path):
+    """The headless run saves eImgTonemapped as .png or, like the reference by default, .jpg (src/renderer.cpp:557-573): both writers on a
+    synthetic image (no GPU), read back with Pillow -- the PNG exactly, the baseline JPEG (quality 90, 4:4:4) within coding error -- and
+    the JPEG also with this repo's own decoder."""
+    PIL_Image = pytest.importorskip("PIL.Image")
+    prefix = str(tmp_path / "img")
+    r = _run(["--saveSelftest", prefix])
+    assert r.returncode == 0, r.stdout + r.stderr
+    yy, xx = np.mgrid[0:61, 0:83]
+    want = np.stack([(127 + 120 * np.sin(xx / 9.0)).astype(np.uint8), (127 + 120 * np.cos(yy / 7.0 + xx / 23.0)).astype(np.uint8), ((xx * 3 + yy * 2) % 256).astype(np.uint8)], -1)
+    png = np.asarray(PIL_Image.open(prefix + ".png").convert("RGBA"))
+    assert png.shape == (61, 83, 4) and (png[..., :3] == want).all() and (png[..., 3] == 255).all()
+    jim = PIL_Image.open(prefix + ".jpg")
+    assert jim.format == "JPEG" and jim.size == (83, 61) and jim.mode == "RGB"
+    jpg = np.asarray(jim).astype(int)
+    err = np.abs(jpg - want.astype(int))
+    assert err.mean() < 3.0 and np.percentile(err, 99) < 24, (err.mean(), np.percentile(err, 99))  # the sawtooth blue channel has hard edges
+    # and through the glTF front end's own JPEG decoder
+    from vk_gltf_renderer_amd import pathtracer as ptmod
+    from vk_gltf_renderer_amd import scenegen
+    b = scenegen.GlbBuilder()
+    t = b.texture(b.image_bytes(open(prefix + ".jpg", "rb").read(), "image/jpeg"))
+    b.material({"pbrMetallicRoughness": {"metallicRoughnessTexture": {"index": t}}})
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    b.node(mesh=b.mesh([b.primitive(pos, np.array([0, 1, 2]), material=0)]))
+    sc = ptmod.Scene(b.save(str(tmp_path / "j.glb")))
+    tex = sc.desc.contents.textures[0]
+    own = np.ctypeslib.as_array(tex.levels[0], shape=(61, 83, 4)).astype(int)
+    assert np.abs(own[..., :3] - jpg).max() <= 4  # stb-style reconstruction vs libjpeg: rounding only

@@ -4,6 +4,8 @@
 // (docs/benchmarking.md:16-23).  Positional arguments ending in .gltf/.glb/.hdr are accepted like in the reference.
 #include <cstdio>
 #include <algorithm>
+#include <cmath>
+#include <vector>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -16,7 +18,7 @@ int main(int argc, char** argv)
   ParameterRegistry registry;
   std::string       sceneFile, hdrFile = "std_env.hdr", outputFile;
   int               size[2] = {1280, 720};
-  std::string       sequenceFile, sequenceString;
+  std::string       sequenceFile, sequenceString, saveSelftest;
   int               frames = 1, framesInFlight = 32;
   bool              headless = false, vvl = false, selftest = false, benchmark = false;
   registry.add("scenefile", "Input scene filename (.gltf / .glb)", &sceneFile);
@@ -30,6 +32,7 @@ int main(int argc, char** argv)
   registry.add("sequencefile", "Benchmark script (.cfg) with SEQUENCE blocks", &sequenceFile);
   registry.add("sequencestring", "Benchmark script given on the command line", &sequenceString);
   registry.add("vvl", "accepted and ignored (Vulkan validation layers)", &vvl, true);
+  registry.add("saveSelftest", "Write <prefix>.png and <prefix>.jpg of a synthetic image (writer check, no GPU needed)", &saveSelftest);
   registry.add("benchmarkSelftest", "Print a fabricated headless log (format check, no GPU needed)", &selftest, true);
   app.registerParameters(&registry);
   std::vector<std::string> positional;
@@ -48,6 +51,21 @@ int main(int argc, char** argv)
       hdrFile = p;
     else
       sceneFile = p;
+  }
+  if(!saveSelftest.empty())
+  {
+    const int                  w = 83, h = 61;  // not multiples of 8: exercises the edge blocks
+    std::vector<unsigned char> img(size_t(w) * h * 4);
+    for(int y = 0; y < h; ++y)
+      for(int x = 0; x < w; ++x)
+      {
+        unsigned char* p = &img[(size_t(y) * w + x) * 4];
+        p[0] = (unsigned char)(127 + 120 * std::sin(x / 9.0));
+        p[1] = (unsigned char)(127 + 120 * std::cos(y / 7.0 + x / 23.0));
+        p[2] = (unsigned char)((x * 3 + y * 2) % 256);
+        p[3] = 255;
+      }
+    return (GltfRenderer::savePng(saveSelftest + ".png", img.data(), w, h) && GltfRenderer::saveJpg(saveSelftest + ".jpg", img.data(), w, h, 90)) ? 0 : 1;
   }
   if(selftest)
   {

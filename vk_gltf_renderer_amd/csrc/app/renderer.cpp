@@ -335,6 +335,213 @@ bool GltfRenderer::savePng(const std::string& path, const unsigned char* rgba8, 
   return true;
 }
 
+// Baseline JPEG (ITU T.81: sequential DCT, Huffman coding, 8-bit, YCbCr 4:4:4, the Annex K example tables; quantisation tables
+// scaled by `quality` the IJG way) -- the reference's default headless output is `<executable>.jpg` (src/renderer.cpp:557-573,
+// written by nvapp's image writer); here it is written directly.
+bool GltfRenderer::saveJpg(const std::string& path, const unsigned char* rgba8, int w, int h, int quality)
+{
+  static const uint8_t zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                     41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                     30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+  static const uint8_t baseQ[2][64] = {{16, 11, 10, 16, 24,  40,  51,  61,  12, 12, 14, 19, 26,  58,  60,  55,  14, 13, 16, 24, 40,  57,
+                                        69, 56, 14, 17, 22,  29,  51,  87,  80, 62, 18, 22, 37,  56,  68,  109, 103, 77, 24, 35, 55,  64,
+                                        81, 104, 113, 92, 49, 64,  78,  87,  103, 121, 120, 101, 72, 92,  95,  98,  112, 100, 103, 99},
+                                       {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99,
+                                        99, 99, 47, 66, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+                                        99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99}};
+  // Huffman table specifications (number of codes of each length 1..16, then the symbols in code order)
+  static const uint8_t dcBits[2][16] = {{0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0}, {0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0}};
+  static const uint8_t dcVals[12]    = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+  static const uint8_t acBits[2][16] = {{0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d}, {0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77}};
+  static const uint8_t acVals[2][162] = {
+      {0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1,
+       0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26,
+       0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56,
+       0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85,
+       0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa,
+       0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6,
+       0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9,
+       0xfa},
+      {0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42,
+       0x91, 0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19,
+       0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55,
+       0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83,
+       0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8,
+       0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4,
+       0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9,
+       0xfa}};
+  if(w <= 0 || h <= 0 || w > 65535 || h > 65535)
+    return false;
+  // the symbols of an AC table must be exactly end-of-block, the 16-zero run and (run, size) for size 1..10: a typing slip in the
+  // lists above would otherwise surface as a corrupt file for some image only
+  for(int t = 0; t < 2; ++t)
+  {
+    bool seen[256] = {};
+    for(uint8_t v : acVals[t])
+      seen[v] = true;
+    for(int v = 0; v < 256; ++v)
+      if(seen[v] != (v == 0x00 || v == 0xf0 || ((v & 15) >= 1 && (v & 15) <= 10)))
+        return false;
+  }
+  quality             = std::min(std::max(quality, 1), 100);
+  const int scale     = quality < 50 ? 5000 / quality : 200 - 2 * quality;
+  uint8_t   q[2][64];
+  for(int t = 0; t < 2; ++t)
+    for(int i = 0; i < 64; ++i)
+      q[t][i] = uint8_t(std::min(std::max((int(baseQ[t][i]) * scale + 50) / 100, 1), 255));
+  // canonical codes from the specifications
+  struct Code
+  {
+    uint16_t code[256];
+    uint8_t  len[256];
+  };
+  auto build = [](const uint8_t* bits, const uint8_t* vals, Code& c) {
+    memset(&c, 0, sizeof(c));
+    uint16_t code = 0;
+    int      k    = 0;
+    for(int l = 1; l <= 16; ++l)
+    {
+      for(int i = 0; i < bits[l - 1]; ++i, ++k)
+      {
+        c.code[vals[k]] = code++;
+        c.len[vals[k]]  = uint8_t(l);
+      }
+      code <<= 1;
+    }
+  };
+  Code dc[2], ac[2];
+  for(int t = 0; t < 2; ++t)
+  {
+    build(dcBits[t], dcVals, dc[t]);
+    build(acBits[t], acVals[t], ac[t]);
+  }
+  std::vector<uint8_t> out;
+  auto put16 = [&](int v) { out.push_back(uint8_t(v >> 8)); out.push_back(uint8_t(v)); };
+  out.push_back(0xff); out.push_back(0xd8);                                                 // SOI
+  const uint8_t app0[] = {0xff, 0xe0, 0, 16, 'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0};  // JFIF 1.1, aspect 1:1
+  out.insert(out.end(), app0, app0 + sizeof(app0));
+  for(int t = 0; t < 2; ++t)  // DQT (tables are stored in zigzag order)
+  {
+    out.push_back(0xff); out.push_back(0xdb); put16(67); out.push_back(uint8_t(t));
+    for(int i = 0; i < 64; ++i)
+      out.push_back(q[t][zigzag[i]]);
+  }
+  out.push_back(0xff); out.push_back(0xc0); put16(17); out.push_back(8); put16(h); put16(w); out.push_back(3);  // SOF0
+  for(int c = 0; c < 3; ++c)
+  {
+    out.push_back(uint8_t(c + 1)); out.push_back(0x11); out.push_back(uint8_t(c ? 1 : 0));
+  }
+  for(int t = 0; t < 2; ++t)  // DHT: DC then AC of each table pair
+  {
+    out.push_back(0xff); out.push_back(0xc4); put16(2 + 1 + 16 + 12); out.push_back(uint8_t(t));
+    out.insert(out.end(), dcBits[t], dcBits[t] + 16);
+    out.insert(out.end(), dcVals, dcVals + 12);
+    out.push_back(0xff); out.push_back(0xc4); put16(2 + 1 + 16 + 162); out.push_back(uint8_t(0x10 | t));
+    out.insert(out.end(), acBits[t], acBits[t] + 16);
+    out.insert(out.end(), acVals[t], acVals[t] + 162);
+  }
+  const uint8_t sos[] = {0xff, 0xda, 0, 12, 3, 1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0};
+  out.insert(out.end(), sos, sos + sizeof(sos));
+  // entropy-coded data
+  uint32_t acc = 0;
+  int      nacc = 0;
+  auto emit = [&](uint32_t code, int len) {
+    acc = (acc << len) | (code & ((1u << len) - 1u));
+    nacc += len;
+    while(nacc >= 8)
+    {
+      const uint8_t b = uint8_t(acc >> (nacc - 8));
+      out.push_back(b);
+      if(b == 0xff)
+        out.push_back(0);  // byte stuffing
+      nacc -= 8;
+    }
+  };
+  float cosTab[8][8];
+  for(int u = 0; u < 8; ++u)
+    for(int x = 0; x < 8; ++x)
+      cosTab[u][x] = float(std::cos((2 * x + 1) * u * 3.14159265358979323846 / 16.0)) * (u == 0 ? float(std::sqrt(0.125)) : 0.5f);
+  int prevDc[3] = {0, 0, 0};
+  for(int by = 0; by < h; by += 8)
+    for(int bx = 0; bx < w; bx += 8)
+    {
+      float block[3][64];
+      for(int y = 0; y < 8; ++y)
+        for(int x = 0; x < 8; ++x)
+        {
+          const unsigned char* p = rgba8 + (size_t(std::min(by + y, h - 1)) * size_t(w) + size_t(std::min(bx + x, w - 1))) * 4;  // edge replication
+          const float          r = p[0], g = p[1], b = p[2];
+          block[0][y * 8 + x]    = 0.299f * r + 0.587f * g + 0.114f * b - 128.0f;
+          block[1][y * 8 + x]    = -0.168736f * r - 0.331264f * g + 0.5f * b;
+          block[2][y * 8 + x]    = 0.5f * r - 0.418688f * g - 0.081312f * b;
+        }
+      for(int c = 0; c < 3; ++c)
+      {
+        const int t = c ? 1 : 0;
+        float     tmp[64], coef[64];
+        for(int y = 0; y < 8; ++y)  // rows, then columns
+          for(int u = 0; u < 8; ++u)
+          {
+            float s = 0;
+            for(int x = 0; x < 8; ++x)
+              s += block[c][y * 8 + x] * cosTab[u][x];
+            tmp[y * 8 + u] = s;
+          }
+        for(int u = 0; u < 8; ++u)
+          for(int v = 0; v < 8; ++v)
+          {
+            float s = 0;
+            for(int y = 0; y < 8; ++y)
+              s += tmp[y * 8 + u] * cosTab[v][y];
+            coef[v * 8 + u] = s;
+          }
+        int zz[64];
+        for(int i = 0; i < 64; ++i)
+          zz[i] = int(std::lround(coef[zigzag[i]] / float(q[t][zigzag[i]])));
+        auto category = [](int v) { int a = v < 0 ? -v : v, n = 0; while(a) { ++n; a >>= 1; } return n; };
+        auto bitsOf   = [](int v, int n) { return uint32_t(v < 0 ? v + (1 << n) - 1 : v); };
+        const int diff = zz[0] - prevDc[c];
+        prevDc[c]      = zz[0];
+        int n          = category(diff);
+        emit(dc[t].code[n], dc[t].len[n]);
+        if(n)
+          emit(bitsOf(diff, n), n);
+        int run = 0, last = 63;
+        while(last > 0 && zz[last] == 0)
+          --last;
+        for(int i = 1; i <= last; ++i)
+        {
+          if(zz[i] == 0)
+          {
+            ++run;
+            continue;
+          }
+          while(run > 15)
+          {
+            emit(ac[t].code[0xf0], ac[t].len[0xf0]);
+            run -= 16;
+          }
+          n             = std::min(category(zz[i]), 10);
+          const int val = std::min(std::max(zz[i], -1023), 1023);
+          emit(ac[t].code[(run << 4) | n], ac[t].len[(run << 4) | n]);
+          emit(bitsOf(val, n), n);
+          run = 0;
+        }
+        if(last < 63)
+          emit(ac[t].code[0x00], ac[t].len[0x00]);  // end of block
+      }
+    }
+  if(nacc)
+    emit(0x7f, 8 - nacc);  // pad the last byte with ones
+  out.push_back(0xff); out.push_back(0xd9);  // EOI
+  FILE* f = fopen(path.c_str(), "wb");
+  if(!f)
+    return false;
+  const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+  fclose(f);
+  return ok;
+}
+
 bool GltfRenderer::saveHdr(const std::string& path, const float* rgba, int w, int h)
 {
   FILE* f = fopen(path.c_str(), "wb");
@@ -376,7 +583,8 @@ void GltfRenderer::saveHeadlessOutputImage()
   const int w = int(m_resources.renderSize.width), h = int(m_resources.renderSize.height);
   if(w <= 0 || !m_pathTracer.handle())
     return;
-  std::string out = m_resources.headlessOutputPath.empty() ? std::string("mi_gltf_renderer.png") : m_resources.headlessOutputPath;
+  // default: <executable name>.jpg in the working directory (reference: src/renderer.cpp:559-561)
+  std::string out = m_resources.headlessOutputPath.empty() ? std::string("mi_gltf_renderer.jpg") : m_resources.headlessOutputPath;
   if(out.size() > 4 && out.substr(out.size() - 4) == ".hdr")
   {  // eImgRendered as it is (reference: src/ui_renderer.cpp:1187-1195)
     std::vector<float> rgba(size_t(w) * size_t(h) * 4);
@@ -400,7 +608,8 @@ void GltfRenderer::saveHeadlessOutputImage()
     }
     for(size_t i = 3; i < ldr.size(); i += 4)
       ldr[i] = 255;  // saved opaque, like the reference's screenshot path
-    if(!savePng(out, ldr.data(), w, h))
+    const bool jpeg = (out.size() > 4 && out.substr(out.size() - 4) == ".jpg") || (out.size() > 5 && out.substr(out.size() - 5) == ".jpeg");
+    if(!(jpeg ? saveJpg(out, ldr.data(), w, h, 90) : savePng(out, ldr.data(), w, h)))
       return;
   }
   printf("Saved headless output image: %s\n", out.c_str());

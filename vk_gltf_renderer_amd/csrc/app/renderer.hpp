@@ -34,6 +34,7 @@ public:
 
   // save helpers: PNG via zlib, Radiance .hdr dump (the tonemapper itself runs on the device: mi_pt_tonemap)
   static bool savePng(const std::string& path, const unsigned char* rgba8, int w, int h);
+  static bool saveJpg(const std::string& path, const unsigned char* rgba8, int w, int h, int quality);
   static bool saveHdr(const std::string& path, const float* rgba, int w, int h);
 
 private:
