@@ -46,6 +46,17 @@ MI_PT_API int                  mi_scene_recompute_tangents(MiScene* scene, int f
 MI_PT_API int                  mi_mikktspace(const float* positions, const float* normals, const float* texCoords, uint32_t numVertices,
                                              const uint32_t* indices, uint32_t numTriangles, float* cornerTangents);
 
+/* Keyframe animation of node transforms (reference: nvvkgltf::AnimationSystem, src/gltf_scene_animation.hpp:93-122; AnimationInfo
+ * src/gltf_scene.hpp:159-189; driven per frame by GltfRenderer::updateAnimation, src/renderer.cpp:2065-2170).  Translation /
+ * rotation / scale channels with LINEAR, STEP and CUBICSPLINE samplers; morph weights, skins and KHR_animation_pointer are not
+ * evaluated.  mi_scene_update_animation poses the scene at `time` (seconds on the clip's own axis, [start, end] as reported by
+ * mi_scene_animation_info) and rewrites the matrices of the render-node table and the light placements of mi_scene_desc() in
+ * place -- same pointers, same counts -- ready for mi_pt_update_render_nodes() + mi_pt_update_lights().  Returns 1 when
+ * something moved, 0 when no channel covered `time`, or a negative MiPtStatus. */
+MI_PT_API int                  mi_scene_num_animations(const MiScene* scene);
+MI_PT_API int                  mi_scene_animation_info(const MiScene* scene, int index, float* start, float* end, char* name, int nameCapacity);
+MI_PT_API int                  mi_scene_update_animation(MiScene* scene, int index, float time);
+
 MI_PT_API int                    mi_hdr_load(const char* path, MiHdr** out);
 MI_PT_API int                    mi_hdr_from_pixels(int width, int height, const float* rgb, MiHdr** out);
 MI_PT_API void                   mi_hdr_destroy(MiHdr* hdr);

@@ -169,6 +169,12 @@ MI_PT_API int mi_pt_create(const MiPtSceneDesc* scene, const MiPtCreateOptions* 
  * the caller restarts accumulation (MI_PT_FIRST_FRAME) like the reference does after a scene change. */
 MI_PT_API int mi_pt_update_render_nodes(MiPt* pt, const MiGltfRenderNode* renderNodes, int numRenderNodes, const uint8_t* renderNodeVisible);
 
+/* replaces the light half of the per-frame scene sync of animated scenes: SceneVk::syncFromScene(eSyncLights) -> uploadLights
+ * (reference: src/gltf_scene_vk.hpp:96-103, called from GltfRenderer::updateAnimation, src/renderer.cpp:2118-2131).  Takes the
+ * light table again (same length as at creation; placement, colour, intensity, cone may have changed).  Synchronises with the
+ * work in flight; the caller restarts accumulation. */
+MI_PT_API int mi_pt_update_lights(MiPt* pt, const MiGltfLight* lights, int numLights);
+
 /* replaces PathTracer::onDetach (reference: src/renderer_base.hpp:40) */
 MI_PT_API int mi_pt_destroy(MiPt* pt);
 

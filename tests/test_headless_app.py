@@ -248,3 +248,43 @@ def test_png_and_jpeg_writers(tmp_path):
     tex = sc.desc.contents.textures[0]
     own = np.ctypeslib.as_array(tex.levels[0], shape=(61, 83, 4)).astype(int)
     assert np.abs(own[..., :3] - jpg).max() <= 4  # stb-style reconstruction vs libjpeg: rounding only
+
+
+@pytest.mark.gpu
+def test_animation_switches(tmp_path, assets):
+    """--animTime poses the clip once and accumulates the still scene; --animStep advances the clip every app frame and restarts
+    the accumulation like GltfRenderer::onRender does after updateAnimation (reference: src/renderer.cpp:657-662, :2065-2170).
+    Both are checked against the C-ABI path on the scene posed through mi_scene_update_animation."""
+    import parity_util as pu
+    from vk_gltf_renderer_amd import pathtracer as ptmod
+    from vk_gltf_renderer_amd import scenegen
+    glb = scenegen.scene_animated(str(tmp_path / "sculpture.glb"))
+    hdr = os.path.join(assets, "std_env.hdr")
+    common = ["--headless", "--size", "192", "128", "--scenefile", glb, "--hdrfile", hdr, "--ptSamples", "1", "--ptAdaptiveSampling", "0", "--envSystem", "1",
+              "--ptMaxDepth", "4"]
+
+    def saved(path):
+        h = ptmod.HdrEnvironment(path=str(path))  # owns the pixels: keep it alive until they are copied
+        e = h.env.contents
+        return np.ctypeslib.as_array(e.rgba, shape=(e.height, e.width, 4))[..., :3].copy()
+
+    def expected(time, frames):
+        st = pu.Setup(glb, 192, 128, hdr_path=hdr, max_depth=4)
+        assert st.scene.update_animation(0, time)
+        return pu.render_gpu(st, frames, collect_counters=False)["accum"][..., :3]
+
+    out = tmp_path / "scrub.hdr"
+    r = _run(common + ["--frames", "6", "--maxFrames", "6", "--animTime", "0.83", "--output", str(out)])
+    assert r.returncode == 0, r.stdout + r.stderr
+    want = expected(0.83, 6)
+    assert np.abs(saved(out) - want).max() <= want.max() / 128 + 1e-3
+    still = tmp_path / "still.hdr"
+    assert _run(common + ["--frames", "6", "--maxFrames", "6", "--output", str(still)]).returncode == 0
+    assert np.abs(saved(still) - want).max() > 0.05  # the rest pose is another image
+
+    out = tmp_path / "play.hdr"
+    r = _run(common + ["--frames", "5", "--maxFrames", "100", "--animStep", "0.25", "--output", str(out)])
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert _records(r.stdout)[-1]["frames"] == 5
+    want = expected(1.25, 1)  # five steps of 0.25 s from the clip's start; every step restarts the accumulation
+    assert np.abs(saved(out) - want).max() <= want.max() / 128 + 1e-3

@@ -161,6 +161,9 @@ HOST_SYMBOLS = {
     "mi_hdr_load": (i32, [C.c_char_p, P(VP)]),
     "mi_scene_recompute_tangents": (i32, [VP, i32, i32]),
     "mi_mikktspace": (i32, [P(f32), P(f32), P(f32), u32, P(u32), u32, P(f32)]),
+    "mi_scene_num_animations": (i32, [VP]),
+    "mi_scene_animation_info": (i32, [VP, i32, P(f32), P(f32), C.c_char_p, i32]),
+    "mi_scene_update_animation": (i32, [VP, i32, f32]),
     "mi_hdr_from_pixels": (i32, [i32, i32, P(f32), P(VP)]),
     "mi_hdr_destroy": (None, [VP]),
     "mi_hdr_env": (P(MiPtEnvironment), [VP]),
@@ -203,6 +206,7 @@ PT_SYMBOLS = {
     "mi_pt_last_error": (C.c_char_p, []),
     "mi_pt_version": (C.c_char_p, []),
     "mi_pt_update_render_nodes": (i32, [VP, P(MiGltfRenderNode), i32, P(C.c_uint8)]),
+    "mi_pt_update_lights": (i32, [VP, P(MiGltfLight), i32]),
 }
 
 

@@ -39,6 +39,12 @@ void GltfRenderer::registerParameters(ParameterRegistry* r)
   r->add("infinitePlaneDistance", "Ground plane height", &s.infinitePlaneDistance);
   r->add("device", "HIP device ordinal", &m_resources.device);
   r->add("recomputeTangents", "Recreate all tangents after loading: [off:0, UV gradient:1, MikkTSpace:2]", &m_recomputeTangents);
+  // animation playback (the reference drives AnimationControl from its UI strip only; these switches are this port's headless handle)
+  AnimationControl& ac = m_resources.animationControl;
+  r->add("animation", "Animation clip index", &ac.currentAnimation);
+  r->add("animStep", "Animation: seconds advanced per app frame (0 = paused); every step restarts the accumulation", &ac.stepSeconds);
+  r->add("animSpeed", "Animation: playback multiplier", &ac.speed);
+  r->add("animTime", "Animation: pose the clip at this time once (scrub), then render the still scene", &ac.scrubTime);
   // tonemapper (reference: src/renderer.cpp:173-179 -- same names, same members)
   MiTonemapperData& tm = m_resources.tonemapperData;
   r->add("tmMethod", "Tonemapper method: [Filmic:0, Uncharted:1, Clip:2, ACES:3, AgX:4, KhronosPBR:5]", &tm.method);
@@ -242,9 +248,72 @@ BenchmarkController::HeadlessFrameInfo GltfRenderer::benchmarkFrameInfo(uint32_t
   return info;
 }
 
+// Update the scene animation (reference: src/renderer.cpp:2065-2170): advance the clip, evaluate its channels, recompute the world
+// matrices, sync render nodes and lights to the device, refresh the acceleration structure.  Returns true when the scene changed.
+bool GltfRenderer::updateAnimation()
+{
+  AnimationControl& ac = m_resources.animationControl;
+  MiScene*          sc = m_resources.scene;
+  if(!sc || !m_pathTracer.handle())
+    return false;
+  const int nAnim = mi_scene_num_animations(sc);
+  if(nAnim <= 0)
+    return false;
+  if(ac.currentAnimation < 0 || ac.currentAnimation >= nAnim)
+    ac.currentAnimation = 0;
+  float start = 0, end = 0;
+  mi_scene_animation_info(sc, ac.currentAnimation, &start, &end, nullptr, 0);
+  if(!(end > start))  // hasPlayableAnimation: a clip with a positive duration
+    return false;
+  if(m_animClip != ac.currentAnimation)
+  {
+    m_animClip = ac.currentAnimation;
+    m_animTime = start;
+  }
+  if(ac.scrubTime >= 0.0f)  // scrubTo: clamp, pause, evaluate once
+  {
+    m_animTime   = std::min(std::max(ac.scrubTime, start), end);
+    ac.scrubTime = -1.0f;
+    ac.play      = false;
+    ac.runOnce   = true;
+  }
+  else if(ac.stepSeconds != 0.0f)
+    ac.play = true;
+  if(!ac.doAnimation())
+    return false;
+  if(ac.isReset())
+    m_animTime = start;
+  else if(ac.play)
+  {
+    // AnimationInfo::incrementTime with loop = true (reference: src/gltf_scene.hpp:166-188)
+    const float duration = end - start;
+    float       wrapped  = std::fmod(m_animTime + ac.deltaTime() - start, duration);
+    if(wrapped < 0.0f)
+      wrapped += duration;
+    m_animTime = start + wrapped;
+  }
+  ac.clearStates();
+  if(ac.stepSeconds == 0.0f)
+    ac.play = false;
+  if(mi_scene_update_animation(sc, ac.currentAnimation, m_animTime) <= 0)
+    return false;
+  const MiPtSceneDesc* d = mi_scene_desc(sc);
+  if(mi_pt_update_render_nodes(m_pathTracer.handle(), d->renderNodes, d->numRenderNodes, d->renderNodeVisible) != MI_PT_OK
+     || mi_pt_update_lights(m_pathTracer.handle(), d->lights, d->numLights) != MI_PT_OK)
+  {
+    fprintf(stderr, "updateAnimation: %s\n", mi_pt_last_error());
+    return false;
+  }
+  return true;
+}
+
 void GltfRenderer::onRender(StreamHandle cmd, bool headless, uint32_t headlessFrames, int batch)
 {
   m_benchmark.beginHeadlessTimingIfNeeded(headless, benchmarkFrameInfo(headlessFrames));
+  if(updateAnimation())  // reference: src/renderer.cpp:657-662
+    resetFrame();
+  if(m_resources.animationControl.play)
+    batch = 1;  // the scene changes between app frames
   // `batch` app frames in one go (headless runs, --framesInFlight): the library traces them as one set of wavefront launches and
   // folds them into the accumulator in frame order -- the image of `batch` successive onRender calls, bit for bit
   // (mi_pt_render_frames).  Only frames that would all accumulate (below maxFrames) are batched.

@@ -20,6 +20,7 @@ public:
   void onAttach(const Extent2D& size);
   void onRender(StreamHandle cmd, bool headless, uint32_t headlessFrames, int batch = 1);  // reference: src/renderer.cpp:588-742
   void onLastHeadlessFrame(uint32_t headlessFrames);                        // reference: src/renderer.cpp:762-767
+  bool updateAnimation();                                                    // reference: :2065-2170
   void resetFrame() { m_resources.frameCount = -1; }                        // reference: :1939-1942
   // Scripted benchmark sequences (reference: nvutils::ParameterSequencer driven from src/main.cpp:85-160 with --benchmark 1
   // --sequencefile / --sequencestring; docs/benchmarking.md "Scripted sequencer"): every `SEQUENCE "name"` block sets parameters
@@ -50,6 +51,8 @@ private:
   bool                m_haveRefCamera{false};
   int                 m_envSystem{0};
   int                 m_recomputeTangents{0};
+  int                 m_animClip{-1};
+  float               m_animTime{0.0f};
   // sequencer state (set through the registry by the script)
   int                 m_seqFrames{256}, m_seqAverages{64}, m_seqResetFrames{0}, m_seqRenderSystem{0}, m_gltfCamera{0};
   bool                m_seqFlag{false};

@@ -29,6 +29,24 @@ struct Settings  // reference defaults: src/resources.hpp:82-131
   float         shadowCatcherDarkness  = 0.0f;
 };
 
+// reference: AnimationControl (src/ui_animation.hpp:51-85).  Interactive playback there advances by the UI's frame time; a
+// headless run here advances by a fixed `stepSeconds` per app frame so that a run is reproducible (0 = paused), or is scrubbed
+// to `scrubTime` once (scrubTo: pause + one evaluation).
+struct AnimationControl
+{
+  bool  play             = false;
+  bool  runOnce          = false;
+  bool  reset            = false;
+  float speed            = 1.0f;
+  int   currentAnimation = 0;
+  float stepSeconds      = 0.0f;
+  float scrubTime        = -1.0f;
+  bool  doAnimation() const { return play || runOnce || reset; }
+  float deltaTime() const { return (runOnce ? 1.0f / 60.0f : stepSeconds) * speed; }
+  bool  isReset() const { return reset; }
+  void  clearStates() { runOnce = reset = false; }
+};
+
 struct Resources
 {
   MiScene*                scene{nullptr};  // nvvkgltf::Scene + SceneVk tables (libmi_host)
@@ -42,4 +60,5 @@ struct Resources
   int                     frameCount{0};
   int                     device{0};
   Settings                settings;
+  AnimationControl        animationControl;
 };

@@ -690,6 +690,18 @@ int mi_pt_update_render_nodes(MiPt* pt, const MiGltfRenderNode* renderNodes, int
   return buildAcceleration(pt);
 }
 
+int mi_pt_update_lights(MiPt* pt, const MiGltfLight* lights, int numLights)
+{
+  if(!pt || numLights != pt->scene.numLights || (numLights > 0 && !lights))
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_update_lights: the light count must be the one the instance was created with");
+  if(numLights == 0)
+    return MI_PT_OK;
+  HIP_TRY(hipSetDevice(pt->device));
+  HIP_TRY(hipDeviceSynchronize());  // frames in flight still sample the old table
+  HIP_TRY(hipMemcpy(pt->lights.ptr, lights, sizeof(MiGltfLight) * size_t(numLights), hipMemcpyHostToDevice));
+  return MI_PT_OK;
+}
+
 int mi_pt_destroy(MiPt* pt)
 {
   if(!pt)

@@ -1081,7 +1081,7 @@ void GltfScene::traverse(int nodeID, const mx::mat4& parent, bool parentVisible,
   const Value& node = m_doc["nodes"][size_t(nodeID)];
   if(!node.isObject())
     return;
-  mx::mat4 world = mx::mul(parent, nodeLocalMatrix(node));
+  mx::mat4 world = mx::mul(parent, localMatrix(nodeID));
   // KHR_node_visibility cascades (reference: src/gltf_scene.cpp:1907-1948)
   bool         visible = parentVisible;
   const Value& vis     = ext(node, "KHR_node_visibility");
@@ -1098,12 +1098,7 @@ void GltfScene::traverse(int nodeID, const mx::mat4& parent, bool parentVisible,
     {
       const Value& gl = lights[size_t(li)];
       MiGltfLight  info{};
-      info.position[0]  = world.at(3, 0);
-      info.position[1]  = world.at(3, 1);
-      info.position[2]  = world.at(3, 2);
-      info.direction[0] = -world.at(2, 0);
-      info.direction[1] = -world.at(2, 1);
-      info.direction[2] = -world.at(2, 2);
+      placeLight(info, world);
       info.innerAngle   = getFloat(gl["spot"], "innerConeAngle", 0.0f);
       info.outerAngle   = getFloat(gl["spot"], "outerConeAngle", 0.7853981633974483f);
       info.color[0] = info.color[1] = info.color[2] = 1.0f;
@@ -1123,6 +1118,7 @@ void GltfScene::traverse(int nodeID, const mx::mat4& parent, bool parentVisible,
         info.angularSizeOrInvRange = range > 0.0 ? 1.0f / float(range) : 0.0f;
       }
       m_lights.push_back(info);
+      m_lightNode.push_back(nodeID);
     }
   }
 
@@ -1182,7 +1178,7 @@ void GltfScene::traverse(int nodeID, const mx::mat4& parent, bool parentVisible,
             }
       }
       materialID = std::min(materialID, int(m_materials.size()) - 1);
-      auto addNode = [&](const mx::mat4& w) {
+      auto addNode = [&](const mx::mat4& w, int instance) {
         MiGltfRenderNode rn{};
         memcpy(rn.objectToWorld, w.m, sizeof(rn.objectToWorld));
         mx::mat4 inv = mx::inverse(w);  // reference: src/gltf_scene_vk.cpp:493-501
@@ -1191,13 +1187,14 @@ void GltfScene::traverse(int nodeID, const mx::mat4& parent, bool parentVisible,
         rn.renderPrimID = rprimID;
         m_renderNodes.push_back(rn);
         m_renderNodeVisible.push_back(visible ? 1 : 0);
+        m_renderNodeSource.push_back({nodeID, instance});
         m_numTriangles += m_primData[size_t(rprimID)].indices.size() / 3;
       };
       if(instances)
-        for(const mx::mat4& local : *instances)
-          addNode(mx::mul(world, local));
+        for(size_t i = 0; i < instances->size(); ++i)
+          addNode(mx::mul(world, (*instances)[i]), int(i));
       else
-        addNode(world);
+        addNode(world, -1);
     }
   }
 
@@ -1206,12 +1203,35 @@ void GltfScene::traverse(int nodeID, const mx::mat4& parent, bool parentVisible,
     traverse(children[c].integer(), world, visible, primMap);
 }
 
+mx::mat4 GltfScene::localMatrix(int nodeID) const
+{
+  // a node that carries "matrix" keeps it, animated or not (reference: src/tinygltf_utils.cpp:641-654)
+  const Value& m = m_doc["nodes"][size_t(nodeID)]["matrix"];
+  if(size_t(nodeID) < m_nodePose.size() && m_nodePose[size_t(nodeID)].animated && !(m.isArray() && m.arr.size() == 16))
+  {
+    const NodePose& p = m_nodePose[size_t(nodeID)];
+    return mx::mul(mx::mul(mx::translate({p.t[0], p.t[1], p.t[2]}), mx::fromQuat(p.q[0], p.q[1], p.q[2], p.q[3])), mx::scale({p.s[0], p.s[1], p.s[2]}));
+  }
+  return nodeLocalMatrix(m_doc["nodes"][size_t(nodeID)]);
+}
+
+// reference: src/gltf_scene.cpp:2269-2300 (position = the node's origin, direction = its -Z axis)
+void GltfScene::placeLight(MiGltfLight& info, const mx::mat4& world) const
+{
+  info.position[0]  = world.at(3, 0);
+  info.position[1]  = world.at(3, 1);
+  info.position[2]  = world.at(3, 2);
+  info.direction[0] = -world.at(2, 0);
+  info.direction[1] = -world.at(2, 1);
+  info.direction[2] = -world.at(2, 2);
+}
+
 void GltfScene::traverseCameras(int nodeID, const mx::mat4& parent)  // reference: src/gltf_scene.cpp:2215-2267
 {
   const Value& node = m_doc["nodes"][size_t(nodeID)];
   if(!node.isObject())
     return;
-  mx::mat4 world = mx::mul(parent, nodeLocalMatrix(node));
+  mx::mat4 world = mx::mul(parent, localMatrix(nodeID));
   int      camID = getInt(node, "camera", -1);
   if(camID >= 0 && size_t(camID) < m_doc["cameras"].size())
   {
@@ -1286,6 +1306,11 @@ bool GltfScene::parse(const std::string& baseDir)  // reference: src/gltf_scene.
   m_lights.clear();
   m_cameras.clear();
   m_gpuInstanceLocalMatrices.clear();
+  m_renderNodeSource.clear();
+  m_lightNode.clear();
+  m_roots.clear();
+  m_animations.clear();
+  m_nodePose.assign(m_doc["nodes"].size(), NodePose{});
   m_numTriangles = 0;
 
   if(m_doc["nodes"].size() == 0)
@@ -1319,6 +1344,8 @@ bool GltfScene::parse(const std::string& baseDir)  // reference: src/gltf_scene.
   }
   for(int r : roots)
     traverse(r, mx::identity(), true, primMap);
+  m_roots = roots;
+  parseAnimations();
 
   // scene bounds over visible render nodes (reference: src/gltf_scene.cpp:2303-2336)
   bool  any     = false;

@@ -3,7 +3,9 @@
 // tracer (reference: src/gltf_scene.cpp:298-330 load, :1350-1470 parseScene, :2139-2165 buildPrimitiveKeyMap,
 // :2269-2300 lights, :2338-2429 render nodes + EXT_mesh_gpu_instancing, :1561-1594 default camera;
 // src/gltf_material_cache.cpp:103-260; src/gltf_scene_vk.cpp:493-501, :741-870, :909-947, :1102-1154, :1354-1392).
-// Editing, saving, merging, animation, skinning and variants UI are out of scope.
+// Keyframe animation of node transforms (gltf_scene_animation.cpp here; reference: src/gltf_scene_animation.cpp:355-700) feeds
+// mi_pt_update_render_nodes / mi_pt_update_lights.  Editing, saving, merging, skinning, morph targets, KHR_animation_pointer
+// and the variants UI are out of scope.
 #pragma once
 #include <cstdint>
 #include <map>
@@ -45,6 +47,15 @@ struct TextureData
   int wrapS = MI_WRAP_REPEAT, wrapT = MI_WRAP_REPEAT;
 };
 
+// reference: nvvkgltf::AnimationInfo (src/gltf_scene.hpp:159-189)
+struct AnimationInfo
+{
+  std::string name;
+  float       start = 3.402823466e+38f, end = -3.402823466e+38f, currentTime = 0.0f;
+  float       reset() { return currentTime = start; }
+  float       incrementTime(float deltaTime, bool loop = true);
+};
+
 class GltfScene
 {
 public:
@@ -66,6 +77,13 @@ public:
   // Mikkelsen's with vertex splitting at tangent discontinuities.  Returns the number of vertices the splitting added; desc() is
   // rebuilt (its pointers change).
   uint32_t recomputeTangents(bool forceCreation, bool mikktspace);
+  // Animation clips (translation / rotation / scale channels; LINEAR, STEP, CUBICSPLINE).  updateAnimation evaluates clip `index`
+  // at its info's currentTime, recomputes the world matrices and rewrites the matrices of renderNodes() and the placement of
+  // lights() IN PLACE (same order, same count, desc() pointers stay valid).  Returns true when something moved.
+  int            numAnimations() const { return int(m_animations.size()); }
+  AnimationInfo& animationInfo(int index) { return m_animations[size_t(index)].info; }
+  bool           updateAnimation(int index);
+  const std::vector<uint8_t>& renderNodeVisible() const { return m_renderNodeVisible; }
   void bounds(float bmin[3], float bmax[3]) const;
   float boundsRadius() const;
 
@@ -81,6 +99,40 @@ private:
   void traverseCameras(int nodeID, const mx::mat4& parent);
   void finalizeDesc();
   uint16_t addTextureInfo(const mijson::Value& texInfo);
+  mx::mat4 localMatrix(int nodeID) const;
+  void     parseAnimations();
+  void     placeLight(MiGltfLight& info, const mx::mat4& world) const;
+
+  struct AnimationSampler
+  {
+    enum Interpolation { eLinear, eStep, eCubicSpline } interpolation = eLinear;
+    std::vector<float> inputs, outputs;  // outputs: `components` floats per keyframe (x3 for CUBICSPLINE: in-tangent, value, out-tangent)
+    int                components = 0;
+  };
+  struct AnimationChannel
+  {
+    enum Path { eTranslation, eRotation, eScale } path = eTranslation;
+    int node = -1, sampler = 0;
+  };
+  struct Animation
+  {
+    AnimationInfo                 info;
+    std::vector<AnimationSampler> samplers;
+    std::vector<AnimationChannel> channels;
+  };
+  struct NodePose  // the TRS an animation wrote; nodes never touched keep the document's matrix / TRS
+  {
+    bool  animated = false;
+    float t[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1}, s[3] = {1, 1, 1};
+  };
+  struct RenderNodeSource
+  {
+    int node = -1, instance = -1;  // glTF node, EXT_mesh_gpu_instancing instance (-1: none)
+  };
+  std::vector<Animation>        m_animations;
+  std::vector<NodePose>         m_nodePose;
+  std::vector<RenderNodeSource> m_renderNodeSource;
+  std::vector<int>              m_lightNode, m_roots;
 
   mijson::Value                      m_doc;
   std::vector<std::vector<uint8_t>>  m_buffers;

@@ -75,6 +75,47 @@ int mi_scene_recompute_tangents(MiScene* scene, int forceCreation, int mikktspac
     return MI_PT_ERR_IO;
   }
 }
+int mi_scene_num_animations(const MiScene* scene)
+{
+  return scene ? const_cast<MiScene*>(scene)->scene.numAnimations() : 0;
+}
+int mi_scene_animation_info(const MiScene* scene, int index, float* start, float* end, char* name, int nameCapacity)
+{
+  if(!scene || index < 0 || index >= const_cast<MiScene*>(scene)->scene.numAnimations())
+  {
+    g_hostError = "mi_scene_animation_info: no such animation";
+    return MI_PT_ERR_ARGUMENT;
+  }
+  const mihost::AnimationInfo& info = const_cast<MiScene*>(scene)->scene.animationInfo(index);
+  if(start)
+    *start = info.start;
+  if(end)
+    *end = info.end;
+  if(name && nameCapacity > 0)
+  {
+    strncpy(name, info.name.c_str(), size_t(nameCapacity) - 1);
+    name[nameCapacity - 1] = 0;
+  }
+  return MI_PT_OK;
+}
+int mi_scene_update_animation(MiScene* scene, int index, float time)
+{
+  if(!scene || index < 0 || index >= scene->scene.numAnimations() || !std::isfinite(time))
+  {
+    g_hostError = "mi_scene_update_animation: no such animation, or a non-finite time";
+    return MI_PT_ERR_ARGUMENT;
+  }
+  try
+  {
+    scene->scene.animationInfo(index).currentTime = time;
+    return scene->scene.updateAnimation(index) ? 1 : 0;
+  }
+  catch(const std::exception& e)
+  {
+    g_hostError = e.what();
+    return MI_PT_ERR_IO;
+  }
+}
 int mi_mikktspace(const float* positions, const float* normals, const float* texCoords, uint32_t numVertices, const uint32_t* indices,
                   uint32_t numTriangles, float* cornerTangents)
 {

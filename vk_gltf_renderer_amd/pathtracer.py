@@ -60,6 +60,24 @@ class Scene:
             _check_host(n)
         return n
 
+    @property
+    def num_animations(self):
+        return int(self._h.mi_scene_num_animations(self._p))
+
+    def animation_info(self, index=0):
+        """(name, start, end) of a clip (AnimationInfo of the reference, src/gltf_scene.hpp:159-189)."""
+        a, b, name = C.c_float(), C.c_float(), C.create_string_buffer(256)
+        _check_host(self._h.mi_scene_animation_info(self._p, index, C.byref(a), C.byref(b), name, 256))
+        return name.value.decode(), a.value, b.value
+
+    def update_animation(self, index, time):
+        """Poses the scene at `time`: the render-node matrices and light placements of `desc` change in place.  True when something
+        moved; follow with PathTracer.update_from_scene(scene)."""
+        r = self._h.mi_scene_update_animation(self._p, index, float(time))
+        if r < 0:
+            _check_host(r)
+        return bool(r)
+
     def bounds(self):
         lo, hi = (C.c_float * 3)(), (C.c_float * 3)()
         self._h.mi_scene_bounds(self._p, lo, hi)
@@ -140,6 +158,16 @@ class PathTracer:
     def update_render_nodes(self, render_nodes, count, visible=None):
         """New transforms / materials / visibility for the instances: rebuilds the acceleration structure on the device."""
         _check_pt(self._l.mi_pt_update_render_nodes(self._p, render_nodes, count, visible))
+
+    def update_lights(self, lights, count):
+        """New placement / colour / cone of the lights (same count as at creation)."""
+        _check_pt(self._l.mi_pt_update_lights(self._p, lights, count))
+
+    def update_from_scene(self, scene):
+        """After Scene.update_animation: hands the scene's render-node and light tables to the device again."""
+        d = scene.desc.contents
+        self.update_render_nodes(d.renderNodes, d.numRenderNodes, d.renderNodeVisible)
+        self.update_lights(d.lights, d.numLights)
 
     def set_environment(self, hdr):
         _check_pt(self._l.mi_pt_set_environment(self._p, hdr.env if hdr is not None else None))

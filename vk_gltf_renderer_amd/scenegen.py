@@ -155,6 +155,20 @@ class GlbBuilder:
         ext["lights"].append(light)
         return len(ext["lights"]) - 1
 
+    def animation(self, channels, name=None):
+        """channels: [(node, path, times, values, interpolation)]; CUBICSPLINE values are (keys, 3, n): in-tangent, value, out-tangent."""
+        anim = {"samplers": [], "channels": []}
+        if name:
+            anim["name"] = name
+        for node, path, times, values, interp in channels:
+            values = np.asarray(values, np.float32)
+            out = values.reshape(-1, values.shape[-1])
+            anim["samplers"].append({"input": self.accessor(np.asarray(times, np.float32), minmax=True), "output": self.accessor(out),
+                                     "interpolation": interp})
+            anim["channels"].append({"sampler": len(anim["samplers"]) - 1, "target": {"node": node, "path": path}})
+        self.doc.setdefault("animations", []).append(anim)
+        return len(self.doc["animations"]) - 1
+
     def save(self, path):
         doc = dict(self.doc)
         if self.ext_used:
@@ -824,4 +838,55 @@ def scene_material_zoo(path, group, seed=21, tess=32, tex_size=64, lights="point
         b.camera_node((0.0, 2.6, 6.0), (0, 0.7, 0), ortho=(3.4, 2.55), znear=0.05, zfar=24.0)
     else:
         b.camera_node((0.0, 2.6, 6.0), (0, 0.7, 0), yfov=0.62)
+    return b.save(path)
+
+
+def _quat(axis, angle):
+    axis = np.asarray(axis, np.float64)
+    axis = axis / np.linalg.norm(axis)
+    return [float(v) for v in (*(axis * np.sin(angle / 2)), np.cos(angle / 2))]
+
+
+def scene_animated(path, seed=5, tess=12):
+    """A small kinetic sculpture for the animation path: arm (LINEAR rotation + translation) -> elbow (CUBICSPLINE translation and
+    rotation) -> hand (STEP scale) with an instanced mesh, a point light riding on the elbow, a static floor, and a second clip."""
+    rng = np.random.default_rng(seed)
+    b = GlbBuilder()
+    red = b.material(lambert_material((0.8, 0.25, 0.2)))
+    blue = b.material({"pbrMetallicRoughness": {"baseColorFactor": [0.2, 0.3, 0.8, 1], "metallicFactor": 0.6, "roughnessFactor": 0.35}})
+    grey = b.material(lambert_material((0.6, 0.6, 0.6)))
+    sp, sn, _, si = uv_sphere(tess * 2, tess, 0.35)
+    bp, bn, _, bi = box((0.5, 0.3, 0.4))
+    fp, fn, _, fi = grid(4, 4, (8, 8))
+    ball = b.mesh([b.primitive(sp, si, normals=sn, material=red)])
+    brick = b.mesh([b.primitive(bp, bi, normals=bn, material=blue)])
+    floor = b.mesh([b.primitive(fp, fi, normals=fn, material=grey)])
+    b.node(mesh=floor, translation=[0, -1.2, 0])
+    inst_t = b.accessor(np.asarray([[0, 0, 0], [0.9, 0.1, 0], [-0.9, 0.1, 0.2]], np.float32))
+    inst_s = b.accessor(np.asarray([[1, 1, 1], [0.5, 0.5, 0.5], [0.7, 0.4, 0.7]], np.float32))
+    hand = b.node(root=False, mesh=brick, translation=[0, -0.8, 0], extensions={"EXT_mesh_gpu_instancing": {"attributes": {"TRANSLATION": inst_t, "SCALE": inst_s}}})
+    li = b.light({"type": "point", "color": [1, 0.9, 0.7], "intensity": 60.0})
+    lamp = b.node(root=False, translation=[0.3, 0.5, 0.6], extensions={"KHR_lights_punctual": {"light": li}})
+    elbow = b.node(root=False, mesh=ball, translation=[1.2, 0, 0], rotation=_quat((0, 0, 1), 0.3), children=[hand, lamp])
+    arm = b.node(mesh=ball, translation=[-0.5, 0.4, 0], scale=[1.0, 1.0, 1.0], children=[elbow])
+    still = b.node(mesh=brick, translation=[-2.0, -0.6, -1.0], rotation=_quat((0, 1, 0), 0.7))
+    b.camera_node((0.5, 1.2, 6.0), (0.2, -0.2, 0))
+    b.light({"type": "directional", "intensity": 2.0})
+    b.node(rotation=_quat((1, 0, 0), -1.0), extensions={"KHR_lights_punctual": {"light": 1}})
+    t4 = [0.0, 0.5, 1.25, 2.0]
+    rot = [_quat((0, 1, 0), a) for a in (0.0, 1.4, 3.6, 6.0)]  # 3.6 - 1.4 > pi: the slerp must take the short way round
+    cub_t = rng.uniform(-0.5, 0.5, (4, 3, 3)).astype(np.float32)
+    cub_t[:, 1, :] += [1.2, 0, 0]
+    cub_r = np.zeros((4, 3, 4), np.float32)
+    for k, a in enumerate((0.3, -0.8, 1.1, 0.3)):
+        cub_r[k, 1] = _quat((0, 0.3, 1), a)
+        cub_r[k, 0] = rng.uniform(-0.3, 0.3, 4)
+        cub_r[k, 2] = rng.uniform(-0.3, 0.3, 4)
+    b.animation([(arm, "rotation", t4, rot, "LINEAR"),
+                 (arm, "translation", [0.25, 1.0, 1.75], [[-0.5, 0.4, 0], [0.3, 0.9, -0.4], [-0.5, 0.0, 0.5]], "LINEAR"),
+                 (elbow, "translation", t4, cub_t, "CUBICSPLINE"),
+                 (elbow, "rotation", t4, cub_r, "CUBICSPLINE"),
+                 (hand, "scale", [0.0, 0.7, 1.4, 2.0], [[1, 1, 1], [1.5, 0.6, 1.0], [0.5, 1.4, 0.8], [1, 1, 1]], "STEP")], name="sculpture")
+    b.animation([(still, "translation", [1.0, 3.0], [[-2.0, -0.6, -1.0], [-2.0, 0.8, -1.0]], "LINEAR")], name="lift")
+    b.ext_used.add("EXT_mesh_gpu_instancing")
     return b.save(path)
