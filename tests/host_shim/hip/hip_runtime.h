@@ -16,6 +16,10 @@
 #define __restrict__ __restrict
 #define __launch_bounds__(...)
 
+// v_sin_f32 / v_cos_f32 take revolutions (pt_math.h: sinTurns / cosTurns)
+#define __builtin_amdgcn_sinf(t) std::sin(6.283185307179586f * (t))
+#define __builtin_amdgcn_cosf(t) std::cos(6.283185307179586f * (t))
+
 using std::isfinite;
 using std::max;
 using std::min;

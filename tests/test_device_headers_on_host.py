@@ -106,7 +106,9 @@ def test_bsdf_lobes_device_headers_match_oracle(dev, lobe):
         assert int(a[7]) == int(b[7]), (lobe, a, b)
         events.add(int(a[7]))
         if int(a[7]) != 0:
-            assert np.allclose(a[:7], b[:7], rtol=2e-5, atol=1e-6), (lobe, a, b)
+            # the device headers take sines / cosines of 2 pi u in revolutions (pt_math.h sinTurns: the shim evaluates sin(2 pi t)), the
+            # oracle rounds the angle first: 1e-7 of an angle, which grazing half vectors amplify to some 5e-5 of a weight
+            assert np.allclose(a[:7], b[:7], rtol=1e-4, atol=1e-6), (lobe, a, b)
         k2 = _unit(rng) if rng.random() < 0.5 else (F * 3)(a[0], a[1], a[2])  # random direction, or the sampled one (non-zero eval)
         O.oracle_bsdf_eval(m, k1, k2, xi, eo)
         dev.dev_bsdf_eval(m, k1, k2, xi, ed)

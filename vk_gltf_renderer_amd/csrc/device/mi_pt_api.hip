@@ -859,6 +859,7 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   while((1 << c.fc.tileShift) < pt->tileSize)
     ++c.fc.tileShift;
   c.fc.numSlots  = pt->numSlots;
+  pt::divideMagic(uint32_t(std::max(pt->numSlots, 2)), c.fc.slotsMagic, c.fc.slotsShift);
   c.fc.numFrames = numFrames;
   c.paths        = pt->paths;
   pt->accumFrames   = float(params->totalSamples) / float(params->numSamples) + float(numFrames);

