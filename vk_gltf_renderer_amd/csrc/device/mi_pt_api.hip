@@ -93,6 +93,7 @@ struct MiPt
   DevBuf<pt::DevShadeTri>     shadeTris;
   float4*                     bvhNodes  = nullptr;
   uint4*                      bvh8Nodes = nullptr;
+  DevBuf<float>               bvh8Planes;  // the nodes' planes as floats for the packet walk (DevScene::bvh8Planes)
   pt::DevTri*                 bvhTris   = nullptr;
   bool                        wide      = true;
   pt::DevScene                scene{};
@@ -381,10 +382,17 @@ int buildAcceleration(MiPt* pt)
       pt->scene.bvh8NumNodes = int(b8.numNodes);
       pt->staticStats.bvhNodeCount = b8.numNodes;
       pt->staticStats.bvhNodeBytes = 80;
+      if(getenv("MI_PT_DIAG_NO_PLANES") == nullptr)  // A/B switch of the packet walk's float planes
+      {
+        HIP_TRY(pt->bvh8Planes.alloc(size_t(b8.numNodes) * 48));
+        pt::launchBvh8Planes(b8.nodes, b8.numNodes, pt->bvh8Planes.ptr, nullptr);
+        HIP_TRY(hipGetLastError());
+      }
     }
   }
   pt::DevScene& S = pt->scene;
   S.bvhNodes = pt->bvhNodes; S.bvh8Nodes = pt->bvh8Nodes; S.tris = pt->bvhTris;
+  S.bvh8Planes = pt->bvh8Nodes ? pt->bvh8Planes.ptr : nullptr;
   S.shadeTris = nullptr;
   S.alphaTris = nullptr;
   if(S.numTris > 0)
@@ -653,7 +661,7 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
 
   pt::DevScene& S = pt->scene;
   S.materials = pt->materials.ptr; S.texInfos = pt->texInfos.ptr; S.nodes = pt->nodes.ptr; S.prims = pt->prims.ptr; S.lights = pt->lights.ptr;
-  S.textures = pt->textures.ptr; S.texels = pt->texels.ptr; S.texQuads = pt->texQuads.ptr; S.envPixels = nullptr; S.envAccel = nullptr; S.bvhNodes = nullptr; S.bvh8Nodes = nullptr; S.tris = nullptr;
+  S.textures = pt->textures.ptr; S.texels = pt->texels.ptr; S.texQuads = pt->texQuads.ptr; S.envPixels = nullptr; S.envAccel = nullptr; S.bvhNodes = nullptr; S.bvh8Nodes = nullptr; S.bvh8Planes = nullptr; S.tris = nullptr;
   S.texRefs = pt->texRefs.ptr; S.alphaTris = nullptr; S.shadeTris = nullptr; S.srgbLut = pt->srgbLut.ptr; S.numMaterials = sd->numMaterials; S.numTextures = sd->numTextures;
   S.numLights = sd->numLights; S.numNodes = sd->numRenderNodes;
   S.envWidth = 0; S.envHeight = 0;
@@ -1217,7 +1225,7 @@ int mi_pt_get_memory(MiPt* pt, MiPtMemory* out)
   const pt::DevScene& sc = pt->scene;
   uint64_t scene = bytes(pt->materials) + bytes(pt->texInfos) + bytes(pt->nodes) + bytes(pt->prims) + bytes(pt->lights) + bytes(pt->textures) + bytes(pt->texels) + bytes(pt->texQuads)
                    + bytes(pt->geometry) + bytes(pt->instFlags) + bytes(pt->srgbLut) + bytes(pt->envPixels) + bytes(pt->envAccel) + bytes(pt->alphaTris)
-                   + bytes(pt->shadeTris) + bytes(pt->texRefs);
+                   + bytes(pt->shadeTris) + bytes(pt->texRefs) + bytes(pt->bvh8Planes);
   // the acceleration structure is raw allocations: 64-B BVH2 nodes or 80-B BVH8 nodes + 48-B triangle records
   scene += uint64_t(pt->staticStats.bvhNodeCount) * pt->staticStats.bvhNodeBytes + uint64_t(sc.numTris) * sizeof(pt::DevTri);
   const uint64_t renderer = bytes(pt->pathArrays) + bytes(pt->queueMem) + bytes(pt->queuePayload) + bytes(pt->candPool) + bytes(pt->candLists) + bytes(pt->accumOwn)

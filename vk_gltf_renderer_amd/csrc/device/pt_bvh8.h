@@ -130,6 +130,45 @@ PT_DEV void bvh8TestChildren(const uint4& n0, const uint4& n1, const uint4& n2, 
   tmaskOut = tmask;
 }
 
+// The same test for a PACKET whose rays all point into one octant (k_trace_primary): the node is wave-uniform, so the byte -> float
+// conversions (48 of the 174 vector instructions of a packet node test) and the choice of the near / far plane words by the
+// direction signs (31 more) are no per-lane work at all.  DevScene::bvh8Planes holds every node's 48 plane bytes as floats, six
+// blocks of eight children -- block 2 * axis + side, side 0 = lower planes, 1 = upper -- and the caller fetches the near and the
+// far block of each axis straight into SGPRs (scalar loads at an offset that depends on the octant only).  What is left per lane
+// and child is three packed fmas (two children at a time, the plane pair is an SGPR pair), the two reductions and the mask.
+// The products are those of bvh8TestChildren bit for bit -- float(q) is exact, fma(+-1, d, P) is P +- d -- so both forms return
+// the same mask.  `sgn*` = +1 for a negative direction component, else -1.
+typedef float f32x8s __attribute__((ext_vector_type(8)));
+PT_DEV uint32_t bvh8TestChildrenPlanes(const uint4& n0, const f32x8s& pnx, const f32x8s& pny, const f32x8s& pnz, const f32x8s& pfx, const f32x8s& pfy,
+                                       const f32x8s& pfz, const RaySetup& r, float tmax, float sgnx, float sgny, float sgnz)
+{
+  const float sx = __uint_as_float((n0.w & 0xffu) << 23), sy = __uint_as_float(((n0.w >> 8) & 0xffu) << 23), sz = __uint_as_float(((n0.w >> 16) & 0xffu) << 23);
+  const float Px = __uint_as_float(n0.x) - r.org.x, Py = __uint_as_float(n0.y) - r.org.y, Pz = __uint_as_float(n0.z) - r.org.z;
+  const float k  = 4.76837158e-7f;  // 2^-21
+  const float dx = __fmaf_rn(255.0f, sx, fabsf(Px)) * k, dy = __fmaf_rn(255.0f, sy, fabsf(Py)) * k, dz = __fmaf_rn(255.0f, sz, fabsf(Pz)) * k;
+  const float Ax = sx * r.idir.x, Ay = sy * r.idir.y, Az = sz * r.idir.z;
+  const float Bnx = __fmaf_rn(sgnx, dx, Px) * r.idir.x, Bfx = __fmaf_rn(-sgnx, dx, Px) * r.idir.x;
+  const float Bny = __fmaf_rn(sgny, dy, Py) * r.idir.y, Bfy = __fmaf_rn(-sgny, dy, Py) * r.idir.y;
+  const float Bnz = __fmaf_rn(sgnz, dz, Pz) * r.idir.z, Bfz = __fmaf_rn(-sgnz, dz, Pz) * r.idir.z;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 A2x = {Ax, Ax}, A2y = {Ay, Ay}, A2z = {Az, Az};
+  const f32x2 Bn2x = {Bnx, Bnx}, Bn2y = {Bny, Bny}, Bn2z = {Bnz, Bnz}, Bf2x = {Bfx, Bfx}, Bf2y = {Bfy, Bfy}, Bf2z = {Bfz, Bfz};
+  uint32_t    miss = 0;
+#pragma unroll
+  for(int j = 0; j < 4; ++j)
+  {
+    const int   i   = 6 - 2 * j;  // children i + 1, then i: child 0 ends up in bit 0
+    const f32x2 tnx = __builtin_elementwise_fma(f32x2{pnx[i], pnx[i + 1]}, A2x, Bn2x), tfx = __builtin_elementwise_fma(f32x2{pfx[i], pfx[i + 1]}, A2x, Bf2x);
+    const f32x2 tny = __builtin_elementwise_fma(f32x2{pny[i], pny[i + 1]}, A2y, Bn2y), tfy = __builtin_elementwise_fma(f32x2{pfy[i], pfy[i + 1]}, A2y, Bf2y);
+    const f32x2 tnz = __builtin_elementwise_fma(f32x2{pnz[i], pnz[i + 1]}, A2z, Bn2z), tfz = __builtin_elementwise_fma(f32x2{pfz[i], pfz[i + 1]}, A2z, Bf2z);
+    const float tn1 = fmaxf(fmaxf(tnx.y, tny.y), fmaxf(tnz.y, 0.0f)), tf1 = fminf(fminf(tfx.y, tfy.y), fminf(tfz.y, tmax));
+    miss            = __builtin_amdgcn_alignbit(miss, __float_as_uint(tf1 - tn1), 31);
+    const float tn0 = fmaxf(fmaxf(tnx.x, tny.x), fmaxf(tnz.x, 0.0f)), tf0 = fminf(fminf(tfx.x, tfy.x), fminf(tfz.x, tmax));
+    miss            = __builtin_amdgcn_alignbit(miss, __float_as_uint(tf0 - tn0), 31);
+  }
+  return ~miss & 0xffu;
+}
+
 // One node visit.  The builder guarantees that the decoded boxes fmaf(q, 2^e, p) contain their triangles.  Here every slab
 // plane costs ONE fma: t = q * A + B with A = 2^e / dir and B = (p - org -/+ delta) / dir per axis and per node, the near
 // planes pulled towards the ray's origin and the far planes pushed away by delta = 2^-21 (|p - org| + 255 * 2^e), which

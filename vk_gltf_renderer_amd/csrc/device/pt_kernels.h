@@ -29,6 +29,7 @@ struct LaunchCtx
 void launchBuildShadeRecords(const DevScene& scene, uint32_t numTris, DevShadeTri* out, hipStream_t s);
 void launchBuildAlphaRecords(const DevScene& scene, uint32_t numTris, DevAlphaTri* out, hipStream_t s);
 void dumpTraceProfile();  // prints the -DTRACE_PROFILE section timers (no-op in the product build)
+void launchBvh8Planes(const uint4* nodes, uint32_t numNodes, float* planes, hipStream_t s);
 void launchTextureQuads(const uchar4* texels, uint4* quads, uint32_t offset, int width, int height, int wrapS, int wrapT, hipStream_t s);
 void launchResetCounters(const Queues& Q, hipStream_t s);
 void launchSkyPrecomp(const MiSkyPhysicalParameters& sky, SkyPrecomp* out, hipStream_t stream);

@@ -1036,6 +1036,26 @@ PT_DEV void scalarLoadNode(const uint4* nodes, uint32_t index, uint4& n0, uint4&
   n0 = make_uint4(a[0], a[1], a[2], a[3]); n1 = make_uint4(b[0], b[1], b[2], b[3]); n2 = make_uint4(c[0], c[1], c[2], c[3]);
   n3 = make_uint4(d[0], d[1], d[2], d[3]); n4 = make_uint4(e[0], e[1], e[2], e[3]);
 }
+// Packet node of a one-octant packet: the header words of the 80-B record and, from DevScene::bvh8Planes, the near and the far
+// block of each axis (eight floats = one child plane each), at the byte offsets the octant selects.  All wave-uniform.
+PT_DEV void scalarLoadNodePlanes(const uint4* nodes, const float* planes, uint32_t index, uint32_t offNx, uint32_t offNy, uint32_t offNz, uint32_t offFx,
+                                 uint32_t offFy, uint32_t offFz, uint4& n0, uint4& n1, f32x8s& pnx, f32x8s& pny, f32x8s& pnz, f32x8s& pfx, f32x8s& pfy,
+                                 f32x8s& pfz)
+{
+  const uint64_t addr = uint64_t(reinterpret_cast<uintptr_t>(nodes)) + uint64_t(index) * 80ull;
+  const uint64_t A    = (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(uint32_t(addr >> 32)))) << 32) | uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(uint32_t(addr))));
+  const uint64_t pad  = uint64_t(reinterpret_cast<uintptr_t>(planes)) + uint64_t(index) * 192ull;
+  const uint64_t Pn   = (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(uint32_t(pad >> 32)))) << 32) | uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(uint32_t(pad))));
+  u32x4s         a, b;
+  asm volatile("s_load_dwordx4 %0, %8, 0x0\n\ts_load_dwordx4 %1, %8, 0x10\n\t"
+               "s_load_dwordx8 %2, %9, %10\n\ts_load_dwordx8 %3, %9, %11\n\ts_load_dwordx8 %4, %9, %12\n\t"
+               "s_load_dwordx8 %5, %9, %13\n\ts_load_dwordx8 %6, %9, %14\n\ts_load_dwordx8 %7, %9, %15\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(a), "=&s"(b), "=&s"(pnx), "=&s"(pny), "=&s"(pnz), "=&s"(pfx), "=&s"(pfy), "=&s"(pfz)
+               : "s"(A), "s"(Pn), "s"(offNx), "s"(offNy), "s"(offNz), "s"(offFx), "s"(offFy), "s"(offFz)
+               : "memory");
+  n0 = make_uint4(a[0], a[1], a[2], a[3]);
+  n1 = make_uint4(b[0], b[1], b[2], b[3]);
+}
 PT_DEV DevTri scalarLoadTri(const DevTri* tris, uint32_t index)
 {
   const uint64_t addr = uint64_t(reinterpret_cast<uintptr_t>(tris)) + uint64_t(index) * 48ull;
@@ -1103,6 +1123,12 @@ __global__ void __launch_bounds__(256, PRIMARY_MIN_WAVES) k_trace_primary(DevSce
     uint32_t       gBase = 0, gBits = ((1u << octinv) << 8) | 1u;  // rootGroup
     int            sp = 0;
     bool           overflow = false;
+    // one-octant packets (nearly all of them) test the nodes through the float planes in SGPRs (pt_bvh8.h)
+    const uint32_t oct      = 7u ^ octinv;  // bit a set: direction component a is negative
+    const bool     oneOct   = sc.bvh8Planes != nullptr && __ballot(active && rayOctInv(r.idir) != octinv) == 0ull;
+    const uint32_t offNx = (oct & 1u) ? 32u : 0u, offFx = 32u - offNx, offNy = 64u + ((oct & 2u) ? 32u : 0u), offFy = 160u - offNy;
+    const uint32_t offNz = 128u + ((oct & 4u) ? 32u : 0u), offFz = 288u - offNz;
+    const float    sgnx = (oct & 1u) ? 1.0f : -1.0f, sgny = (oct & 2u) ? 1.0f : -1.0f, sgnz = (oct & 4u) ? 1.0f : -1.0f;
     for(;;)
     {
       if((gBits >> 8) == 0u)
@@ -1134,11 +1160,23 @@ __global__ void __launch_bounds__(256, PRIMARY_MIN_WAVES) k_trace_primary(DevSce
         else
           overflow = true;
       }
-      uint4 n0, n1, n2, n3, n4;
-      scalarLoadNode(sc.bvh8Nodes, child, n0, n1, n2, n3, n4);
-      uint32_t hm = 0, tmaskLane = 0;
-      if(active)
-        bvh8TestChildren(n0, n1, n2, n3, n4, r, best.t, hm, tmaskLane);
+      uint4    n0, n1;
+      uint32_t hm = 0;
+      if(oneOct)
+      {
+        f32x8s pnx, pny, pnz, pfx, pfy, pfz;
+        scalarLoadNodePlanes(sc.bvh8Nodes, sc.bvh8Planes, child, offNx, offNy, offNz, offFx, offFy, offFz, n0, n1, pnx, pny, pnz, pfx, pfy, pfz);
+        if(active)
+          hm = bvh8TestChildrenPlanes(n0, pnx, pny, pnz, pfx, pfy, pfz, r, best.t, sgnx, sgny, sgnz);
+      }
+      else
+      {
+        uint4    n2, n3, n4;
+        uint32_t tmaskLane = 0;
+        scalarLoadNode(sc.bvh8Nodes, child, n0, n1, n2, n3, n4);
+        if(active)
+          bvh8TestChildren(n0, n1, n2, n3, n4, r, best.t, hm, tmaskLane);
+      }
       if(COUNT && lane == firstLane) ++nodes;  // counters = records FETCHED: one per wave here, one per lane in the per-lane kernels
       // a child is entered / its triangles are tested when any lane hits its box
       uint32_t hmU = 0;
@@ -2567,6 +2605,25 @@ void launchBuildShadeRecords(const DevScene& scene, uint32_t numTris, DevShadeTr
 {
   if(numTris)
     hipLaunchKernelGGL(k_shade_records, dim3((numTris + 255) / 256), dim3(256), 0, s, scene, numTris, out);
+}
+// DevScene::bvh8Planes: the 48 quantised plane bytes of every node as floats, block 2 * axis + side (pt_bvh8.h).  One thread per
+// plane word of the node record (12 words: lower x, y, z then upper x, y, z, two words of four children each).
+__global__ void __launch_bounds__(256) k_bvh8_planes(const uint4* __restrict__ nodes, uint32_t numNodes, float* __restrict__ planes)
+{
+  const uint32_t id = blockIdx.x * 256u + threadIdx.x;
+  if(id >= numNodes * 12u)
+    return;
+  const uint32_t  node = id / 12u, word = id % 12u;
+  const uint32_t* rec  = reinterpret_cast<const uint32_t*>(nodes + size_t(node) * 5u) + 8u;  // n2.x ...
+  const uint32_t  w    = rec[word];
+  const uint32_t  pair = word >> 1, axis = pair % 3u, side = pair / 3u;
+  float4          v    = make_float4(float(w & 0xffu), float((w >> 8) & 0xffu), float((w >> 16) & 0xffu), float(w >> 24));
+  reinterpret_cast<float4*>(planes + size_t(node) * 48u + (2u * axis + side) * 8u)[word & 1u] = v;
+}
+void launchBvh8Planes(const uint4* nodes, uint32_t numNodes, float* planes, hipStream_t s)
+{
+  if(numNodes)
+    hipLaunchKernelGGL(k_bvh8_planes, dim3((numNodes * 12u + 255u) / 256u), dim3(256), 0, s, nodes, numNodes, planes);
 }
 void launchTextureQuads(const uchar4* texels, uint4* quads, uint32_t offset, int width, int height, int wrapS, int wrapT, hipStream_t s)
 {

@@ -122,6 +122,7 @@ struct DevScene
   const MiEnvAccel*          envAccel;
   const float4*              bvhNodes;  // BVH2: 4 x float4 per node (see pt_bvh.h); null when the wide BVH is active
   const uint4*               bvh8Nodes; // BVH8: 5 x uint4 per node (see pt_bvh8.h)
+  const float*               bvh8Planes;  // BVH8: the nodes' quantised planes as floats, 48 per node (pt_bvh8.h: bvh8TestChildrenPlanes); may be null
   const DevTri*              tris;      // triangles in the order of the ACTIVE structure (hit records index this array)
   const DevTexRef*           texRefs;   // numTextureInfos entries
   const DevShadeTri*         shadeTris; // same indexing as tris
