@@ -209,6 +209,33 @@ def test_texture_footprint_layout_is_bit_identical(built, tmp_path):
         assert np.array_equal(np.load(out), ref["accum"]), path
 
 
+def test_packet_walk_float_planes_are_bit_identical(built, tmp_path):
+    """One-octant camera-ray packets test the 8-wide nodes through DevScene::bvh8Planes (the quantised planes as floats, fetched into
+    SGPRs at octant-selected offsets, pt_bvh8.h: bvh8TestChildrenPlanes) instead of converting and selecting bytes per lane: the
+    same products, so the same child masks -- image, selection ids and the packet walk's node / triangle counters equal those of
+    the byte path (MI_PT_DIAG_NO_PLANES=1), on scenes whose packets cover every octant (camera inside the atrium) and alpha tests."""
+    import subprocess
+    import sys
+    hdr = os.path.join(os.path.dirname(os.path.dirname(__file__)), "assets", "std_env.hdr")
+    scenes = [scenegen.scene_helmet_class(str(tmp_path / "helmet.glb"), seed=7, tess=48, tex_size=64),
+              scenegen.scene_atrium_class(str(tmp_path / "atrium.glb"), seed=5, detail=0.2, tex_size=64)]
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import parity_util as pu; s = pu.Setup(sys.argv[1], 200, 120, max_depth=3, hdr_path=%r); "
+            "g = pu.render_gpu(s, 2); np.save(sys.argv[2], g['accum']); np.save(sys.argv[3], g['selection']); print(json.dumps(g['stats']))") % (
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), hdr)
+    for k, path in enumerate(scenes):
+        s = pu.Setup(path, 200, 120, max_depth=3, hdr_path=hdr)
+        ref = pu.render_gpu(s, 2)
+        assert ref["stats"]["nodesPrimary"] > 1000
+        out, sel = str(tmp_path / f"noplanes{k}.npy"), str(tmp_path / f"noplanes_sel{k}.npy")
+        r = subprocess.run([sys.executable, "-c", code, path, out, sel], env=dict(os.environ, MI_PT_DIAG_NO_PLANES="1"), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        import json
+        other = json.loads(r.stdout.strip().splitlines()[-1])
+        for key in ("nodesPrimary", "trisPrimary", "segments", "shadowRays", "surfaceHits"):
+            assert other[key] == ref["stats"][key], (key, other[key], ref["stats"][key])
+        assert np.array_equal(np.load(out), ref["accum"]) and np.array_equal(np.load(sel), ref["selection"]), path
+
+
 def test_street_class_instancing(built, tmp_path):
     """BASELINE config 4 stand-in at test size: EXT_mesh_gpu_instancing (hundreds of render nodes from a few meshes), ~130
     materials, alpha-MASK trees, sun + sky."""
