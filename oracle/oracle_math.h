@@ -70,7 +70,13 @@ inline float dot(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z;
 inline float3 cross(float3 a, float3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 inline float length(float3 a) { return std::sqrt(dot(a, a)); }
 inline float length(float2 a) { return std::sqrt(dot(a, a)); }
-inline float3 normalize(float3 a) { return a / length(a); }
+// normalize multiplies by ONE reciprocal (what a shader compiler emits for it; the device code does the same, pt_math.h, so that both
+// sides round alike)
+inline float3 normalize(float3 a)
+{
+  const float r = 1.0f / length(a);
+  return {a.x * r, a.y * r, a.z * r};
+}
 inline float2 normalize(float2 a) { float l = length(a); return {a.x / l, a.y / l}; }
 inline float3 reflect(float3 i, float3 n) { return i - n * (2.0f * dot(n, i)); }
 inline float clampf(float v, float lo, float hi) { return std::fmin(std::fmax(v, lo), hi); }

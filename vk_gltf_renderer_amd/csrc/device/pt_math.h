@@ -63,7 +63,16 @@ PT_DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 PT_DEV f3 cross(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 PT_DEV float length(f3 a) { return sqrtf(dot(a, a)); }
 PT_DEV float length(f2 a) { return sqrtf(dot(a, a)); }
-PT_DEV f3 normalize(f3 a) { return a / length(a); }
+// normalize: ONE correctly rounded reciprocal and three multiplies instead of three divisions (a division is ten vector
+// instructions); the oracle rounds the same way (oracle_math.h).  The products must stay products: a division cannot be contracted
+// into a following add, these multiplies could (hipcc: -ffp-contract=fast-honor-pragmas), and the oracle, built with contraction
+// off, would then differ by an ulp wherever a unit vector is added to something -- hence the pragma.
+PT_DEV f3 normalize(f3 a)
+{
+#pragma clang fp contract(off)
+  const float r = 1.0f / length(a);
+  return {a.x * r, a.y * r, a.z * r};
+}
 PT_DEV f2 normalize(f2 a) { float l = length(a); return {a.x / l, a.y / l}; }
 // sin / cos of an angle given in REVOLUTIONS (angle / 2 pi), |t| <= 256: v_sin_f32 / v_cos_f32 take their argument that way, so
 // phi = 2 pi u needs neither the multiply nor a range reduction.  Max abs error 1.3e-7 on [0, 1) against double precision.
