@@ -83,14 +83,14 @@ def test_depth_of_field_and_orthographic(built, tmp_path):
         p.aperture, p.focalDistance = 0.12, 6.2
     s = pu.Setup(path, 160, 120, max_depth=5, hdr_path=HDR, params_edit=dof)
     o = pu.render_oracle(s, 6)
-    # 6 spp through a lens: a handful of pixels whose paths take another turn (99.97 % of the pixels agree to 1e-4) carry the L2 norm
-    _check(o, pu.render_gpu(s, 6), rel_l2=4e-3)
+    _check(o, pu.render_gpu(s, 6))
     sharp = pu.render_oracle(pu.Setup(path, 160, 120, max_depth=5, hdr_path=HDR), 6)
     assert np.abs(o["accum"][..., :3] - sharp["accum"][..., :3]).mean() > 1e-3  # the aperture does blur
     path = scenegen.scene_material_zoo(str(tmp_path / "ortho.glb"), "specular", camera="ortho")
     s = pu.Setup(path, 160, 120, max_depth=5, hdr_path=HDR)
     assert s.frame_info.flags & capi.MI_SCENE_IS_ORTHOGRAPHIC
-    _check(pu.render_oracle(s, 6), pu.render_gpu(s, 6))
+    # 6 spp: the handful of pixels whose paths take another turn (99.97 % of the pixels agree to 1e-4) carry the L2 norm
+    _check(pu.render_oracle(s, 6), pu.render_gpu(s, 6), rel_l2=4e-3)
 
 
 def test_backplate_env_rotation_intensity(built, assets):
