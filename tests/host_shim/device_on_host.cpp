@@ -33,6 +33,13 @@ PbrMaterial materialFromArray(const float* m)  // layout: oracle/oracle_pt.h
 }  // namespace
 
 extern "C" {
+// FrameConsts::slotsMagic / slotsShift (pt_scene.h: divideMagic) as the camera-ray generation uses them: mulhi(n, magic) >> shift
+__attribute__((visibility("default"))) uint32_t dev_divide_by_magic(uint32_t n, uint32_t d)
+{
+  uint32_t magic, shift;
+  divideMagic(d, magic, shift);
+  return uint32_t((uint64_t(n) * magic) >> 32) >> shift;
+}
 __attribute__((visibility("default"))) void dev_bsdf_eval(const float* m, const float* k1, const float* k2, const float* xi, float* out4)
 {
   BsdfEval e = bsdfEvaluate(mk3(k1), mk3(k2), mk3(xi), materialFromArray(m));

@@ -30,6 +30,7 @@ def dev(built, tmp_path_factory):
                     "-I" + os.path.join(ROOT, "vk_gltf_renderer_amd", "csrc", "device"), "-o", out, os.path.join(shim, "device_on_host.cpp")], check=True)
     L = C.CDLL(out)
     P = C.POINTER
+    L.dev_divide_by_magic.argtypes, L.dev_divide_by_magic.restype = [C.c_uint32, C.c_uint32], C.c_uint32
     L.dev_bsdf_eval.argtypes = [P(F)] * 5
     L.dev_bsdf_sample.argtypes = [P(F)] * 4
     L.dev_sky_eval.argtypes = [P(capi.MiSkyPhysicalParameters), P(F), P(F)]
@@ -173,3 +174,22 @@ def test_lights_device_headers_match_oracle(dev):
         assert np.allclose(a[:], b[:], rtol=3e-5, atol=1e-7), (L.type, a[:], b[:])
         kinds |= 1 << L.type
     assert kinds == (1 << capi.MI_LIGHT_DIRECTIONAL) | (1 << capi.MI_LIGHT_POINT) | (1 << capi.MI_LIGHT_SPOT)
+
+
+def test_slot_division_by_multiply_high_is_exact(dev):
+    """k_trace_primary / k_generate turn `slot / numSlots` into mulhi(slot, magic) >> shift (FrameConsts::slotsMagic, pt_scene.h:
+    divideMagic): exact for every slot below 2^31 -- checked at the multiples of the divisor and their neighbours, at the ends of the
+    range and on random numbers, for the slot counts real resolutions give, powers of two, and awkward divisors."""
+    rng = np.random.default_rng(11)
+    divisors = [2, 3, 256, 1024, 2304, 8192, 921600, 2073600, 2088960, 8294400, 8355840, 1 << 20, (1 << 20) + 1024, 123456789, (1 << 31) - 1]
+    divisors += [int(d) for d in rng.integers(2, 1 << 24, 40)]
+    for d in divisors:
+        ns = {0, 1, d - 1, d, d + 1, (1 << 31) - 1, (1 << 31) - 2}
+        top = ((1 << 31) - 1) // d
+        for q in {1, 2, 3, top // 2, top - 1, top} | {int(q) for q in rng.integers(0, top + 1, 50)}:
+            for n in (q * d - 1, q * d, q * d + 1):
+                if 0 <= n < (1 << 31):
+                    ns.add(n)
+        ns |= {int(n) for n in rng.integers(0, 1 << 31, 200)}
+        for n in ns:
+            assert dev.dev_divide_by_magic(n, d) == n // d, (n, d)
