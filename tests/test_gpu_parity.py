@@ -413,3 +413,33 @@ def test_update_render_nodes_rebuilds_on_device(built, tmp_path):
     sel = tr.read_selection()
     assert (sel != 3).all() and (sel == 2).any() and (sel == 4).any()
     tr.close()
+
+
+def test_non_finite_geometry_does_not_hang_or_poison_the_frame(built, tmp_path):
+    """Vertex buffers and node transforms are untrusted: NaN / infinite / overflowing positions in one primitive and an instance
+    scaled by 1e30 must not fail or hang the device build or the walks (k_tri_setup turns such triangles into points no ray hits),
+    and the rest of the scene renders."""
+    b = scenegen.GlbBuilder()
+    good = b.material(scenegen.lambert_material((0.7, 0.6, 0.5)))
+    pos, nrm, uv, idx = scenegen.grid(8, 8, (4, 4), "y")
+    b.node(mesh=b.mesh([b.primitive(pos, idx, nrm, uv, material=good)]))
+    sp = scenegen.uv_sphere(16, 8, 0.5)
+    bad = sp[0].copy()
+    bad[5] = [np.nan, 0.0, 0.0]
+    bad[9] = [np.inf, 1.0, -np.inf]
+    bad[17] = [1e38, -1e38, 1e38]
+    prim = b.primitive(bad, sp[3], sp[1], sp[2], material=good)
+    acc = b.doc["accessors"][prim["attributes"]["POSITION"]]  # JSON has no NaN: declare the bounds of the intact sphere
+    acc["min"], acc["max"] = [-0.5, -0.5, -0.5], [0.5, 0.5, 0.5]
+    b.node(mesh=b.mesh([prim]), translation=[0.0, 0.6, 0.0])
+    ball = b.mesh([b.primitive(sp[0], sp[3], sp[1], sp[2], material=good)])
+    b.node(mesh=ball, translation=[1.5, 0.6, 0.0])
+    b.node(mesh=ball, translation=[-1.5, 0.6, 0.0], scale=[1e30, 1.0, 1.0])
+    b.camera_node((0.0, 2.0, 5.0), (0, 0.5, 0), yfov=0.7)
+    path = b.save(str(tmp_path / "nan.glb"))
+    s = pu.Setup(path, 160, 120, max_depth=3)
+    g = pu.render_gpu(s, 2)
+    img = g["accum"]
+    finite = np.isfinite(img).all(axis=-1)
+    assert finite.mean() > 0.9  # at most the pixels that look at the damaged sphere
+    assert (g["selection"] == 3).any()  # the intact sphere is found

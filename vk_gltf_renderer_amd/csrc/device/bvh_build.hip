@@ -64,6 +64,16 @@ __global__ void k_tri_setup(BuildTables T, uint32_t numTris, DevTri* tris, float
     f3 p0 = mulPoint(rn.objectToWorld, mk3(rp.positions + 3 * size_t(i0)));
     f3 p1 = mulPoint(rn.objectToWorld, mk3(rp.positions + 3 * size_t(i1)));
     f3 p2 = mulPoint(rn.objectToWorld, mk3(rp.positions + 3 * size_t(i2)));
+    // Vertex buffers and instance matrices are untrusted bytes.  A triangle with a NaN, an infinity or a coordinate whose square
+    // overflows would poison the scene bounds, the Morton keys and the surface areas the clustering compares; it becomes a point at
+    // the origin instead -- zero area, so no ray hits it -- and the rest of the scene builds and renders as if it were not there.
+    {
+      const float big = 1.0e18f;
+      const bool  ok  = fabsf(p0.x) < big && fabsf(p0.y) < big && fabsf(p0.z) < big && fabsf(p1.x) < big && fabsf(p1.y) < big && fabsf(p1.z) < big
+                      && fabsf(p2.x) < big && fabsf(p2.y) < big && fabsf(p2.z) < big;  // false for NaN as well
+      if(!ok)
+        p0 = p1 = p2 = mk3(0.0f);
+    }
     f3 e1 = p1 - p0, e2 = p2 - p0;
     DevTri tri;
     tri.a   = make_float4(p0.x, p0.y, p0.z, __int_as_float(rnode));

@@ -1081,6 +1081,10 @@ void GltfScene::traverse(int nodeID, const mx::mat4& parent, bool parentVisible,
   const Value& node = m_doc["nodes"][size_t(nodeID)];
   if(!node.isObject())
     return;
+  // glTF node hierarchies are strict trees (specification 3.5.2); a file that closes a cycle must not recurse without end
+  if(size_t(nodeID) >= m_onPath.size() || m_onPath[size_t(nodeID)])
+    return;
+  m_onPath[size_t(nodeID)] = 1;
   mx::mat4 world = mx::mul(parent, localMatrix(nodeID));
   // KHR_node_visibility cascades (reference: src/gltf_scene.cpp:1907-1948)
   bool         visible = parentVisible;
@@ -1200,7 +1204,8 @@ void GltfScene::traverse(int nodeID, const mx::mat4& parent, bool parentVisible,
 
   const Value& children = node["children"];
   for(size_t c = 0; c < children.size(); ++c)
-    traverse(children[c].integer(), world, visible, primMap);
+    traverse(children[c].integer(-1), world, visible, primMap);
+  m_onPath[size_t(nodeID)] = 0;
 }
 
 mx::mat4 GltfScene::localMatrix(int nodeID) const
@@ -1229,8 +1234,9 @@ void GltfScene::placeLight(MiGltfLight& info, const mx::mat4& world) const
 void GltfScene::traverseCameras(int nodeID, const mx::mat4& parent)  // reference: src/gltf_scene.cpp:2215-2267
 {
   const Value& node = m_doc["nodes"][size_t(nodeID)];
-  if(!node.isObject())
+  if(!node.isObject() || size_t(nodeID) >= m_onPath.size() || m_onPath[size_t(nodeID)])
     return;
+  m_onPath[size_t(nodeID)] = 1;
   mx::mat4 world = mx::mul(parent, localMatrix(nodeID));
   int      camID = getInt(node, "camera", -1);
   if(camID >= 0 && size_t(camID) < m_doc["cameras"].size())
@@ -1283,7 +1289,8 @@ void GltfScene::traverseCameras(int nodeID, const mx::mat4& parent)  // referenc
   }
   const Value& children = node["children"];
   for(size_t c = 0; c < children.size(); ++c)
-    traverseCameras(children[c].integer(), world);
+    traverseCameras(children[c].integer(-1), world);
+  m_onPath[size_t(nodeID)] = 0;
 }
 
 void GltfScene::bounds(float bmin[3], float bmax[3]) const
@@ -1311,6 +1318,7 @@ bool GltfScene::parse(const std::string& baseDir)  // reference: src/gltf_scene.
   m_roots.clear();
   m_animations.clear();
   m_nodePose.assign(m_doc["nodes"].size(), NodePose{});
+  m_onPath.assign(m_doc["nodes"].size(), 0);
   m_numTriangles = 0;
 
   if(m_doc["nodes"].size() == 0)
@@ -1357,11 +1365,18 @@ bool GltfScene::parse(const std::string& baseDir)  // reference: src/gltf_scene.
       continue;
     float pmin[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, pmax[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     for(size_t v = 0; v < pd.positions.size() / 3; ++v)
+    {
+      const float* p = &pd.positions[3 * v];
+      if(!(std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2])))
+        continue;  // vertex buffers are untrusted bytes: a damaged vertex must not blow up the scene bounds (camera, z range)
       for(int c = 0; c < 3; ++c)
       {
-        pmin[c] = std::min(pmin[c], pd.positions[3 * v + size_t(c)]);
-        pmax[c] = std::max(pmax[c], pd.positions[3 * v + size_t(c)]);
+        pmin[c] = std::min(pmin[c], p[c]);
+        pmax[c] = std::max(pmax[c], p[c]);
       }
+    }
+    if(pmin[0] > pmax[0])
+      continue;  // no finite vertex at all
     mx::mat4 w;
     memcpy(w.m, m_renderNodes[n].objectToWorld, sizeof(w.m));
     for(int corner = 0; corner < 8; ++corner)

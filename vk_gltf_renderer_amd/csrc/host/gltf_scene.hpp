@@ -133,6 +133,7 @@ private:
   std::vector<NodePose>         m_nodePose;
   std::vector<RenderNodeSource> m_renderNodeSource;
   std::vector<int>              m_lightNode, m_roots;
+  std::vector<uint8_t>          m_onPath;  // nodes on the current traversal path (cycle guard)
 
   mijson::Value                      m_doc;
   std::vector<std::vector<uint8_t>>  m_buffers;

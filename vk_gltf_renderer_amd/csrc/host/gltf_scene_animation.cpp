@@ -56,6 +56,17 @@ void GltfScene::parseAnimations()
         sm.outputs.clear();
         sm.components = 1;
       }
+      // key times and values of a usable sampler are finite (a NaN time would pass every range test below and pose the node at NaN)
+      bool finite = true;
+      for(float t : sm.inputs)
+        finite = finite && std::isfinite(t);
+      for(float v : sm.outputs)
+        finite = finite && std::isfinite(v);
+      if(!finite)
+      {
+        sm.inputs.clear();
+        sm.outputs.clear();
+      }
       for(float t : sm.inputs)
       {
         anim.info.start = std::min(anim.info.start, t);
@@ -148,7 +159,7 @@ bool GltfScene::updateAnimation(int index)
     if(i + 1 >= nk)
       i = nk - 2;
     const float t0 = sm.inputs[i], t1 = sm.inputs[i + 1];
-    if(time < t0 || time > t1)
+    if(!(time >= t0 && time <= t1))
       continue;
     const float keyDelta = t1 - t0;
     const float t        = std::fabs(keyDelta) < std::numeric_limits<float>::epsilon() ? 0.0f : std::min(std::max((time - t0) / keyDelta, 0.0f), 1.0f);
