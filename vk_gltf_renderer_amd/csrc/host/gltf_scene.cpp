@@ -1384,6 +1384,8 @@ bool GltfScene::parse(const std::string& baseDir)  // reference: src/gltf_scene.
       mx::vec3 p  = {(corner & 1) ? pmax[0] : pmin[0], (corner & 2) ? pmax[1] : pmin[1], (corner & 4) ? pmax[2] : pmin[2]};
       mx::vec3 wp = mx::transformPoint(w, p);
       float    a[3] = {wp.x, wp.y, wp.z};
+      if(!(std::fabs(a[0]) < 1e18f && std::fabs(a[1]) < 1e18f && std::fabs(a[2]) < 1e18f))
+        continue;  // an instance blown up by its matrix: the device build drops such triangles too (bvh_build.hip: k_tri_setup)
       for(int c = 0; c < 3; ++c)
       {
         bmin[c] = std::min(bmin[c], a[c]);
