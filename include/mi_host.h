@@ -46,6 +46,14 @@ MI_PT_API int                  mi_scene_recompute_tangents(MiScene* scene, int f
 MI_PT_API int                  mi_mikktspace(const float* positions, const float* normals, const float* texCoords, uint32_t numVertices,
                                              const uint32_t* indices, uint32_t numTriangles, float* cornerTangents);
 
+/* Load-time bake for alpha-MASK geometry, this renderer's counterpart of the reference's opacity micro-map bake
+ * (src/gltf_scene_omm.cpp; UI switch "Use OMM" src/ui_renderer.cpp): every alpha-MASK triangle is cut into subdivisions^2
+ * sub-triangles (2..16, 8 is a good default) and the ones on which the alpha test cannot pass -- no texel a fetch inside them may
+ * touch reaches alphaCutoff -- are dropped, so that rays through the empty part of a leaf card meet no candidate at all.  The
+ * image is unchanged up to float rounding of the interpolated vertices.  Returns the number of (sub-)triangles dropped (>= 0)
+ * or a negative MiPtStatus; the MiPtSceneDesc changes (fetch mi_scene_desc again, create the renderer afterwards). */
+MI_PT_API int64_t              mi_scene_cut_alpha(MiScene* scene, int subdivisions);
+
 /* Keyframe animation of node transforms (reference: nvvkgltf::AnimationSystem, src/gltf_scene_animation.hpp:93-122; AnimationInfo
  * src/gltf_scene.hpp:159-189; driven per frame by GltfRenderer::updateAnimation, src/renderer.cpp:2065-2170).  Translation /
  * rotation / scale channels with LINEAR, STEP and CUBICSPLINE samplers; morph weights, skins and KHR_animation_pointer are not

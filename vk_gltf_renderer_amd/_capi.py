@@ -161,6 +161,7 @@ HOST_SYMBOLS = {
     "mi_hdr_load": (i32, [C.c_char_p, P(VP)]),
     "mi_scene_recompute_tangents": (i32, [VP, i32, i32]),
     "mi_mikktspace": (i32, [P(f32), P(f32), P(f32), u32, P(u32), u32, P(f32)]),
+    "mi_scene_cut_alpha": (C.c_int64, [VP, i32]),
     "mi_scene_num_animations": (i32, [VP]),
     "mi_scene_animation_info": (i32, [VP, i32, P(f32), P(f32), C.c_char_p, i32]),
     "mi_scene_update_animation": (i32, [VP, i32, f32]),

@@ -39,6 +39,10 @@ void GltfRenderer::registerParameters(ParameterRegistry* r)
   r->add("infinitePlaneDistance", "Ground plane height", &s.infinitePlaneDistance);
   r->add("device", "HIP device ordinal", &m_resources.device);
   r->add("recomputeTangents", "Recreate all tangents after loading: [off:0, UV gradient:1, MikkTSpace:2]", &m_recomputeTangents);
+  // the reference consumes baked opacity micro-maps (EXT_mesh_opacity_micromap) when --useOpacityMicromap is on (src/main.cpp:114-115);
+  // the counterpart here is baked at load time from the alpha texture (mi_scene_cut_alpha)
+  r->add("useOpacityMicromap", "Bake alpha-MASK geometry at load time (see --alphaCut)", &m_useOpacityMicromap);
+  r->add("alphaCut", "Alpha bake: subdivisions per triangle edge [2..16], 0 = off", &m_alphaCut);
   // animation playback (the reference drives AnimationControl from its UI strip only; these switches are this port's headless handle)
   AnimationControl& ac = m_resources.animationControl;
   r->add("animation", "Animation clip index", &ac.currentAnimation);
@@ -191,6 +195,14 @@ bool GltfRenderer::createScene(const std::string& sceneFile)
       fprintf(stderr, "recomputeTangents: %s\n", mi_host_last_error());
     else if(m_recomputeTangents == 2)
       printf("MikkTSpace: %d vertices added for tangent discontinuities\n", added);
+  }
+  if(m_useOpacityMicromap && m_alphaCut > 0)
+  {
+    const long long dropped = mi_scene_cut_alpha(m_resources.scene, m_alphaCut);
+    if(dropped < 0)
+      fprintf(stderr, "alphaCut: %s\n", mi_host_last_error());
+    else if(dropped > 0)
+      printf("alphaCut: %lld (sub-)triangles of alpha-MASK geometry dropped\n", dropped);
   }
   // addSceneCamerasToWidget: first glTF camera -> manipulator (reference: src/gltf_camera_utils.hpp:62-90)
   mi_scene_camera(m_resources.scene, 0, &m_resources.camera);

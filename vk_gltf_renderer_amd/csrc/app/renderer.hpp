@@ -51,6 +51,8 @@ private:
   bool                m_haveRefCamera{false};
   int                 m_envSystem{0};
   int                 m_recomputeTangents{0};
+  bool                m_useOpacityMicromap{true};
+  int                 m_alphaCut{4};
   int                 m_animClip{-1};
   float               m_animTime{0.0f};
   // sequencer state (set through the registry by the script)

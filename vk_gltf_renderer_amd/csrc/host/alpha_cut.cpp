@@ -1,0 +1,252 @@
+// "Alpha cut": a load-time bake for alpha-MASK geometry -- this renderer's counterpart of the reference's opacity micro-map bake
+// (src/gltf_scene_omm.cpp: classify micro-triangles of alpha-tested triangles once, so that the traversal does not have to run
+// the alpha test on them).  There is no micro-map hardware here and a software look-up in the walk did not pay;
+// what does is removing the work instead of classifying it at run time: every alpha-MASK triangle is cut into N x N sub-triangles
+// and the sub-triangles on which the alpha test CANNOT pass -- no texel that a fetch inside the sub-triangle may touch reaches the
+// cutoff -- are dropped from the geometry.  A ray through the empty part of a leaf card then meets no candidate at all: no
+// triangle test, no alpha record, no texel fetch, no continued traversal behind it.
+//
+// The rendered function is unchanged up to what cannot be observed: the dropped regions are those where
+// `rand <= opacity` (raytracer_interface.h.slang:76-111) has opacity 0, which the reference accepts only for a draw of exactly 0
+// (2^-23); new vertices carry linearly interpolated attributes, i.e. the same linear functions the hit-attribute interpolation
+// evaluates, up to float rounding.  Primitives the classification cannot be sure about are left alone: vertex alpha, a
+// transformed texture coordinate set, MIRRORED_REPEAT, non-MASK modes, materials shared with other alpha settings.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+
+#include "gltf_scene.hpp"
+
+namespace mihost {
+
+namespace {
+
+// Summed-area table of "this texel may pass the cutoff": count(x0..x1, y0..y1) in O(1)
+struct PassTable
+{
+  int                   w = 0, h = 0;
+  std::vector<uint32_t> sat;  // (w + 1) x (h + 1)
+  uint32_t count(int x0, int y0, int x1, int y1) const  // inclusive, inside the image
+  {
+    const size_t W = size_t(w) + 1;
+    return sat[size_t(y1 + 1) * W + size_t(x1 + 1)] - sat[size_t(y0) * W + size_t(x1 + 1)] - sat[size_t(y1 + 1) * W + size_t(x0)] + sat[size_t(y0) * W + size_t(x0)];
+  }
+};
+
+// the texel range [a, b] (unwrapped, any integers) as at most two ranges inside [0, n) under the sampler's address mode
+int wrapRange(int a, int b, int n, int mode, int out[2][2])
+{
+  if(mode == MI_WRAP_CLAMP_TO_EDGE)
+  {
+    out[0][0] = std::min(std::max(a, 0), n - 1);
+    out[0][1] = std::min(std::max(b, 0), n - 1);
+    return 1;
+  }
+  if(b - a + 1 >= n)
+  {
+    out[0][0] = 0;
+    out[0][1] = n - 1;
+    return 1;
+  }
+  const int m0 = ((a % n) + n) % n, m1 = ((b % n) + n) % n;
+  if(m0 <= m1)
+  {
+    out[0][0] = m0;
+    out[0][1] = m1;
+    return 1;
+  }
+  out[0][0] = m0; out[0][1] = n - 1;
+  out[1][0] = 0;  out[1][1] = m1;
+  return 2;
+}
+
+}  // namespace
+
+uint64_t GltfScene::cutAlphaMasked(int subdivisions)
+{
+  const int N = std::min(std::max(subdivisions, 2), 16);
+  // one material per primitive (all render nodes that use the primitive agree), and that material qualifies
+  std::vector<int> primMaterial(m_primData.size(), -1);
+  for(const MiGltfRenderNode& rn : m_renderNodes)
+  {
+    if(rn.renderPrimID < 0 || size_t(rn.renderPrimID) >= m_primData.size())
+      continue;
+    int& pm = primMaterial[size_t(rn.renderPrimID)];
+    const int m = std::max(0, rn.materialID);
+    pm = (pm == -1 || pm == m) ? m : -2;
+  }
+  std::map<std::pair<int, int>, PassTable> tables;  // (texture, threshold byte)
+  uint64_t removed = 0;
+  for(size_t p = 0; p < m_primData.size(); ++p)
+  {
+    RenderPrimitiveData& d = m_primData[p];
+    const int            mi = primMaterial[p];
+    if(mi < 0 || size_t(mi) >= m_materials.size() || d.indices.size() < 3 || d.positions.empty() || !d.colors.empty())
+      continue;
+    const MiGltfShadeMaterial& mat = m_materials[size_t(mi)];
+    if(mat.alphaMode != MI_ALPHA_MASK)
+      continue;
+    const bool     sg     = mat.pbrModel == MI_PBR_SPECULAR_GLOSSINESS;
+    const uint16_t slot   = sg ? mat.pbrDiffuseTexture : mat.pbrBaseColorTexture;
+    const float    factor = sg ? mat.pbrDiffuseFactor[3] : mat.pbrBaseColorFactor[3];
+    if(slot == 0 || size_t(slot) >= m_textureInfos.size() || !(factor > 0.0f) || !(mat.alphaCutoff > 0.0f))
+      continue;
+    const MiGltfTextureInfo& info = m_textureInfos[slot];
+    if(info.index < 0 || size_t(info.index) >= m_textures.size())
+      continue;
+    const float* xf = info.uvTransform;  // KHR_texture_transform: only the identity (compared as numbers: -0.0 is 0)
+    if(!(xf[0] == 1.0f && xf[1] == 0.0f && xf[2] == 0.0f && xf[3] == 1.0f && xf[4] == 0.0f && xf[5] == 0.0f))
+      continue;
+    const TextureData&        tex = m_textures[size_t(info.index)];
+    const std::vector<float>& tc  = info.texCoord == 0 ? d.texCoords0 : d.texCoords1;
+    if(tc.size() < size_t(d.vertexCount) * 2 || tex.levels.empty() || tex.wrapS == MI_WRAP_MIRRORED_REPEAT || tex.wrapT == MI_WRAP_MIRRORED_REPEAT)
+      continue;
+    const int w = tex.width, h = tex.height;
+    if(w < 1 || h < 1 || tex.levels[0].size() < size_t(w) * size_t(h) * 4)
+      continue;
+    // smallest alpha byte that may reach the cutoff: factor * (a / 255), with a margin for the run-time arithmetic (bilinear weights,
+    // the product) -- a texel below it can never contribute to a passing fetch
+    int threshold = 256;
+    for(int a = 0; a < 256; ++a)
+      if(factor * (float(a) / 255.0f) * (1.0f + 1e-5f) + 1e-6f >= mat.alphaCutoff)
+      {
+        threshold = a;
+        break;
+      }
+    if(threshold == 0)
+      continue;  // everything passes: nothing to cut
+    PassTable& T = tables[{info.index, threshold}];
+    if(T.sat.empty())
+    {
+      T.w = w; T.h = h;
+      T.sat.assign((size_t(w) + 1) * (size_t(h) + 1), 0);
+      const uint8_t* px = tex.levels[0].data();
+      for(int y = 0; y < h; ++y)
+      {
+        uint32_t row = 0;
+        for(int x = 0; x < w; ++x)
+        {
+          row += px[(size_t(y) * size_t(w) + size_t(x)) * 4 + 3] >= threshold ? 1u : 0u;
+          T.sat[size_t(y + 1) * (size_t(w) + 1) + size_t(x + 1)] = T.sat[size_t(y) * (size_t(w) + 1) + size_t(x + 1)] + row;
+        }
+      }
+    }
+    // can a fetch with a uv inside the triangle (uv_a, uv_b, uv_c) touch a texel that may pass?
+    auto mayPass = [&](const float* ua, const float* ub, const float* uc) {
+      const float fx0 = std::min({ua[0], ub[0], uc[0]}) * float(w), fx1 = std::max({ua[0], ub[0], uc[0]}) * float(w);
+      const float fy0 = std::min({ua[1], ub[1], uc[1]}) * float(h), fy1 = std::max({ua[1], ub[1], uc[1]}) * float(h);
+      if(!(std::fabs(fx0) < 1e6f && std::fabs(fx1) < 1e6f && std::fabs(fy0) < 1e6f && std::fabs(fy1) < 1e6f))
+        return true;
+      // nearest touches floor(f); bilinear floor(f - 0.5) and the next one; one more texel either side for the rounding of the run-time uv
+      const int x0 = int(std::floor(fx0 - 0.5f)) - 1, x1 = int(std::floor(fx1 - 0.5f)) + 2;
+      const int y0 = int(std::floor(fy0 - 0.5f)) - 1, y1 = int(std::floor(fy1 - 0.5f)) + 2;
+      int rx[2][2], ry[2][2];
+      const int nx = wrapRange(x0, x1, w, tex.wrapS, rx), ny = wrapRange(y0, y1, h, tex.wrapT, ry);
+      for(int a = 0; a < nx; ++a)
+        for(int b = 0; b < ny; ++b)
+          if(T.count(rx[a][0], ry[b][0], rx[a][1], ry[b][1]) != 0)
+            return true;
+      return false;
+    };
+
+    const size_t numTris = d.indices.size() / 3;
+    std::vector<uint32_t> outIdx;
+    outIdx.reserve(d.indices.size());
+    const bool hasN = d.normals.size() >= size_t(d.vertexCount) * 3, hasT = d.tangents.size() >= size_t(d.vertexCount) * 4;
+    const bool has0 = d.texCoords0.size() >= size_t(d.vertexCount) * 2, has1 = d.texCoords1.size() >= size_t(d.vertexCount) * 2;
+    auto lerp3 = [](std::vector<float>& v, int nc, uint32_t a, uint32_t b, uint32_t c, float wa, float wb, float wc) {
+      for(int k = 0; k < nc; ++k)
+        v.push_back(v[size_t(a) * nc + k] * wa + v[size_t(b) * nc + k] * wb + v[size_t(c) * nc + k] * wc);
+    };
+    std::vector<uint8_t>  keep(size_t(N) * size_t(N) * 2);
+    std::vector<uint32_t> grid(size_t(N + 1) * size_t(N + 1));
+    for(size_t t = 0; t < numTris; ++t)
+    {
+      const uint32_t ia = d.indices[3 * t], ib = d.indices[3 * t + 1], ic = d.indices[3 * t + 2];
+      if(ia >= d.vertexCount || ib >= d.vertexCount || ic >= d.vertexCount)
+      {
+        outIdx.insert(outIdx.end(), {ia, ib, ic});
+        continue;
+      }
+      const float* ua = &tc[size_t(ia) * 2];
+      const float* ub = &tc[size_t(ib) * 2];
+      const float* uc = &tc[size_t(ic) * 2];
+      if(!mayPass(ua, ub, uc))
+      {
+        ++removed;  // the whole triangle is empty
+        continue;
+      }
+      // classify the sub-triangles: corner (i, j) has barycentrics u = i / N (towards b), v = j / N (towards c)
+      auto uvAt = [&](int i, int j, float* out) {
+        const float u = float(i) / float(N), v = float(j) / float(N), wgt = 1.0f - u - v;
+        out[0] = ua[0] * wgt + ub[0] * u + uc[0] * v;
+        out[1] = ua[1] * wgt + ub[1] * u + uc[1] * v;
+      };
+      int kept = 0, total = 0;
+      for(int j = 0; j < N; ++j)
+        for(int i = 0; i + j < N; ++i)
+          for(int up = 0; up < 2; ++up)
+          {
+            if(up && i + j + 1 >= N)
+              continue;
+            float c0[2], c1[2], c2[2];
+            if(!up) { uvAt(i, j, c0); uvAt(i + 1, j, c1); uvAt(i, j + 1, c2); }
+            else    { uvAt(i + 1, j, c0); uvAt(i + 1, j + 1, c1); uvAt(i, j + 1, c2); }
+            const bool k = mayPass(c0, c1, c2);
+            keep[(size_t(j) * N + i) * 2 + up] = k ? 1 : 0;
+            kept += k ? 1 : 0;
+            ++total;
+          }
+      if(kept == total)
+      {
+        outIdx.insert(outIdx.end(), {ia, ib, ic});  // nothing to gain: the triangle stays as it is
+        continue;
+      }
+      // emit the kept sub-triangles; grid vertices are created on demand (the corners are the original vertices)
+      std::fill(grid.begin(), grid.end(), 0xffffffffu);
+      grid[0]                         = ia;
+      grid[size_t(N)]                 = ib;               // (i = N, j = 0)
+      grid[size_t(N) * size_t(N + 1)] = ic;               // (i = 0, j = N)
+      auto vertexAt = [&](int i, int j) -> uint32_t {
+        uint32_t& g = grid[size_t(j) * size_t(N + 1) + size_t(i)];
+        if(g != 0xffffffffu)
+          return g;
+        const float u = float(i) / float(N), v = float(j) / float(N), wgt = 1.0f - u - v;
+        lerp3(d.positions, 3, ia, ib, ic, wgt, u, v);
+        if(hasN) lerp3(d.normals, 3, ia, ib, ic, wgt, u, v);
+        if(hasT) lerp3(d.tangents, 4, ia, ib, ic, wgt, u, v);
+        if(has0) lerp3(d.texCoords0, 2, ia, ib, ic, wgt, u, v);
+        if(has1) lerp3(d.texCoords1, 2, ia, ib, ic, wgt, u, v);
+        g = d.vertexCount++;
+        return g;
+      };
+      for(int j = 0; j < N; ++j)
+        for(int i = 0; i + j < N; ++i)
+          for(int up = 0; up < 2; ++up)
+          {
+            if(up && i + j + 1 >= N)
+              continue;
+            if(!keep[(size_t(j) * N + i) * 2 + up])
+              continue;
+            if(!up)
+              outIdx.insert(outIdx.end(), {vertexAt(i, j), vertexAt(i + 1, j), vertexAt(i, j + 1)});
+            else
+              outIdx.insert(outIdx.end(), {vertexAt(i + 1, j), vertexAt(i + 1, j + 1), vertexAt(i, j + 1)});
+          }
+      m_alphaCutStats.subTrianglesDropped += uint64_t(total - kept);
+      m_alphaCutStats.trianglesSplit += 1;
+    }
+    d.indices.swap(outIdx);
+  }
+  m_alphaCutStats.trianglesRemoved += removed;
+  // triangle total of the scene (every render node counts its primitive's triangles)
+  m_numTriangles = 0;
+  for(const MiGltfRenderNode& rn : m_renderNodes)
+    if(rn.renderPrimID >= 0 && size_t(rn.renderPrimID) < m_primData.size())
+      m_numTriangles += m_primData[size_t(rn.renderPrimID)].indices.size() / 3;
+  finalizeDesc();
+  return m_alphaCutStats.trianglesRemoved + m_alphaCutStats.subTrianglesDropped;
+}
+
+}  // namespace mihost

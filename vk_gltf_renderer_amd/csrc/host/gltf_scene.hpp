@@ -84,6 +84,15 @@ public:
   AnimationInfo& animationInfo(int index) { return m_animations[size_t(index)].info; }
   bool           updateAnimation(int index);
   const std::vector<uint8_t>& renderNodeVisible() const { return m_renderNodeVisible; }
+  // Load-time bake for alpha-MASK geometry (alpha_cut.cpp; the counterpart of the reference's opacity micro-map bake,
+  // src/gltf_scene_omm.cpp): triangles are cut into subdivisions x subdivisions sub-triangles and those on which the alpha test
+  // cannot pass are dropped.  Returns the number of (sub-)triangles dropped; desc() is rebuilt (its pointers change).
+  struct AlphaCutStats
+  {
+    uint64_t trianglesRemoved = 0, trianglesSplit = 0, subTrianglesDropped = 0;
+  };
+  uint64_t             cutAlphaMasked(int subdivisions);
+  const AlphaCutStats& alphaCutStats() const { return m_alphaCutStats; }
   void bounds(float bmin[3], float bmax[3]) const;
   float boundsRadius() const;
 
@@ -133,6 +142,7 @@ private:
   std::vector<NodePose>         m_nodePose;
   std::vector<RenderNodeSource> m_renderNodeSource;
   std::vector<int>              m_lightNode, m_roots;
+  AlphaCutStats                 m_alphaCutStats;
   std::vector<uint8_t>          m_onPath;  // nodes on the current traversal path (cycle guard)
 
   mijson::Value                      m_doc;

@@ -75,6 +75,23 @@ int mi_scene_recompute_tangents(MiScene* scene, int forceCreation, int mikktspac
     return MI_PT_ERR_IO;
   }
 }
+int64_t mi_scene_cut_alpha(MiScene* scene, int subdivisions)
+{
+  if(!scene)
+  {
+    g_hostError = "mi_scene_cut_alpha: null scene";
+    return MI_PT_ERR_ARGUMENT;
+  }
+  try
+  {
+    return int64_t(scene->scene.cutAlphaMasked(subdivisions));
+  }
+  catch(const std::exception& e)
+  {
+    g_hostError = e.what();
+    return MI_PT_ERR_IO;
+  }
+}
 int mi_scene_num_animations(const MiScene* scene)
 {
   return scene ? const_cast<MiScene*>(scene)->scene.numAnimations() : 0;

@@ -60,6 +60,14 @@ class Scene:
             _check_host(n)
         return n
 
+    def cut_alpha(self, subdivisions=8):
+        """Load-time bake for alpha-MASK geometry (mi_scene_cut_alpha): drops the parts of alpha-tested triangles on which the test
+        cannot pass.  Returns the number of (sub-)triangles dropped.  The scene's desc changes: create PathTracers after this call."""
+        n = self._h.mi_scene_cut_alpha(self._p, int(subdivisions))
+        if n < 0:
+            _check_host(int(n))
+        return int(n)
+
     @property
     def num_animations(self):
         return int(self._h.mi_scene_num_animations(self._p))
