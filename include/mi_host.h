@@ -50,7 +50,8 @@ MI_PT_API int                  mi_mikktspace(const float* positions, const float
  * (src/gltf_scene_omm.cpp; UI switch "Use OMM" src/ui_renderer.cpp): every alpha-MASK triangle is cut into subdivisions^2
  * sub-triangles (2..16, 8 is a good default) and the ones on which the alpha test cannot pass -- no texel a fetch inside them may
  * touch reaches alphaCutoff -- are dropped, so that rays through the empty part of a leaf card meet no candidate at all.  The
- * image is unchanged up to float rounding of the interpolated vertices.  Returns the number of (sub-)triangles dropped (>= 0)
+ * image is unchanged up to float rounding of the interpolated vertices; the selection image (TraceLow treats every triangle as
+ * opaque) reports what is seen through a removed part instead of the alpha-tested instance itself.  Returns the number of (sub-)triangles dropped (>= 0)
  * or a negative MiPtStatus; the MiPtSceneDesc changes (fetch mi_scene_desc again, create the renderer afterwards). */
 MI_PT_API int64_t              mi_scene_cut_alpha(MiScene* scene, int subdivisions);
 
