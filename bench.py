@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-ALPHA_CUT_DEFAULT = 4  # measured: atrium +4.4 %, street +12.6 % at 4; 5..8 lose to the triangle count, 2..3 find nothing to drop
+ALPHA_CUT_DEFAULT = 4  # measured (adaptive cut): atrium 462 -> 483 / 479 / 494 and street 455 -> 510 / 507 / 490 Msamples/s at 4 / 8 / 16
 WORKLOADS = {
     # name: (BASELINE config, generator kwargs, width, height, maxDepth, env)
     "helmet": dict(config="configs[1]: DamagedHelmet-class + std_env.hdr, 1920x1080, depth 8", gen="scene_helmet_class",

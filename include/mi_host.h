@@ -47,8 +47,8 @@ MI_PT_API int                  mi_mikktspace(const float* positions, const float
                                              const uint32_t* indices, uint32_t numTriangles, float* cornerTangents);
 
 /* Load-time bake for alpha-MASK geometry, this renderer's counterpart of the reference's opacity micro-map bake
- * (src/gltf_scene_omm.cpp; UI switch "Use OMM" src/ui_renderer.cpp): every alpha-MASK triangle is cut into subdivisions^2
- * sub-triangles (2..16, 8 is a good default) and the ones on which the alpha test cannot pass -- no texel a fetch inside them may
+ * (src/gltf_scene_omm.cpp; UI switch "Use OMM" src/ui_renderer.cpp): every alpha-MASK triangle is cut adaptively along a
+ * subdivisions x subdivisions barycentric grid (rounded up to 2, 4, 8 or 16; 4 is a good default) and the pieces on which the alpha test cannot pass -- no texel a fetch inside them may
  * touch reaches alphaCutoff -- are dropped, so that rays through the empty part of a leaf card meet no candidate at all.  The
  * image is unchanged up to float rounding of the interpolated vertices; the selection image (TraceLow treats every triangle as
  * opaque) reports what is seen through a removed part instead of the alpha-tested instance itself.  Returns the number of (sub-)triangles dropped (>= 0)

@@ -1,9 +1,9 @@
 // "Alpha cut": a load-time bake for alpha-MASK geometry -- this renderer's counterpart of the reference's opacity micro-map bake
 // (src/gltf_scene_omm.cpp: classify micro-triangles of alpha-tested triangles once, so that the traversal does not have to run
 // the alpha test on them).  There is no micro-map hardware here and a software look-up in the walk did not pay;
-// what does is removing the work instead of classifying it at run time: every alpha-MASK triangle is cut into N x N sub-triangles
-// and the sub-triangles on which the alpha test CANNOT pass -- no texel that a fetch inside the sub-triangle may touch reaches the
-// cutoff -- are dropped from the geometry.  A ray through the empty part of a leaf card then meets no candidate at all: no
+// what does is removing the work instead of classifying it at run time: every alpha-MASK triangle is cut, adaptively, along an
+// N x N barycentric grid, and the pieces on which the alpha test CANNOT pass -- no texel that a fetch inside the piece may touch
+// reaches the cutoff -- are dropped from the geometry; pieces that survive whole are merged back into their parent.  A ray through the empty part of a leaf card then meets no candidate at all: no
 // triangle test, no alpha record, no texel fetch, no continued traversal behind it.
 //
 // The rendered function is unchanged up to what cannot be observed: the dropped regions are those where
@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <map>
 
 #include "gltf_scene.hpp"
@@ -32,6 +33,11 @@ struct PassTable
     const size_t W = size_t(w) + 1;
     return sat[size_t(y1 + 1) * W + size_t(x1 + 1)] - sat[size_t(y0) * W + size_t(x1 + 1)] - sat[size_t(y1 + 1) * W + size_t(x0)] + sat[size_t(y0) * W + size_t(x0)];
   }
+};
+
+struct Cell  // a triangle of three points (i, j) of the barycentric grid
+{
+  int i0, j0, i1, j1, i2, j2;
 };
 
 // the texel range [a, b] (unwrapped, any integers) as at most two ranges inside [0, n) under the sampler's address mode
@@ -65,7 +71,9 @@ int wrapRange(int a, int b, int n, int mode, int out[2][2])
 
 uint64_t GltfScene::cutAlphaMasked(int subdivisions)
 {
-  const int N = std::min(std::max(subdivisions, 2), 16);
+  int N = 2;
+  while(N < std::min(std::max(subdivisions, 2), 16))
+    N *= 2;  // the adaptive cut halves cells: 2, 4, 8 or 16 per edge
   // one material per primitive (all render nodes that use the primitive agree), and that material qualifies
   std::vector<int> primMaterial(m_primData.size(), -1);
   for(const MiGltfRenderNode& rn : m_renderNodes)
@@ -159,8 +167,8 @@ uint64_t GltfScene::cutAlphaMasked(int subdivisions)
       for(int k = 0; k < nc; ++k)
         v.push_back(v[size_t(a) * nc + k] * wa + v[size_t(b) * nc + k] * wb + v[size_t(c) * nc + k] * wc);
     };
-    std::vector<uint8_t>  keep(size_t(N) * size_t(N) * 2);
     std::vector<uint32_t> grid(size_t(N + 1) * size_t(N + 1));
+    std::vector<Cell>     cells;
     for(size_t t = 0; t < numTris; ++t)
     {
       const uint32_t ia = d.indices[3 * t], ib = d.indices[3 * t + 1], ic = d.indices[3 * t + 2];
@@ -177,33 +185,53 @@ uint64_t GltfScene::cutAlphaMasked(int subdivisions)
         ++removed;  // the whole triangle is empty
         continue;
       }
-      // classify the sub-triangles: corner (i, j) has barycentrics u = i / N (towards b), v = j / N (towards c)
+      // Adaptive cut over the N x N barycentric grid (N a power of two): a cell is a triangle of three grid points (i, j) -- u = i / N
+      // towards b, v = j / N towards c.  A cell on which the test cannot pass is dropped whole; at the finest level a cell is kept;
+      // otherwise its four children decide, and if all four are kept whole the cell is kept as ONE triangle (the interior of a
+      // leaf stays coarse, only its rim is refined).
       auto uvAt = [&](int i, int j, float* out) {
         const float u = float(i) / float(N), v = float(j) / float(N), wgt = 1.0f - u - v;
         out[0] = ua[0] * wgt + ub[0] * u + uc[0] * v;
         out[1] = ua[1] * wgt + ub[1] * u + uc[1] * v;
       };
-      int kept = 0, total = 0;
-      for(int j = 0; j < N; ++j)
-        for(int i = 0; i + j < N; ++i)
-          for(int up = 0; up < 2; ++up)
-          {
-            if(up && i + j + 1 >= N)
-              continue;
-            float c0[2], c1[2], c2[2];
-            if(!up) { uvAt(i, j, c0); uvAt(i + 1, j, c1); uvAt(i, j + 1, c2); }
-            else    { uvAt(i + 1, j, c0); uvAt(i + 1, j + 1, c1); uvAt(i, j + 1, c2); }
-            const bool k = mayPass(c0, c1, c2);
-            keep[(size_t(j) * N + i) * 2 + up] = k ? 1 : 0;
-            kept += k ? 1 : 0;
-            ++total;
-          }
-      if(kept == total)
+      cells.clear();
+      int dropped = 0;
+      // returns true when the cell is kept whole (nothing emitted yet: the caller emits or merges it)
+      std::function<bool(const Cell&, int)> visit = [&](const Cell& c, int size) -> bool {
+        float c0[2], c1[2], c2[2];
+        uvAt(c.i0, c.j0, c0); uvAt(c.i1, c.j1, c1); uvAt(c.i2, c.j2, c2);
+        if(!mayPass(c0, c1, c2))
+        {
+          dropped += size * size;  // in units of finest cells
+          return false;
+        }
+        if(size == 1)
+          return true;
+        // children: the three corner cells and the inverted middle one, from the edge midpoints
+        const int m01i = (c.i0 + c.i1) / 2, m01j = (c.j0 + c.j1) / 2, m12i = (c.i1 + c.i2) / 2, m12j = (c.j1 + c.j2) / 2, m20i = (c.i2 + c.i0) / 2, m20j = (c.j2 + c.j0) / 2;
+        const Cell child[4] = {{c.i0, c.j0, m01i, m01j, m20i, m20j}, {m01i, m01j, c.i1, c.j1, m12i, m12j}, {m20i, m20j, m12i, m12j, c.i2, c.j2}, {m01i, m01j, m12i, m12j, m20i, m20j}};
+        bool whole[4];
+        bool all = true;
+        for(int k = 0; k < 4; ++k)
+        {
+          whole[k] = visit(child[k], size / 2);
+          all      = all && whole[k];
+        }
+        if(all)
+          return true;
+        for(int k = 0; k < 4; ++k)
+          if(whole[k])
+            cells.push_back(child[k]);
+        return false;
+      };
+      const Cell root{0, 0, N, 0, 0, N};
+      if(visit(root, N))
       {
         outIdx.insert(outIdx.end(), {ia, ib, ic});  // nothing to gain: the triangle stays as it is
         continue;
       }
-      // emit the kept sub-triangles; grid vertices are created on demand (the corners are the original vertices)
+      const int total = N * N, kept = total - dropped;
+      // emit the kept cells; grid vertices are created on demand (the corners are the original vertices)
       std::fill(grid.begin(), grid.end(), 0xffffffffu);
       grid[0]                         = ia;
       grid[size_t(N)]                 = ib;               // (i = N, j = 0)
@@ -221,19 +249,8 @@ uint64_t GltfScene::cutAlphaMasked(int subdivisions)
         g = d.vertexCount++;
         return g;
       };
-      for(int j = 0; j < N; ++j)
-        for(int i = 0; i + j < N; ++i)
-          for(int up = 0; up < 2; ++up)
-          {
-            if(up && i + j + 1 >= N)
-              continue;
-            if(!keep[(size_t(j) * N + i) * 2 + up])
-              continue;
-            if(!up)
-              outIdx.insert(outIdx.end(), {vertexAt(i, j), vertexAt(i + 1, j), vertexAt(i, j + 1)});
-            else
-              outIdx.insert(outIdx.end(), {vertexAt(i + 1, j), vertexAt(i + 1, j + 1), vertexAt(i, j + 1)});
-          }
+      for(const Cell& c : cells)
+        outIdx.insert(outIdx.end(), {vertexAt(c.i0, c.j0), vertexAt(c.i1, c.j1), vertexAt(c.i2, c.j2)});
       m_alphaCutStats.subTrianglesDropped += uint64_t(total - kept);
       m_alphaCutStats.trianglesSplit += 1;
     }
