@@ -547,3 +547,28 @@ def test_webp_decode(built, tmp_path):
     assert got[1].shape == refs[1].shape and (got[1] == refs[1]).all()
     bad = _scene_with_images(tmp_path, "wbad.glb", [b"RIFF\x10\x00\x00\x00WEBPVP8 " + bytes(8)], "image/webp", "EXT_texture_webp")[0]
     assert bad.shape == (1, 1, 4) and tuple(bad[0, 0]) == (255, 0, 255, 255)
+
+
+def test_image_headers_that_claim_absurd_sizes_are_refused_before_allocating(built, tmp_path):
+    """Found by tools/fuzz (ASAN): a PNG / JPEG header may claim any size; the decoders used to size their buffers from it before looking
+    at the data.  A few hundred bytes claiming 30000 x 30000 (PNG) or 32768 x 32768 (JPEG) must come back as the 1x1 fallback at once."""
+    import io
+    import struct
+    import time
+    import zlib
+    from PIL import Image
+    rgba = np.full((8, 8, 4), 200, np.uint8)
+    buf = io.BytesIO(); Image.fromarray(rgba).save(buf, "PNG")
+    png = bytearray(buf.getvalue())
+    # IHDR is the first chunk: 8-byte signature, 4 length, 4 type, then width / height
+    struct.pack_into(">II", png, 16, 30000, 30000)
+    struct.pack_into(">I", png, 29, zlib.crc32(bytes(png[12:29])) & 0xffffffff)
+    buf = io.BytesIO(); Image.fromarray(rgba[..., :3]).save(buf, "JPEG")
+    jpg = bytearray(buf.getvalue())
+    sof = jpg.find(b"\xff\xc0")
+    struct.pack_into(">HH", jpg, sof + 5, 32768, 32768)
+    t0 = time.time()
+    for k, (data, mime) in enumerate(((bytes(png), "image/png"), (bytes(jpg), "image/jpeg"))):
+        (img,) = _scene_with_images(tmp_path, f"huge{k}.glb", [data], mime)
+        assert img.shape == (1, 1, 4)  # the reference's fallback for an image that cannot be decoded
+    assert time.time() - t0 < 5.0

@@ -213,7 +213,7 @@ bool decodeDds(const uint8_t* data, size_t size, Image& out, std::string* error)
   const uint32_t pfFlags = le32(data + 80), pfFourCC = le32(data + 84), pfBits = le32(data + 88);
   uint32_t       rMask = le32(data + 92), gMask = le32(data + 96), bMask = le32(data + 100), aMask = le32(data + 104);
   const uint32_t caps2 = le32(data + 112);
-  if(width == 0 || height == 0 || width > 32768 || height > 32768)
+  if(!saneImageSize(width, height))
     return fail("bad dimensions");
   if((caps2 & 0x200u) || ((caps2 & 0x200000u) && depth > 1))
     return fail("cube maps and volume textures are not supported");

@@ -245,6 +245,8 @@ bool decodePng(const uint8_t* data, size_t size, Image& out, std::string* error)
   }
   if(!gotIhdr || info.w == 0 || info.h == 0 || channelsOf(info.colorType) == 0)
     return fail("bad PNG header");
+  if(!saneImageSize(info.w, info.h))
+    return fail("PNG: image dimensions out of range");
   if(info.colorType == 3 && info.hasTrns == false)
     memset(info.paletteAlpha, 255, sizeof(info.paletteAlpha));
 
@@ -270,6 +272,9 @@ bool decodePng(const uint8_t* data, size_t size, Image& out, std::string* error)
     if(pw && ph)
       total += (rowBytesOf(pw) + 1) * ph;
   }
+  // deflate expands by at most 1032 : 1: a stream that short cannot hold the image the header claims (checked before allocating)
+  if(total > idat.size() * 1032 + 1024)
+    return fail("PNG: the compressed data cannot hold an image of the declared size");
   std::vector<uint8_t> raw(total);
   uLongf               destLen = uLongf(total);
   int                  zr      = uncompress(raw.data(), &destLen, idat.data(), uLong(idat.size()));

@@ -12,6 +12,13 @@ struct Image
   std::vector<uint8_t> rgba;  // width*height*4
 };
 
+// Image files are untrusted input: a header may claim any size.  Every decoder checks the claimed dimensions here before it allocates:
+// sides up to 32768 (the device limit is 65535) and at most 2^28 texels (1 GiB of RGBA8), so that a few bytes cannot ask for terabytes.
+inline bool saneImageSize(uint64_t w, uint64_t h)
+{
+  return w >= 1 && h >= 1 && w <= 32768 && h <= 32768 && w * h <= (1ull << 28);
+}
+
 bool    isPng(const uint8_t* data, size_t size);
 bool    decodePng(const uint8_t* data, size_t size, Image& out, std::string* error);
 bool    isJpeg(const uint8_t* data, size_t size);

@@ -43,6 +43,7 @@ struct Decoder
 {
   const uint8_t* p;
   const uint8_t* end;
+  size_t         fileSize = 0;
   std::string*   error;
   uint16_t       quant[4][64] = {};  // natural order
   Huffman        dc[4], ac[4];
@@ -180,7 +181,9 @@ struct Decoder
     height = (s[1] << 8) | s[2];
     width  = (s[3] << 8) | s[4];
     ncomp  = s[5];
-    if(width <= 0 || height <= 0 || width > 32768 || height > 32768)
+    // (the coefficient and plane arrays below are sized by these: an entropy-coded 8x8 block takes at least a few bits, so a file
+    // of `fileSize` bytes cannot describe more than some hundred pixels per byte)
+    if(width <= 0 || height <= 0 || !saneImageSize(uint64_t(width), uint64_t(height)) || uint64_t(width) * uint64_t(height) > uint64_t(fileSize) * 512ull + 65536ull)
       return fail("bad dimensions");
     if((ncomp != 1 && ncomp != 3) || len < 6 + 3 * ncomp)
       return fail("only 1- or 3-component images are supported");
@@ -739,8 +742,9 @@ bool decodeJpeg(const uint8_t* data, size_t size, Image& out, std::string* error
 {
   Decoder d;
   d.p     = data;
-  d.end   = data + size;
-  d.error = error;
+  d.end      = data + size;
+  d.fileSize = size;
+  d.error    = error;
   return d.run(out);
 }
 

@@ -146,7 +146,7 @@ bool decodeKtx(const uint8_t* data, size_t size, Image& out, std::string* error)
       return fail("truncated header");
     const uint32_t vkFormat = le32(data + 12), width = le32(data + 20), height = le32(data + 24), depth = le32(data + 28);
     const uint32_t layers = le32(data + 32), faces = le32(data + 36), levels = le32(data + 40), scheme = le32(data + 44);
-    if(width == 0 || height == 0 || width > 32768 || height > 32768)
+    if(!saneImageSize(width, height))
       return fail("bad dimensions");
     if(depth > 1 || layers > 1 || faces != 1)
       return fail("only plain 2D images are supported (no volume, array or cube textures)");
@@ -199,7 +199,7 @@ bool decodeKtx(const uint8_t* data, size_t size, Image& out, std::string* error)
     return fail("big-endian KTX 1 files are not supported");
   const uint32_t glType = le32(data + 16), glInternal = le32(data + 28), width = le32(data + 36), height = le32(data + 40), depth = le32(data + 44);
   const uint32_t elements = le32(data + 48), faces = le32(data + 52), kvBytes = le32(data + 60);
-  if(width == 0 || height == 0 || width > 32768 || height > 32768)
+  if(!saneImageSize(width, height))
     return fail("bad dimensions");
   if(depth > 1 || elements > 1 || faces != 1)
     return fail("only plain 2D images are supported (no volume, array or cube textures)");
@@ -241,7 +241,7 @@ bool decodeWebp(const uint8_t* data, size_t size, Image& out, std::string* error
   if(!getInfo || !decodeInto)
     return fail("libwebp could not be loaded");
   int w = 0, h = 0;
-  if(!getInfo(data, size, &w, &h) || w <= 0 || h <= 0 || w > 32768 || h > 32768)
+  if(!getInfo(data, size, &w, &h) || w <= 0 || h <= 0 || !saneImageSize(uint64_t(w), uint64_t(h)))
     return fail("bad header");
   out.width  = w;
   out.height = h;
