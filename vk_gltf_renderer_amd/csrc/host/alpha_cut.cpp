@@ -9,8 +9,8 @@
 // The rendered function is unchanged up to what cannot be observed: the dropped regions are those where
 // `rand <= opacity` (raytracer_interface.h.slang:76-111) has opacity 0, which the reference accepts only for a draw of exactly 0
 // (2^-23); new vertices carry linearly interpolated attributes, i.e. the same linear functions the hit-attribute interpolation
-// evaluates, up to float rounding.  Primitives the classification cannot be sure about are left alone: vertex alpha, a
-// transformed texture coordinate set, MIRRORED_REPEAT, non-MASK modes, materials shared with other alpha settings.
+// evaluates, up to float rounding.  Primitives the classification cannot be sure about are left alone: vertex alpha,
+// MIRRORED_REPEAT, non-MASK modes, materials shared with other alpha settings.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -103,9 +103,8 @@ uint64_t GltfScene::cutAlphaMasked(int subdivisions)
     const MiGltfTextureInfo& info = m_textureInfos[slot];
     if(info.index < 0 || size_t(info.index) >= m_textures.size())
       continue;
-    const float* xf = info.uvTransform;  // KHR_texture_transform: only the identity (compared as numbers: -0.0 is 0)
-    if(!(xf[0] == 1.0f && xf[1] == 0.0f && xf[2] == 0.0f && xf[3] == 1.0f && xf[4] == 0.0f && xf[5] == 0.0f))
-      continue;
+    // (KHR_texture_transform plays no part: getOpacity samples with the raw interpolated texture coordinate,
+    //  pathtrace_functions.h.slang:189-234, and so do the alpha records of the walks)
     const TextureData&        tex = m_textures[size_t(info.index)];
     const std::vector<float>& tc  = info.texCoord == 0 ? d.texCoords0 : d.texCoords1;
     if(tc.size() < size_t(d.vertexCount) * 2 || tex.levels.empty() || tex.wrapS == MI_WRAP_MIRRORED_REPEAT || tex.wrapT == MI_WRAP_MIRRORED_REPEAT)
