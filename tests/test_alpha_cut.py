@@ -77,6 +77,8 @@ def test_no_passing_point_loses_its_geometry(built, tmp_path, case):
     cut = Scene(path)
     dropped = cut.cut_alpha(8)
     assert dropped > 0
+    tris = cut.num_triangles
+    assert cut.cut_alpha(8) == 0 and cut.num_triangles == tris  # once per loaded scene
     idx1, uv1, pos1 = _prim_arrays(cut)
     assert idx1.max() < len(uv1) and len(idx1) != len(idx0)
     # the new vertices lie on the original triangles' planes (z = 0 quad) and inside the quad

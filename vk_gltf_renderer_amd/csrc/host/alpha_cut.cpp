@@ -71,6 +71,9 @@ int wrapRange(int a, int b, int n, int mode, int out[2][2])
 
 uint64_t GltfScene::cutAlphaMasked(int subdivisions)
 {
+  if(m_alphaCutDone)
+    return 0;  // the bake is applied once per loaded scene: cutting the pieces again would only add triangles
+  m_alphaCutDone = true;
   int N = 2;
   while(N < std::min(std::max(subdivisions, 2), 16))
     N *= 2;  // the adaptive cut halves cells: 2, 4, 8 or 16 per edge

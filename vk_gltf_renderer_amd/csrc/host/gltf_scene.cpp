@@ -1319,6 +1319,8 @@ bool GltfScene::parse(const std::string& baseDir)  // reference: src/gltf_scene.
   m_animations.clear();
   m_nodePose.assign(m_doc["nodes"].size(), NodePose{});
   m_onPath.assign(m_doc["nodes"].size(), 0);
+  m_alphaCutDone  = false;
+  m_alphaCutStats = AlphaCutStats{};
   m_numTriangles = 0;
 
   if(m_doc["nodes"].size() == 0)

@@ -143,6 +143,7 @@ private:
   std::vector<RenderNodeSource> m_renderNodeSource;
   std::vector<int>              m_lightNode, m_roots;
   AlphaCutStats                 m_alphaCutStats;
+  bool                          m_alphaCutDone = false;
   std::vector<uint8_t>          m_onPath;  // nodes on the current traversal path (cycle guard)
 
   mijson::Value                      m_doc;
