@@ -18,8 +18,9 @@ Rank 0 prints ONE JSON line.  Besides the driver's fields it carries
   roofline      the dominant kernel against the roof that bounds it ("hbm": algorithmic bytes per launch over the launch time vs
                 8 TB/s; "valu": useful vector-lane operations per launch over the launch time vs 78.6 Tlaneop/s), and under
                 "kernels" the same for every kernel of the step (DESIGN.md §4 states the byte / operation model);
-  also          the Sponza-class atrium workload (configs[2], the one the north-star target is stated on) measured right after the default
-                helmet workload on the same GPU: value, per-kernel table, counters;
+  also          measured right after the default helmet workload on the same GPU: "atrium", the Sponza-class workload (configs[2], the one the
+                north-star target is stated on) with its own cpu_baseline + parity, and "helmet_4k", the default workload at 3840x2160
+                (the metric's 4K half): value, per-kernel table, counters, 5 timed steps each;
   cpu_baseline  the CPU oracle timed on the host cores on a bounded sample of the same frames;
   parity        the GPU accumulator against the oracle's on exactly those sample tiles (same frames, same seeds).
 """
@@ -125,16 +126,99 @@ def kernel_table(all_b, first_b, timing, frames):
     return rows
 
 
-def secondary_line(name, args, device):
-    """Throughput + per-kernel roofline table of another workload on this GPU (same step definition, 64 frames x 2 steps timed)."""
+# path slots (frames in flight x pixels) per GPU: ~0.3 KB of path state and queue entries per slot, ~85 GB of the 288
+SLOT_BUDGET = 2.8e8
+
+
+def alpha_cut_note(subdivisions, triangles_loaded, dropped):
+    if subdivisions <= 0:
+        return None
+    return {"subdivisions": subdivisions, "triangles_loaded": triangles_loaded, "sub_triangles_dropped": dropped,
+            "note": "GEOMETRY BAKED AT LOAD: alpha-MASK triangles are re-tessellated and the pieces on which the alpha test cannot pass are removed "
+                    "(mi_scene_cut_alpha, the counterpart of the reference's opacity micro-map bake); the parity leg renders the scene AS LOADED (uncut) with the CPU oracle"}
+
+
+def pmc_traffic(workload, kernel, F, W, H, avg_launch_ms):
+    """HBM bytes per launch of `kernel` from the committed counter passes of this workload (profiles/pmc_latest_<workload>.json, written by
+    tools/make_pmc_latest.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command), or nulls when no pass matches the
+    configuration.  Never measured inside this run: counter collection serialises the kernels."""
+    for f in (os.path.join(ROOT, "profiles", f"pmc_latest_{workload}.json"), os.path.join(ROOT, "profiles", "pmc_latest.json")):
+        try:
+            pmc = json.load(open(f))
+        except Exception:
+            continue
+        if pmc.get("workload") == workload and pmc.get("frames_in_flight") == F and pmc.get("resolution") == [W, H]:
+            traffic = pmc.get("bench_kernel_traffic", {}).get(kernel)
+            if traffic is not None:
+                src = (f"profiles/{os.path.basename(f)} ({pmc.get('command', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes')}; round {pmc.get('round')}; "
+                       f"FETCH_SIZE factor {pmc.get('fetch_size_factor', 2.0)} from {pmc.get('fetch_size_calibration', 'the guide (wide streaming reads)')}): not measured in this run")
+                return {"traffic": traffic, "traffic_source": src, "traffic_GBps": round(traffic / (avg_launch_ms * 1e-3) / 1e9, 1)}
+    return {"traffic": None, "traffic_source": None, "traffic_GBps": None}
+
+
+def cpu_baseline_and_parity(scene, w, W, H, F, cpu_seconds, make_gpu_tracer, gpu_params):
+    """The CPU oracle timed on the host cores on a bounded sample of the workload -- every 16th 64x64 tile of the same frames (same
+    scene bytes, seeds, depth), as many frames as fit `cpu_seconds` -- and the GPU accumulator of exactly those frames compared with
+    the oracle's on exactly those tiles.  The oracle is used here only as the timed CPU baseline and as the checker of the GPU image
+    (it renders the scene AS LOADED: no alpha cut)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import parity_util as pu
+    import oracle_lib
+    from vk_gltf_renderer_amd import pathtracer as ptmod
+    setup = pu.Setup(scene.path, W, H, hdr_path=os.path.join(ROOT, "assets", "std_env.hdr") if w["hdr"] else None, max_depth=w["depth"])
+    O = oracle_lib.lib()
+    o = C.c_void_p()
+    O.oracle_pt_create(setup.scene.desc, C.byref(o))
+    if setup.hdr is not None:
+        O.oracle_pt_set_environment(o, setup.hdr.env)
+    cores = os.cpu_count() or 1
+    O.oracle_pt_resize(o, W, H)
+    O.oracle_pt_set_frame_info(o, C.byref(setup.frame_info))
+    O.oracle_pt_set_sky(o, C.byref(setup.sky))
+    tx, ty = (W + 63) // 64, (H + 63) // 64
+    tiles_total = tx * ty
+    part = 16
+    O.oracle_pt_set_tile_partition(o, 0, part, 64)
+    owned = [t for t in range(tiles_total) if t % part == 0]
+    px_owned = sum(min(64, W - (t % tx) * 64) * min(64, H - (t // tx) * 64) for t in owned)
+    done_px, frames_done, t_cpu0 = 0, 0, time.perf_counter()
+    while time.perf_counter() - t_cpu0 < cpu_seconds and frames_done < 4096:
+        p = setup.frame_params(frames_done, frames_done)
+        O.oracle_pt_render_frame(o, C.byref(p), cores)
+        frames_done += 1
+        done_px += px_owned
+    t_cpu = time.perf_counter() - t_cpu0
+    cpu_img = np.ctypeslib.as_array(O.oracle_pt_accum(o), shape=(H, W, 4)).copy()
+    O.oracle_pt_destroy(o)
+    cpu = {"value": round(done_px / t_cpu / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+           "sample": f"{frames_done} frame(s) x {len(owned)}/{tiles_total} tiles (every {part}th 64x64 tile) of the same workload, {t_cpu:.1f} s"}
+    # parity at the FULL configuration: the same frames on the GPU, compared on the tiles the oracle rendered
+    chk = make_gpu_tracer()
+    ptmod.HeadlessRenderer(chk, gpu_params).render(frames_done, in_flight=min(F, frames_done))
+    gpu_img = chk.read_accum()
+    chk.close()
+    mask = np.zeros((H, W), bool)
+    for t in owned:
+        mask[(t // tx) * 64:(t // tx) * 64 + 64, (t % tx) * 64:(t % tx) * 64 + 64] = True
+    m = pu.compare_images(cpu_img[mask][None], gpu_img[mask][None])
+    parity = {"rel_l2": float(f"{m['rel_l2']:.3e}"), "frac_within_1e-2": round(m["frac_within_1e-2"], 5), "frac_within_1e-4": round(m["frac_within_1e-4"], 5),
+              "frac_exact": round(m["frac_exact"], 5), "tiles": len(owned), "pixels": int(mask.sum()), "frames": frames_done,
+              "resolution": [W, H], "reference": "CPU oracle (oracle/oracle_pt.cpp), same scene bytes (as loaded: no alpha cut), seeds and frame indices"}
+    return cpu, parity
+
+
+def secondary_line(name, args, device, width=0, height=0, steps=5, cpu_seconds=0.0):
+    """Throughput + per-kernel roofline table of another workload (or the same one at another resolution) on this GPU: the same
+    step definition as the headline (frames in flight x 2 frames per step, `steps` steps timed after one warm-up batch), and with
+    `cpu_seconds` > 0 the same CPU-oracle baseline + full-size parity leg as the headline."""
     import torch
     from vk_gltf_renderer_amd import _capi as capi
     from vk_gltf_renderer_amd import pathtracer as ptmod
     w = WORKLOADS[name]
-    W, H = w["width"], w["height"]
+    W, H = width or w["width"], height or w["height"]
     scene = ptmod.Scene(scene_path(name, 0))
-    if args.alpha_cut > 0:
-        scene.cut_alpha(args.alpha_cut)
+    triangles_loaded = scene.num_triangles
+    dropped = scene.cut_alpha(args.alpha_cut) if args.alpha_cut > 0 else 0
     hdr = ptmod.HdrEnvironment(path=os.path.join(ROOT, "assets", "std_env.hdr")) if w["hdr"] else None
     frame_info, pixel_angle, focal = ptmod.camera_frame_info(scene.camera(0), W, H)
     if hdr is not None:
@@ -154,8 +238,8 @@ def secondary_line(name, args, device):
         t.set_sky(ptmod.default_sky())
         return t
 
-    F = w.get("in_flight", 64)
-    frames_step, steps = 2 * F, 2
+    F = max(1, min(w.get("in_flight", 64), int(SLOT_BUDGET // (W * H))))
+    frames_step = 2 * F
     t = tracer(False)
     r = ptmod.HeadlessRenderer(t, params(w["depth"]))
     r.render(F, in_flight=F)  # warm-up
@@ -183,10 +267,18 @@ def secondary_line(name, args, device):
     kernels = kernel_table(per_frame, first, timing, frames)
     dominant = max(kernels, key=lambda k: kernels[k]["avg_launch_ms"] * kernels[k]["launches"])
     keys = ("cameraPaths", "segments", "surfaceHits", "shadowRays", "nodesPrimary", "trisPrimary", "nodesClosest", "trisClosest", "nodesShadow", "trisShadow", "textureTaps")
-    return {"value": round(float(W) * H * frames / elapsed / 1e6, 3), "unit": "Msamples/s", "ms_per_frame": round(elapsed / frames * 1e3, 5),
-            "config": {"workload": w["config"] + " (seeded synthetic stand-in)", "scene_triangles": scene.num_triangles, "resolution": [W, H],
-                       "frames_in_flight": F, "max_depth": w["depth"], "frames_timed": frames}, "timed_region_s": round(elapsed, 3),
-            "roofline": dict(kernels[dominant], kernel=dominant), "kernels": kernels, "per_frame": {k: round(per_frame[k], 1) for k in keys}}
+    roof = dict(kernels[dominant], kernel=dominant)
+    roof.update(pmc_traffic(name, dominant, F, W, H, roof["avg_launch_ms"]))
+    line = {"value": round(float(W) * H * frames / elapsed / 1e6, 3), "unit": "Msamples/s", "ms_per_frame": round(elapsed / frames * 1e3, 5),
+            "config": {"workload": w["config"] + " (seeded synthetic stand-in)", "scene_triangles": scene.num_triangles,
+                       "alpha_cut": alpha_cut_note(args.alpha_cut, triangles_loaded, dropped), "resolution": [W, H],
+                       "frames_in_flight": F, "max_depth": w["depth"], "frames_timed": frames, "steps": steps}, "timed_region_s": round(elapsed, 3),
+            "roofline": roof, "kernels": kernels, "per_frame": {k: round(per_frame[k], 1) for k in keys},
+            "node_visits_per_secondary_ray": round(per_frame["nodesClosest"] / max(1.0, per_frame["segments"] - per_frame["cameraPaths"]), 2),
+            "triangle_tests_per_secondary_ray": round(per_frame["trisClosest"] / max(1.0, per_frame["segments"] - per_frame["cameraPaths"]), 2)}
+    if cpu_seconds > 0:
+        line["cpu_baseline"], line["parity"] = cpu_baseline_and_parity(scene, w, W, H, F, cpu_seconds, lambda: tracer(False), params(w["depth"]))
+    return line
 
 
 def main():
@@ -204,9 +296,9 @@ def main():
     ap.add_argument("--bvh", type=int, default=0, help="bit0: 0 = 8-wide compressed BVH (default), 1 = plain BVH2; bit1: 0 = PLOC topology (default), 1 = LBVH")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--also", default=None,
-                    help="a second workload measured after the main one on a single GPU (a shorter timed region, no CPU leg) and reported "
-                         "under \"also\": by default the Sponza-class atrium next to the helmet, because that is the workload the north-star "
-                         "target is stated on; `--also none` switches it off")
+                    help="comma-separated workloads measured after the main one on a single GPU and reported under \"also\": by default "
+                         "`atrium,helmet_4k` next to the helmet (the Sponza-class workload the north-star target is stated on, with its own CPU "
+                         "baseline and parity leg, and the helmet at 3840x2160); `--also none` switches it off")
     ap.add_argument("--denoise", action="store_true",
                     help="configs[4]'s denoise pass: the guide layers are captured with every frame and one variance-guided a-trous pass (mi_pt_denoise_svgf, "
                          "5 iterations) closes every step inside the timed region -- on rank 0, after the reduce, when N > 1")
@@ -313,7 +405,9 @@ def main():
     # to keep the rays in flight per GPU constant (weak scaling).
     F = min(1024, max(1, args.in_flight) * world)
     # ... within a budget of 2.8e8 path slots per GPU (~85 GB of path state and queues at ~0.3 KB per slot): 4K frames run 33 in flight
-    F = max(1, min(F, int(2.8e8 * world // (W * H))))
+    F = max(1, min(F, int(SLOT_BUDGET * world // (W * H))))
+    # (a rank owns numSlots = its tiles' pixels, ~W*H/world: F frames in flight are F*W*H/world path slots on this GPU)
+    assert F * float(W) * float(H) / world <= SLOT_BUDGET * 1.02, "path slots per GPU beyond the budget"
     frames_step = max(1, args.frames_per_step) * world
 
     def step():
@@ -381,29 +475,18 @@ def main():
         kernels = kernel_table(per_frame, first, timing, frames_timed)
         dominant = max(kernels, key=lambda k: kernels[k]["avg_launch_ms"] * kernels[k]["launches"])
         roof = dict(kernels[dominant])
-        traffic, traffic_src = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc_file):
-            try:
-                pmc = json.load(open(pmc_file))
-                if pmc.get("workload") == args.workload and pmc.get("frames_in_flight") == F and pmc.get("resolution") == [W, H] and world == 1:
-                    traffic = pmc.get("bench_kernel_traffic", {}).get(dominant)
-                    if traffic is not None:
-                        traffic_src = f"profiles/pmc_latest.json ({pmc.get('command', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes')}; round {pmc.get('round')}): not measured in this run"
-            except Exception:
-                traffic = None
-        roof.update({"kernel": dominant, "traffic": traffic, "traffic_source": traffic_src,
-                     "traffic_GBps": (round(traffic / (roof["avg_launch_ms"] * 1e-3) / 1e9, 1) if traffic else None)})
+        roof.update({"kernel": dominant})
+        roof.update(pmc_traffic(args.workload, dominant, F, W, H, roof["avg_launch_ms"]) if world == 1 else {"traffic": None, "traffic_source": None, "traffic_GBps": None})
         keys = ("cameraPaths", "segments", "surfaceHits", "shadowRays", "nodesPrimary", "trisPrimary", "nodesClosest", "trisClosest", "nodesShadow", "trisShadow", "textureTaps")
         result = {
             "metric": "Msamples/s (and ms/frame @ fixed spp) 1080p & 4K, 1/2/4/8 MI355X", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": w["config"] + " (seeded synthetic stand-in)" if w["gen"] else w["config"], "scene_triangles": scene.num_triangles,
-                       "alpha_cut": ({"subdivisions": args.alpha_cut, "triangles_loaded": triangles_loaded, "sub_triangles_dropped": alpha_cut_dropped,
-                                      "note": "load-time bake of alpha-MASK geometry (mi_scene_cut_alpha); the parity leg renders the UNCUT scene"} if args.alpha_cut > 0 else None),
+                       "alpha_cut": alpha_cut_note(args.alpha_cut, triangles_loaded, alpha_cut_dropped),
                        "resolution": [W, H], "spp_per_step": frames_step, "frames_in_flight": F, "max_depth": w["depth"], "tile": args.tile,
                        "parallelism": f"tiles{world}" if world > 1 else "single", "world_size_reported_by_backend": (dist.get_world_size() if dist is not None else 1),
+                       "devices_visible": torch.cuda.device_count(),
                        "reduce": ((f"one RCCL reduce(sum) of {frame_buf.numel() * 4 / 1e6:.1f} MB (RGBA32F accumulator" + (" + albedo / normal guides + depth" if args.denoise else "") + ") per step") if dist is not None else None),
                        "denoise": ("variance-guided a-trous (mi_pt_denoise_svgf, 5 iterations) once per step, inside the timed region" if args.denoise else None),
                        "library": capi.pt_lib().mi_pt_version().decode()},
@@ -416,52 +499,19 @@ def main():
             "frame_ms_device": round(timing["totalMs"] / frames_timed, 4),
         }
         if not args.no_cpu_baseline and world == 1:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import parity_util as pu  # the oracle is used here only as the timed CPU baseline and as the checker of the GPU image
-            setup = pu.Setup(scene.path, W, H, hdr_path=os.path.join(ROOT, "assets", "std_env.hdr") if w["hdr"] else None, max_depth=w["depth"])
-            import oracle_lib
-            O = oracle_lib.lib()
-            o = C.c_void_p()
-            O.oracle_pt_create(setup.scene.desc, C.byref(o))
-            if setup.hdr is not None:
-                O.oracle_pt_set_environment(o, setup.hdr.env)
-            cores = os.cpu_count() or 1
-            # bounded sample: every 16th 64x64 tile of the same frames (same scene bytes, seeds, depth), as many frames as fit the budget
-            O.oracle_pt_resize(o, W, H)
-            O.oracle_pt_set_frame_info(o, C.byref(setup.frame_info))
-            O.oracle_pt_set_sky(o, C.byref(setup.sky))
-            tx, ty = (W + 63) // 64, (H + 63) // 64
-            tiles_total = tx * ty
-            part = 16
-            O.oracle_pt_set_tile_partition(o, 0, part, 64)
-            owned = [t for t in range(tiles_total) if t % part == 0]
-            px_owned = sum(min(64, W - (t % tx) * 64) * min(64, H - (t // tx) * 64) for t in owned)
-            done_px, frames_done, t_cpu0 = 0, 0, time.perf_counter()
-            while time.perf_counter() - t_cpu0 < args.cpu_seconds and frames_done < 4096:
-                p = setup.frame_params(frames_done, frames_done)
-                O.oracle_pt_render_frame(o, C.byref(p), cores)
-                frames_done += 1
-                done_px += px_owned
-            t_cpu = time.perf_counter() - t_cpu0
-            cpu_img = np.ctypeslib.as_array(O.oracle_pt_accum(o), shape=(H, W, 4)).copy()
-            O.oracle_pt_destroy(o)
-            result["cpu_baseline"] = {"value": round(done_px / t_cpu / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-                                      "sample": f"{frames_done} frame(s) x {len(owned)}/{tiles_total} tiles (every {part}th 64x64 tile) of the same workload, {t_cpu:.1f} s"}
-            # parity at the FULL configuration: the same frames on the GPU, compared on the tiles the oracle rendered
-            chk = make_tracer(False, partition=False)
-            ptmod.HeadlessRenderer(chk, params).render(frames_done, in_flight=min(F, frames_done))
-            gpu_img = chk.read_accum()
-            chk.close()
-            mask = np.zeros((H, W), bool)
-            for t in owned:
-                mask[(t // tx) * 64:(t // tx) * 64 + 64, (t % tx) * 64:(t % tx) * 64 + 64] = True
-            m = pu.compare_images(cpu_img[mask][None], gpu_img[mask][None])
-            result["parity"] = {"rel_l2": float(f"{m['rel_l2']:.3e}"), "frac_within_1e-2": round(m["frac_within_1e-2"], 5), "frac_within_1e-4": round(m["frac_within_1e-4"], 5),
-                                "frac_exact": round(m["frac_exact"], 5), "tiles": len(owned), "pixels": int(mask.sum()), "frames": frames_done,
-                                "resolution": [W, H], "reference": "CPU oracle (oracle/oracle_pt.cpp), same scene bytes, seeds and frame indices"}
-        also = args.also if args.also is not None else ("atrium" if args.workload == "helmet" and not (args.width or args.height) else "none")
+            result["cpu_baseline"], result["parity"] = cpu_baseline_and_parity(scene, w, W, H, F, args.cpu_seconds, lambda: make_tracer(False, partition=False), params)
+        # Next to the default line (helmet, 1080p), on the same GPU: the Sponza-class atrium -- the workload the north-star target is
+        # stated on -- with its own CPU baseline + full-size parity leg, and the helmet at 3840x2160 (the metric's "4K" half).
+        default_run = args.workload == "helmet" and not (args.width or args.height)
+        also = args.also if args.also is not None else ("atrium,helmet_4k" if default_run else "none")
         if also != "none" and world == 1:
-            result["also"] = {also: secondary_line(also, args, local_rank)}
+            tracer.close()  # (its ~40 GB of path state are not needed any more)
+            result["also"] = {}
+            for name in also.split(","):
+                if name == "helmet_4k":
+                    result["also"][name] = secondary_line("helmet", args, local_rank, width=3840, height=2160, steps=5)
+                else:
+                    result["also"][name] = secondary_line(name, args, local_rank, steps=5, cpu_seconds=0.0 if args.no_cpu_baseline else args.cpu_seconds)
         print(json.dumps(result), flush=True)
     tracer.close()
     if dist is not None:

@@ -412,6 +412,23 @@ def test_update_render_nodes_rebuilds_on_device(built, tmp_path):
     tr.render_frame(sb.frame_params(0, 0))
     sel = tr.read_selection()
     assert (sel != 3).all() and (sel == 2).any() and (sel == 4).any()
+    # a rebuild that FAILS after the old structure has been released must leave an empty scene behind, not dangling pointers:
+    # the call reports the error, the next frame renders the environment only, and a later good rebuild restores the scene
+    os.environ["MI_PT_DIAG_FAIL_BUILD"] = "1"
+    try:
+        with pytest.raises(ptmod.MiError):
+            tr.update_render_nodes(db.renderNodes, db.numRenderNodes)
+    finally:
+        del os.environ["MI_PT_DIAG_FAIL_BUILD"]
+    tr.render_frame(sb.frame_params(0, 0))
+    assert (tr.read_selection() == 0).all() and np.isfinite(tr.read_accum()).all()
+    tr.update_render_nodes(db.renderNodes, db.numRenderNodes)
+    total = 0
+    for f in range(3):
+        p = sb.frame_params(f, total)
+        tr.render_frame(p)
+        total += p.numSamples
+    assert (tr.read_accum() == fresh["accum"]).all()
     tr.close()
 
 

@@ -1,0 +1,739 @@
+// CPU laboratory for the TOPOLOGY of the acceleration structure (no GPU needed): rebuilds what csrc/device/bvh_build.hip + bvh8.hip
+// build (Morton-63 order, PLOC with a +-16 window, greedy 8-wide collapse, octant-ordered slots, 8-bit quantised child boxes),
+// variants of it, and counts what the per-lane walk of pt_kernels.hip would do -- node visits and triangle tests per ray -- on
+// seeded incoherent rays (cosine-distributed bounce rays leaving random surface points).  It decides which builder changes are
+// worth a GPU run; the numbers the design quotes are the device's own counters (MiPtStats).
+//
+//   g++ -O2 -std=c++17 -fopenmp -o /tmp/lab/bvh_lab tools/lab/bvh_lab.cpp
+//   /tmp/lab/bvh_lab /tmp/lab/atrium.bin [options]      (input: tools/lab/dump_tris.py)
+// options: builder=ploc|sah|lbvh  radius=16  leaf=2  collapse=greedy|sahdp  reinsert=N  rays=200000  order=octant|dist  split=F
+#include <algorithm>
+#include <cassert>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <numeric>
+#include <random>
+#include <string>
+#include <vector>
+
+struct V3
+{
+  float x, y, z;
+  float operator[](int i) const { return (&x)[i]; }
+  float& operator[](int i) { return (&x)[i]; }
+};
+static V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+static V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+static V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+static float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+static V3 normalize(V3 a) { return a * (1.0f / std::sqrt(dot(a, a))); }
+
+struct Box
+{
+  V3 lo{FLT_MAX, FLT_MAX, FLT_MAX}, hi{-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  void grow(V3 p) { for(int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); } }
+  void grow(const Box& b) { for(int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); } }
+  float area() const { float ex = hi.x - lo.x, ey = hi.y - lo.y, ez = hi.z - lo.z; return ex * ey + ey * ez + ez * ex; }
+  bool valid() const { return lo.x <= hi.x; }
+};
+static Box unite(const Box& a, const Box& b) { Box r = a; r.grow(b); return r; }
+
+struct Tri { V3 p0, p1, p2; };
+
+// ---- BVH2: nodes[i] = {child refs (>= 0 inner, < 0 leaf ~ref index), boxes of both children, count} --------------------------------
+struct Node2
+{
+  int  c[2];
+  Box  b[2];
+  int  cnt;
+  int  parent = -1;
+};
+struct Bvh2
+{
+  std::vector<Node2> nodes;
+  int                root = -1;
+  std::vector<int>   refTri;  // leaf ref -> triangle index (a triangle may have several refs after splitting)
+  std::vector<Box>   refBox;
+};
+
+static uint64_t expandBits21(uint32_t v)
+{
+  uint64_t x = v & 0x1fffffu;
+  x = (x | x << 32) & 0x1f00000000ffffull;
+  x = (x | x << 16) & 0x1f0000ff0000ffull;
+  x = (x | x << 8) & 0x100f00f00f00f00full;
+  x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+  x = (x | x << 2) & 0x1249249249249249ull;
+  return x;
+}
+
+static std::vector<int> mortonOrder(const std::vector<Box>& boxes)
+{
+  Box cb;
+  for(const Box& b : boxes) cb.grow((b.lo + b.hi) * 0.5f);
+  std::vector<std::pair<uint64_t, int>> keys(boxes.size());
+  for(size_t i = 0; i < boxes.size(); ++i)
+  {
+    V3       c = (boxes[i].lo + boxes[i].hi) * 0.5f;
+    uint32_t q[3];
+    for(int a = 0; a < 3; ++a)
+    {
+      float ext = cb.hi[a] - cb.lo[a];
+      float n   = ext > 0 ? (c[a] - cb.lo[a]) / ext : 0.0f;
+      q[a]      = uint32_t(std::min(std::max(n * 2097152.0f, 0.0f), 2097151.0f));
+    }
+    keys[i] = {(expandBits21(q[0]) << 2) | (expandBits21(q[1]) << 1) | expandBits21(q[2]), int(i)};
+  }
+  std::stable_sort(keys.begin(), keys.end());
+  std::vector<int> order(boxes.size());
+  for(size_t i = 0; i < keys.size(); ++i) order[i] = keys[i].second;
+  return order;
+}
+
+// PLOC as bvh_build.hip does it (mutual nearest neighbours in a +-radius window over the Morton order).
+static Bvh2 buildPloc(const std::vector<int>& refTri, const std::vector<Box>& refBox, int radius)
+{
+  Bvh2 B;
+  B.refTri = refTri;
+  B.refBox = refBox;
+  const int n = int(refBox.size());
+  std::vector<int> order = mortonOrder(refBox);
+  std::vector<int> cid(n), cnt(n, 1);
+  std::vector<Box> cb(n);
+  for(int i = 0; i < n; ++i) { cid[i] = ~order[i]; cb[i] = refBox[order[i]]; }
+  B.nodes.reserve(n);
+  int m = n;
+  std::vector<int> nn(n), cid2(n), cnt2(n);
+  std::vector<Box> cb2(n);
+  while(m > 1)
+  {
+#pragma omp parallel for schedule(static)
+    for(int i = 0; i < m; ++i)
+    {
+      float best = FLT_MAX;
+      int   bj   = -1;
+      for(int d = -radius; d <= radius; ++d)
+      {
+        int g = i + d;
+        if(d == 0 || g < 0 || g >= m) continue;
+        float a = unite(cb[i], cb[g]).area();
+        if(a < best) { best = a; bj = g; }
+      }
+      nn[i] = bj;
+    }
+    int p = 0;
+    for(int i = 0; i < m; ++i)
+    {
+      int  j      = nn[i];
+      bool mutual = j >= 0 && nn[j] == i;
+      if(mutual && i > j) continue;
+      if(mutual)
+      {
+        Node2 N;
+        N.c[0] = cid[i]; N.c[1] = cid[j]; N.b[0] = cb[i]; N.b[1] = cb[j]; N.cnt = cnt[i] + cnt[j];
+        int k = int(B.nodes.size());
+        B.nodes.push_back(N);
+        cid2[p] = k; cb2[p] = unite(cb[i], cb[j]); cnt2[p] = N.cnt;
+      }
+      else { cid2[p] = cid[i]; cb2[p] = cb[i]; cnt2[p] = cnt[i]; }
+      ++p;
+    }
+    m = p;
+    std::swap(cid, cid2); std::swap(cb, cb2); std::swap(cnt, cnt2);
+  }
+  B.root = cid[0];
+  for(int i = 0; i < int(B.nodes.size()); ++i)
+    for(int k = 0; k < 2; ++k)
+      if(B.nodes[i].c[k] >= 0) B.nodes[B.nodes[i].c[k]].parent = i;
+  return B;
+}
+
+// Top-down binned SAH (32 bins), leaves of one reference: the quality yardstick.
+static Bvh2 buildSah(const std::vector<int>& refTri, const std::vector<Box>& refBox)
+{
+  Bvh2 B;
+  B.refTri = refTri;
+  B.refBox = refBox;
+  const int n = int(refBox.size());
+  std::vector<int> idx(n);
+  std::iota(idx.begin(), idx.end(), 0);
+  B.nodes.reserve(n);
+  std::function<int(int, int, Box&)> rec = [&](int lo, int hi, Box& outBox) -> int {
+    Box bb, cb;
+    for(int i = lo; i < hi; ++i) { bb.grow(refBox[idx[i]]); cb.grow((refBox[idx[i]].lo + refBox[idx[i]].hi) * 0.5f); }
+    outBox = bb;
+    if(hi - lo == 1) return ~idx[lo];
+    constexpr int NB = 32;
+    float bestCost = FLT_MAX; int bestAxis = -1, bestBin = -1;
+    for(int a = 0; a < 3; ++a)
+    {
+      float ext = cb.hi[a] - cb.lo[a];
+      if(!(ext > 0)) continue;
+      Box bins[NB]; int cnts[NB] = {};
+      for(int i = lo; i < hi; ++i)
+      {
+        const Box& b = refBox[idx[i]];
+        int k = std::min(NB - 1, int(((b.lo[a] + b.hi[a]) * 0.5f - cb.lo[a]) / ext * NB));
+        bins[k].grow(b); cnts[k]++;
+      }
+      float rightA[NB]; int rightC[NB]; Box acc; int c = 0;
+      for(int k = NB - 1; k > 0; --k) { if(cnts[k]) acc.grow(bins[k]); c += cnts[k]; rightA[k] = c ? acc.area() : 0; rightC[k] = c; }
+      acc = Box(); c = 0;
+      for(int k = 0; k < NB - 1; ++k)
+      {
+        if(cnts[k]) acc.grow(bins[k]); c += cnts[k];
+        if(c == 0 || rightC[k + 1] == 0) continue;
+        float cost = acc.area() * c + rightA[k + 1] * rightC[k + 1];
+        if(cost < bestCost) { bestCost = cost; bestAxis = a; bestBin = k; }
+      }
+    }
+    int mid;
+    if(bestAxis < 0) mid = (lo + hi) / 2;
+    else
+    {
+      float ext = cb.hi[bestAxis] - cb.lo[bestAxis];
+      mid = int(std::partition(idx.begin() + lo, idx.begin() + hi, [&](int t) {
+              const Box& b = refBox[t];
+              int k = std::min(NB - 1, int(((b.lo[bestAxis] + b.hi[bestAxis]) * 0.5f - cb.lo[bestAxis]) / ext * NB));
+              return k <= bestBin; }) - idx.begin());
+      if(mid == lo || mid == hi) mid = (lo + hi) / 2;
+    }
+    int me = int(B.nodes.size());
+    B.nodes.push_back(Node2());
+    Box b0, b1;
+    int c0 = rec(lo, mid, b0), c1 = rec(mid, hi, b1);
+    Node2& N = B.nodes[me];
+    N.c[0] = c0; N.c[1] = c1; N.b[0] = b0; N.b[1] = b1; N.cnt = hi - lo;
+    if(c0 >= 0) B.nodes[c0].parent = me;
+    if(c1 >= 0) B.nodes[c1].parent = me;
+    return me;
+  };
+  Box rb;
+  B.root = rec(0, n, rb);
+  return B;
+}
+
+static Box nodeBox(const Bvh2& B, int ref) { return ref < 0 ? B.refBox[~ref] : unite(B.nodes[ref].b[0], B.nodes[ref].b[1]); }
+static int refCount(const Bvh2& B, int ref) { return ref < 0 ? 1 : B.nodes[ref].cnt; }
+
+static double sahCost2(const Bvh2& B)
+{
+  double rootA = nodeBox(B, B.root).area(), c = 0;
+  for(const Node2& N : B.nodes) c += unite(N.b[0], N.b[1]).area() / rootA * 1.0;
+  return c;  // inner-node term only (leaves have one reference each)
+}
+
+// ---- reinsertion (Bittner et al. 2013 flavour, simplified): take a node whose removal saves the most area, re-insert its subtree at the
+// position that minimises the area increase (branch and bound over the tree).  `passes` sweeps over a fraction of the nodes.
+static void refitUp(Bvh2& B, int node)
+{
+  while(node >= 0)
+  {
+    Node2& N = B.nodes[node];
+    for(int k = 0; k < 2; ++k) N.b[k] = nodeBox(B, N.c[k]);
+    N.cnt = refCount(B, N.c[0]) + refCount(B, N.c[1]);
+    node  = N.parent;
+  }
+}
+static void reinsertPass(Bvh2& B, double fraction, std::vector<int>& leafParent)
+{
+  const int nn = int(B.nodes.size());
+  // candidates: inner nodes (not root, not children of root), by area * (some inefficiency measure); simple: by area
+  std::vector<std::pair<float, int>> cand;
+  for(int i = 0; i < nn; ++i)
+    if(i != B.root && B.nodes[i].parent >= 0 && B.nodes[i].parent != B.root) cand.push_back({unite(B.nodes[i].b[0], B.nodes[i].b[1]).area(), i});
+  std::sort(cand.begin(), cand.end(), [](auto& a, auto& b) { return a.first > b.first; });
+  int todo = int(cand.size() * fraction);
+  for(int t = 0; t < todo; ++t)
+  {
+    int x = cand[t].second;          // subtree to move
+    int p = B.nodes[x].parent;
+    if(p < 0 || p == B.root) continue;
+    int g = B.nodes[p].parent;
+    if(g < 0) continue;
+    // detach: sibling replaces p in g; p becomes the free node that will sit above x at the new position
+    int sibSlot = B.nodes[p].c[0] == x ? 1 : 0;
+    int sib     = B.nodes[p].c[sibSlot];
+    int gslot   = B.nodes[g].c[0] == p ? 0 : 1;
+    B.nodes[g].c[gslot] = sib;
+    if(sib >= 0) B.nodes[sib].parent = g; else leafParent[~sib] = g;
+    refitUp(B, g);
+    Box xb = nodeBox(B, x);
+    // search best position: branch and bound on induced cost
+    struct Item { float induced; int ref; int parent; int slot; };
+    float bestCost = FLT_MAX; int bestParent = -1, bestSlot = -1;
+    std::vector<Item> stack;
+    // start at root's two children positions
+    {
+      stack.push_back({0.0f, B.root, -1, 0});
+    }
+    float xa = xb.area();
+    while(!stack.empty())
+    {
+      Item it = stack.back(); stack.pop_back();
+      if(it.induced + xa >= bestCost) continue;
+      Box  nb     = nodeBox(B, it.ref);
+      float direct = unite(nb, xb).area();
+      float total  = it.induced + direct;
+      if(it.parent >= 0 && total < bestCost) { bestCost = total; bestParent = it.parent; bestSlot = it.slot; }
+      if(it.ref >= 0)
+      {
+        float ind = it.induced + direct - nb.area();
+        if(ind + xa < bestCost)
+          for(int k = 0; k < 2; ++k) stack.push_back({ind, B.nodes[it.ref].c[k], it.ref, k});
+      }
+    }
+    if(bestParent < 0)
+    {  // put back where it was
+      bestParent = g; bestSlot = gslot;
+    }
+    // insert p between bestParent and its child at bestSlot
+    int old = B.nodes[bestParent].c[bestSlot];
+    B.nodes[bestParent].c[bestSlot] = p;
+    B.nodes[p].parent = bestParent;
+    B.nodes[p].c[0] = old; B.nodes[p].c[1] = x;
+    if(old >= 0) B.nodes[old].parent = p; else leafParent[~old] = p;
+    B.nodes[x].parent = p;
+    refitUp(B, p);
+  }
+}
+
+// ---- 8-wide node ------------------------------------------------------------------------------------------------------------------
+struct Node8
+{
+  Box      box[8];      // decoded (quantised) child boxes; !valid() = empty slot
+  int      child[8];    // inner: index of the Node8; leaf: -1; empty: -2
+  int      triBase[8], triCnt[8];
+};
+struct Bvh8
+{
+  std::vector<Node8> nodes;
+  std::vector<int>   tris;  // triangle indices in leaf order
+  double             sah = 0;
+};
+
+struct CollapseCfg { int maxLeaf = 2; bool sahdp = false; bool quantise = true; float cLeafTri = 0.24f; };
+
+// optimal (SAH, dynamic programming) collapse after Ylitie et al. 2017, section 3: cost(n, i) = cheapest way to represent subtree n as
+// at most i roots of 8-wide (sub)trees; cLeaf per triangle and 1 per inner node, weighted by area.
+struct Dp
+{
+  const Bvh2& B;
+  int         maxLeaf;
+  float       cTri;
+  std::vector<float> cost;   // [node][i], i = 1..7 -> index node*8+i  (i = 1: the subtree as ONE child: either a leaf or an inner node)
+  std::vector<int8_t> split; // for i >= 2: how many roots go to the left child; for i == 1: 0 = leaf, 1 = inner node
+  std::vector<float> areaN;
+  Dp(const Bvh2& b, int ml, float ct) : B(b), maxLeaf(ml), cTri(ct)
+  {
+    const int n = int(B.nodes.size());
+    cost.assign(size_t(n) * 8, FLT_MAX); split.assign(size_t(n) * 8, 0); areaN.resize(n);
+    // post-order
+    std::vector<int> order; order.reserve(n);
+    std::vector<int> st{B.root};
+    while(!st.empty()) { int r = st.back(); st.pop_back(); if(r < 0) continue; order.push_back(r); st.push_back(B.nodes[r].c[0]); st.push_back(B.nodes[r].c[1]); }
+    for(int k = n - 1; k >= 0; --k) solve(order[k]);
+  }
+  float leafCost(int ref) const { return nodeBox(B, ref).area() * cTri * refCount(B, ref); }
+  float get(int ref, int i) const
+  {
+    if(ref < 0) return leafCost(ref);  // a single reference is one leaf child whatever i
+    return cost[size_t(ref) * 8 + std::min(i, 7)];
+  }
+  void solve(int nd)
+  {
+    const Node2& N = B.nodes[nd];
+    float* c = &cost[size_t(nd) * 8];
+    int8_t* s = &split[size_t(nd) * 8];
+    // distribute i roots over the two children
+    for(int i = 2; i <= 7; ++i)
+    {
+      float best = FLT_MAX; int bk = 1;
+      for(int k = 1; k < i; ++k)
+      {
+        float v = get(N.c[0], k) + get(N.c[1], i - k);
+        if(v < best) { best = v; bk = k; }
+      }
+      c[i] = best; s[i] = int8_t(bk);
+    }
+    // as ONE child: a leaf (if small enough) or an inner 8-wide node whose children are the best 8-root forest... 8 = k + (8-k)
+    float inner = FLT_MAX; int bk = 1;
+    for(int k = 1; k < 8; ++k)
+    {
+      float v = get(N.c[0], k) + get(N.c[1], 8 - k);
+      if(v < inner) { inner = v; bk = k; }
+    }
+    inner += areaN[nd] = unite(N.b[0], N.b[1]).area();
+    float leaf = N.cnt <= maxLeaf ? leafCost(nd) : FLT_MAX;
+    if(leaf <= inner) { c[1] = leaf; s[1] = 0; }
+    else { c[1] = inner; s[1] = 1; }
+    s[0] = int8_t(bk);  // the 8-split of the inner-node option
+    for(int i = 2; i <= 7; ++i)
+      if(c[1] < c[i]) { c[i] = c[1]; s[i] = -1; }  // fewer roots than allowed is fine too
+  }
+  // the roots of the forest that represents `ref` with at most i roots
+  void roots(int ref, int i, std::vector<int>& out) const
+  {
+    if(ref < 0) { out.push_back(ref); return; }
+    if(i == 1 || split[size_t(ref) * 8 + i] == -1) { out.push_back(ref); return; }
+    int k = split[size_t(ref) * 8 + i];
+    roots(B.nodes[ref].c[0], k, out);
+    roots(B.nodes[ref].c[1], i - k, out);
+  }
+  bool isLeafRoot(int ref) const { return ref < 0 || split[size_t(ref) * 8 + 1] == 0; }
+  void children(int ref, std::vector<int>& out) const
+  {
+    int k = split[size_t(ref) * 8 + 0];
+    roots(B.nodes[ref].c[0], k, out);
+    roots(B.nodes[ref].c[1], 8 - k, out);
+  }
+};
+
+static void collectRefs(const Bvh2& B, int ref, std::vector<int>& out)
+{
+  if(ref < 0) { out.push_back(~ref); return; }
+  collectRefs(B, B.nodes[ref].c[0], out);
+  collectRefs(B, B.nodes[ref].c[1], out);
+}
+
+static Bvh8 collapse(const Bvh2& B, const CollapseCfg& cfg)
+{
+  Bvh8 W;
+  std::unique_ptr<Dp> dp;
+  if(cfg.sahdp) dp.reset(new Dp(B, cfg.maxLeaf, cfg.cLeafTri));
+  struct Item { int ref; int node8; };
+  std::vector<int> level{B.root};
+  W.nodes.push_back(Node8());
+  std::vector<int> levelNode{0};
+  const double rootA = nodeBox(B, B.root).area();
+  while(!level.empty())
+  {
+    std::vector<int> next, nextNode;
+    for(size_t li = 0; li < level.size(); ++li)
+    {
+      int ref = level[li];
+      std::vector<int> kids;
+      if(cfg.sahdp) dp->children(ref, kids);
+      else
+      {
+        kids = {B.nodes[ref].c[0], B.nodes[ref].c[1]};
+        while(kids.size() < 8)
+        {
+          int best = -1; float bestA = -1;
+          for(size_t k = 0; k < kids.size(); ++k)
+            if(kids[k] >= 0 && refCount(B, kids[k]) > cfg.maxLeaf)
+            {
+              float a = nodeBox(B, kids[k]).area();
+              if(a > bestA) { bestA = a; best = int(k); }
+            }
+          if(best < 0) break;
+          int r = kids[best];
+          kids[best] = B.nodes[r].c[0];
+          kids.push_back(B.nodes[r].c[1]);
+        }
+      }
+      const int count = int(kids.size());
+      std::vector<Box> kb(count);
+      Box nb;
+      for(int k = 0; k < count; ++k) { kb[k] = nodeBox(B, kids[k]); nb.grow(kb[k]); }
+      W.sah += nb.area() / rootA;
+      // octant slot assignment, as k_collapse_emit
+      int candOfSlot[8]; bool slotUsed[8] = {}, done[8] = {};
+      std::fill(candOfSlot, candOfSlot + 8, -1);
+      for(int round = 0; round < count; ++round)
+      {
+        float bestCost = -FLT_MAX; int bc = -1, bs = -1;
+        for(int c = 0; c < count; ++c)
+        {
+          if(done[c]) continue;
+          float d[3];
+          for(int a = 0; a < 3; ++a) d[a] = 0.5f * (kb[c].lo[a] + kb[c].hi[a]) - 0.5f * (nb.lo[a] + nb.hi[a]);
+          for(int sl = 0; sl < 8; ++sl)
+          {
+            if(slotUsed[sl]) continue;
+            float cost = ((sl & 1) ? d[0] : -d[0]) + ((sl & 2) ? d[1] : -d[1]) + ((sl & 4) ? d[2] : -d[2]);
+            if(cost > bestCost) { bestCost = cost; bc = c; bs = sl; }
+          }
+        }
+        candOfSlot[bs] = bc; slotUsed[bs] = true; done[bc] = true;
+      }
+      Node8 N;
+      // quantisation frame
+      float scale[3];
+      for(int a = 0; a < 3; ++a)
+      {
+        float ext = nb.hi[a] - nb.lo[a];
+        int   e   = ext > 0 ? int(std::ceil(std::log2(double(ext) / 255.0))) : -126;
+        scale[a]  = std::ldexp(1.0f, e);
+      }
+      for(int sl = 0; sl < 8; ++sl)
+      {
+        N.child[sl] = -2; N.triBase[sl] = 0; N.triCnt[sl] = 0; N.box[sl] = Box();
+        if(candOfSlot[sl] < 0) continue;
+        int        k = candOfSlot[sl];
+        Box        q = kb[k];
+        if(cfg.quantise)
+          for(int a = 0; a < 3; ++a)
+          {
+            q.lo[a] = nb.lo[a] + std::floor((kb[k].lo[a] - nb.lo[a]) / scale[a]) * scale[a];
+            q.hi[a] = nb.lo[a] + std::ceil((kb[k].hi[a] - nb.lo[a]) / scale[a]) * scale[a];
+          }
+        N.box[sl] = q;
+        bool leaf = cfg.sahdp ? dp->isLeafRoot(kids[k]) : (kids[k] < 0 || refCount(B, kids[k]) <= cfg.maxLeaf);
+        if(leaf)
+        {
+          std::vector<int> refs;
+          collectRefs(B, kids[k], refs);
+          N.child[sl] = -1; N.triBase[sl] = int(W.tris.size()); N.triCnt[sl] = int(refs.size());
+          for(int r : refs) W.tris.push_back(B.refTri[r]);
+        }
+        else
+        {
+          N.child[sl] = int(W.nodes.size() + next.size());  // placeholder, fixed below (BFS order = append order)
+          next.push_back(kids[k]);
+        }
+      }
+      W.nodes[levelNode[li]] = N;
+    }
+    // allocate the next level's nodes and patch indices: children were numbered W.nodes.size() + position in `next` at the time;
+    // since nodes are appended only here, recompute
+    size_t base = W.nodes.size();
+    // fix child indices of this level: they were assigned as (size at that time + index), size was constant during the level => ok
+    for(size_t i = 0; i < next.size(); ++i) { W.nodes.push_back(Node8()); nextNode.push_back(int(base + i)); }
+    level.swap(next); levelNode.swap(nextNode);
+  }
+  return W;
+}
+
+// ---- rays ----------------------------------------------------------------------------------------------------------------------------
+struct Ray { V3 o, d; };
+static bool hitTri(const Tri& T, const Ray& r, float tmax, float& t)
+{
+  V3 e1 = T.p1 - T.p0, e2 = T.p2 - T.p0, p = cross(r.d, e2);
+  float det = dot(e1, p);
+  if(std::fabs(det) < 1e-20f) return false;
+  float inv = 1.0f / det;
+  V3 s = r.o - T.p0;
+  float u = dot(s, p) * inv;
+  if(u < 0 || u > 1) return false;
+  V3 q = cross(s, e1);
+  float v = dot(r.d, q) * inv;
+  if(v < 0 || u + v > 1) return false;
+  t = dot(e2, q) * inv;
+  return t > 0 && t < tmax;
+}
+static bool slab(const Box& b, const Ray& r, V3 idir, float tmax, float& tn)
+{
+  float t0 = 0, t1 = tmax;
+  for(int a = 0; a < 3; ++a)
+  {
+    float ta = (b.lo[a] - r.o[a]) * idir[a], tb = (b.hi[a] - r.o[a]) * idir[a];
+    if(ta > tb) std::swap(ta, tb);
+    t0 = std::max(t0, ta); t1 = std::min(t1, tb);
+  }
+  tn = t0;
+  return t0 <= t1;
+}
+
+struct WalkStats { double nodes = 0, tris = 0, rays = 0, hits = 0, maxStack = 0; };
+
+// mode 0: octant order, triangles tested immediately (the ideal of the device walk); 1: distance order; 2: octant order with the
+// device's deferral model: leaf hits are parked and tested only after `defer` further node visits (tmax tightens late)
+static void walk(const Bvh8& W, const std::vector<Tri>& tris, const std::vector<uint8_t>& alpha, const Ray& r, int mode, int defer, uint32_t seed, WalkStats& S)
+{
+  V3 idir{1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
+  const uint32_t octinv = 7u ^ ((idir.x < 0 ? 1u : 0u) | (idir.y < 0 ? 2u : 0u) | (idir.z < 0 ? 4u : 0u));
+  float tmax = FLT_MAX;
+  struct Entry { int node; float tn; };
+  std::vector<Entry> stack;
+  stack.push_back({0, 0});
+  struct Parked { int base, cnt, due; };
+  std::vector<Parked> parked;
+  int visits = 0;
+  auto testLeaf = [&](int base, int cnt) {
+    for(int k = 0; k < cnt; ++k)
+    {
+      int   ti = W.tris[base + k];
+      float t;
+      S.tris += 1;
+      if(hitTri(tris[ti], r, tmax, t))
+      {
+        if(alpha[ti])
+        {
+          uint32_t h = (seed ^ uint32_t(ti) * 2654435761u); h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+          if((h & 0xffff) < 0x9999) continue;  // 60 % of the candidates on alpha-tested cards are passed through
+        }
+        tmax = t;
+      }
+    }
+  };
+  while(!stack.empty())
+  {
+    Entry e = stack.back(); stack.pop_back();
+    if(mode == 1 && e.tn > tmax) continue;
+    const Node8& N = W.nodes[e.node];
+    S.nodes += 1; ++visits;
+    // due parked leaves
+    if(mode == 2)
+    {
+      for(size_t k = 0; k < parked.size();)
+        if(parked[k].due <= visits) { testLeaf(parked[k].base, parked[k].cnt); parked[k] = parked.back(); parked.pop_back(); }
+        else ++k;
+    }
+    struct H { int slot; float tn; };
+    H hit[8]; int nh = 0;
+    for(int sl = 0; sl < 8; ++sl)
+    {
+      if(N.child[sl] == -2) continue;
+      float tn;
+      if(!slab(N.box[sl], r, idir, tmax, tn)) continue;
+      if(N.child[sl] == -1)
+      {
+        if(mode == 2) parked.push_back({N.triBase[sl], N.triCnt[sl], visits + defer});
+        else testLeaf(N.triBase[sl], N.triCnt[sl]);
+      }
+      else hit[nh++] = {sl, tn};
+    }
+    // push in reverse priority so that the nearest is popped first
+    if(mode == 1) std::sort(hit, hit + nh, [](const H& a, const H& b) { return a.tn > b.tn; });
+    else std::sort(hit, hit + nh, [&](const H& a, const H& b) { return (uint32_t(a.slot) ^ octinv) < (uint32_t(b.slot) ^ octinv); });
+    for(int k = 0; k < nh; ++k) stack.push_back({N.child[hit[k].slot], hit[k].tn});
+    S.maxStack = std::max(S.maxStack, double(stack.size()));
+    if(mode == 2 && stack.empty())
+    {
+      for(auto& p : parked) testLeaf(p.base, p.cnt);
+      parked.clear();
+      // (a tightened tmax cannot prune anything any more)
+    }
+  }
+  if(mode == 2) for(auto& p : parked) testLeaf(p.base, p.cnt);
+  S.rays += 1;
+  if(tmax < FLT_MAX) S.hits += 1;
+}
+
+int main(int argc, char** argv)
+{
+  if(argc < 2) { fprintf(stderr, "usage: bvh_lab tris.bin [key=value ...]\n"); return 1; }
+  std::map<std::string, std::string> opt;
+  for(int i = 2; i < argc; ++i) { std::string a = argv[i]; size_t e = a.find('='); if(e != std::string::npos) opt[a.substr(0, e)] = a.substr(e + 1); }
+  auto get = [&](const char* k, const char* d) { return opt.count(k) ? opt[k] : std::string(d); };
+  FILE* f = fopen(argv[1], "rb");
+  if(!f) { perror("open"); return 1; }
+  int n = 0;
+  if(fread(&n, 4, 1, f) != 1) return 1;
+  std::vector<Tri> tris(n);
+  std::vector<uint8_t> alpha(n);
+  if(fread(tris.data(), sizeof(Tri), n, f) != size_t(n) || fread(alpha.data(), 1, n, f) != size_t(n)) return 1;
+  float cam[6] = {};
+  if(fread(cam, 4, 6, f) != 6) return 1;
+  fclose(f);
+
+  // references (optionally pre-split: a triangle whose box area exceeds split x mean is cut along its box's longest axis, recursively)
+  std::vector<int> refTri; std::vector<Box> refBox;
+  const float splitF = std::stof(get("split", "0"));
+  {
+    double meanA = 0;
+    std::vector<Box> tb(n);
+    for(int i = 0; i < n; ++i) { tb[i].grow(tris[i].p0); tb[i].grow(tris[i].p1); tb[i].grow(tris[i].p2); meanA += tb[i].area(); }
+    meanA /= n;
+    for(int i = 0; i < n; ++i)
+    {
+      if(splitF <= 0 || tb[i].area() <= splitF * meanA) { refTri.push_back(i); refBox.push_back(tb[i]); continue; }
+      // clip polygon against box halves recursively
+      std::function<void(std::vector<V3>, int)> rec = [&](std::vector<V3> poly, int depth) {
+        Box b; for(V3 p : poly) b.grow(p);
+        if(depth >= 6 || b.area() <= splitF * meanA) { refTri.push_back(i); refBox.push_back(b); return; }
+        int ax = 0; float ext = 0;
+        for(int a = 0; a < 3; ++a) if(b.hi[a] - b.lo[a] > ext) { ext = b.hi[a] - b.lo[a]; ax = a; }
+        float mid = 0.5f * (b.lo[ax] + b.hi[ax]);
+        std::vector<V3> L, R;
+        for(size_t k = 0; k < poly.size(); ++k)
+        {
+          V3 a = poly[k], c = poly[(k + 1) % poly.size()];
+          bool ia = a[ax] <= mid, ic = c[ax] <= mid;
+          if(ia) L.push_back(a); if(!ia || a[ax] == mid) R.push_back(a);
+          if(ia != ic) { float t = (mid - a[ax]) / (c[ax] - a[ax]); V3 p = a + (c - a) * t; p[ax] = mid; L.push_back(p); R.push_back(p); }
+        }
+        if(L.size() >= 3) rec(L, depth + 1);
+        if(R.size() >= 3) rec(R, depth + 1);
+      };
+      rec({tris[i].p0, tris[i].p1, tris[i].p2}, 0);
+    }
+  }
+  printf("triangles %d references %zu\n", n, refTri.size());
+
+  const std::string builder = get("builder", "ploc");
+  Bvh2 B = builder == "sah" ? buildSah(refTri, refBox) : buildPloc(refTri, refBox, std::stoi(get("radius", "16")));
+  printf("BVH2 %s: inner-node SAH %.2f\n", builder.c_str(), sahCost2(B));
+  const int passes = std::stoi(get("reinsert", "0"));
+  if(passes > 0)
+  {
+    std::vector<int> leafParent(refTri.size(), -1);
+    for(int i = 0; i < int(B.nodes.size()); ++i) for(int k = 0; k < 2; ++k) if(B.nodes[i].c[k] < 0) leafParent[~B.nodes[i].c[k]] = i;
+    for(int p = 0; p < passes; ++p)
+    {
+      reinsertPass(B, std::stod(get("fraction", "0.02")), leafParent);
+      printf("  reinsertion pass %d: SAH %.2f\n", p + 1, sahCost2(B));
+    }
+  }
+  CollapseCfg cfg;
+  cfg.maxLeaf  = std::stoi(get("leaf", "2"));
+  cfg.sahdp    = get("collapse", "greedy") == "sahdp";
+  cfg.cLeafTri = std::stof(get("ctri", "0.24"));
+  cfg.quantise = get("quantise", "1") == "1";
+  Bvh8 W = collapse(B, cfg);
+  double leafChildren = 0, innerChildren = 0;
+  for(const Node8& N : W.nodes) for(int s = 0; s < 8; ++s) { if(N.child[s] == -1) leafChildren++; else if(N.child[s] >= 0) innerChildren++; }
+  printf("BVH8 (%s, leaf <= %d): %zu nodes, SAH(nodes) %.2f, fill %.2f children/node (%.2f leaf), %.2f tris/leaf\n", cfg.sahdp ? "sahdp" : "greedy", cfg.maxLeaf,
+         W.nodes.size(), W.sah, (leafChildren + innerChildren) / W.nodes.size(), leafChildren / W.nodes.size(), W.tris.size() / std::max(1.0, leafChildren));
+
+  // rays: bounce rays from random surface points (area-weighted), cosine-distributed
+  const int nrays = std::stoi(get("rays", "200000"));
+  std::vector<double> cdf(n);
+  double acc = 0;
+  for(int i = 0; i < n; ++i) { V3 c = cross(tris[i].p1 - tris[i].p0, tris[i].p2 - tris[i].p0); acc += 0.5 * std::sqrt(dot(c, c)); cdf[i] = acc; }
+  std::vector<Ray> rays(nrays);
+  std::mt19937 rng(12345);
+  std::uniform_real_distribution<float> U(0, 1);
+  // seed rays by tracing from the camera would be closer to the real distribution; use surface points seen from the eye when possible:
+  // here: half area-weighted surface points, half points hit by random rays from the eye
+  for(int i = 0; i < nrays; ++i)
+  {
+    int t = int(std::lower_bound(cdf.begin(), cdf.end(), U(rng) * acc) - cdf.begin());
+    t = std::min(t, n - 1);
+    float a = U(rng), b = U(rng);
+    if(a + b > 1) { a = 1 - a; b = 1 - b; }
+    V3 p = tris[t].p0 + (tris[t].p1 - tris[t].p0) * a + (tris[t].p2 - tris[t].p0) * b;
+    V3 nrm = normalize(cross(tris[t].p1 - tris[t].p0, tris[t].p2 - tris[t].p0));
+    if(U(rng) < 0.5f) nrm = nrm * -1.0f;
+    float u1 = U(rng), u2 = U(rng), rr = std::sqrt(u1), ph = 6.2831853f * u2;
+    V3 tx = normalize(std::fabs(nrm.x) > 0.5f ? cross(nrm, V3{0, 1, 0}) : cross(nrm, V3{1, 0, 0})), ty = cross(nrm, tx);
+    V3 d = tx * (rr * std::cos(ph)) + ty * (rr * std::sin(ph)) + nrm * std::sqrt(std::max(0.0f, 1 - u1));
+    rays[i] = {p + nrm * 1e-3f, normalize(d)};
+  }
+  for(int mode : {0, 2, 1})
+  {
+    WalkStats S;
+    const int defer = std::stoi(get("defer", "3"));
+#pragma omp parallel
+    {
+      WalkStats L;
+#pragma omp for schedule(dynamic, 256)
+      for(int i = 0; i < nrays; ++i) walk(W, tris, alpha, rays[i], mode, defer, uint32_t(i) * 7919u + 17u, L);
+#pragma omp critical
+      { S.nodes += L.nodes; S.tris += L.tris; S.rays += L.rays; S.hits += L.hits; S.maxStack = std::max(S.maxStack, L.maxStack); }
+    }
+    printf("walk %-28s: %.2f node visits + %.2f triangle tests per ray  (cost 235n+56t = %.0f; hit rate %.3f, max stack %.0f)\n",
+           mode == 0 ? "octant order, immediate" : (mode == 1 ? "distance order, immediate" : "octant order, deferred"), S.nodes / S.rays, S.tris / S.rays,
+           (235 * S.nodes + 56 * S.tris) / S.rays, S.hits / S.rays, S.maxStack);
+  }
+  return 0;
+}

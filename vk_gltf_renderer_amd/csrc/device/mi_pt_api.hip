@@ -290,7 +290,31 @@ hipEvent_t getEvent(MiPt* pt, size_t& cursor)
 // needs is resident (geometry pool, materials) or kept on the host in MiPt (node matrices, visibility), so it serves the scene
 // build (mi_pt_create; reference: SceneRtx BLAS + TLAS build, src/gltf_scene_rtx.cpp:173-385) and the transform / visibility
 // updates of animated scenes (mi_pt_update_render_nodes; reference: TLAS update, src/gltf_scene_transform_vk.cpp:534-639) alike.
+int buildAccelerationUnguarded(MiPt* pt);
+// A failed (re)build must not leave the scene descriptor pointing at freed or half-built arrays: mi_pt_update_render_nodes runs
+// this once per animated frame, and the next mi_pt_render_frame would walk them.  On any error the instance falls back to an
+// EMPTY structure (frames render the environment only) and the error is returned to the caller.
 int buildAcceleration(MiPt* pt)
+{
+  const int rc = buildAccelerationUnguarded(pt);
+  if(rc != MI_PT_OK)
+  {
+    const std::string why = g_lastError;  // (the frees below must not disturb the message)
+    if(pt->bvhNodes) (void)hipFree(pt->bvhNodes);
+    if(pt->bvhTris) (void)hipFree(pt->bvhTris);
+    if(pt->bvh8Nodes) (void)hipFree(pt->bvh8Nodes);
+    pt->bvhNodes = nullptr; pt->bvhTris = nullptr; pt->bvh8Nodes = nullptr;
+    pt->bvh8Planes.release(); pt->shadeTris.release(); pt->alphaTris.release();
+    pt::DevScene& S = pt->scene;
+    S.bvhNodes = nullptr; S.bvh8Nodes = nullptr; S.tris = nullptr; S.bvh8Planes = nullptr; S.shadeTris = nullptr; S.alphaTris = nullptr;
+    S.numTris = 0; S.bvh8NumNodes = 0; S.bvhRoot = pt::BVH_EMPTY;
+    pt->staticStats.bvhNodeCount = pt->staticStats.bvhTriangleCount = 0;
+    pt->sceneDevDirty = true;
+    g_lastError = why;
+  }
+  return rc;
+}
+int buildAccelerationUnguarded(MiPt* pt)
 {
   const int numNodes = int(pt->hostNodes.size()), numMaterials = int(pt->matInstFlags.size()), numPrims = int(pt->primTriangles.size());
   std::vector<uint8_t>  flags(size_t(std::max(numNodes, 1)), 0);
@@ -337,6 +361,9 @@ int buildAcceleration(MiPt* pt)
   if(pt->bvhTris) (void)hipFree(pt->bvhTris);
   if(pt->bvh8Nodes) (void)hipFree(pt->bvh8Nodes);
   pt->bvhNodes = nullptr; pt->bvhTris = nullptr; pt->bvh8Nodes = nullptr;
+  if(const char* e = getenv("MI_PT_DIAG_FAIL_BUILD"))  // test hook: a rebuild that fails after the old structure is gone
+    if(atoi(e) != 0)
+      return fail(MI_PT_ERR_HIP, "BVH build failed: MI_PT_DIAG_FAIL_BUILD");
   {
     DevBuf<uint32_t> dOffset;
     DevBuf<int32_t>  dEntry;
