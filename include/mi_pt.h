@@ -55,6 +55,11 @@ typedef struct MiPtRenderPrimitive
   const float*    tangents;   /* 4 floats / vertex or NULL */
   const float*    texCoords0; /* 2 floats / vertex or NULL */
   const float*    texCoords1; /* 2 floats / vertex or NULL */
+  /* Triangles [0, opaqueTriangleCount) are known to pass their material's alpha test everywhere (alpha-MASK geometry classified at
+   * load, mi_scene_cut_alpha -- the OPAQUE state of the reference's opacity micro-maps, src/gltf_scene_omm.cpp): the walks treat them
+   * like triangles of a FORCE_OPAQUE instance.  0 = nothing known (every triangle of a non-opaque material is alpha-tested). */
+  uint32_t        opaqueTriangleCount;
+  uint32_t        reserved; /* 0 */
 } MiPtRenderPrimitive;
 
 enum MiPtFilter { MI_FILTER_NEAREST = 0, MI_FILTER_LINEAR = 1 };

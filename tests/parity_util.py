@@ -13,8 +13,9 @@ class Setup:
     """Scene + camera + frame constants shared by both renderers."""
 
     def __init__(self, scene_path, width, height, hdr_path=None, hdr_pixels=None, max_depth=5, spp_per_frame=1, camera=None,
-                 flags=0, frame_info_edit=None, params_edit=None, sky_edit=None):
+                 flags=0, frame_info_edit=None, params_edit=None, sky_edit=None, alpha_cut=0):
         self.scene = ptmod.Scene(scene_path)
+        self.alpha_cut_dropped = self.scene.cut_alpha(alpha_cut) if alpha_cut > 0 else 0  # (load-time bake, mi_scene_cut_alpha)
         self.width, self.height = width, height
         cam = camera if camera is not None else self.scene.camera(0)
         self.frame_info, pixel_angle, focal = ptmod.camera_frame_info(cam, width, height)

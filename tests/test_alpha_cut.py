@@ -103,6 +103,19 @@ def test_no_passing_point_loses_its_geometry(built, tmp_path, case):
         v = (py * (B[k, 0] - A[k, 0]) - px * (B[k, 1] - A[k, 1])) / d[k]
         covered |= (u >= -1e-5) & (v >= -1e-5) & (u + v <= 1 + 1e-5)
     assert covered.all(), (case, int((~covered).sum()))
+    # the other half of the classification: triangles [0, opaqueTriangleCount) are those the walks will NOT alpha-test -- every
+    # point of them must pass the test (random points inside each, alpha evaluated as above)
+    n_opaque = cut.desc.contents.renderPrimitives[0].opaqueTriangleCount
+    assert 0 <= n_opaque <= len(idx1)
+    if case != "bilinear_repeat_tiled":
+        assert n_opaque > 0, case
+    if n_opaque:
+        to = rng.integers(0, n_opaque, 40000)
+        bo = rng.dirichlet((1, 1, 1), 40000)
+        uvo = (uv1[idx1[to]] * bo[..., None]).sum(axis=1)
+        ao = factor * _alpha_at(img, uvo, mag == 9729, wrap, wrap)
+        assert (ao >= cutoff).all(), (case, int((ao < cutoff).sum()), float(ao.min()))
+        print(case, "opaque triangles", n_opaque, "of", len(idx1))
     # and the cut is worth something: a good part of the failing area is gone
     area = lambda i, p: 0.5 * np.abs(np.cross(p[i[:, 1]] - p[i[:, 0]], p[i[:, 2]] - p[i[:, 0]])[:, 2]).sum()
     print(case, "triangles", len(idx0), "->", len(idx1), "area kept", area(idx1, pos1) / area(idx0, pos0), "passing fraction", (alpha >= cutoff).mean())

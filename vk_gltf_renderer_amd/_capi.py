@@ -88,7 +88,7 @@ TONEMAP_METHODS = ("filmic", "uncharted", "clip", "aces", "agx", "khronos_pbr") 
 class MiPtRenderPrimitive(C.Structure):
     _fields_ = [("indices", C.POINTER(u32)), ("triangleCount", u32), ("vertexCount", u32), ("positions", C.POINTER(f32)),
                 ("normals", C.POINTER(f32)), ("colors", C.POINTER(u32)), ("tangents", C.POINTER(f32)),
-                ("texCoords0", C.POINTER(f32)), ("texCoords1", C.POINTER(f32))]
+                ("texCoords0", C.POINTER(f32)), ("texCoords1", C.POINTER(f32)), ("opaqueTriangleCount", u32), ("reserved", u32)]
 
 
 class MiPtTexture(C.Structure):

@@ -78,7 +78,8 @@ __global__ void k_tri_setup(BuildTables T, uint32_t numTris, DevTri* tris, float
     DevTri tri;
     tri.a   = make_float4(p0.x, p0.y, p0.z, __int_as_float(rnode));
     tri.b   = make_float4(e1.x, e1.y, e1.z, __int_as_float(int(t)));
-    tri.c   = make_float4(e2.x, e2.y, e2.z, __uint_as_float(uint32_t(T.instFlags[rnode])));
+    // (a triangle the load-time classification found opaque -- DevPrim::opaqueTriangles -- counts as FORCE_OPAQUE like an opaque instance)
+    tri.c   = make_float4(e2.x, e2.y, e2.z, __uint_as_float(uint32_t(T.instFlags[rnode]) | (t < rp.opaqueTriangles ? uint32_t(INST_FORCE_OPAQUE) : 0u)));
     tris[g] = tri;
     // bounds from the same p0 + e arithmetic the intersector sees
     f3 q1 = p0 + e1, q2 = p0 + e2;

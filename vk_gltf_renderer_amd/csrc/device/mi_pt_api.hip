@@ -559,6 +559,8 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
       d.tangents   = reinterpret_cast<const float*>(put(p.tangents, size_t(p.vertexCount) * 16));
       d.texCoords0 = reinterpret_cast<const float*>(put(p.texCoords0, size_t(p.vertexCount) * 8));
       d.texCoords1 = reinterpret_cast<const float*>(put(p.texCoords1, size_t(p.vertexCount) * 8));
+      d.opaqueTriangles = getenv("MI_PT_DIAG_NO_OPAQUE_TRIS") ? 0u : std::min(p.opaqueTriangleCount, p.triangleCount);  // (A/B switch: alpha-test them all)
+      d._pad            = 0;
       {
         std::vector<float> iv(size_t(p.vertexCount) * 12, 0.0f);
         for(uint32_t v = 0; v < p.vertexCount; ++v)
@@ -921,6 +923,11 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
     // MI_PT_SORT = 0 | 1 | 2 is the A/B switch of the generic kernel.
     static const char* sortEnv = getenv("MI_PT_SORT");
     c.sortMode = sortEnv ? atoi(sortEnv) : 2;
+    // The SIMPLE kernel's later bounces: keyed by next-event technique where sampleLights() has a coin to flip -- punctual lights
+    // AND an environment with weight (getDirectLightingTechniqueProbabilities) -- otherwise as it is.  MI_PT_SORT_SIMPLE = 0 | 1 | 3.
+    static const char* sortSimpleEnv = getenv("MI_PT_SORT_SIMPLE");
+    const bool envActive = !(pt->frameInfo.flags & MI_SCENE_USE_HDR_ENVIRONMENT) || pt->frameInfo.envIntensity > 0.0f;
+    c.sortModeSimple     = sortSimpleEnv ? atoi(sortSimpleEnv) : ((pt->scene.numLights > 0 && envActive) ? 3 : 0);
   }
   // descriptor copies for the kernels that read them through a pointer
   if(pt->sceneDevDirty)

@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(256) k_generate(DevScene sc, FrameConsts fc, P
 // Diagnostics build only (-DTRACE_PROFILE): shader-clock ticks per wave spent in the sections of k_trace_closest.
 // [8..15]: lane occupancy -- node steps / lanes visiting / triangle rounds / lanes testing / refills / lanes idle at refill /
 // triangle phases / lanes blocked (both park records full) per node step
-__device__ unsigned long long g_traceProf[18];
+__device__ unsigned long long g_traceProf[20];  // [18] alpha rounds, [19] triangle-round publish
 __device__ unsigned long long g_shadowProf[16];  // the same for k_trace_shadow (8-wide BVH, deferring modes)
 #define PROF_T() __builtin_amdgcn_s_memtime()
 #define PROF_ADD(i, t0) profAcc[i] += PROF_T() - (t0)
@@ -805,8 +805,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
   uint32_t pPos = 0, pSlot = QUEUE_DEAD;
   float4   pO = make_float4(0, 0, 0, 0), pD = make_float4(0, 0, 0, 0);
 #ifdef TRACE_PROFILE
-  unsigned long long profAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long profCnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long profAcc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long profCnt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long profStart = PROF_T();
 #endif
   for(;;)
@@ -937,8 +937,11 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
           const int  waiting = __popcll(__ballot(walked && aPending));
           if(aCount >= ALPHA_ROUND_MIN || lastVisiting < TRI_PHASE_LANES || waiting >= ALPHA_ROUND_WAITING)
           {
+            const unsigned long long tAlpha = PROF_T();
             bool none = false;
             alphaRound<false>(sc, seed0, waveAlpha, aCount, aPending, best, none);
+            PROF_ADD(8, tAlpha);
+            PROF_CNT(8, 1);
           }
         }
         PROF_ADD(2, tTri);
@@ -991,6 +994,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
       atomicAdd(&g_traceProf[8 + i], profCnt[i]);
     atomicAdd(&g_traceProf[16], profAcc[3]);
     atomicAdd(&g_traceProf[17], profAcc[7]);
+    atomicAdd(&g_traceProf[18], profAcc[8]);
+    atomicAdd(&g_traceProf[19], profCnt[8]);
   }
 #endif
   if(COUNT)
@@ -1353,8 +1358,11 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
   __shared__ uint32_t s_prefix[NSUB + 1];
   __shared__ uint32_t s_push[4];
   __shared__ float    s_srgb[256];  // sRGB decode table next to the ALU: 3 lookups per texel, up to 8 texels per tap
-  __shared__ uint32_t s_order[SIMPLE ? 1 : SORT_WINDOW];                     // queue positions of the window's live entries, sorted by bin
-  __shared__ uint16_t s_segCount[SIMPLE ? 1 : SORT_SEGMENTS][SORT_BINS];     // entries of a bin in one (round, wave) segment -> exclusive prefix inside the bin
+  // The window sort exists in the generic kernel (key: material) and in the later bounces of the SIMPLE kernel (key: next-event
+  // technique); the bounce-0 launch of the SIMPLE kernel gets its hits packed by k_trace_primary and walks the queue as it is.
+  constexpr bool CAN_SORT = !SIMPLE || !FIRST;
+  __shared__ uint32_t s_order[CAN_SORT ? SORT_WINDOW : 1];                   // queue positions of the window's live entries, sorted by bin
+  __shared__ uint16_t s_segCount[CAN_SORT ? SORT_SEGMENTS : 1][SORT_BINS];   // entries of a bin in one (round, wave) segment -> exclusive prefix inside the bin
   __shared__ uint32_t s_binBase[SORT_BINS + 1];                 // first sorted index of each bin; [SORT_BINS] = live entries of the window
   static_assert(SHADE_BLOCK == 256, "one table entry per thread");
   if(blockIdx.x == 0 && threadIdx.x < 8)
@@ -1362,10 +1370,15 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
   queuePrefix(&Q.counters[cur ? QC_PAIR1 : QC_PAIR0], s_prefix);
   const uint32_t count      = s_prefix[NSUB];
   const int      nxt        = cur ^ 1;
-  // The per-bounce sort exists in the generic kernel only: where every material runs the same code (SIMPLE) grouping the hits
-  // buys nothing and the window bookkeeping costs registers (measured: +9 % on the helmet workload's bounce-0 launch), so that
-  // flavour walks the queue chunk by chunk as it is.
-  constexpr uint32_t ROUNDS = SIMPLE ? 1u : SORT_ROUNDS;
+  // Where every material runs the same code (SIMPLE) grouping the hits by MATERIAL buys nothing (measured: +9 % on the helmet
+  // workload's bounce-0 launch for the window bookkeeping, +13 % / +5 % on the later bounces of atrium / street).  What diverges
+  // there is the next-event technique -- sampleLights() flips a coin between the punctual lights and the environment
+  // (pathtrace_functions.h.slang:357-464), so the light sampler, the sky sampler + evaluation and, next to them, the sky
+  // evaluation of the paths that left the scene each ran in a third of the lanes (PMC: 28 of 64 lanes per vector instruction
+  // on the atrium).  sortMode 3 keys the window by exactly that: escaped | surface hit x technique; the coin is the first draw
+  // of sampleLights and a function of the path's seed alone, so it is known before anything is shaded.  Paths are independent:
+  // the processing order changes no result.
+  constexpr uint32_t ROUNDS = CAN_SORT ? SORT_ROUNDS : 1u;
   constexpr uint32_t WINDOW = ROUNDS * SHADE_BLOCK;
   const uint32_t     numWindows = (count + WINDOW - 1) / WINDOW;
   if(blockIdx.x >= numWindows)
@@ -1382,8 +1395,11 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
     // (round, wave) segment comes from ballots over the distinct bins of the wave (usually one to three), the segments of a bin
     // are laid out in queue order.  Paths are independent, so the processing order cannot change any result.
     uint32_t live = min(WINDOW, count - win * WINDOW);  // no sort: the window as it is, dead entries and all
-    if(!SIMPLE && sortMode != 0)
+    if(CAN_SORT && sortMode != 0)
     {
+    float lightWeight = 0.0f, envWeight = 0.0f;
+    if(sortMode == 3)
+      getDirectLightingTechniqueProbabilities(sc, fc, lightWeight, envWeight);
     uint32_t myPos[SORT_ROUNDS], myBin[SORT_ROUNDS], myRank[SORT_ROUNDS];
     for(uint32_t t = threadIdx.x; t < SORT_SEGMENTS * SORT_BINS; t += SHADE_BLOCK)
       (&s_segCount[0][0])[t] = 0;
@@ -1401,8 +1417,17 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
         if(slot != QUEUE_DEAD)
         {
           const int tri = __float_as_int(Q.active[cur].aux[myPos[k]].y);
-          // sortMode 1: surface hits / the rest / dead; 2: surface hits grouped by material as well
-          bin           = tri >= 0 ? (sortMode >= 2 ? uint32_t(sc.shadeTris[tri].materialID) % SORT_BIN_MISS : 0u) : SORT_BIN_MISS;
+          // sortMode 1: surface hits / the rest / dead; 2: surface hits grouped by material as well; 3: surface hits grouped by the
+          // next-event technique their path is about to draw (sampleLights: `rnd(seed) < lightWeight`, the path's next draw)
+          if(tri < 0)
+            bin = SORT_BIN_MISS;
+          else if(sortMode == 3)
+          {
+            uint32_t seedPeek = __float_as_uint(P.misc[slot].z);
+            bin               = rnd(seedPeek) < lightWeight ? 0u : 1u;
+          }
+          else
+            bin = sortMode >= 2 ? uint32_t(sc.shadeTris[tri].materialID) % SORT_BIN_MISS : 0u;
         }
       }
       myBin[k] = bin;
@@ -1457,7 +1482,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
     const uint32_t chunk   = win * ROUNDS + round;  // 256 processed entries append to sub-queue chunk % NSUB, like a chunk of the queue
     const uint32_t e       = round * SHADE_BLOCK + threadIdx.x;
     const bool     inRange = e < live;
-    const uint32_t inPos   = !inRange ? 0u : ((!SIMPLE && sortMode != 0) ? s_order[e] : queuePos(Q.subCap, s_prefix, win * WINDOW + e));
+    const uint32_t inPos   = !inRange ? 0u : ((CAN_SORT && sortMode != 0) ? s_order[e] : queuePos(Q.subCap, s_prefix, win * WINDOW + e));
     uint32_t       slot    = inRange ? Q.active[cur].slot[inPos] : QUEUE_DEAD;
     bool           alive = false, pushShadow = false;
     unsigned       taps = 0;
@@ -1811,7 +1836,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
         Q.shadow.aux2[posShadow] = make_float4(shCon2.x, shCon2.y, shCon2.z, __uint_as_float(alive ? posNext : 0xffffffffu));
     }
    }  // rounds of the window
-   if(!SIMPLE)
+   if(CAN_SORT)
      __syncthreads();  // s_order / s_segCount are rebuilt for the next window
   }
 }
@@ -2578,7 +2603,7 @@ void launchBuildAlphaRecords(const DevScene& scene, uint32_t numTris, DevAlphaTr
 void dumpTraceProfile()
 {
 #ifdef TRACE_PROFILE
-  unsigned long long h[18] = {};
+  unsigned long long h[20] = {};
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_traceProf), sizeof(h));
   const double tot = double(h[3]) > 0 ? double(h[3]) : 1.0;
@@ -2586,7 +2611,8 @@ void dumpTraceProfile()
           100.0 * h[7] / tot);
   fprintf(stderr, "[mi_pt trace profile] waves %llu total ticks %.4g: feed %.1f%% node %.1f%% tri %.1f%% other %.1f%%\n", h[4], tot, 100.0 * h[0] / tot,
           100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * (tot - h[0] - h[1] - h[2]) / tot);
-  fprintf(stderr, "[mi_pt trace profile] triangle rounds: test (permutes, intersection, alpha) %.1f%% gather %.1f%% of total\n", 100.0 * h[16] / tot, 100.0 * h[17] / tot);
+  fprintf(stderr, "[mi_pt trace profile] triangle rounds: test (permutes, intersection, alpha) %.1f%% gather %.1f%% of total; alpha rounds %.1f%% of total (%llu rounds)\n",
+          100.0 * h[16] / tot, 100.0 * h[17] / tot, 100.0 * h[18] / tot, h[19]);
   unsigned long long g[16] = {};
   (void)hipMemcpyFromSymbol(g, HIP_SYMBOL(g_shadowProf), sizeof(g));
   const double st = double(g[5]) > 0 ? double(g[5]) : 1.0;
@@ -2737,7 +2763,7 @@ void launchShade(const LaunchCtx& c, int cur, bool first)
 {
   dim3 grid(c.persistentBlocks), block(SHADE_BLOCK);
 #define MI_LAUNCH_SHADE(C, S, F) \
-  hipLaunchKernelGGL((k_shade<C, S, F>), grid, block, 0, c.stream, c.sceneDev, c.fcDev, c.paths, c.queues, cur, c.sortMode, c.stats)
+  hipLaunchKernelGGL((k_shade<C, S, F>), grid, block, 0, c.stream, c.sceneDev, c.fcDev, c.paths, c.queues, cur, (S ? (F ? 0 : c.sortModeSimple) : c.sortMode), c.stats)
 #define MI_LAUNCH_SHADE_F(C, S) do { if(first) MI_LAUNCH_SHADE(C, S, true); else MI_LAUNCH_SHADE(C, S, false); } while(0)
   if(c.simpleMaterials)
   {

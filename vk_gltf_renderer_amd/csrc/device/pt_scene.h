@@ -53,6 +53,10 @@ struct DevPrim
   // the hit-attribute fetch of the shade kernel touches 3 cache lines per hit instead of 12 (the separate streams above stay
   // for the builders, the alpha records, uv1 and colours).  Absent attributes are zero; the stream pointers say which exist.
   const float4*   verts;
+  // triangles [0, opaqueTriangles) pass their material's alpha test everywhere (MiPtRenderPrimitive::opaqueTriangleCount): the
+  // build gives them INST_FORCE_OPAQUE in their triangle record, so the walks never defer an alpha test for them
+  uint32_t        opaqueTriangles;
+  uint32_t        _pad;
 };
 
 enum : uint32_t

@@ -5,6 +5,11 @@
 // N x N barycentric grid, and the pieces on which the alpha test CANNOT pass -- no texel that a fetch inside the piece may touch
 // reaches the cutoff -- are dropped from the geometry; pieces that survive whole are merged back into their parent.  A ray through the empty part of a leaf card then meets no candidate at all: no
 // triangle test, no alpha record, no texel fetch, no continued traversal behind it.
+// The other half of the micro-map's job (round 3): pieces on which the test cannot FAIL -- every texel a fetch inside the piece may
+// touch reaches the cutoff with a margin -- are marked OPAQUE.  They are moved to the front of the primitive's index buffer and counted
+// (RenderPrimitiveData::opaqueTriangles -> MiPtRenderPrimitive::opaqueTriangleCount); the device build flags them like the triangles
+// of a FORCE_OPAQUE instance, so a hit in the interior of a leaf card commits without alpha record, texel fetch or deferred alpha
+// round.  Only the rim of the card keeps its alpha test.  MASK opacity is 0 or 1, `rand <= 1` always accepts: the same image.
 //
 // The rendered function is unchanged up to what cannot be observed: the dropped regions are those where
 // `rand <= opacity` (raytracer_interface.h.slang:76-111) has opacity 0, which the reference accepts only for a draw of exactly 0
@@ -13,6 +18,7 @@
 // MIRRORED_REPEAT, non-MASK modes, materials shared with other alpha settings.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -87,7 +93,7 @@ uint64_t GltfScene::cutAlphaMasked(int subdivisions)
     const int m = std::max(0, rn.materialID);
     pm = (pm == -1 || pm == m) ? m : -2;
   }
-  std::map<std::pair<int, int>, PassTable> tables;  // (texture, threshold byte)
+  std::map<std::pair<int, int>, PassTable> tables, failTables;  // (texture, threshold byte)
   uint64_t removed = 0;
   for(size_t p = 0; p < m_primData.size(); ++p)
   {
@@ -142,8 +148,37 @@ uint64_t GltfScene::cutAlphaMasked(int subdivisions)
         }
       }
     }
-    // can a fetch with a uv inside the triangle (uv_a, uv_b, uv_c) touch a texel that may pass?
-    auto mayPass = [&](const float* ua, const float* ub, const float* uc) {
+    // smallest alpha byte that reaches the cutoff whatever the run-time rounding does: a fetch that only touches such texels passes
+    int sure = 256;
+    for(int a = 255; a >= 0; --a)
+    {
+      if(factor * (float(a) / 255.0f) * (1.0f - 1e-5f) - 1e-6f >= mat.alphaCutoff)
+        sure = a;
+      else
+        break;
+    }
+    PassTable* F = nullptr;  // "this texel may FAIL the cutoff" (none when no byte is sure to pass: nothing can be marked opaque)
+    if(sure <= 255)
+    {
+      F = &failTables[{info.index, sure}];
+      if(F->sat.empty())
+      {
+        F->w = w; F->h = h;
+        F->sat.assign((size_t(w) + 1) * (size_t(h) + 1), 0);
+        const uint8_t* px = tex.levels[0].data();
+        for(int y = 0; y < h; ++y)
+        {
+          uint32_t row = 0;
+          for(int x = 0; x < w; ++x)
+          {
+            row += px[(size_t(y) * size_t(w) + size_t(x)) * 4 + 3] < sure ? 1u : 0u;
+            F->sat[size_t(y + 1) * (size_t(w) + 1) + size_t(x + 1)] = F->sat[size_t(y) * (size_t(w) + 1) + size_t(x + 1)] + row;
+          }
+        }
+      }
+    }
+    // can a fetch with a uv inside the triangle (uv_a, uv_b, uv_c) touch a texel that may pass (table T) / that may fail (table F)?
+    auto touches = [&](const PassTable& T, const float* ua, const float* ub, const float* uc) {
       const float fx0 = std::min({ua[0], ub[0], uc[0]}) * float(w), fx1 = std::max({ua[0], ub[0], uc[0]}) * float(w);
       const float fy0 = std::min({ua[1], ub[1], uc[1]}) * float(h), fy1 = std::max({ua[1], ub[1], uc[1]}) * float(h);
       if(!(std::fabs(fx0) < 1e6f && std::fabs(fx1) < 1e6f && std::fabs(fy0) < 1e6f && std::fabs(fy1) < 1e6f))
@@ -159,9 +194,58 @@ uint64_t GltfScene::cutAlphaMasked(int subdivisions)
             return true;
       return false;
     };
+    // The same question for the TRIANGLE instead of its bounding box (a triangular cell fills half of its box, and a leaf's outline
+    // is round): texel row by texel row, the x extent of the part of the triangle whose fetches can reach that row -- sample
+    // positions fy in [r - 1.5, r + 2.5), the same one-texel slack either side as above -- against that row of the table.
+    // Only asked when the box test is inconclusive.
+    auto touchesExact = [&](const PassTable& T, const float* ua, const float* ub, const float* uc) {
+      const float px[3] = {ua[0] * float(w), ub[0] * float(w), uc[0] * float(w)}, py[3] = {ua[1] * float(h), ub[1] * float(h), uc[1] * float(h)};
+      const float fy0 = std::min({py[0], py[1], py[2]}), fy1 = std::max({py[0], py[1], py[2]});
+      if(!(std::fabs(fy0) < 1e6f && std::fabs(fy1) < 1e6f && std::fabs(px[0]) < 1e6f && std::fabs(px[1]) < 1e6f && std::fabs(px[2]) < 1e6f))
+        return true;
+      const int r0 = int(std::floor(fy0 - 0.5f)) - 1, r1 = int(std::floor(fy1 - 0.5f)) + 2;
+      if(r1 - r0 > 4096)
+        return true;
+      for(int r = r0; r <= r1; ++r)
+      {
+        const float ya = float(r) - 1.5f - 1e-3f, yb = float(r) + 2.5f + 1e-3f;
+        float       xmin = 3.0e38f, xmax = -3.0e38f;
+        for(int e = 0; e < 3; ++e)
+        {
+          const float x0 = px[e], y0 = py[e], x1 = px[(e + 1) % 3], y1 = py[(e + 1) % 3];
+          if(y0 >= ya && y0 <= yb)
+          {
+            xmin = std::min(xmin, x0);
+            xmax = std::max(xmax, x0);
+          }
+          for(const float yc : {ya, yb})
+            if((y0 - yc) * (y1 - yc) < 0.0f)
+            {
+              const float x = x0 + (x1 - x0) * ((yc - y0) / (y1 - y0));
+              xmin = std::min(xmin, x);
+              xmax = std::max(xmax, x);
+            }
+        }
+        if(xmin > xmax)
+          continue;  // the band misses the triangle
+        const int x0 = int(std::floor(xmin - 0.5f - 1e-3f)) - 1, x1 = int(std::floor(xmax - 0.5f + 1e-3f)) + 2;
+        int rx[2][2], ry[2][2];
+        const int nx = wrapRange(x0, x1, w, tex.wrapS, rx), ny = wrapRange(r, r, h, tex.wrapT, ry);
+        for(int a = 0; a < nx; ++a)
+          for(int b = 0; b < ny; ++b)
+            if(T.count(rx[a][0], ry[b][0], rx[a][1], ry[b][1]) != 0)
+              return true;
+      }
+      return false;
+    };
+    static const bool exactCells = getenv("MI_HOST_ALPHA_CUT_BOXES") == nullptr;  // (A/B: bounding boxes only, the round-2 classification)
+    auto mayPass = [&](const float* ua, const float* ub, const float* uc) { return touches(T, ua, ub, uc) && (!exactCells || touchesExact(T, ua, ub, uc)); };
+    auto mayFail = [&](const float* ua, const float* ub, const float* uc) {
+      return F == nullptr || (touches(*F, ua, ub, uc) && (!exactCells || touchesExact(*F, ua, ub, uc)));
+    };
 
     const size_t numTris = d.indices.size() / 3;
-    std::vector<uint32_t> outIdx;
+    std::vector<uint32_t> outIdx, opaqueIdx;  // triangles that keep their alpha test / that cannot fail it
     outIdx.reserve(d.indices.size());
     const bool hasN = d.normals.size() >= size_t(d.vertexCount) * 3, hasT = d.tangents.size() >= size_t(d.vertexCount) * 4;
     const bool has0 = d.texCoords0.size() >= size_t(d.vertexCount) * 2, has1 = d.texCoords1.size() >= size_t(d.vertexCount) * 2;
@@ -170,7 +254,8 @@ uint64_t GltfScene::cutAlphaMasked(int subdivisions)
         v.push_back(v[size_t(a) * nc + k] * wa + v[size_t(b) * nc + k] * wb + v[size_t(c) * nc + k] * wc);
     };
     std::vector<uint32_t> grid(size_t(N + 1) * size_t(N + 1));
-    std::vector<Cell>     cells;
+    std::vector<Cell>     cells, opaqueCells;
+    enum { DROPPED = 0, WHOLE_OPAQUE = 1, WHOLE_TESTED = 2, EMITTED = 3 };
     for(size_t t = 0; t < numTris; ++t)
     {
       const uint32_t ia = d.indices[3 * t], ib = d.indices[3 * t + 1], ic = d.indices[3 * t + 2];
@@ -188,48 +273,57 @@ uint64_t GltfScene::cutAlphaMasked(int subdivisions)
         continue;
       }
       // Adaptive cut over the N x N barycentric grid (N a power of two): a cell is a triangle of three grid points (i, j) -- u = i / N
-      // towards b, v = j / N towards c.  A cell on which the test cannot pass is dropped whole; at the finest level a cell is kept;
-      // otherwise its four children decide, and if all four are kept whole the cell is kept as ONE triangle (the interior of a
-      // leaf stays coarse, only its rim is refined).
+      // towards b, v = j / N towards c.  A cell on which the test cannot pass is dropped whole, one on which it cannot fail is opaque
+      // whole; at the finest level a cell is kept as it is; otherwise its four children decide, and if all four come back whole and of
+      // one kind the cell stays ONE triangle (the interior of a leaf stays coarse, only its rim is refined).
       auto uvAt = [&](int i, int j, float* out) {
         const float u = float(i) / float(N), v = float(j) / float(N), wgt = 1.0f - u - v;
         out[0] = ua[0] * wgt + ub[0] * u + uc[0] * v;
         out[1] = ua[1] * wgt + ub[1] * u + uc[1] * v;
       };
       cells.clear();
+      opaqueCells.clear();
       int dropped = 0;
-      // returns true when the cell is kept whole (nothing emitted yet: the caller emits or merges it)
-      std::function<bool(const Cell&, int)> visit = [&](const Cell& c, int size) -> bool {
+      // returns what became of the cell; for the two WHOLE kinds nothing is emitted yet (the caller emits or merges it)
+      std::function<int(const Cell&, int)> visit = [&](const Cell& c, int size) -> int {
         float c0[2], c1[2], c2[2];
         uvAt(c.i0, c.j0, c0); uvAt(c.i1, c.j1, c1); uvAt(c.i2, c.j2, c2);
         if(!mayPass(c0, c1, c2))
         {
           dropped += size * size;  // in units of finest cells
-          return false;
+          return DROPPED;
         }
+        if(!mayFail(c0, c1, c2))
+          return WHOLE_OPAQUE;
         if(size == 1)
-          return true;
+          return WHOLE_TESTED;
         // children: the three corner cells and the inverted middle one, from the edge midpoints
         const int m01i = (c.i0 + c.i1) / 2, m01j = (c.j0 + c.j1) / 2, m12i = (c.i1 + c.i2) / 2, m12j = (c.j1 + c.j2) / 2, m20i = (c.i2 + c.i0) / 2, m20j = (c.j2 + c.j0) / 2;
         const Cell child[4] = {{c.i0, c.j0, m01i, m01j, m20i, m20j}, {m01i, m01j, c.i1, c.j1, m12i, m12j}, {m20i, m20j, m12i, m12j, c.i2, c.j2}, {m01i, m01j, m12i, m12j, m20i, m20j}};
-        bool whole[4];
-        bool all = true;
+        int  kind[4];
+        bool allTested = true;
         for(int k = 0; k < 4; ++k)
         {
-          whole[k] = visit(child[k], size / 2);
-          all      = all && whole[k];
+          kind[k]   = visit(child[k], size / 2);
+          allTested = allTested && kind[k] == WHOLE_TESTED;
         }
-        if(all)
-          return true;
+        if(allTested)
+          return WHOLE_TESTED;  // (four opaque children cannot happen: the parent would have been opaque)
         for(int k = 0; k < 4; ++k)
-          if(whole[k])
+        {
+          if(kind[k] == WHOLE_TESTED)
             cells.push_back(child[k]);
-        return false;
+          else if(kind[k] == WHOLE_OPAQUE)
+            opaqueCells.push_back(child[k]);
+        }
+        return EMITTED;
       };
       const Cell root{0, 0, N, 0, 0, N};
-      if(visit(root, N))
+      const int  rootKind = visit(root, N);
+      if(rootKind == WHOLE_TESTED || rootKind == WHOLE_OPAQUE)
       {
-        outIdx.insert(outIdx.end(), {ia, ib, ic});  // nothing to gain: the triangle stays as it is
+        std::vector<uint32_t>& dst = rootKind == WHOLE_OPAQUE ? opaqueIdx : outIdx;
+        dst.insert(dst.end(), {ia, ib, ic});  // nothing to cut: the triangle stays as it is
         continue;
       }
       const int total = N * N, kept = total - dropped;
@@ -253,9 +347,16 @@ uint64_t GltfScene::cutAlphaMasked(int subdivisions)
       };
       for(const Cell& c : cells)
         outIdx.insert(outIdx.end(), {vertexAt(c.i0, c.j0), vertexAt(c.i1, c.j1), vertexAt(c.i2, c.j2)});
+      for(const Cell& c : opaqueCells)
+        opaqueIdx.insert(opaqueIdx.end(), {vertexAt(c.i0, c.j0), vertexAt(c.i1, c.j1), vertexAt(c.i2, c.j2)});
       m_alphaCutStats.subTrianglesDropped += uint64_t(total - kept);
       m_alphaCutStats.trianglesSplit += 1;
     }
+    // opaque triangles first: the device build flags triangles [0, opaqueTriangles) of the primitive
+    d.opaqueTriangles = uint32_t(opaqueIdx.size() / 3);
+    m_alphaCutStats.trianglesOpaque += d.opaqueTriangles;
+    opaqueIdx.insert(opaqueIdx.end(), outIdx.begin(), outIdx.end());
+    outIdx.swap(opaqueIdx);
     d.indices.swap(outIdx);
   }
   m_alphaCutStats.trianglesRemoved += removed;

@@ -1441,6 +1441,8 @@ void GltfScene::finalizeDesc()
     p.tangents                   = d.tangents.empty() ? nullptr : d.tangents.data();
     p.texCoords0                 = d.texCoords0.empty() ? nullptr : d.texCoords0.data();
     p.texCoords1                 = d.texCoords1.empty() ? nullptr : d.texCoords1.data();
+    p.opaqueTriangleCount        = d.opaqueTriangles;
+    p.reserved                   = 0;
   }
   m_textureDescs.resize(m_textures.size());
   for(size_t i = 0; i < m_textures.size(); ++i)

@@ -35,6 +35,7 @@ struct RenderPrimitiveData
   std::vector<uint32_t> colors;
   int                   meshID = -1;
   uint32_t              vertexCount = 0;
+  uint32_t              opaqueTriangles = 0;  // triangles [0, n) cannot fail their material's alpha test (cutAlphaMasked)
 };
 
 struct TextureData
@@ -89,7 +90,7 @@ public:
   // cannot pass are dropped.  Returns the number of (sub-)triangles dropped; desc() is rebuilt (its pointers change).
   struct AlphaCutStats
   {
-    uint64_t trianglesRemoved = 0, trianglesSplit = 0, subTrianglesDropped = 0;
+    uint64_t trianglesRemoved = 0, trianglesSplit = 0, subTrianglesDropped = 0, trianglesOpaque = 0;
   };
   uint64_t             cutAlphaMasked(int subdivisions);
   const AlphaCutStats& alphaCutStats() const { return m_alphaCutStats; }
