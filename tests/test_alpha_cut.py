@@ -185,3 +185,40 @@ def test_gpu_renders_the_cut_scene_like_the_oracle_renders_the_uncut_one(built, 
         assert m["rel_l2"] < 6e-3 and m["frac_within_1e-2"] > 0.99 and m["frac_within_1e-4"] > 0.95
         # the point of the bake: fewer surface-less candidates.  Paths are the same ones (same segments up to rounding-induced turns)
         assert abs(g["stats"]["segments"] - h["stats"]["segments"]) <= 0.002 * h["stats"]["segments"]
+
+
+@pytest.mark.gpu
+def test_gpu_opaque_class_and_shade_sort_change_no_bit(built, tmp_path):
+    """Two switches that only move work around: (1) the OPAQUE class of the bake -- triangles that cannot fail their alpha test skip
+    it in the walks -- against the same baked scene with every triangle alpha-tested (MI_PT_DIAG_NO_OPAQUE_TRIS); (2) the window
+    sort of the SIMPLE shade kernel's later bounces (MI_PT_SORT_SIMPLE = 1: hits / misses, 3: next-event technique) against the
+    queue as it is.  Same paths, same arithmetic: bit-identical images, selection ids and path counters."""
+    import os
+    import parity_util as pu
+    path = scenegen.scene_atrium_class(str(tmp_path / "atrium.glb"), seed=5, detail=0.2, tex_size=64)
+    baked = pu.Setup(path, 160, 96, max_depth=6, alpha_cut=8)
+    d = baked.scene.desc.contents
+    assert sum(d.renderPrimitives[i].opaqueTriangleCount for i in range(d.numRenderPrimitives)) > 0
+
+    def render(**env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            return pu.render_gpu(baked, 6, collect_counters=True, in_flight=3)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+
+    ref = render()
+    tested = render(MI_PT_DIAG_NO_OPAQUE_TRIS="1")
+    assert (ref["accum"] == tested["accum"]).all() and (ref["selection"] == tested["selection"]).all()
+    for k in ("segments", "surfaceHits", "shadowRays", "textureTaps"):
+        assert ref["stats"][k] == tested["stats"][k], k
+    for mode in ("1", "3"):
+        s = render(MI_PT_SORT_SIMPLE=mode)
+        assert (ref["accum"] == s["accum"]).all(), mode
+        for k in ("segments", "surfaceHits", "shadowRays", "textureTaps"):
+            assert ref["stats"][k] == s["stats"][k], (mode, k)

@@ -141,18 +141,20 @@ def test_converged_atrium_class_within_north_star_tolerance(built, tmp_path):
     """North-star tolerance on the KIND of scene the target is stated on (configs[2], Sponza class): alpha-MASK foliage cards, a
     directional light through a skylight plus the physical sky (next-event estimation picks sun or sky per path, technique MIS),
     depth 12.  The sun is a 1e5 x brighter source than anything else: at a few samples per pixel one path whose sun-cone test flips
-    on an ulp moves the relative L2 by itself (1.2e-3 at 49 spp at the full 1080p size, bench.py's parity leg), so this runs
-    1536 spp (24 frames x 64 spp) on a small image and must land inside 1e-3.  The GPU renders the scene WITH the load-time alpha
-    cut (the bench default), the oracle renders it as loaded."""
+    on an ulp moves the relative L2 by itself (1.2e-3 at 49 spp at the full 1080p size, bench.py's parity leg).  Like the glass case
+    above the difference is a few paths per million that take another way on the two sides (a Russian-roulette or alpha-rim
+    comparison that flips on the last bit), both sides staying unbiased: measured on the MI355X box 1.08e-3 at 1536 spp on this small
+    image, falling like Monte-Carlo noise -- so this runs 4096 spp (64 frames x 64 spp) and must land inside 1e-3.  The second half
+    renders the GPU side WITH the load-time alpha cut (the bench default) against the oracle on the scene as loaded."""
     path = scenegen.scene_atrium_class(str(tmp_path / "atrium_small.glb"), seed=4321, detail=0.18, tex_size=128)
     s = pu.Setup(path, 96, 56, max_depth=12, spp_per_frame=64)
-    o = pu.render_oracle(s, 24)
-    g = pu.render_gpu(s, 24, in_flight=8)
+    o = pu.render_oracle(s, 64)
+    g = pu.render_gpu(s, 64, in_flight=16)
     # (depth / selection: last-sample depth of frame 0 and foliage silhouettes, see the glass case above)
-    m = _check(o, g, rel_l2=1e-3, within_1e4=0.9, alpha_tol=5e-3, depth_tol=1.0)
+    m = _check(o, g, rel_l2=1e-3, within_1e2=0.98, within_1e4=0.9, alpha_tol=5e-3, depth_tol=1.0)
     print("converged parity (atrium class, uncut):", m)
     s2 = pu.Setup(path, 96, 56, max_depth=12, spp_per_frame=64, alpha_cut=4)
-    g2 = pu.render_gpu(s2, 24, in_flight=8)
+    g2 = pu.render_gpu(s2, 64, in_flight=16)
     m2 = pu.compare_images(o["accum"], g2["accum"])
     print("converged parity (atrium class, alpha cut 4 on the GPU side):", m2)
     assert m2["rel_l2"] <= 1e-3, m2

@@ -320,7 +320,7 @@ struct Bvh8
   double             sah = 0;
 };
 
-struct CollapseCfg { int maxLeaf = 2; bool sahdp = false; bool quantise = true; float cLeafTri = 0.24f; };
+struct CollapseCfg { int maxLeaf = 2; bool sahdp = false; bool quantise = true; float cLeafTri = 0.24f; int width = 8; bool optimalSlots = false; };
 
 // optimal (SAH, dynamic programming) collapse after Ylitie et al. 2017, section 3: cost(n, i) = cheapest way to represent subtree n as
 // at most i roots of 8-wide (sub)trees; cLeaf per triangle and 1 per inner node, weighted by area.
@@ -425,7 +425,7 @@ static Bvh8 collapse(const Bvh2& B, const CollapseCfg& cfg)
       else
       {
         kids = {B.nodes[ref].c[0], B.nodes[ref].c[1]};
-        while(kids.size() < 8)
+        while(int(kids.size()) < cfg.width)
         {
           int best = -1; float bestA = -1;
           for(size_t k = 0; k < kids.size(); ++k)
@@ -464,6 +464,31 @@ static Bvh8 collapse(const Bvh2& B, const CollapseCfg& cfg)
           }
         }
         candOfSlot[bs] = bc; slotUsed[bs] = true; done[bc] = true;
+      }
+      if(cfg.optimalSlots)
+      {
+        // maximise the sum of dot(centroid - centre, diagonal(slot)) over all assignments: DP over subsets of slots
+        float cost[8][8];
+        for(int c = 0; c < count; ++c)
+        {
+          float d[3];
+          for(int a = 0; a < 3; ++a) d[a] = 0.5f * (kb[c].lo[a] + kb[c].hi[a]) - 0.5f * (nb.lo[a] + nb.hi[a]);
+          for(int sl = 0; sl < 8; ++sl) cost[c][sl] = ((sl & 1) ? d[0] : -d[0]) + ((sl & 2) ? d[1] : -d[1]) + ((sl & 4) ? d[2] : -d[2]);
+        }
+        std::vector<float> best(256, -FLT_MAX); std::vector<int> from(256, -1);
+        best[0] = 0;
+        for(int mask = 0; mask < 256; ++mask)
+        {
+          if(best[mask] == -FLT_MAX) continue;
+          int c = __builtin_popcount(mask);
+          if(c >= count) continue;
+          for(int sl = 0; sl < 8; ++sl)
+            if(!(mask & (1 << sl)) && best[mask] + cost[c][sl] > best[mask | (1 << sl)]) { best[mask | (1 << sl)] = best[mask] + cost[c][sl]; from[mask | (1 << sl)] = sl; }
+        }
+        int bm = -1; float bv = -FLT_MAX;
+        for(int mask = 0; mask < 256; ++mask) if(__builtin_popcount(mask) == count && best[mask] > bv) { bv = best[mask]; bm = mask; }
+        std::fill(candOfSlot, candOfSlot + 8, -1);
+        for(int c = count - 1, mask = bm; c >= 0; --c) { int sl = from[mask]; candOfSlot[sl] = c; mask &= ~(1 << sl); }
       }
       Node8 N;
       // quantisation frame
@@ -578,7 +603,7 @@ static void walk(const Bvh8& W, const std::vector<Tri>& tris, const std::vector<
   while(!stack.empty())
   {
     Entry e = stack.back(); stack.pop_back();
-    if(mode == 1 && e.tn > tmax) continue;
+    if((mode == 1 || mode == 3) && e.tn > tmax) continue;  // mode 3: octant order, but a child whose entry distance lies beyond the current hit is dropped when popped
     const Node8& N = W.nodes[e.node];
     S.nodes += 1; ++visits;
     // due parked leaves
@@ -617,6 +642,47 @@ static void walk(const Bvh8& W, const std::vector<Tri>& tris, const std::vector<
   if(mode == 2) for(auto& p : parked) testLeaf(p.base, p.cnt);
   S.rays += 1;
   if(tmax < FLT_MAX) S.hits += 1;
+}
+
+// any-hit (shadow) walk: order 0 = octant order (what the device does), 1 = largest child box first, 2 = nearest first, 3 = leaf children first then octant
+static void walkAny(const Bvh8& W, const std::vector<Tri>& tris, const std::vector<uint8_t>& alpha, const Ray& r, int order, uint32_t seed, WalkStats& S)
+{
+  V3 idir{1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
+  const uint32_t octinv = 7u ^ ((idir.x < 0 ? 1u : 0u) | (idir.y < 0 ? 2u : 0u) | (idir.z < 0 ? 4u : 0u));
+  std::vector<int> stack{0};
+  bool occluded = false;
+  while(!stack.empty() && !occluded)
+  {
+    int nd = stack.back(); stack.pop_back();
+    const Node8& N = W.nodes[nd];
+    S.nodes += 1;
+    struct H { int slot; float key; };
+    H hit[8]; int nh = 0;
+    for(int sl = 0; sl < 8 && !occluded; ++sl)
+    {
+      if(N.child[sl] == -2) continue;
+      float tn;
+      if(!slab(N.box[sl], r, idir, FLT_MAX, tn)) continue;
+      if(N.child[sl] == -1)
+      {
+        for(int k = 0; k < N.triCnt[sl] && !occluded; ++k)
+        {
+          int ti = W.tris[N.triBase[sl] + k]; float t;
+          S.tris += 1;
+          if(hitTri(tris[ti], r, FLT_MAX, t))
+          {
+            if(alpha[ti]) { uint32_t h = (seed ^ uint32_t(ti) * 2654435761u); h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; if((h & 0xffff) < 0x9999) continue; }
+            occluded = true;
+          }
+        }
+      }
+      else hit[nh++] = {sl, order == 1 ? N.box[sl].area() : (order == 2 ? -tn : float(uint32_t(sl) ^ octinv))};
+    }
+    std::sort(hit, hit + nh, [](const H& a, const H& b) { return a.key < b.key; });  // highest key popped first
+    for(int k = 0; k < nh; ++k) stack.push_back(N.child[hit[k].slot]);
+  }
+  S.rays += 1;
+  if(occluded) S.hits += 1;
 }
 
 int main(int argc, char** argv)
@@ -689,6 +755,8 @@ int main(int argc, char** argv)
   cfg.sahdp    = get("collapse", "greedy") == "sahdp";
   cfg.cLeafTri = std::stof(get("ctri", "0.24"));
   cfg.quantise = get("quantise", "1") == "1";
+  cfg.width    = std::stoi(get("width", "8"));
+  cfg.optimalSlots = get("slots", "greedy") == "optimal";
   Bvh8 W = collapse(B, cfg);
   double leafChildren = 0, innerChildren = 0;
   for(const Node8& N : W.nodes) for(int s = 0; s < 8; ++s) { if(N.child[s] == -1) leafChildren++; else if(N.child[s] >= 0) innerChildren++; }
@@ -719,7 +787,7 @@ int main(int argc, char** argv)
     V3 d = tx * (rr * std::cos(ph)) + ty * (rr * std::sin(ph)) + nrm * std::sqrt(std::max(0.0f, 1 - u1));
     rays[i] = {p + nrm * 1e-3f, normalize(d)};
   }
-  for(int mode : {0, 2, 1})
+  for(int mode : {0, 2, 3, 1})
   {
     WalkStats S;
     const int defer = std::stoi(get("defer", "3"));
@@ -731,9 +799,36 @@ int main(int argc, char** argv)
 #pragma omp critical
       { S.nodes += L.nodes; S.tris += L.tris; S.rays += L.rays; S.hits += L.hits; S.maxStack = std::max(S.maxStack, L.maxStack); }
     }
-    printf("walk %-28s: %.2f node visits + %.2f triangle tests per ray  (cost 235n+56t = %.0f; hit rate %.3f, max stack %.0f)\n",
-           mode == 0 ? "octant order, immediate" : (mode == 1 ? "distance order, immediate" : "octant order, deferred"), S.nodes / S.rays, S.tris / S.rays,
-           (235 * S.nodes + 56 * S.tris) / S.rays, S.hits / S.rays, S.maxStack);
+    const double cnode = 59 + 22 * cfg.width;
+    printf("walk %-28s: %.2f node visits + %.2f triangle tests per ray  (cost (59+22w)n+56t = %.0f; hit rate %.3f, max stack %.0f)\n",
+           mode == 0 ? "octant order, immediate" : (mode == 1 ? "distance order, immediate" : (mode == 3 ? "octant order + cull at pop" : "octant order, deferred")), S.nodes / S.rays, S.tris / S.rays,
+           (cnode * S.nodes + 56 * S.tris) / S.rays, S.hits / S.rays, S.maxStack);
+  }
+  // shadow rays: from the same surface points, half towards a fixed sun direction (through the skylight), half uniform over the sphere
+  {
+    std::vector<Ray> sh(nrays);
+    V3 sun = normalize(V3{0.0f, std::cos(0.35f), std::sin(0.35f)});
+    for(int i = 0; i < nrays; ++i)
+    {
+      V3 d;
+      if(i & 1) d = sun;
+      else { float z = 1 - 2 * U(rng), rr = std::sqrt(std::max(0.0f, 1 - z * z)), ph = 6.2831853f * U(rng); d = V3{rr * std::cos(ph), z, rr * std::sin(ph)}; }
+      sh[i] = {rays[i].o, d};
+    }
+    for(int order : {0, 1, 2})
+    {
+      WalkStats S;
+#pragma omp parallel
+      {
+        WalkStats L;
+#pragma omp for schedule(dynamic, 256)
+        for(int i = 0; i < nrays; ++i) walkAny(W, tris, alpha, sh[i], order, uint32_t(i) * 7919u + 17u, L);
+#pragma omp critical
+        { S.nodes += L.nodes; S.tris += L.tris; S.rays += L.rays; S.hits += L.hits; }
+      }
+      printf("any-hit %-24s: %.2f node visits + %.2f triangle tests per ray (occluded %.3f)\n", order == 0 ? "octant order" : (order == 1 ? "largest box first" : "nearest first"),
+             S.nodes / S.rays, S.tris / S.rays, S.hits / S.rays);
+    }
   }
   return 0;
 }
