@@ -1,5 +1,5 @@
-"""What ONE rank of an N-GPU `bench.py` run executes (minus the RCCL reduce), timed on a single GPU: tile partition r/N,
-32*N frames in flight.  Prints the per-rank step times for a few tile sizes next to the 1-GPU step, and checks that the partial
+"""What ONE rank of an N-GPU `bench.py` run executes (minus the RCCL reduce), timed on a single GPU: tile partition r/N, the scene
+with bench.py's load-time alpha cut, bench.py's frames in flight (64 per GPU, within its path-slot budget).  Prints the per-rank step times for a few tile sizes next to the 1-GPU step, and checks that the partial
 accumulators sum to the unpartitioned image bit for bit.   usage: tools/check_rank_of_8.py [workload] [world]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,6 +12,10 @@ world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 w = bench.WORKLOADS[name]
 W, H = w["width"], w["height"]
 scene = ptmod.Scene(bench.scene_path(name, 0))
+if bench.ALPHA_CUT_DEFAULT > 0:
+    scene.cut_alpha(bench.ALPHA_CUT_DEFAULT)
+F1 = max(1, min(w.get("in_flight", 64), int(bench.SLOT_BUDGET // (W * H))))
+FN = max(1, min(1024, w.get("in_flight", 64) * world, int(bench.SLOT_BUDGET * world // (W * H))))
 hdr = ptmod.HdrEnvironment(path=os.path.join(bench.ROOT, "assets", "std_env.hdr")) if w["hdr"] else None
 fi, pixel_angle, focal = ptmod.camera_frame_info(scene.camera(0), W, H)
 if hdr is not None:
@@ -41,10 +45,10 @@ def run(rank, nranks, frames, tile=32, timed=True):
     img = acc.cpu().numpy(); t.close()
     return img, dt * 1e3
 
-one = run(0, 1, 32)[1]
-print(f"{name}: 1 GPU, 32 frames in flight, whole image: {one:.2f} ms/step")
+one = run(0, 1, F1)[1] / F1
+print(f"{name} {W}x{H}: 1 GPU, {F1} frames in flight, whole image: {one:.3f} ms/frame; one rank of {world}: {FN} frames in flight")
 ref = run(0, 1, 4, timed=False)[0]
 print(f"sum of the {world} partial accumulators == unpartitioned image:", bool((np.sum([run(r, world, 4, timed=False)[0] for r in range(world)], axis=0) == ref).all()))
 for tile in (64, 32, 16):
-    times = [run(r, world, min(256, 32 * world), tile)[1] for r in range(world)]
-    print(f"tile {tile}: rank steps (ms):", " ".join(f"{t:.2f}" for t in times), f"-> max {max(times):.2f} (1-GPU step / max = {one / max(times):.3f})")
+    times = [run(r, world, FN, tile)[1] * world / FN for r in range(world)]  # ms per frame-equivalent of work (a rank renders 1/world of each frame)
+    print(f"tile {tile}: rank ms per 1-GPU-frame of work:", " ".join(f"{t:.3f}" for t in times), f"-> max {max(times):.3f} (weak-scaling bound before the reduce = {one / max(times):.3f})")

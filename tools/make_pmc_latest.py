@@ -1,10 +1,35 @@
 #!/usr/bin/env python3
-"""profiles/pmc_latest.json from a tools/summarize_pmc.py summary: per-kernel HBM bytes per launch (FETCH_SIZE doubled as
-MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE) and the per-group averages bench.py quotes as `roofline.traffic`.
-usage: tools/make_pmc_latest.py gpurun_out/prof_r02_helmet/summary.json helmet 32 [round] > profiles/pmc_latest.json"""
-import json, sys
+"""profiles/pmc_latest_<workload>.json from a tools/summarize_pmc.py summary: per-kernel HBM bytes per launch from the separate
+FETCH_SIZE / WRITE_SIZE passes, corrected with the factors MEASURED on this renderer's access patterns (tools/calib_fetch.hip ->
+profiles/r03_fetch_calibration.json; MI355X_MICROARCH.md: the counter reports half of a wide stream's bytes, other widths must be
+calibrated), and what bench.py quotes as `roofline.traffic`.  Without a calibration file FETCH_SIZE is doubled (the guide's figure
+for wide streams) like in round 2.
+usage: tools/make_pmc_latest.py <summary.json> <workload> <frames in flight> [round] [calibration.json] [W H] > profiles/pmc_latest_<workload>.json"""
+import json, os, sys
 
 summary, workload, frames = json.load(open(sys.argv[1]))["kernels"], sys.argv[2], int(sys.argv[3])
+calib_path = sys.argv[5] if len(sys.argv) > 5 else None
+calib = json.load(open(calib_path))["factors"] if calib_path else None
+res = [int(sys.argv[6]), int(sys.argv[7])] if len(sys.argv) > 7 else [1920, 1080]
+
+
+def mean(*v):
+    v = [x for x in v if x]
+    return sum(v) / len(v) if v else None
+
+
+# counter / true bytes per kernel class: what the kernel mostly reads and writes
+if calib:
+    r_fetch = {"shade_first": mean(calib["fetch_gather16"], calib["fetch_gather48"]),   # texel footprints, vertices, 16-B path-state records by slot
+               "shade": mean(calib["fetch_gather16"], calib["fetch_gather48"]),
+               "trace_closest": mean(calib["fetch_gather80"], calib["fetch_gather48"]),   # BVH8 nodes, triangles
+               "trace_shadow": mean(calib["fetch_gather80"], calib["fetch_gather48"]),
+               "trace_primary": mean(calib["fetch_gather80"], calib["fetch_gather48"]),
+               "shadow_resolve": calib["fetch_stream16"], "finish_sample": mean(calib["fetch_stream16"], calib["fetch_gather16"]), "generate": calib["fetch_stream16"]}
+    r_write = {k: mean(calib["write_stream16"], calib["write_scatter16"]) for k in r_fetch}   # queue appends (streams) + path state by slot (scatters)
+    r_write["shadow_resolve"] = calib["write_scatter16"]
+else:
+    r_fetch, r_write = {}, {}
 # the timed (non-counting) template instances: k_shade<COUNT, SIMPLE, FIRST>, k_trace_closest<WIDE, HAS_ALPHA, COUNT>,
 # k_trace_primary<HAS_ALPHA, COUNT>, k_trace_shadow<WIDE, MODE, COUNT>
 pick = {"shade_first": lambda n: n.startswith("k_shade<false") and n.endswith("true>"),
@@ -15,16 +40,21 @@ pick = {"shade_first": lambda n: n.startswith("k_shade<false") and n.endswith("t
         "shadow_resolve": lambda n: n.startswith("k_shadow_resolve"),
         "finish_sample": lambda n: n.startswith("k_finish_sample"),
         "generate": lambda n: n.startswith("k_generate")}
-out = {"round": int(sys.argv[4]) if len(sys.argv) > 4 else 2, "workload": workload, "frames_in_flight": frames, "resolution": [1920, 1080],
+out = {"round": int(sys.argv[4]) if len(sys.argv) > 4 else 2, "workload": workload, "frames_in_flight": frames, "resolution": res,
+       "fetch_size_calibration": (os.path.join("profiles", os.path.basename(calib_path)) + " (tools/calib_fetch.hip: counter / true bytes measured for 16-B streams and 16 / 48 / 80-B gathers)") if calib else "the guide (wide streaming reads): FETCH_SIZE x 2",
+       "fetch_size_factor": "per kernel, see kernels[*].fetch_counter_over_true" if calib else 2.0,
        "command": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --workload {workload} --steps 3 --warmup 1 --no-cpu-baseline",
-       "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE as reported (KB).", "kernels": {}}
+       "note": "hbm_bytes_per_launch = FETCH_SIZE / (counter-over-true ratio of the kernel's access class) + WRITE_SIZE / (ratio of its writes); the raw counters and the bounds [raw, 2 x raw] are kept next to it", "kernels": {}}
 for key, match in pick.items():
     for name, k in summary.items():
         if match(name) and "FETCH_SIZE" in k and "WRITE_SIZE" in k:
             d = max(1, k.get("dispatches_pmc", 1))
             fetch, write = k["FETCH_SIZE"] * 1024 / d, k["WRITE_SIZE"] * 1024 / d
+            rf, rw = r_fetch.get(key) or 0.5, r_write.get(key) or 1.0
             out["kernels"][key] = {"kernel": name, "dispatches": d, "fetch_size_bytes_per_launch_raw": round(fetch), "write_size_bytes_per_launch": round(write),
-                                   "hbm_bytes_per_launch": round(2 * fetch + write), "avg_us": round(k.get("avg_us", 0.0), 1)}
+                                   "fetch_counter_over_true": round(rf, 4), "write_counter_over_true": round(rw, 4),
+                                   "hbm_bytes_per_launch": round(fetch / rf + write / rw), "hbm_bytes_bounds": [round(fetch + write), round(2 * fetch + write)],
+                                   "avg_us": round(k.get("avg_us", 0.0), 1)}
 K = out["kernels"]
 
 
