@@ -2956,6 +2956,57 @@ void  oracle_hg_sample(float u, float v, float g, const float* wi, float* wo)
   float3 r = sampleHenyeyGreenstein(float2(u, v), g, normalize(float3(wi)));
   wo[0] = r.x; wo[1] = r.y; wo[2] = r.z;
 }
+// ---- round 3: the remaining nvshaders pieces that were restated without a pin (tests/test_oracle_pins.py)
+float oracle_sheen_ndf(float invRoughness, float nh) { return hvd_sheen_eval(invRoughness, nh); }  // density of h over solid angle
+void  oracle_sheen_sample(float u, float v, float invRoughness, float* h)
+{
+  float3 r = hvd_sheen_sample(float2(u, v), invRoughness);
+  h[0] = r.x; h[1] = r.y; h[2] = r.z;
+}
+float oracle_vcavities_g(float nh, float k1h, float k1z, float k2h, float k2z)
+{
+  float G1, G2;
+  return vcavities_shadow_mask(G1, G2, nh, float3(0, 0, k1z), k1h, float3(0, 0, k2z), k2h);
+}
+void oracle_lobe_weights(const float* m, float VdotN, float* w6)  // LOBE_* order of computeLobeWeights
+{
+  PbrMaterial mat = materialFromArray(m);
+  float3      tint = mat.baseColor;
+  float       w[LOBE_COUNT];
+  computeLobeWeights(mat, VdotN, tint, w);
+  for(int i = 0; i < LOBE_COUNT && i < 6; ++i)
+    w6[i] = w[i];
+}
+int  oracle_lobe_index(const char* name)
+{
+  auto is = [&](const char* s) { return std::strcmp(name, s) == 0; };
+  if(is("diffuse")) return LOBE_DIFFUSE_REFLECTION;
+  if(is("specular_transmission")) return LOBE_SPECULAR_TRANSMISSION;
+  if(is("specular")) return LOBE_SPECULAR_REFLECTION;
+  if(is("metal")) return LOBE_METAL_REFLECTION;
+  if(is("sheen")) return LOBE_SHEEN_REFLECTION;
+  if(is("clearcoat")) return LOBE_CLEARCOAT_REFLECTION;
+  return -1;
+}
+void oracle_env_sample(const MiPtEnvironment* env, const float* xi, float* out7)  // direction, rgb, pdf of environmentSample
+{
+  Scene sc;
+  sc.env = env;
+  float3 dir;
+  float4 r = environmentSample(sc, float3(xi), dir);
+  out7[0] = dir.x; out7[1] = dir.y; out7[2] = dir.z; out7[3] = r.x; out7[4] = r.y; out7[5] = r.z; out7[6] = r.w;
+}
+void oracle_point_offset(const float* p, const float* tri9, const float* nrm9, const float* bary, float* out3)
+{
+  float3 r = pointOffset(float3(p), float3(tri9), float3(tri9 + 3), float3(tri9 + 6), float3(nrm9), float3(nrm9 + 3), float3(nrm9 + 6), float3(bary));
+  out3[0] = r.x; out3[1] = r.y; out3[2] = r.z;
+}
+float oracle_ray_cone_footprint(float width, float spreadAngle, float hitT, const float* n, const float* v)
+{
+  RayCone c;
+  c.width = width; c.spreadAngle = spreadAngle;
+  return rayConeWorldFootprint(c, hitT, float3(n), float3(v));
+}
 void oracle_light_contribution(const MiGltfLight* light, const float* pos, const float* xi, float* out8)
 {
   LightContrib c = singleLightContribution(*light, float3(pos), float3(0, 0, 1), float2(xi[0], xi[1]));

@@ -56,6 +56,14 @@ def lib():
             "oracle_hg_pdf": (f32, [f32, f32]),
             "oracle_hg_sample": (None, [f32, f32, f32, P(f32), P(f32)]),
             "oracle_light_contribution": (None, [P(capi.MiGltfLight), P(f32), P(f32), P(f32)]),
+            "oracle_sheen_ndf": (f32, [f32, f32]),
+            "oracle_sheen_sample": (None, [f32, f32, f32, P(f32)]),
+            "oracle_vcavities_g": (f32, [f32, f32, f32, f32, f32]),
+            "oracle_lobe_weights": (None, [P(f32), f32, P(f32)]),
+            "oracle_lobe_index": (i32, [C.c_char_p]),
+            "oracle_env_sample": (None, [P(capi.MiPtEnvironment), P(f32), P(f32)]),
+            "oracle_point_offset": (None, [P(f32), P(f32), P(f32), P(f32), P(f32)]),
+            "oracle_ray_cone_footprint": (f32, [f32, f32, f32, P(f32), P(f32)]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)

@@ -174,3 +174,126 @@ def test_rng_is_xxh32_and_the_jcgt_pcg_hash(built):
             u = O.oracle_rand(C.byref(s))
             assert u == np.float32(np.uint32((0x3f800000 | (o >> 9))).view(np.float32) - np.float32(1.0))
         assert s.value == e["final_state"]
+
+
+def test_sheen_lobe_shape_and_vcavities_masking(built):
+    """KHR_materials_sheen: the sin^n half-vector density (Conty Estevez & Kulla 2017 eq. 2, as a density over the solid angle of h)
+    on a grid, its normalisation by float64 quadrature, its sampler against the analytic mean E[sin(theta_h)] = (n + 2) / (n + 3),
+    and the V-cavities masking term (Torrance & Sparrow 1967)."""
+    O = oracle_lib.lib()
+    for e in GOLD["sheen"]:
+        assert O.oracle_sheen_ndf(e["n"], e["cos_h"]) == pytest.approx(e["pdf_h"], rel=5e-5, abs=1e-30), e
+    for n in (1.0, 11.11, 100.0):
+        c = (np.arange(20000) + 0.5) / 20000  # cos(theta_h) in (0, 1): d(omega) = 2 pi d(cos)
+        assert sum(O.oracle_sheen_ndf(n, float(x)) for x in c[::20]) * 2 * np.pi * (20 / 20000) == pytest.approx(1.0, abs=4e-3)
+    rng = np.random.default_rng(11)
+    h = (F * 3)()
+    for n in (2.0, 25.0, 400.0):
+        s = []
+        for a, b in rng.random((20000, 2)):
+            O.oracle_sheen_sample(a, b, n, h)
+            assert np.linalg.norm(h[:]) == pytest.approx(1.0, abs=1e-5) and h[2] >= 0.0
+            s.append(np.hypot(h[0], h[1]))
+        assert np.mean(s) == pytest.approx((n + 2.0) / (n + 3.0), abs=4e-3)
+    for e in GOLD["vcavities"]:
+        assert O.oracle_vcavities_g(e["nh"], e["k1h"], e["k1z"], e["k2h"], e["k2z"]) == pytest.approx(e["G"], rel=2e-5), e
+
+
+def test_clearcoat_lobe_probability_is_the_fresnel_term_of_an_ior_1_5_layer(built):
+    """KHR_materials_clearcoat: the coat reflects with probability clearcoat x F(1.5 / ior1, cos) and everything below shares the
+    rest (the lobe weights sum to one)."""
+    O = oracle_lib.lib()
+    coat = O.oracle_lobe_index(b"clearcoat")
+    assert coat >= 0
+    w = (F * 6)()
+    for e in GOLD["clearcoat_weight"]:
+        m = np.zeros(29, np.float32)
+        m[0:3] = 0.8; m[3] = m[4] = 0.3; m[5] = 0.2; m[6], m[7], m[8] = e["ior1"], 1.5, 1.0; m[9:12] = 1.0
+        m[14], m[15] = e["clearcoat"], 0.1; m[21], m[22] = 1.5, 100.0; m[24:27] = 1.0
+        O.oracle_lobe_weights((F * 29)(*m), e["cos"], w)
+        assert w[coat] == pytest.approx(e["w"], rel=3e-5, abs=1e-7), (e, w[:])
+        assert sum(w[:]) == pytest.approx(1.0, abs=1e-5)
+        assert all(x >= 0.0 for x in w[:])
+
+
+def test_shadow_terminator_offset_and_ray_cone_footprint(built):
+    """pointOffset against Hanika's listing in float64, and its two defining properties: a triangle whose vertex normals are its
+    geometric normal is not moved, and on a convex tessellated sphere the offset point leaves the facet outwards and stays below the
+    highest of the three vertex tangent planes it blends (a convex combination of projections onto them).
+    rayConeWorldFootprint against the ray-cone formulas of Akenine-Moller et al. 2019."""
+    O = oracle_lib.lib()
+    out = (F * 3)()
+    for e in GOLD["point_offset"]:
+        O.oracle_point_offset(f3(e["p"]), (F * 9)(*e["tri"]), (F * 9)(*e["nrm"]), f3(e["bary"]), out)
+        assert np.allclose(out[:], e["offset_p"], rtol=2e-5, atol=2e-6), (e, out[:])
+    rng = np.random.default_rng(3)
+    for _ in range(32):
+        tri = rng.normal(size=(3, 3))
+        ng = np.cross(tri[1] - tri[0], tri[2] - tri[0]); ng /= np.linalg.norm(ng)
+        b = rng.dirichlet((1, 1, 1))
+        P = b @ tri
+        O.oracle_point_offset(f3(P), (F * 9)(*tri.reshape(-1)), (F * 9)(*np.tile(ng, 3)), f3(b), out)
+        assert np.allclose(out[:], P, atol=2e-6)
+        c = rng.normal(size=3)
+        v = rng.normal(size=(3, 3)) * 0.2 + c / np.linalg.norm(c)
+        v /= np.linalg.norm(v, axis=1, keepdims=True)  # three nearby points of the unit sphere, normals = positions
+        P = b @ v
+        O.oracle_point_offset(f3(P), (F * 9)(*v.reshape(-1)), (F * 9)(*v.reshape(-1)), f3(b), out)
+        r = np.linalg.norm(out[:])
+        Ph = P / np.linalg.norm(P)
+        assert np.linalg.norm(P) - 1e-6 <= r <= 1.0 / min(float(Ph @ v[i]) for i in range(3)) + 1e-5
+    for e in GOLD["ray_cone"]:
+        n, v = [0.0, 0.0, 1.0], [float(np.sqrt(max(0.0, 1 - e["cos"] ** 2))), 0.0, e["cos"]]
+        assert O.oracle_ray_cone_footprint(e["width"], e["spread"], e["t"], f3(n), f3(v)) == pytest.approx(e["footprint"], rel=3e-5), e
+
+
+def test_hdr_importance_table_and_sampler_against_numpy(built, assets):
+    """nvvk::HdrIbl's job (src/renderer.cpp:1982-2017) as libmi_host does it, on the reference's own std_env.hdr: (1) the pdf stored
+    in alpha is max(r, g, b) / integral of max(r, g, b) over the sphere (float64 numpy, exact texel solid angles); (2) the alias
+    table selects texel i with probability importance_i / total (Vose's construction, checked by summing the table's mass per
+    texel); (3) the oracle's environmentSample lands in coarse bins of the map with the frequencies the numpy distribution
+    predicts, inside the texel the table chose, and returns the map's bilinear (rgb, pdf) there."""
+    O = oracle_lib.lib()
+    hdr = ptmod.HdrEnvironment(path=os.path.join(assets, "std_env.hdr"))
+    env = hdr.env.contents if hasattr(hdr.env, "contents") else hdr.env
+    w, h = env.width, env.height
+    rgba = np.ctypeslib.as_array(env.rgba, shape=(h, w, 4)).astype(np.float64)
+    m = rgba[..., :3].max(axis=-1)
+    theta = np.arange(h + 1) * np.pi / h
+    area = (np.cos(theta[:-1]) - np.cos(theta[1:]))[:, None] * (2 * np.pi / w)  # solid angle of the texels of a row
+    imp = m * area
+    total = imp.sum()
+    assert env.integral == pytest.approx(total, rel=1e-5)
+    assert np.allclose(rgba[..., 3], m / total, rtol=2e-5, atol=1e-12)
+    assert (rgba[..., 3] * area).sum() == pytest.approx(1.0, rel=1e-5)  # a density over the sphere
+    acc = np.ctypeslib.as_array(C.cast(env.accel, C.POINTER(C.c_uint32)), shape=(h * w, 2))
+    alias, q = acc[:, 0].astype(np.int64), acc[:, 1].copy().view(np.float32).astype(np.float64)
+    assert (q >= 0).all() and (q <= 1.0 + 1e-6).all() and (alias < h * w).all()
+    mass = q.copy()
+    np.add.at(mass, alias, 1.0 - q)
+    p_table, p_true = mass / (h * w), imp.reshape(-1) / total
+    assert np.abs(p_table - p_true).max() < 2e-6 * p_true.max() + 1e-9 and np.abs(p_table - p_true).sum() < 2e-4
+    # the sampler: bins of 8 x 4 texel blocks ... coarse enough for 200k samples
+    rng = np.random.default_rng(9)
+    n = 200000
+    bx, by = next(d for d in (16, 15, 12, 10, 8, 5, 4, 2, 1) if w % d == 0), next(d for d in (8, 10, 6, 5, 4, 2, 1) if h % d == 0)
+    counts = np.zeros((by, bx))
+    out = (F * 7)()
+    xi = rng.random((n, 3)).astype(np.float32)
+    for k in range(n):
+        O.oracle_env_sample(hdr.env, f3(xi[k]), out)
+        d = np.array(out[:3], np.float64)
+        assert abs(np.linalg.norm(d) - 1.0) < 1e-4
+        u = (np.arctan2(d[2], d[0]) + np.pi) / (2 * np.pi)
+        v = np.arccos(np.clip(d[1], -1, 1)) / np.pi
+        counts[min(by - 1, int(v * by)), min(bx - 1, int(u * bx))] += 1
+        if k < 2000:  # the returned (rgb, pdf) is the map's bilinear value at the sampled direction
+            fx, fy = u * w - 0.5, v * h - 0.5
+            x0, y0 = int(np.floor(fx)), int(np.floor(fy))
+            tx, ty = fx - x0, fy - y0
+            px = lambda x, y: rgba[min(max(y, 0), h - 1), x % w]
+            ref = (px(x0, y0) * (1 - tx) + px(x0 + 1, y0) * tx) * (1 - ty) + (px(x0, y0 + 1) * (1 - tx) + px(x0 + 1, y0 + 1) * tx) * ty
+            assert np.allclose(out[3:7], ref, rtol=2e-2, atol=1e-3 * ref.max()), (k, out[:], ref)
+    expect = p_true.reshape(by, h // by, bx, w // bx).sum(axis=(1, 3)) * n
+    sigma = np.sqrt(np.maximum(expect, 1.0))
+    assert (np.abs(counts - expect) < 5 * sigma + 3).all(), (counts - expect) / sigma

@@ -22,6 +22,17 @@ Sources
   xxhash32             Collet, xxHash specification (XXH32), via the `xxhash` Python package: the 3-word hash of nvshaders
                        equals XXH32 of the 8 bytes (x, y) with seed z - 8                                                   [xxhash32: gltf_pathtrace.slang:560]
   pcg                  Jarzynski & Olano 2020, "Hash Functions for GPU Rendering" (JCGT 9(3)), listing `pcg`                   [rand]
+  sheen                Conty Estevez & Kulla 2017, "Production Friendly Microfacet Sheen BRDF", eq. 2: D(h) = (2 + n) sin^n(theta_h) / (2 pi)
+                       (n = 1 / alpha; the MDL-lineage lobe restated here uses n = 1 / roughness^2), a density over the solid angle of h
+                       once multiplied by cos(theta_h); V-cavities masking of Torrance & Sparrow 1967, G = min(1, 2 (n.h)(n.k1)/(k1.h), 2 (n.h)(n.k2)/(k2.h))   [KHR_materials_sheen inside bsdfEvaluate / bsdfSample]
+  clearcoat            KHR_materials_clearcoat (Khronos glTF extension text): a dielectric layer of IOR 1.5 (F0 = 0.04) on top, reflected with
+                       probability clearcoat x Fresnel(1.5, cos), the layers below attenuated by the rest                          [lobe weights of bsdfEvaluate / bsdfSample]
+  point_offset         Hanika 2021, "Hacking the Shadow Terminator" (Ray Tracing Gems II, ch. 4), listing 4-1                        [pointOffset: get_hit.h.slang:124-131 call site]
+  ray_cone             Akenine-Moller et al. 2019, "Texture Level of Detail Strategies for Real-Time Ray Tracing" (Ray Tracing Gems, ch. 20),
+                       eq. 29-30: cone width w = w0 + gamma t, footprint on the surface w / |n . d|                                  [rayConeWorldFootprint: pathtrace_functions.h.slang:174-178]
+  hdr_importance       definition of importance sampling a lat-long map by max(r, g, b) x texel solid angle (Pharr, Jakob, Humphreys, PBRT 3rd ed.
+                       section 14.2.4 for the distribution, Vose 1991 for the alias method): checked in tests/test_oracle_pins.py directly against
+                       numpy float64 on assets/std_env.hdr -- no fixture needed, the asset is in the tree                              [nvvk::HdrIbl::loadEnvironment, environmentSample]
 """
 import json
 import math
@@ -200,6 +211,31 @@ def main():
             s, o = pcg_hash(s)
             seq.append(o)
         out["pcg"].append({"seed": s0, "outputs": seq, "final_state": s})
+    # sheen: density of h over solid angle D(h) cos(theta_h), D = (n + 2) sin^n / (2 pi); V-cavities G
+    out["sheen"] = [{"n": n, "cos_h": c, "pdf_h": (n + 2.0) * (1.0 - c * c) ** (0.5 * n) / (2.0 * math.pi) * c} for n in (1.0, 4.0, 11.11, 100.0, 400.0) for c in (0.02, 0.2, 0.5, 0.8, 0.98)]
+    out["vcavities"] = []
+    for _ in range(40):
+        k1 = rng.normal(size=3); k1[2] = abs(k1[2]) + 0.05; k1 = np.array(unit(k1))
+        k2 = rng.normal(size=3); k2[2] = abs(k2[2]) + 0.05; k2 = np.array(unit(k2))
+        h = (k1 + k2) / np.linalg.norm(k1 + k2)
+        out["vcavities"].append({"nh": float(h[2]), "k1h": float(k1 @ h), "k1z": float(k1[2]), "k2h": float(k2 @ h), "k2z": float(k2[2]),
+                                 "G": float(min(1.0, 2 * h[2] * k1[2] / (k1 @ h), 2 * h[2] * k2[2] / (k2 @ h)))})
+    # clearcoat lobe probability: clearcoat x unpolarised Fresnel of an IOR-1.5 layer seen from a medium of IOR ior1
+    out["clearcoat_weight"] = [{"clearcoat": cc, "ior1": n1, "cos": c, "w": cc * fresnel_dielectric(1.5 / n1, c)} for cc in (1.0, 0.6, 0.25) for n1 in (1.0, 1.33) for c in (1.0, 0.8, 0.5, 0.2, 0.05)]
+    # Hanika's shadow-terminator offset, float64, on random triangles with perturbed vertex normals
+    out["point_offset"] = []
+    for _ in range(48):
+        tri = rng.normal(size=(3, 3))
+        ng = np.cross(tri[1] - tri[0], tri[2] - tri[0]); ng /= np.linalg.norm(ng)
+        nrm = np.array([unit(ng + 0.6 * rng.normal(size=3)) for _ in range(3)])
+        b = rng.dirichlet((1, 1, 1))
+        P = b @ tri
+        t = [P - tri[i] for i in range(3)]
+        t = [t[i] - min(0.0, float(t[i] @ nrm[i])) * nrm[i] for i in range(3)]
+        out["point_offset"].append({"tri": tri.reshape(-1).tolist(), "nrm": nrm.reshape(-1).tolist(), "bary": b.tolist(), "p": P.tolist(),
+                                    "offset_p": (P + b[0] * t[0] + b[1] * t[1] + b[2] * t[2]).tolist()})
+    out["ray_cone"] = [{"width": w0, "spread": g, "t": t, "cos": c, "footprint": (w0 + g * t) / max(abs(c), 1e-3)} for w0 in (0.0, 0.01, 0.3) for g in (0.0, 5e-4, 2e-3) for t in (0.1, 3.0, 50.0)
+                       for c in (1.0, -0.6, 0.2, 1e-5)]
     path = os.path.join(ROOT, "tests", "golden", "pins_closed_forms.json")
     json.dump(out, open(path, "w"), indent=1)
     print("wrote", path, {k: len(v) for k, v in out.items() if isinstance(v, list)})

@@ -1670,25 +1670,27 @@ void HdrEnvironment::buildAccel()
     m_rgba[4 * i + 3] = std::max(m_rgba[4 * i], std::max(m_rgba[4 * i + 1], m_rgba[4 * i + 2])) * invIntegral;
 
   // Vose's alias method on q_i = importance_i * n / total
-  std::vector<float>    q(n);
+  // (the running q of a bright texel takes thousands of donations: in float32 its mass drifts by 1e-4 -- measured against numpy
+  //  in tests/test_oracle_pins.py -- so the bookkeeping is done in double and only the final entries are rounded)
+  std::vector<double>   q(n);
   std::vector<uint32_t> small, large;
   small.reserve(n);
   large.reserve(n);
   const double scale = double(n) / total;
   for(size_t i = 0; i < n; ++i)
   {
-    q[i] = float(double(importance[i]) * scale);
-    (q[i] < 1.0f ? small : large).push_back(uint32_t(i));
+    q[i] = double(importance[i]) * scale;
+    (q[i] < 1.0 ? small : large).push_back(uint32_t(i));
   }
   while(!small.empty() && !large.empty())
   {
     uint32_t s = small.back();
     small.pop_back();
     uint32_t l       = large.back();
-    m_accel[s].q     = q[s];
+    m_accel[s].q     = float(q[s]);
     m_accel[s].alias = l;
-    q[l]             = (q[l] + q[s]) - 1.0f;
-    if(q[l] < 1.0f)
+    q[l]             = (q[l] + q[s]) - 1.0;
+    if(q[l] < 1.0)
     {
       large.pop_back();
       small.push_back(l);
