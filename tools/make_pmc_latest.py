@@ -18,16 +18,25 @@ def mean(*v):
     return sum(v) / len(v) if v else None
 
 
-# counter / true bytes per kernel class: what the kernel mostly reads and writes
+# Counter / true bytes per kernel.  What the calibration shows (profiles/r03_fetch_calibration.json): the counter tallies REQUESTS at 64 B
+# each -- a gather that stays inside one 64-B line (16-B texel footprints, 48-B vertex / triangle records) is counted exactly (1.00),
+# a wide request (consecutive 16-B words of a wave: queue entries; an 80-B node record that straddles two lines) is a 128-B request
+# counted as 64 (0.50 / 0.52).  A kernel's ratio is the harmonic mix of the two by the share s of its ALGORITHMIC read bytes that
+# come as wide requests (bench.py's byte model):  r = 1 / (s / r_wide + (1 - s) / r_line).
 if calib:
-    r_fetch = {"shade_first": mean(calib["fetch_gather16"], calib["fetch_gather48"]),   # texel footprints, vertices, 16-B path-state records by slot
-               "shade": mean(calib["fetch_gather16"], calib["fetch_gather48"]),
-               "trace_closest": mean(calib["fetch_gather80"], calib["fetch_gather48"]),   # BVH8 nodes, triangles
-               "trace_shadow": mean(calib["fetch_gather80"], calib["fetch_gather48"]),
-               "trace_primary": mean(calib["fetch_gather80"], calib["fetch_gather48"]),
-               "shadow_resolve": calib["fetch_stream16"], "finish_sample": mean(calib["fetch_stream16"], calib["fetch_gather16"]), "generate": calib["fetch_stream16"]}
-    r_write = {k: mean(calib["write_stream16"], calib["write_scatter16"]) for k in r_fetch}   # queue appends (streams) + path state by slot (scatters)
-    r_write["shadow_resolve"] = calib["write_scatter16"]
+    r_wide, r_line, r_node = calib["fetch_stream16"], mean(calib["fetch_gather16"], calib["fetch_gather48"]), calib["fetch_gather80"]
+
+    def mix(s_wide, wide=r_wide):
+        return 1.0 / (s_wide / wide + (1.0 - s_wide) / r_line)
+
+    r_fetch = {"shade_first": mix(52.0 / 980.0),    # per hit: queue entry 52 B as a stream; misc 16 + shade record / attributes 192 + records 480 + ~5 taps x 48 as gathers
+               "shade": mix(52.0 / 1012.0),           # + throughput / radiance 32 B by slot
+               "trace_closest": mix(0.8, r_node),     # ~80 % of the bytes are 80-B node records (20 visits x 80 B against 8 triangles x 48 B)
+               "trace_shadow": mix(0.8, r_node),
+               "trace_primary": r_line,               # nodes and triangles through the scalar cache: 64-B lines
+               "shadow_resolve": r_wide, "finish_sample": mix(0.5), "generate": r_wide}
+    # WRITE_SIZE: a wide stream is counted exactly; a lone 16-B store is tallied as 32 B (the memory's write granule) -- taken as reported
+    r_write = {k: calib["write_stream16"] for k in r_fetch}
 else:
     r_fetch, r_write = {}, {}
 # the timed (non-counting) template instances: k_shade<COUNT, SIMPLE, FIRST>, k_trace_closest<WIDE, HAS_ALPHA, COUNT>,
