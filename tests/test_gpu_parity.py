@@ -277,13 +277,22 @@ def test_image_independent_of_acceleration_structure(built, tmp_path):
     two structures must give bit-identical images (and the oracle's own SAH tree a tolerance-identical one)."""
     path = scenegen.scene_atrium_class(str(tmp_path / "atrium.glb"), seed=5, detail=0.12, tex_size=64)
     s = pu.Setup(path, 160, 96, max_depth=8)
-    wide = pu.render_gpu(s, 2, bvh=0)
     bvh2 = pu.render_gpu(s, 2, bvh=1)
-    assert (wide["accum"] == bvh2["accum"]).all()
-    assert (wide["selection"] == bvh2["selection"]).all() and (wide["depth"] == bvh2["depth"]).all()
-    for k in ("segments", "shadowRays", "textureTaps"):
-        assert wide["stats"][k] == bvh2["stats"][k]
-    assert wide["stats"]["nodesClosest"] < 0.6 * bvh2["stats"]["nodesClosest"]  # the point of the wide structure
+    nodes = {}
+    for collapse in ("greedy", "sah"):  # which BVH2 subtrees become the children of an 8-wide node: greedy by area / SAH-optimal (bvh8.hip)
+        os.environ["MI_PT_COLLAPSE"] = collapse
+        try:
+            wide = pu.render_gpu(s, 2, bvh=0)
+        finally:
+            del os.environ["MI_PT_COLLAPSE"]
+        assert (wide["accum"] == bvh2["accum"]).all(), collapse
+        assert (wide["selection"] == bvh2["selection"]).all() and (wide["depth"] == bvh2["depth"]).all()
+        for k in ("segments", "shadowRays", "textureTaps"):
+            assert wide["stats"][k] == bvh2["stats"][k]
+        assert wide["stats"]["nodesClosest"] < 0.6 * bvh2["stats"]["nodesClosest"]  # the point of the wide structure
+        nodes[collapse] = (wide["stats"]["bvhNodeCount"], wide["stats"]["nodesClosest"], wide["stats"]["trisClosest"])
+    print("8-wide nodes / node visits / triangle tests: greedy", nodes["greedy"], "sah", nodes["sah"])
+    assert nodes["sah"][0] < 0.8 * nodes["greedy"][0]  # fuller nodes: the SAH-optimal collapse needs far fewer of them
     path = scenegen.scene_glass_class(str(tmp_path / "glass.glb"), seed=3, tess=24)
     s = pu.Setup(path, 128, 80, max_depth=12, hdr_path=os.path.join(os.path.dirname(os.path.dirname(__file__)), "assets", "std_env.hdr"))
     assert (pu.render_gpu(s, 2, bvh=0)["accum"] == pu.render_gpu(s, 2, bvh=1)["accum"]).all()
@@ -350,12 +359,16 @@ def test_device_bvh8_collapse_equals_host_collapse(built, tmp_path):
     import sys
     path = scenegen.scene_atrium_class(str(tmp_path / "atrium.glb"), seed=5, detail=0.2, tex_size=64)
     s = pu.Setup(path, 160, 96, max_depth=6)
-    dev = pu.render_gpu(s, 2)
+    os.environ["MI_PT_COLLAPSE"] = "greedy"  # (the host reference implements the greedy collapse only)
+    try:
+        dev = pu.render_gpu(s, 2)
+    finally:
+        del os.environ["MI_PT_COLLAPSE"]
     code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import parity_util as pu; s = pu.Setup(%r, 160, 96, max_depth=6); "
             "g = pu.render_gpu(s, 2); np.save(%r, g['accum']); print({k: g['stats'][k] for k in ('nodesClosest', 'trisClosest', 'nodesShadow', 'trisShadow', 'nodesPrimary', "
             "'trisPrimary', 'bvhNodeCount')})") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), path,
                                                    str(tmp_path / "host.npy"))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MI_PT_HOST_COLLAPSE="1"), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MI_PT_HOST_COLLAPSE="1", MI_PT_COLLAPSE="greedy"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     host_stats = eval(r.stdout.strip().splitlines()[-1])
     assert (np.load(tmp_path / "host.npy") == dev["accum"]).all()

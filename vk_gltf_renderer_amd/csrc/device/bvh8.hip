@@ -54,6 +54,7 @@ static_assert(sizeof(Node8) == 80, "Node8 must be 80 bytes");
 
 // Largest leaf child.  A node addresses its triangles through a 31-bit mask, so eight children of 3 always fit; with 4 a node
 // whose leaves would hold more than 31 falls back to 3 (MI_PT_LEAF_TRIS: tuning knob, the images do not depend on it).
+constexpr bool COLLAPSE_SAH_DEFAULT = false;  // (A/B first: MI_PT_COLLAPSE=sah)
 constexpr int MAX_LEAF_TRIS_DEFAULT = 2;  // measured: 2 beats 1, 3 and 4 on the helmet, atrium and street workloads (+0.4 .. +2.5 % over 3)
 
 static int maxLeafTris()
@@ -109,10 +110,171 @@ __device__ __forceinline__ float d_area(const DCand& c)
   const float ex = c.hi[0] - c.lo[0], ey = c.hi[1] - c.lo[1], ez = c.hi[2] - c.lo[2];
   return __fadd_rn(__fadd_rn(__fmul_rn(ex, ey), __fmul_rn(ey, ez)), __fmul_rn(ez, ex));  // (no contraction: the host reference computes the same value)
 }
+// ---- SAH-optimal collapse (Ylitie, Karras, Laine 2017, section 3.2) ------------------------------------------------------------
+// cost[n][i], i = 1..7: the cheapest way to represent the BVH2 subtree n as AT MOST i children of some 8-wide node -- each such child
+// either a leaf (the subtree has <= maxLeaf triangles; cost = area x C_TRI x triangles) or an inner 8-wide node (cost = area x 1 +
+// the cheapest forest of <= 8 children below it).  C_TRI = 56 / 235: a triangle test against a node visit in vector instructions.
+// split[n][i]: how many of the i roots go to the left BVH2 child (-1: the subtree stays one child); split[n][1]: 0 = leaf, 1 = inner
+// node; split[n][0]: the left share of the inner node's eight.  Filled bottom-up (second arrival at a node solves it, like k_fit),
+// read top-down by the level kernels instead of the greedy opening.
+constexpr float DP_C_TRI = 56.0f / 235.0f;
+struct DpTables
+{
+  float*  cost;   // numInner x 8 ([0] unused)
+  int8_t* split;  // numInner x 8
+};
+__device__ __forceinline__ float d_boxArea(const float lo[3], const float hi[3])
+{
+  const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+  return __fadd_rn(__fadd_rn(__fmul_rn(ex, ey), __fmul_rn(ey, ez)), __fmul_rn(ez, ex));
+}
+__global__ void k_dp_parents(int numInner, const float4* nodes2, int* parent, int* leafParent, int root)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= numInner)
+    return;
+  for(int k = 0; k < 2; ++k)
+  {
+    const int c = d_childRef(nodes2, i, k);
+    if(c >= 0)
+      parent[c] = i;
+    else
+      leafParent[~c] = i;
+  }
+  if(i == root)
+    parent[i] = -1;
+}
+__device__ void d_dpSolve(const float4* nodes2, DpTables dp, int nd, uint32_t maxLeaf)
+{
+  int   ref[2];
+  float leafCost[2];  // cost of a child that is a single triangle
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for(int k = 0; k < 2; ++k)
+  {
+    ref[k] = d_childRef(nodes2, nd, k);
+    float l[3], h[3];
+    d_childBox(nodes2, nd, k, l, h);
+    leafCost[k] = d_boxArea(l, h) * DP_C_TRI;
+    for(int a = 0; a < 3; ++a)
+    {
+      lo[a] = fminf(lo[a], l[a]);
+      hi[a] = fmaxf(hi[a], h[a]);
+    }
+  }
+  const float area = d_boxArea(lo, hi);
+  auto get = [&](int k, int i) { return ref[k] < 0 ? leafCost[k] : dp.cost[size_t(ref[k]) * 8 + size_t(min(i, 7))]; };
+  float*  c = dp.cost + size_t(nd) * 8;
+  int8_t* s = dp.split + size_t(nd) * 8;
+  for(int i = 2; i <= 7; ++i)
+  {
+    float best = FLT_MAX;
+    int   bk   = 1;
+    for(int k = 1; k < i; ++k)
+    {
+      const float v = get(0, k) + get(1, i - k);
+      if(v < best)
+      {
+        best = v;
+        bk   = k;
+      }
+    }
+    c[i] = best;
+    s[i] = int8_t(bk);
+  }
+  float inner = FLT_MAX;
+  int   bk    = 1;
+  for(int k = 1; k < 8; ++k)
+  {
+    const float v = get(0, k) + get(1, 8 - k);
+    if(v < inner)
+    {
+      inner = v;
+      bk    = k;
+    }
+  }
+  inner += area;
+  const uint32_t cnt  = d_triCount(nodes2, nd);
+  const float    leaf = cnt <= maxLeaf ? area * DP_C_TRI * float(cnt) : FLT_MAX;
+  c[0] = 0.0f;
+  c[1] = leaf <= inner ? leaf : inner;
+  s[1] = leaf <= inner ? 0 : 1;
+  s[0] = int8_t(bk);
+  for(int i = 2; i <= 7; ++i)
+    if(c[1] < c[i])
+    {
+      c[i] = c[1];
+      s[i] = -1;
+    }
+}
+__global__ void k_dp_solve(int numLeaves, const float4* nodes2, const int* parent, const int* leafParent, unsigned* arrive, DpTables dp, uint32_t maxLeaf)
+{
+  const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
+  if(leaf >= numLeaves)
+    return;
+  int cur = leafParent[leaf];
+  while(cur >= 0)
+  {
+    __threadfence();  // release: tables written below this node are visible before the ticket
+    if(atomicAdd(&arrive[cur], 1u) == 0u)
+      return;  // first arrival: the sibling subtree finishes this node
+    __threadfence();  // acquire
+    d_dpSolve(nodes2, dp, cur, maxLeaf);
+    cur = parent[cur];
+  }
+}
+// is the candidate an INNER child (an 8-wide node of its own) or a leaf child?  greedy: by its triangle count; DP: as the table decided
+__device__ __forceinline__ bool d_isInner(const float4* nodes2, const DpTables& dp, int ref, uint32_t maxLeaf)
+{
+  if(ref < 0)
+    return false;
+  if(dp.split)
+    return dp.split[size_t(ref) * 8 + 1] != 0;
+  return d_triCount(nodes2, ref) > maxLeaf;
+}
+// The children of the 8-wide node rooted at BVH2 node `ref` as the DP tables chose them.
+__device__ int d_expandDp(const float4* nodes2, const DpTables& dp, int ref, DCand cands[8])
+{
+  struct Item
+  {
+    int ref, parentNode, which, share;
+  };
+  Item stack[16];
+  int  sp = 0, count = 0;
+  const int k0 = dp.split[size_t(ref) * 8 + 0];
+  stack[sp++] = Item{d_childRef(nodes2, ref, 1), ref, 1, 8 - k0};  // (right first: popped last, so the children come out left to right)
+  stack[sp++] = Item{d_childRef(nodes2, ref, 0), ref, 0, k0};
+  while(sp > 0)
+  {
+    const Item it = stack[--sp];
+    const int  sh = min(it.share, 7);
+    const int  sv = it.ref >= 0 ? int(dp.split[size_t(it.ref) * 8 + size_t(sh)]) : -1;
+    if(it.ref < 0 || sh <= 1 || sv < 0)
+    {
+      if(count < 8)
+      {
+        cands[count].ref = it.ref;
+        d_childBox(nodes2, it.parentNode, it.which, cands[count].lo, cands[count].hi);
+        ++count;
+      }
+      continue;
+    }
+    if(sp + 2 <= 16)
+    {
+      stack[sp++] = Item{d_childRef(nodes2, it.ref, 1), it.ref, 1, sh - sv};
+      stack[sp++] = Item{d_childRef(nodes2, it.ref, 0), it.ref, 0, sv};
+    }
+  }
+  return count;
+}
 // The children of the 8-wide node that starts at BVH2 node `ref`: greedy, always open the inner child of largest surface area that
 // holds more than maxLeaf triangles, until there are eight (or nothing left to open).  Returns how many, and the leaf size used.
-__device__ int d_expand(const float4* nodes2, int ref, uint32_t maxLeafIn, DCand cands[8], uint32_t& maxLeafOut)
+__device__ int d_expand(const float4* nodes2, const DpTables& dp, int ref, uint32_t maxLeafIn, DCand cands[8], uint32_t& maxLeafOut)
 {
+  if(dp.split)
+  {
+    maxLeafOut = maxLeafIn;  // (<= 3 in this mode: eight leaf children always fit the node's triangle mask)
+    return d_expandDp(nodes2, dp, ref, cands);
+  }
   uint32_t maxLeaf = maxLeafIn;
   int      count;
   for(;;)
@@ -160,19 +322,19 @@ __device__ int d_expand(const float4* nodes2, int ref, uint32_t maxLeafIn, DCand
   return count;
 }
 // pass 1 of a level: how many inner children (low word) and leaf triangles (high word) each node of the level will have
-__global__ void k_collapse_count(int numItems, const int* items, const float4* nodes2, uint32_t maxLeaf, unsigned long long* counts)
+__global__ void k_collapse_count(int numItems, const int* items, const float4* nodes2, DpTables dp, uint32_t maxLeaf, unsigned long long* counts)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if(i >= numItems)
     return;
   DCand    cands[8];
   uint32_t ml;
-  const int count = d_expand(nodes2, items[i], maxLeaf, cands, ml);
+  const int count = d_expand(nodes2, dp, items[i], maxLeaf, cands, ml);
   uint32_t  inner = 0, tris = 0;
   for(int k = 0; k < count; ++k)
   {
     const uint32_t tc = d_triCount(nodes2, cands[k].ref);
-    if(cands[k].ref >= 0 && tc > ml)
+    if(d_isInner(nodes2, dp, cands[k].ref, ml))
       ++inner;
     else
       tris += tc;
@@ -180,7 +342,7 @@ __global__ void k_collapse_count(int numItems, const int* items, const float4* n
   counts[i] = (unsigned long long)inner | ((unsigned long long)tris << 32);
 }
 // pass 2: the node records, the next level's work list, the triangle permutation
-__global__ void k_collapse_emit(int numItems, const int* items, const float4* nodes2, uint32_t maxLeaf, const unsigned long long* counts,
+__global__ void k_collapse_emit(int numItems, const int* items, const float4* nodes2, DpTables dp, uint32_t maxLeaf, const unsigned long long* counts,
                                 const unsigned long long* offsets, uint32_t levelStart, uint32_t nextLevelStart, uint32_t triLevelBase, Node8* nodes8,
                                 int* nextItems, uint32_t* perm, unsigned long long* totals)
 {
@@ -191,7 +353,7 @@ __global__ void k_collapse_emit(int numItems, const int* items, const float4* no
     *totals = offsets[i] + counts[i];
   DCand    cands[8];
   uint32_t ml;
-  const int count = d_expand(nodes2, items[i], maxLeaf, cands, ml);
+  const int count = d_expand(nodes2, dp, items[i], maxLeaf, cands, ml);
   // node frame
   float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   for(int k = 0; k < count; ++k)
@@ -287,7 +449,7 @@ __global__ void k_collapse_emit(int numItems, const int* items, const float4* no
       continue;
     const DCand&   c  = cands[candOfSlot[sl]];
     const uint32_t tc = d_triCount(nodes2, c.ref);
-    if(c.ref >= 0 && tc > ml)
+    if(d_isInner(nodes2, dp, c.ref, ml))
     {
       N.imask |= uint8_t(1u << sl);
       N.meta[sl]                          = 0xff;
@@ -345,6 +507,9 @@ bool buildBvh8(const BvhBuildOutput& b2, Bvh8Output& out, hipStream_t stream, st
     size_t              scanBytes = 0;
     bool                ok        = true;
     uint32_t            numNodes8 = 0, trisPlaced = 0;
+    DpTables            dp{nullptr, nullptr};
+    int *               dpParent = nullptr, *dpLeafParent = nullptr;
+    unsigned*           dpArrive = nullptr;
     do
     {
       // every 8-wide node is rooted at a distinct BVH2 inner node: numInner bounds their number and the length of any level
@@ -360,13 +525,29 @@ bool buildBvh8(const BvhBuildOutput& b2, Bvh8Output& out, hipStream_t stream, st
       const int root = b2.root;
       if(!(ok = check(hipMemcpyAsync(itemsA, &root, sizeof(int), hipMemcpyHostToDevice, stream), "seed level 0"))) break;
       uint32_t levelStart = 0, levelCount = 1;
-      const uint32_t maxLeaf = uint32_t(maxLeafTris());
+      uint32_t maxLeaf = uint32_t(maxLeafTris());
+      // MI_PT_COLLAPSE = sah | greedy: which BVH2 subtrees become the children of an 8-wide node (the images do not depend on it)
+      const char* modeEnv = getenv("MI_PT_COLLAPSE");
+      const bool  sahDp   = modeEnv ? strcmp(modeEnv, "sah") == 0 : COLLAPSE_SAH_DEFAULT;
+      if(sahDp)
+      {
+        maxLeaf = std::min(maxLeaf, 3u);
+        if(!(ok = check(hipMalloc(&dp.cost, sizeof(float) * 8 * size_t(numInner)), "alloc DP cost"))) break;
+        if(!(ok = check(hipMalloc(&dp.split, 8 * size_t(numInner)), "alloc DP split"))) break;
+        if(!(ok = check(hipMalloc(&dpParent, sizeof(int) * size_t(numInner)), "alloc DP parents"))) break;
+        if(!(ok = check(hipMalloc(&dpLeafParent, sizeof(int) * size_t(n)), "alloc DP leaf parents"))) break;
+        if(!(ok = check(hipMalloc(&dpArrive, sizeof(unsigned) * size_t(numInner)), "alloc DP tickets"))) break;
+        if(!(ok = check(hipMemsetAsync(dpArrive, 0, sizeof(unsigned) * size_t(numInner), stream), "clear DP tickets"))) break;
+        hipLaunchKernelGGL(k_dp_parents, dim3((numInner + 255u) / 256u), dim3(256), 0, stream, int(numInner), b2.nodes, dpParent, dpLeafParent, root);
+        hipLaunchKernelGGL(k_dp_solve, dim3((n + 255u) / 256u), dim3(256), 0, stream, int(n), b2.nodes, dpParent, dpLeafParent, dpArrive, dp, maxLeaf);
+        if(!(ok = check(hipGetLastError(), "DP kernels"))) break;
+      }
       while(levelCount > 0)
       {
         const unsigned g = (levelCount + 127u) / 128u;
-        hipLaunchKernelGGL(k_collapse_count, dim3(g), dim3(128), 0, stream, int(levelCount), itemsA, b2.nodes, maxLeaf, counts);
+        hipLaunchKernelGGL(k_collapse_count, dim3(g), dim3(128), 0, stream, int(levelCount), itemsA, b2.nodes, dp, maxLeaf, counts);
         if(!(ok = check(hipcub::DeviceScan::ExclusiveSum(scanTemp, scanBytes, counts, offsets, int(levelCount), stream), "scan"))) break;
-        hipLaunchKernelGGL(k_collapse_emit, dim3(g), dim3(128), 0, stream, int(levelCount), itemsA, b2.nodes, maxLeaf, counts, offsets, levelStart,
+        hipLaunchKernelGGL(k_collapse_emit, dim3(g), dim3(128), 0, stream, int(levelCount), itemsA, b2.nodes, dp, maxLeaf, counts, offsets, levelStart,
                            levelStart + levelCount, trisPlaced, dNodes, itemsB, dPerm, totals);
         unsigned long long t = 0;
         if(!(ok = check(hipGetLastError(), "collapse kernels"))) break;
@@ -400,6 +581,7 @@ bool buildBvh8(const BvhBuildOutput& b2, Bvh8Output& out, hipStream_t stream, st
     } while(0);
     (void)hipFree(dNodes); (void)hipFree(itemsA); (void)hipFree(itemsB); (void)hipFree(dPerm); (void)hipFree(counts); (void)hipFree(offsets);
     (void)hipFree(totals); (void)hipFree(scanTemp);
+    (void)hipFree(dp.cost); (void)hipFree(dp.split); (void)hipFree(dpParent); (void)hipFree(dpLeafParent); (void)hipFree(dpArrive);
     if(!ok)
     {
       if(out.nodes) (void)hipFree(out.nodes);
