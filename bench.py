@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the path-trace hot path on N MI355X GPUs of one node.
 
-A "step" is one pass of the hot path over one batch of synthetic input: `--frames-per-step` (default 192) consecutive frames
+A "step" is one pass of the hot path over one batch of synthetic input: `--frames-per-step` (default 256) consecutive frames
 per GPU, each ptSamples = 1 sample per pixel like the reference's headless run `--frames K --ptSamples 1`
 (docs/benchmarking.md:16-23), of the workload BASELINE.json's metric is quoted on and that fits one GPU: configs[1],
 DamagedHelmet-class + std_env.hdr, 1920x1080, depth 8 (the asset itself is not available offline;
 vk_gltf_renderer_amd.scenegen writes a seeded stand-in of the same class as a .glb).  The frames of a step are issued through
-mi_pt_render_frames in groups of `--in-flight` (default 64) that share every wavefront launch (bit-identical to rendering them
+mi_pt_render_frames in groups of `--in-flight` (default 128) that share every wavefront launch (bit-identical to rendering them
 one after the other; --in-flight 1 gives exactly that).  Metric = the reference's throughput_MSps (src/benchmarking.cpp:272-279):
 W*H*spp / wall_s / 1e6 with spp = all samples of the timed region, inputs resident in HBM before the timed region.
 
@@ -37,6 +37,9 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
+# Frames in flight per GPU and frames per step: 64 -> 96 -> 128 frames measured 3809 / 3896 / 3927 Msamples/s on the helmet and 484 / 489 / 492
+# on the atrium (round 3; a batch of 128 1080p frames is 2.65e8 path slots, ~80 GB of the 288)
+IN_FLIGHT_DEFAULT, FRAMES_PER_STEP_DEFAULT = 128, 256
 ALPHA_CUT_DEFAULT = 4  # measured (adaptive cut): atrium 462 -> 483 / 479 / 494 and street 455 -> 510 / 507 / 490 Msamples/s at 4 / 8 / 16
 WORKLOADS = {
     # name: (BASELINE config, generator kwargs, width, height, maxDepth, env)
@@ -238,7 +241,7 @@ def secondary_line(name, args, device, width=0, height=0, steps=5, cpu_seconds=0
         t.set_sky(ptmod.default_sky())
         return t
 
-    F = max(1, min(w.get("in_flight", 64), int(SLOT_BUDGET // (W * H))))
+    F = max(1, min(w.get("in_flight", IN_FLIGHT_DEFAULT), int(SLOT_BUDGET // (W * H))))
     frames_step = 2 * F
     t = tracer(False)
     r = ptmod.HeadlessRenderer(t, params(w["depth"]))
@@ -306,11 +309,11 @@ def main():
                     help="load-time bake for alpha-MASK geometry (mi_scene_cut_alpha: the counterpart of the reference's opacity micro-map bake): "
                          "subdivisions per triangle edge, 0 = off.  The parity leg renders the UNCUT scene with the CPU oracle")
     ap.add_argument("--frames-per-step", type=int, default=0,
-                    help="frames (1 spp each) per GPU and step (default 192; glass 256); a step renders frames_per_step * n_gpus frames")
+                    help="frames (1 spp each) per GPU and step (default 256); a step renders frames_per_step * n_gpus frames")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="frames in flight per GPU (mi_pt_render_frames, bit-identical to sequential frames): the frames of a step are issued in "
-                         "groups of in_flight * n_gpus (capped at 1024).  Default 64; 128 for the glass workload, whose volume random walks leave a "
-                         "long tail of ~100 nearly empty bounce iterations per batch (238 -> 469 Msamples/s from 32 to 128 frames)")
+                         "groups of in_flight * n_gpus (capped at 1024).  Default 128 (helmet 3809 / 3927 Msamples/s at 64 / 128; the glass workload's volume "
+                         "random walks leave a long tail of ~100 nearly empty bounce iterations per batch: 238 -> 469 Msamples/s from 32 to 128 frames)")
     args = ap.parse_args()
 
     import torch
@@ -342,8 +345,8 @@ def main():
         assert dist.get_world_size() == world
 
     w = WORKLOADS[args.workload]
-    args.in_flight = args.in_flight or w.get("in_flight", 64)
-    args.frames_per_step = args.frames_per_step or w.get("frames_per_step", 192)
+    args.in_flight = args.in_flight or w.get("in_flight", IN_FLIGHT_DEFAULT)
+    args.frames_per_step = args.frames_per_step or w.get("frames_per_step", FRAMES_PER_STEP_DEFAULT)
     W, H = args.width or w["width"], args.height or w["height"]
     scene = ptmod.Scene(scene_path(args.workload, rank))
     triangles_loaded = scene.num_triangles

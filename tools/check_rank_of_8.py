@@ -1,5 +1,5 @@
 """What ONE rank of an N-GPU `bench.py` run executes (minus the RCCL reduce), timed on a single GPU: tile partition r/N, the scene
-with bench.py's load-time alpha cut, bench.py's frames in flight (64 per GPU, within its path-slot budget).  Prints the per-rank step times for a few tile sizes next to the 1-GPU step, and checks that the partial
+with bench.py's load-time alpha cut, bench.py's frames in flight (128 per GPU, within its path-slot budget).  Prints the per-rank step times for a few tile sizes next to the 1-GPU step, and checks that the partial
 accumulators sum to the unpartitioned image bit for bit.   usage: tools/check_rank_of_8.py [workload] [world]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,8 +14,8 @@ W, H = w["width"], w["height"]
 scene = ptmod.Scene(bench.scene_path(name, 0))
 if bench.ALPHA_CUT_DEFAULT > 0:
     scene.cut_alpha(bench.ALPHA_CUT_DEFAULT)
-F1 = max(1, min(w.get("in_flight", 64), int(bench.SLOT_BUDGET // (W * H))))
-FN = max(1, min(1024, w.get("in_flight", 64) * world, int(bench.SLOT_BUDGET * world // (W * H))))
+F1 = max(1, min(w.get("in_flight", bench.IN_FLIGHT_DEFAULT), int(bench.SLOT_BUDGET // (W * H))))
+FN = max(1, min(1024, w.get("in_flight", bench.IN_FLIGHT_DEFAULT) * world, int(bench.SLOT_BUDGET * world // (W * H))))
 hdr = ptmod.HdrEnvironment(path=os.path.join(bench.ROOT, "assets", "std_env.hdr")) if w["hdr"] else None
 fi, pixel_angle, focal = ptmod.camera_frame_info(scene.camera(0), W, H)
 if hdr is not None:

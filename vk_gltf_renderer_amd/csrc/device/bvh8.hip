@@ -16,8 +16,9 @@
 // `slot ^ (7 ^ rayOctant)` is a front-to-back priority.
 //
 // The collapse runs ON THE DEVICE, level by level over the BVH2 the builder left in HBM (no download): one thread per 8-wide node of
-// the level opens BVH2 children greedily by surface area until it holds eight, orders them by octant, quantises their boxes and
-// writes the 80-byte record; a prefix sum over the level hands every node the indices of its inner children (= the next level's
+// the level picks its (up to eight) children -- by default the SAH-optimal choice of Ylitie et al. 2017, read from tables a bottom-up
+// dynamic programme over the BVH2 leaves behind (k_dp_solve); MI_PT_COLLAPSE=greedy opens BVH2 children by surface area instead --
+// orders them by octant, quantises their boxes and writes the 80-byte record; a prefix sum over the level hands every node the indices of its inner children (= the next level's
 // work list, breadth-first order) and the positions of its leaf triangles.  Two kernels and one scan per level, ~10 levels.  The
 // single-threaded host collapse it replaces (0.6 s of a 0.86 s scene build at 2.6 M triangles in round 1) is kept behind
 // MI_PT_HOST_COLLAPSE=1 as the A/B reference: both emit the same node array.
@@ -54,7 +55,10 @@ static_assert(sizeof(Node8) == 80, "Node8 must be 80 bytes");
 
 // Largest leaf child.  A node addresses its triangles through a 31-bit mask, so eight children of 3 always fit; with 4 a node
 // whose leaves would hold more than 31 falls back to 3 (MI_PT_LEAF_TRIS: tuning knob, the images do not depend on it).
-constexpr bool COLLAPSE_SAH_DEFAULT = false;  // (A/B first: MI_PT_COLLAPSE=sah)
+// SAH-optimal collapse by default: against the greedy one (MI_PT_COLLAPSE=greedy) 40 % fewer, fuller nodes (atrium 68.8 k -> 44 k),
+// node visits per secondary ray 19.74 -> 19.27 (atrium), 28.66 -> 27.55 (street), 8.01 -> 7.91 (helmet), and
+// atrium 482 -> 490, street 512 -> 518, helmet 3799 -> 3878, glass 537 -> 551 Msamples/s (round 3)
+constexpr bool COLLAPSE_SAH_DEFAULT = true;
 constexpr int MAX_LEAF_TRIS_DEFAULT = 2;  // measured: 2 beats 1, 3 and 4 on the helmet, atrium and street workloads (+0.4 .. +2.5 % over 3)
 
 static int maxLeafTris()

@@ -120,24 +120,9 @@ PT_DEV PushPos queuePushBlock2(bool predNext, bool predShadow, uint32_t subCap, 
   return p;
 }
 
-PT_DEV uint32_t laneCountBelowMask(unsigned long long mask) { return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u)); }
-// The same append per WAVE: one 64-bit global atomic per wave for both tails, no barrier -- the waves of a block run their chunks
-// independently of one another (A/B switch SHADE_WAVE_PUSH: the block version makes every wave wait for the block's slowest at three
-// barriers per chunk, in a kernel whose waves are long chains of dependent gathers).
-PT_DEV PushPos queuePushWave2(bool predNext, bool predShadow, uint32_t subCap, uint32_t* pair, uint32_t sub)
-{
-  const unsigned long long maskN = __ballot(predNext), maskS = __ballot(predShadow);
-  const uint32_t           lane  = laneId();
-  const uint32_t           nN = uint32_t(__popcll(maskN)), nS = uint32_t(__popcll(maskS));
-  unsigned long long       base = 0ull;
-  if(lane == 0 && (nN | nS) != 0u)
-    base = atomicAdd(reinterpret_cast<unsigned long long*>(pair), (static_cast<unsigned long long>(nS) << 32) | nN);
-  const uint32_t baseN = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(base)))), baseS = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(base >> 32))));
-  PushPos        p;
-  p.next   = sub * subCap + baseN + laneCountBelowMask(maskN);
-  p.shadow = sub * subCap + baseS + laneCountBelowMask(maskS);
-  return p;
-}
+// (A per-WAVE version of this append -- one 64-bit global atomic per wave, no barrier, so that the waves of a block run their chunks
+//  independently -- was measured in round 3: helmet 3793 against 3799 Msamples/s, atrium 478 / 482, street 504 / 512, glass 529 / 537.
+//  The three barriers per chunk are not what the shade kernel waits for; four times the device-scope atomics are.)
 
 // ---- slot <-> pixel -----------------------------------------------------------------------------------------------------------
 // Slots are tile-major; inside a tile 8x8 micro-tiles, so one 64-lane wave owns one 8x8 pixel block (coherent camera rays).
@@ -1838,12 +1823,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
       if(COUNT && (meshHit || hitInfinitePlane))
         atomicAdd(&stats->surfaceHits, 1ull);
     }
-#ifdef SHADE_WAVE_PUSH
-    const uint32_t pushSub = (chunk * 4u + wave) % NSUB;
-    const PushPos  pp      = queuePushWave2(alive, pushShadow, Q.subCap, &Q.counters[(nxt ? QC_PAIR1 : QC_PAIR0) + 2 * pushSub], pushSub);
-#else
     const PushPos  pp      = queuePushBlock2(alive, pushShadow, Q.subCap, &Q.counters[(nxt ? QC_PAIR1 : QC_PAIR0) + 2 * (chunk % NSUB)], chunk % NSUB, s_push);
-#endif
     const uint32_t posNext = pp.next, posShadow = pp.shadow;
     if(alive)
     {
