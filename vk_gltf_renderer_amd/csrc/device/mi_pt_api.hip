@@ -185,7 +185,7 @@ namespace {
 
 size_t align16(size_t v) { return (v + 15u) & ~size_t(15); }
 
-// Path state and ray queues for `frames` frames in flight (path slot = frame * numSlots + pixel slot).
+// Path state and ray queues for `frames` frames in flight (path slots are micro-tile major: pt::pathSlot).
 int allocPathResources(MiPt* pt, int frames)
 {
   if(size_t(pt->numSlots) * size_t(frames) >= 0x7fffffffull)
@@ -896,8 +896,8 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   while((1 << c.fc.tileShift) < pt->tileSize)
     ++c.fc.tileShift;
   c.fc.numSlots  = pt->numSlots;
-  pt::divideMagic(uint32_t(std::max(pt->numSlots, 2)), c.fc.slotsMagic, c.fc.slotsShift);
   c.fc.numFrames = numFrames;
+  pt::divideMagic(uint32_t(std::max(numFrames, 2)), c.fc.framesMagic, c.fc.framesShift);
   c.paths        = pt->paths;
   pt->accumFrames   = float(params->totalSamples) / float(params->numSamples) + float(numFrames);
   const bool guides = (params->flags & MI_PT_USE_OPTIX_DENOISER) != 0;

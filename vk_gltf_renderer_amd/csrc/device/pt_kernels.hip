@@ -182,6 +182,7 @@ PT_DEV void unpackMedium(uint4 m, f3& ext, f3& sc, float& g)
 struct CameraPath
 {
   bool     valid;  // the slot maps to a pixel of the image
+  uint32_t frame;  // frame of the batch the slot belongs to (wave-uniform)
   uint32_t seed;   // RNG state after the camera draws
   f3       origin, direction;
 };
@@ -191,8 +192,8 @@ struct CameraPath
 // medium is written when a path first enters one, firstHit by the first shade of the path, pixelSum by k_finish_sample.
 // Cost note: the bounce-0 kernel is bound by vector-instruction issue (2 500 per wave of 64 camera rays, of which this function
 // was 900 in its first form).  What is wave-uniform runs on the scalar unit: a wave's 64 slots are consecutive and 64-aligned
-// and numSlots is a multiple of 64, so the frame index, the tile and the micro-tile are computed once per wave (the division
-// by numSlots is a multiply-high by FrameConsts::slotsMagic).  With aperture = 0 (wave-uniform) the lens offset is
+// and the slots are micro-tile major (FrameConsts::numFrames), so the frame index, the tile and the micro-tile are computed once per
+// wave (the division by numFrames is a multiply-high by FrameConsts::framesMagic).  With aperture = 0 (wave-uniform) the lens offset is
 // (cos, sin) * sqrt(0) = 0 whatever the angle: the two draws still advance the seed, the sine and cosine are skipped.
 // The arithmetic that forms the ray stays correctly rounded (IEEE division, square root) -- it is what makes the camera rays,
 // and with them coverage, selection ids and the segment counters, agree with the oracle bit for bit; hardware reciprocals and
@@ -200,14 +201,19 @@ struct CameraPath
 PT_DEV CameraPath generateCameraPath(const FrameConsts& fc, const PathSoA& P, const uint32_t* ownedTiles, uint32_t slot, int sampleIndex)
 {
   CameraPath cp;
+  cp.frame     = 0u;
   cp.seed      = 0u;
   cp.origin    = mk3(0.0f);
   cp.direction = mk3(0.0f);
   // ---- slot -> (frame, pixel): see slotToPixel; per wave
   const uint32_t lane      = laneId();
   const uint32_t base      = __builtin_amdgcn_readfirstlane(slot - lane);
-  const uint32_t frame     = __umulhi(base, fc.slotsMagic) >> fc.slotsShift;  // base / numSlots
-  const uint32_t pixelBase = base - frame * uint32_t(fc.numSlots);
+  // wave w = base / 64 works on micro-tile w / numFrames of frame w % numFrames (pathSlot)
+  const uint32_t waveIdx   = base >> 6;
+  const uint32_t mtile     = fc.numFrames > 1 ? (__umulhi(waveIdx, fc.framesMagic) >> fc.framesShift) : waveIdx;
+  const uint32_t frame     = waveIdx - mtile * uint32_t(fc.numFrames);
+  const uint32_t pixelBase = mtile * 64u;
+  cp.frame                 = frame;
   const uint32_t tile      = ownedTiles[pixelBase >> (2 * fc.tileShift)];
   const uint32_t micro     = (pixelBase & ((1u << (2 * fc.tileShift)) - 1u)) >> 6;
   const uint32_t mshift    = uint32_t(fc.tileShift) - 3u;
@@ -1257,7 +1263,7 @@ __global__ void __launch_bounds__(256, PRIMARY_MIN_WAVES) k_trace_primary(DevSce
   // radiance and k_finish_sample, which reads that record anyway and runs one dense thread per pixel, evaluates it.
   if(active && !toShade)
   {
-    if(hasFlag(fc.pc.flags, MI_PT_FIRST_FRAME) && slot < uint32_t(fc.numSlots))  // NDC depth input of a first frame (k_finish_sample)
+    if(hasFlag(fc.pc.flags, MI_PT_FIRST_FRAME) && cp.frame == 0u)  // NDC depth input of a first frame (k_finish_sample)
       P.firstHit[slot] = make_float4(cp.direction.x, cp.direction.y, cp.direction.z, 0.0f);
     P.radiance[slot] = make_float4(cp.direction.x, cp.direction.y, cp.direction.z, 0.0f);                                    // maxRoughness.x = 0
     P.misc[slot]     = make_float4(0.0f, __uint_as_float(PF_NOT_SOLID | PF_PRIMARY_MISS), __uint_as_float(cp.seed), 0.0f);  // depth 0, not alive
@@ -1512,7 +1518,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
       const bool firstRay = (surfaceDepth == 0);
       const int  maxDepth = fc.pc.maxDepth;
       // the first-hit position only feeds the NDC depth of a first frame (k_finish_sample), i.e. frame 0 of the batch
-      const bool needFirstHit = hasFlag(fc.pc.flags, MI_PT_FIRST_FRAME) && slot < uint32_t(fc.numSlots);
+      const bool needFirstHit = hasFlag(fc.pc.flags, MI_PT_FIRST_FRAME) && pathSlotFrame(fc, slot) == 0u;
 
       float hitT   = hit4.x;
       int   triIdx = __float_as_int(hit4.y);
@@ -2472,7 +2478,7 @@ __global__ void __launch_bounds__(256) k_finish_sample(FrameConsts fc, const Dev
   bool         loaded = false;
   for(int f = 0; f < fc.numFrames; ++f)
   {
-    const uint32_t slot  = uint32_t(f) * uint32_t(fc.numSlots) + pslot;
+    const uint32_t slot  = pathSlot(fc, pslot, uint32_t(f));
     float4         rad4  = P.radiance[slot];
     const uint32_t flags = __float_as_uint(P.misc[slot].y);
     const bool     solid = !(flags & PF_NOT_SOLID);

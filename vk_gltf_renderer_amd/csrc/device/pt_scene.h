@@ -162,8 +162,12 @@ struct FrameConsts
   int                     width, height;
   int                     tileSize, tileShift;  // tileSize = 1 << tileShift, >= 16
   int                     numSlots;             // owned tiles * tileSize^2 (a multiple of QCHUNK): pixel slots of ONE frame
-  int                     numFrames;            // frames in flight; path slot = frame * numSlots + pixel slot
-  uint32_t                slotsMagic, slotsShift;  // slot / numSlots == mulhi(slot, slotsMagic) >> slotsShift for slot < 2^31 (divideMagic)
+  // Frames in flight.  Path slots are MICRO-TILE MAJOR: slot = ((pixelSlot / 64) * numFrames + frame) * 64 + pixelSlot % 64 -- the
+  // numFrames samples of an 8x8 pixel block are adjacent, so the waves that run side by side on the device work on the same few
+  // pixels: the same BVH nodes, the same triangles, vertices and texels for their camera rays and first hits (round 3; before, the
+  // slots were frame major -- frame * numSlots + pixelSlot -- and concurrent waves covered a tenth of a frame).  See pathSlot().
+  int                     numFrames;
+  uint32_t                framesMagic, framesShift;  // w / numFrames == mulhi(w, framesMagic) >> framesShift for w < 2^31 (divideMagic; numFrames >= 2)
 };
 
 // Exact division of a 31-bit number by d >= 2 as multiply-high + shift: with k = floor(log2 d) and m = ceil(2^(32+k) / d) (< 2^32
@@ -184,6 +188,21 @@ inline void divideMagic(uint32_t d, uint32_t& magic, uint32_t& shift)
   magic                      = uint32_t((p + d - 1ull) / d);
   shift                      = k;
 }
+
+// slot <-> (pixel slot, frame) of the micro-tile-major layout (FrameConsts::numFrames)
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint32_t pathSlot(const FrameConsts& fc, uint32_t pixelSlot, uint32_t frame)
+{
+  return ((pixelSlot >> 6) * uint32_t(fc.numFrames) + frame) * 64u + (pixelSlot & 63u);
+}
+__device__ __forceinline__ uint32_t pathSlotFrame(const FrameConsts& fc, uint32_t slot)
+{
+  if(fc.numFrames <= 1)
+    return 0u;
+  const uint32_t w = slot >> 6, mt = __umulhi(w, fc.framesMagic) >> fc.framesShift;
+  return w - mt * uint32_t(fc.numFrames);
+}
+#endif
 
 // ---- per-path state, structure of arrays indexed by slot -----------------------------------------------------------------
 // Per-segment traffic (read + write) is accounted in DESIGN.md §5; keep records 16-byte sized for dwordx4 access.
