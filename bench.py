@@ -129,8 +129,15 @@ def kernel_table(all_b, first_b, timing, frames):
     return rows
 
 
-# path slots (frames in flight x pixels) per GPU: ~0.3 KB of path state and queue entries per slot, ~85 GB of the 288
-SLOT_BUDGET = 2.8e8
+# path slots (frames in flight x pixels) per GPU: ~0.3 KB of path state and queue entries per slot, ~160 GB of the 288 -- enough for 64
+# 4K frames: a multiple of 64 frames in flight lays the path slots out pixel major (a wave = 64 samples of one pixel)
+SLOT_BUDGET = 5.4e8
+
+
+def frames_in_flight(wanted, width, height, world=1):
+    """Frames in flight within the slot budget; rounded down to a multiple of 64 when at least 64 fit (pixel-major path slots)."""
+    f = max(1, min(wanted, int(SLOT_BUDGET * world // (width * height))))
+    return f - f % 64 if f >= 64 else f
 
 
 def alpha_cut_note(subdivisions, triangles_loaded, dropped):
@@ -241,7 +248,7 @@ def secondary_line(name, args, device, width=0, height=0, steps=5, cpu_seconds=0
         t.set_sky(ptmod.default_sky())
         return t
 
-    F = max(1, min(w.get("in_flight", IN_FLIGHT_DEFAULT), int(SLOT_BUDGET // (W * H))))
+    F = frames_in_flight(w.get("in_flight", IN_FLIGHT_DEFAULT), W, H)
     frames_step = 2 * F
     t = tracer(False)
     r = ptmod.HeadlessRenderer(t, params(w["depth"]))
@@ -308,6 +315,7 @@ def main():
     ap.add_argument("--alpha-cut", type=int, default=ALPHA_CUT_DEFAULT,
                     help="load-time bake for alpha-MASK geometry (mi_scene_cut_alpha: the counterpart of the reference's opacity micro-map bake): "
                          "subdivisions per triangle edge, 0 = off.  The parity leg renders the UNCUT scene with the CPU oracle")
+    ap.add_argument("--exact-in-flight", action="store_true", help="do not round the frames in flight down to a multiple of 64 (A/B of the slot layouts)")
     ap.add_argument("--frames-per-step", type=int, default=0,
                     help="frames (1 spp each) per GPU and step (default 256); a step renders frames_per_step * n_gpus frames")
     ap.add_argument("--in-flight", type=int, default=0,
@@ -407,8 +415,8 @@ def main():
     # Every rank owns 1/world of the tiles of each frame, so the frames per step and the frames in flight grow with the world size
     # to keep the rays in flight per GPU constant (weak scaling).
     F = min(1024, max(1, args.in_flight) * world)
-    # ... within a budget of 2.8e8 path slots per GPU (~85 GB of path state and queues at ~0.3 KB per slot): 4K frames run 33 in flight
-    F = max(1, min(F, int(SLOT_BUDGET * world // (W * H))))
+    # ... within the budget of path slots per GPU (SLOT_BUDGET): 4K frames run 64 in flight
+    F = frames_in_flight(F, W, H, world) if not args.exact_in_flight else max(1, min(F, int(SLOT_BUDGET * world // (W * H))))
     # (a rank owns numSlots = its tiles' pixels, ~W*H/world: F frames in flight are F*W*H/world path slots on this GPU)
     assert F * float(W) * float(H) / world <= SLOT_BUDGET * 1.02, "path slots per GPU beyond the budget"
     frames_step = max(1, args.frames_per_step) * world

@@ -503,8 +503,12 @@ def test_ktx_decode(built, tmp_path):
     rows = b"".join(rgb[y].tobytes() + bytes((-6 * 3) % 4) for y in range(3))
     files["ktx1_rgb"] = (b"\xabKTX 11\xbb\r\n\x1a\n" + struct.pack("<IIIIIIIIIIIII", 0x04030201, 0x1401, 1, 0x1907, 0x8051, 0x1907, 6, 3, 0, 0, 1, 1, 0)
                          + struct.pack("<I", len(rows)) + rows)
+    # ... and the CLIENT format decides the byte order: GL_BGR data under the same GL_RGB8 internal format is blue first
+    files["ktx1_bgr"] = (b"\xabKTX 11\xbb\r\n\x1a\n" + struct.pack("<IIIIIIIIIIIII", 0x04030201, 0x1401, 1, 0x80E0, 0x8051, 0x1907, 6, 3, 0, 0, 1, 1, 0)
+                         + struct.pack("<I", len(rows)) + rows)
     names = list(files)
     tex = dict(zip(names, _scene_with_images(tmp_path, "k.glb", [files[k] for k in names], "image/ktx2", "KHR_texture_basisu")))
+    assert (tex["ktx1_bgr"][..., :3] == rgb[..., ::-1]).all() and (tex["ktx1_bgr"][..., 3] == 255).all()
     assert (tex["rgba"] == rgba).all() and (tex["rgba_srgb_zlib"] == rgba).all() and (tex["rgba_zstd"] == rgba).all()
     assert (tex["bgra"] == rgba[..., [2, 1, 0, 3]]).all()
     assert (tex["rgb"][..., :3] == rgb).all() and (tex["rgb"][..., 3] == 255).all() and (tex["ktx1_rgb"] == tex["rgb"]).all()

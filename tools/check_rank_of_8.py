@@ -14,8 +14,8 @@ W, H = w["width"], w["height"]
 scene = ptmod.Scene(bench.scene_path(name, 0))
 if bench.ALPHA_CUT_DEFAULT > 0:
     scene.cut_alpha(bench.ALPHA_CUT_DEFAULT)
-F1 = max(1, min(w.get("in_flight", bench.IN_FLIGHT_DEFAULT), int(bench.SLOT_BUDGET // (W * H))))
-FN = max(1, min(1024, w.get("in_flight", bench.IN_FLIGHT_DEFAULT) * world, int(bench.SLOT_BUDGET * world // (W * H))))
+F1 = bench.frames_in_flight(w.get("in_flight", bench.IN_FLIGHT_DEFAULT), W, H)
+FN = bench.frames_in_flight(min(1024, w.get("in_flight", bench.IN_FLIGHT_DEFAULT) * world), W, H, world)
 hdr = ptmod.HdrEnvironment(path=os.path.join(bench.ROOT, "assets", "std_env.hdr")) if w["hdr"] else None
 fi, pixel_angle, focal = ptmod.camera_frame_info(scene.camera(0), W, H)
 if hdr is not None:

@@ -142,6 +142,8 @@ struct MiPt
   float4*                 normalImg() { return normalBound ? normalBound : normal.ptr; }
   float*                  depthImg() { return depthBound ? depthBound : depth.ptr; }
   float                   accumFrames = 0.0f;  // frames folded into the accumulator (variance of the mean, SVGF pass)
+  float                   momentFrames = 0.0f; // frames folded into the luminance second moment (normal.w): only batches rendered with the guides on
+                                               // feed it, so it may lag behind accumFrames -- the SVGF pass then falls back to its spatial variance
   const float4*           denoised = nullptr;  // result of the last mi_pt_denoise (one of denoiseA / denoiseB)
   DevBuf<uint32_t>        tonemapped, tmHistogram;
   DevBuf<float>           tmAutoState;
@@ -787,6 +789,7 @@ int mi_pt_resize(MiPt* pt, int width, int height)
   pt->height      = height;
   pt->denoised    = nullptr;
   pt->accumFrames = 0.0f;
+  pt->momentFrames = 0.0f;
   return allocFrameResources(pt);
 }
 
@@ -898,9 +901,15 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   c.fc.numSlots  = pt->numSlots;
   c.fc.numFrames = numFrames;
   pt::divideMagic(uint32_t(std::max(numFrames, 2)), c.fc.framesMagic, c.fc.framesShift);
+  c.fc.slotLayout = (numFrames % 64 == 0 && getenv("MI_PT_MICROTILE_SLOTS") == nullptr) ? 1 : 0;  // (A/B switch: micro-tile major at any batch size)
   c.paths        = pt->paths;
   pt->accumFrames   = float(params->totalSamples) / float(params->numSamples) + float(numFrames);
   const bool guides = (params->flags & MI_PT_USE_OPTIX_DENOISER) != 0;
+  // the second moment covers the accumulation only if every batch since its start carried the guides
+  if(guides && (params->totalSamples == 0 || pt->momentFrames == pt->accumFrames - float(numFrames)))
+    pt->momentFrames = pt->accumFrames;
+  else if(!guides || params->totalSamples == 0)
+    pt->momentFrames = 0.0f;
   if(!guides)
   {
     c.paths.guideAlbedo = nullptr;
@@ -1103,6 +1112,8 @@ int mi_pt_write_accum(MiPt* pt, const float* host)
   HIP_TRY(hipSetDevice(pt->device));
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(pt->accum, host, size_t(pt->width) * size_t(pt->height) * sizeof(float4), hipMemcpyHostToDevice));
+  pt->accumFrames  = 1.0f;  // a frame from elsewhere: denoisable, with no temporal moment behind it
+  pt->momentFrames = 0.0f;
   return MI_PT_OK;
 }
 int mi_pt_read_guides(MiPt* pt, float* albedo, float* normal)
@@ -1183,8 +1194,11 @@ int mi_pt_denoise_svgf(MiPt* pt, int iterations, float sigmaLuminance, float sig
     HIP_TRY(pt->denoiseA.alloc(px));
     HIP_TRY(pt->denoiseB.alloc(px));
   }
+  // (mean and second moment must cover the same frames for E[l^2] - E[l]^2 to mean anything: otherwise -- guides switched on
+  //  mid-accumulation, or an accumulator written by mi_pt_write_accum -- the pass estimates the variance spatially, as it does below 4 frames)
+  const float varianceFrames = pt->momentFrames == pt->accumFrames ? pt->accumFrames : 1.0f;
   pt->denoised = pt::launchSvgf(pt->accum, pt->albedoImg(), pt->normalImg(), pt->depthImg(), pt->denoiseA.ptr, pt->denoiseB.ptr, pt->width, pt->height, iterations,
-                                pt->accumFrames, sigmaLuminance, sigmaNormal, sigmaDepth, stream);
+                                varianceFrames, sigmaLuminance, sigmaNormal, sigmaDepth, stream);
   HIP_TRY(hipGetLastError());
   if(host)
   {

@@ -208,17 +208,30 @@ PT_DEV CameraPath generateCameraPath(const FrameConsts& fc, const PathSoA& P, co
   // ---- slot -> (frame, pixel): see slotToPixel; per wave
   const uint32_t lane      = laneId();
   const uint32_t base      = __builtin_amdgcn_readfirstlane(slot - lane);
-  // wave w = base / 64 works on micro-tile w / numFrames of frame w % numFrames (pathSlot)
-  const uint32_t waveIdx   = base >> 6;
-  const uint32_t mtile     = fc.numFrames > 1 ? (__umulhi(waveIdx, fc.framesMagic) >> fc.framesShift) : waveIdx;
-  const uint32_t frame     = waveIdx - mtile * uint32_t(fc.numFrames);
-  const uint32_t pixelBase = mtile * 64u;
+  uint32_t frame, pixelBase, inMicro;
+  if(fc.slotLayout == 1)
+  {
+    // pixel major: the wave is 64 consecutive frames of pixel slot base / numFrames
+    const uint32_t pslot = __umulhi(base, fc.framesMagic) >> fc.framesShift;
+    frame                = base - pslot * uint32_t(fc.numFrames) + lane;
+    pixelBase            = pslot & ~63u;
+    inMicro              = pslot & 63u;
+  }
+  else
+  {
+    // micro-tile major: wave w = base / 64 works on micro-tile w / numFrames of frame w % numFrames (pathSlot)
+    const uint32_t waveIdx = base >> 6;
+    const uint32_t mtile   = fc.numFrames > 1 ? (__umulhi(waveIdx, fc.framesMagic) >> fc.framesShift) : waveIdx;
+    frame                  = waveIdx - mtile * uint32_t(fc.numFrames);
+    pixelBase              = mtile * 64u;
+    inMicro                = lane;
+  }
   cp.frame                 = frame;
   const uint32_t tile      = ownedTiles[pixelBase >> (2 * fc.tileShift)];
   const uint32_t micro     = (pixelBase & ((1u << (2 * fc.tileShift)) - 1u)) >> 6;
   const uint32_t mshift    = uint32_t(fc.tileShift) - 3u;
-  const int      px        = int((tile & 0xffffu) + (micro & ((1u << mshift) - 1u)) * 8u + (lane & 7u));
-  const int      py        = int((tile >> 16) + (micro >> mshift) * 8u + (lane >> 3));
+  const int      px        = int((tile & 0xffffu) + (micro & ((1u << mshift) - 1u)) * 8u + (inMicro & 7u));
+  const int      py        = int((tile >> 16) + (micro >> mshift) * 8u + (inMicro >> 3));
   cp.valid                 = px < fc.width && py < fc.height;
   if(!cp.valid)
     return cp;
@@ -2476,11 +2489,30 @@ __global__ void __launch_bounds__(256) k_finish_sample(FrameConsts fc, const Dev
   const bool   guides   = P.guideAlbedo && albedoOut;
   float4       acc = make_float4(0, 0, 0, 0), accA = acc, accN = acc;
   bool         loaded = false;
-  for(int f = 0; f < fc.numFrames; ++f)
+  // Four frames' records are fetched ahead of their (serial, in frame order) fold: with pixel-major slots a pixel's records are
+  // consecutive -- the four share a 64-byte line, which a thread must ask for while it is hot, its neighbours' lines lying 16 x
+  // numFrames bytes apart -- and in either layout the four gathers overlap instead of queueing behind one another.
+  for(int f0 = 0; f0 < fc.numFrames; f0 += 4)
   {
+   float4   radAhead[4];
+   uint32_t flagsAhead[4];
+#pragma unroll
+   for(int j = 0; j < 4; ++j)
+     if(f0 + j < fc.numFrames)
+     {
+       const uint32_t sj = pathSlot(fc, pslot, uint32_t(f0 + j));
+       radAhead[j]       = P.radiance[sj];
+       flagsAhead[j]     = __float_as_uint(P.misc[sj].y);
+     }
+#pragma unroll
+   for(int j = 0; j < 4; ++j)
+   {
+    const int f = f0 + j;
+    if(f >= fc.numFrames)
+      break;
     const uint32_t slot  = pathSlot(fc, pslot, uint32_t(f));
-    float4         rad4  = P.radiance[slot];
-    const uint32_t flags = __float_as_uint(P.misc[slot].y);
+    float4         rad4  = radAhead[j];
+    const uint32_t flags = flagsAhead[j];
     const bool     solid = !(flags & PF_NOT_SOLID);
     if(flags & PF_PRIMARY_MISS)
     {
@@ -2556,6 +2588,7 @@ __global__ void __launch_bounds__(256) k_finish_sample(FrameConsts fc, const Dev
         accN = make_float4(accN.x * wOld + nn.x * wNew, accN.y * wOld + nn.y * wNew, accN.z * wOld + nn.z * wNew, accN.w * wOld + nn.w * wNew);
       }
     }
+   }
   }
   if(lastSample)
   {

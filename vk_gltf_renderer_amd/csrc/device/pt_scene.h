@@ -166,8 +166,13 @@ struct FrameConsts
   // numFrames samples of an 8x8 pixel block are adjacent, so the waves that run side by side on the device work on the same few
   // pixels: the same BVH nodes, the same triangles, vertices and texels for their camera rays and first hits (round 3; before, the
   // slots were frame major -- frame * numSlots + pixelSlot -- and concurrent waves covered a tenth of a frame).  See pathSlot().
+  // With a multiple of 64 frames in flight the layout goes one step further, PIXEL major (slotLayout 1): slot = pixelSlot * numFrames
+  // + frame -- a wave is 64 samples of ONE pixel.  Its camera rays are the tightest packet there is, and its first hits share the
+  // triangle, the vertices, the material and (within the pixel's footprint) the texels: the bounce-0 gathers of a wave touch a
+  // handful of cache lines instead of 64.
   int                     numFrames;
   uint32_t                framesMagic, framesShift;  // w / numFrames == mulhi(w, framesMagic) >> framesShift for w < 2^31 (divideMagic; numFrames >= 2)
+  int                     slotLayout;                // 0: micro-tile major, 1: pixel major (numFrames % 64 == 0)
 };
 
 // Exact division of a 31-bit number by d >= 2 as multiply-high + shift: with k = floor(log2 d) and m = ceil(2^(32+k) / d) (< 2^32
@@ -193,14 +198,16 @@ inline void divideMagic(uint32_t d, uint32_t& magic, uint32_t& shift)
 #if defined(__HIPCC__)
 __device__ __forceinline__ uint32_t pathSlot(const FrameConsts& fc, uint32_t pixelSlot, uint32_t frame)
 {
+  if(fc.slotLayout == 1)
+    return pixelSlot * uint32_t(fc.numFrames) + frame;
   return ((pixelSlot >> 6) * uint32_t(fc.numFrames) + frame) * 64u + (pixelSlot & 63u);
 }
 __device__ __forceinline__ uint32_t pathSlotFrame(const FrameConsts& fc, uint32_t slot)
 {
   if(fc.numFrames <= 1)
     return 0u;
-  const uint32_t w = slot >> 6, mt = __umulhi(w, fc.framesMagic) >> fc.framesShift;
-  return w - mt * uint32_t(fc.numFrames);
+  const uint32_t w = fc.slotLayout == 1 ? slot : (slot >> 6), q = __umulhi(w, fc.framesMagic) >> fc.framesShift;
+  return w - q * uint32_t(fc.numFrames);
 }
 #endif
 

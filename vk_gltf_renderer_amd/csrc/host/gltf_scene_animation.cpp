@@ -23,6 +23,8 @@ float AnimationInfo::incrementTime(float deltaTime, bool loop)  // reference: sr
   if(loop)
   {
     const float duration = end - start;
+    if(!(duration > 0.0f))  // a clip with one keyframe (or none): fmod(x, 0) is NaN and would stick -- the clip has one pose
+      return currentTime = start;
     float       wrapped  = std::fmod(currentTime - start, duration);
     if(wrapped < 0.0f)
       wrapped += duration;

@@ -205,6 +205,19 @@ bool decodeKtx(const uint8_t* data, size_t size, Image& out, std::string* error)
     return fail("only plain 2D images are supported (no volume, array or cube textures)");
   if(!layoutOfGlFormat(glInternal, L) || (!L.block && glType != 0x1401u /* GL_UNSIGNED_BYTE */))
     return fail("unsupported glInternalFormat");
+  if(!L.block)
+  {
+    // the CLIENT format (glFormat, offset 24) gives the channel order of the stored bytes: GL_BGR / GL_BGRA data under an RGB8 /
+    // RGBA8 internal format is blue first; anything but the plain 8-bit orders with the channel count of the internal format is refused
+    const uint32_t glFormat = le32(data + 24);
+    const bool     rgbOrder = glFormat == 0x1903u /* GL_RED */ || glFormat == 0x8227u /* GL_RG */ || glFormat == 0x1907u /* GL_RGB */ || glFormat == 0x1908u /* GL_RGBA */
+                          || glFormat == 0x1909u /* GL_LUMINANCE */ || glFormat == 0x190Au /* GL_LUMINANCE_ALPHA */;
+    const bool bgrOrder = (glFormat == 0x80E0u /* GL_BGR */ && L.channels == 3) || (glFormat == 0x80E1u /* GL_BGRA */ && L.channels == 4);
+    if(bgrOrder)
+      L.bgr = true;
+    else if(!rgbOrder)
+      return fail("unsupported glFormat");
+  }
   if(kvBytes > size - 64 - 4)
     return fail("truncated key/value data");
   const size_t   at = 64 + size_t(kvBytes);
