@@ -49,8 +49,11 @@ MI_PT_API int                  mi_mikktspace(const float* positions, const float
 /* Load-time bake for alpha-MASK geometry, this renderer's counterpart of the reference's opacity micro-map bake
  * (src/gltf_scene_omm.cpp; UI switch "Use OMM" src/ui_renderer.cpp): every alpha-MASK triangle is cut adaptively along a
  * subdivisions x subdivisions barycentric grid (rounded up to 2, 4, 8 or 16; 4 is a good default) and the pieces on which the alpha test cannot pass -- no texel a fetch inside them may
- * touch reaches alphaCutoff -- are dropped, so that rays through the empty part of a leaf card meet no candidate at all.  The
- * image is unchanged up to float rounding of the interpolated vertices; the selection image (TraceLow treats every triangle as
+ * touch reaches alphaCutoff -- are dropped, so that rays through the empty part of a leaf card meet no candidate at all; the pieces on
+ * which it cannot FAIL are moved to the front of their primitive and counted in MiPtRenderPrimitive::opaqueTriangleCount (the walks skip
+ * the alpha test for them).  The
+ * image is unchanged up to float rounding of the interpolated vertices (and up to sub-ulp T-junction cracks where a merged coarse piece
+ * meets refined ones: ~1e-7 of a card's area, csrc/host/alpha_cut.cpp); the selection image (TraceLow treats every triangle as
  * opaque) reports what is seen through a removed part instead of the alpha-tested instance itself.  Returns the number of (sub-)triangles dropped (>= 0)
  * or a negative MiPtStatus; the MiPtSceneDesc changes (fetch mi_scene_desc again, create the renderer afterwards). */
 MI_PT_API int64_t              mi_scene_cut_alpha(MiScene* scene, int subdivisions);

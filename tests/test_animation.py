@@ -282,3 +282,31 @@ def test_hostile_hierarchies_and_animations_do_not_crash(built, tmp_path):
     sc.update_animation(0, 0.5)
     m = np.array(sc.desc.contents.renderNodes[0].objectToWorld[:])
     assert np.isfinite(m).all()
+
+
+def test_a_node_with_two_parents_is_posed_under_each_of_them(built, tmp_path):
+    """glTF hierarchies are strict trees; a file that lists one node as a child of TWO parents is still loaded -- the node is
+    instantiated under each (like the load-time traversal of the reference) -- and an animation must pose each instance along ITS
+    path: before round 3 the world-matrix pass visited a node once, so after the first animated frame the second instance took the
+    first one's matrix.  Also: a clip of a single keyframe has no duration and must not turn the clock into NaN."""
+    from vk_gltf_renderer_amd.pathtracer import Scene
+    b = scenegen.GlbBuilder()
+    pos, nrm, uv, idx = scenegen.grid(1, 1)
+    m = b.mesh([b.primitive(pos, idx, nrm, uv, material=b.material(scenegen.lambert_material()))])
+    shared = b.node(root=False, mesh=m)
+    b.node(children=[shared], translation=[10.0, 0.0, 0.0])
+    b.node(children=[shared], translation=[-5.0, 2.0, 0.0])
+    b.animation([(shared, "translation", [0.0, 1.0], [[0, 0, 0], [0, 0, 4]], "LINEAR")])
+    sc = Scene(b.save(str(tmp_path / "two_parents.glb")))
+    d = sc.desc.contents
+    assert d.numRenderNodes == 2
+    at = lambda i: np.array(d.renderNodes[i].objectToWorld[:], np.float64).reshape(4, 4).T[:3, 3]
+    rest = sorted([tuple(at(0)), tuple(at(1))])
+    assert rest == [(-5.0, 2.0, 0.0), (10.0, 0.0, 0.0)]
+    assert sc.update_animation(0, 0.5)
+    posed = sorted([tuple(at(0)), tuple(at(1))])
+    assert posed == [(-5.0, 2.0, 2.0), (10.0, 0.0, 2.0)], posed
+    for i in range(2):  # worldToObject follows
+        o2w = np.array(d.renderNodes[i].objectToWorld[:], np.float64).reshape(4, 4).T
+        w2o = np.array(d.renderNodes[i].worldToObject[:], np.float64).reshape(4, 4).T
+        assert np.allclose(o2w @ w2o, np.eye(4), atol=1e-6)

@@ -16,6 +16,11 @@
 // (2^-23); new vertices carry linearly interpolated attributes, i.e. the same linear functions the hit-attribute interpolation
 // evaluates, up to float rounding.  Primitives the classification cannot be sure about are left alone: vertex alpha,
 // MIRRORED_REPEAT, non-MASK modes, materials shared with other alpha settings.
+// One caveat of the adaptive merge: a coarse cell next to refined ones leaves T-junctions -- the refined cells' edge vertices are
+// float interpolations that do not lie exactly on the coarse cell's edge (the same across an original edge whose two triangles are
+// refined to different depths) -- so a ray can slip through a crack of a few ulps inside the opaque part of a card, or hit both
+// sides of an overlap (the closest-hit tie-break makes the latter harmless).  The measure of such rays is ~1e-7 of a card's
+// area: below what the parity tests can see, but not zero; a uniform cut (no merge) does not have it.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>

@@ -1085,6 +1085,7 @@ void GltfScene::traverse(int nodeID, const mx::mat4& parent, bool parentVisible,
   if(size_t(nodeID) >= m_onPath.size() || m_onPath[size_t(nodeID)])
     return;
   m_onPath[size_t(nodeID)] = 1;
+  m_curPath.push_back(nodeID);
   mx::mat4 world = mx::mul(parent, localMatrix(nodeID));
   // KHR_node_visibility cascades (reference: src/gltf_scene.cpp:1907-1948)
   bool         visible = parentVisible;
@@ -1123,6 +1124,7 @@ void GltfScene::traverse(int nodeID, const mx::mat4& parent, bool parentVisible,
       }
       m_lights.push_back(info);
       m_lightNode.push_back(nodeID);
+      m_lightPath.push_back(m_curPath);
     }
   }
 
@@ -1191,7 +1193,7 @@ void GltfScene::traverse(int nodeID, const mx::mat4& parent, bool parentVisible,
         rn.renderPrimID = rprimID;
         m_renderNodes.push_back(rn);
         m_renderNodeVisible.push_back(visible ? 1 : 0);
-        m_renderNodeSource.push_back({nodeID, instance});
+        m_renderNodeSource.push_back({nodeID, instance, m_curPath});
         m_numTriangles += m_primData[size_t(rprimID)].indices.size() / 3;
       };
       if(instances)
@@ -1206,6 +1208,7 @@ void GltfScene::traverse(int nodeID, const mx::mat4& parent, bool parentVisible,
   for(size_t c = 0; c < children.size(); ++c)
     traverse(children[c].integer(-1), world, visible, primMap);
   m_onPath[size_t(nodeID)] = 0;
+  m_curPath.pop_back();
 }
 
 mx::mat4 GltfScene::localMatrix(int nodeID) const
@@ -1315,6 +1318,8 @@ bool GltfScene::parse(const std::string& baseDir)  // reference: src/gltf_scene.
   m_gpuInstanceLocalMatrices.clear();
   m_renderNodeSource.clear();
   m_lightNode.clear();
+  m_lightPath.clear();
+  m_curPath.clear();
   m_roots.clear();
   m_animations.clear();
   m_nodePose.assign(m_doc["nodes"].size(), NodePose{});

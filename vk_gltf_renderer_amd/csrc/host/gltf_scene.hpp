@@ -137,8 +137,12 @@ private:
   };
   struct RenderNodeSource
   {
-    int node = -1, instance = -1;  // glTF node, EXT_mesh_gpu_instancing instance (-1: none)
+    int              node = -1, instance = -1;  // glTF node, EXT_mesh_gpu_instancing instance (-1: none)
+    std::vector<int> path;                      // the nodes from a scene root down to `node`: a file whose nodes have several parents is
+                                                // instantiated once per path at load (traverse), and posed per path by updateAnimation
   };
+  std::vector<int>              m_curPath;      // traverse(): the path to the node being visited
+  std::vector<std::vector<int>> m_lightPath;    // per light, like RenderNodeSource::path
   std::vector<Animation>        m_animations;
   std::vector<NodePose>         m_nodePose;
   std::vector<RenderNodeSource> m_renderNodeSource;

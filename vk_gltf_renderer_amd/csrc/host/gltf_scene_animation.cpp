@@ -8,6 +8,7 @@
 // is outside the instance-update boundary (mi_pt_update_render_nodes).
 #include <algorithm>
 #include <cmath>
+#include <map>
 #include <cstring>
 #include <limits>
 
@@ -237,30 +238,24 @@ bool GltfScene::updateAnimation(int index)
   if(!any)
     return false;
 
-  // world matrices of all nodes reachable from the scene roots (reference: Scene::updateNodeWorldMatrices)
-  const size_t          numNodes = m_doc["nodes"].size();
-  std::vector<mx::mat4> world(numNodes, mx::identity());
-  std::vector<uint8_t>  reached(numNodes, 0);
-  std::vector<std::pair<int, int>> stack;  // node, parent (-1: root)
-  for(int r : m_roots)
-    stack.push_back({r, -1});
-  while(!stack.empty())
-  {
-    const auto [n, parent] = stack.back();
-    stack.pop_back();
-    if(n < 0 || size_t(n) >= numNodes || reached[size_t(n)] || !m_doc["nodes"][size_t(n)].isObject())
-      continue;
-    reached[size_t(n)] = 1;
-    const mx::mat4 local = localMatrix(n);
-    world[size_t(n)]     = parent < 0 ? local : mx::mul(world[size_t(parent)], local);
-    const Value& children = m_doc["nodes"][size_t(n)]["children"];
-    for(size_t c = 0; c < children.size(); ++c)
-      stack.push_back({children[c].integer(), n});
-  }
+  // World matrices (reference: Scene::updateNodeWorldMatrices), per PATH from a scene root: glTF hierarchies are strict trees, but
+  // load-time traversal instantiates a node of a non-conforming file under every parent it is listed by -- each such render node
+  // (and light) keeps the path it was reached by and is posed along it, with the multiplication order of traverse().
+  std::map<std::vector<int>, mx::mat4> cache;  // (distinct paths are few: render nodes of one glTF node share theirs)
+  auto worldOf = [&](const std::vector<int>& path) {
+    auto it = cache.find(path);
+    if(it != cache.end())
+      return it->second;
+    mx::mat4 w = mx::identity();
+    for(size_t i = 0; i < path.size(); ++i)
+      w = i == 0 ? localMatrix(path[i]) : mx::mul(w, localMatrix(path[i]));
+    cache.emplace(path, w);
+    return w;
+  };
   for(size_t n = 0; n < m_renderNodes.size(); ++n)
   {
     const RenderNodeSource& src = m_renderNodeSource[n];
-    mx::mat4                w   = world[size_t(src.node)];
+    mx::mat4                w   = worldOf(src.path);
     if(src.instance >= 0)
       w = mx::mul(w, m_gpuInstanceLocalMatrices.at(src.node)[size_t(src.instance)]);
     MiGltfRenderNode& rn = m_renderNodes[n];
@@ -269,7 +264,7 @@ bool GltfScene::updateAnimation(int index)
     memcpy(rn.worldToObject, inv.m, sizeof(rn.worldToObject));
   }
   for(size_t l = 0; l < m_lights.size(); ++l)
-    placeLight(m_lights[l], world[size_t(m_lightNode[l])]);
+    placeLight(m_lights[l], worldOf(m_lightPath[l]));
   return true;
 }
 
