@@ -50,7 +50,7 @@ WORKLOADS = {
     "street": dict(config="configs[3]: BistroExterior-class (instanced street, ~2.8 M triangles, ~1000 render nodes, 130 materials), 3840x2160, depth 8",
                    gen="scene_street_class", kw=dict(seed=777, detail=1.27, tex_size=256), width=3840, height=2160, depth=8, hdr=False),
     "glass": dict(config="configs[4]: TransmissionTest-class, 1920x1080, depth 24", gen="scene_glass_class",
-                  kw=dict(seed=99, tess=96), width=1920, height=1080, depth=24, hdr=True, in_flight=128, frames_per_step=256),
+                  kw=dict(seed=99, tess=96), width=1920, height=1080, depth=24, hdr=True, in_flight=256, frames_per_step=512),
     "box": dict(config="configs[0]: resources/Box.glb, 256x256, depth 4", gen=None, kw={}, width=256, height=256, depth=4, hdr=True),
 }
 # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy); 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T
@@ -320,8 +320,9 @@ def main():
                     help="frames (1 spp each) per GPU and step (default 256); a step renders frames_per_step * n_gpus frames")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="frames in flight per GPU (mi_pt_render_frames, bit-identical to sequential frames): the frames of a step are issued in "
-                         "groups of in_flight * n_gpus (capped at 1024).  Default 128 (helmet 3809 / 3927 Msamples/s at 64 / 128; the glass workload's volume "
-                         "random walks leave a long tail of ~100 nearly empty bounce iterations per batch: 238 -> 469 Msamples/s from 32 to 128 frames)")
+                         "groups of in_flight * n_gpus (capped at 1024).  Default 128 (helmet 3809 / 3927 Msamples/s at 64 / 128; 256 on the glass workload, whose "
+                         "volume random walks leave a long tail of ~100 nearly empty bounce iterations per batch: 238 / 469 / 559 / 605 Msamples/s at 32 / 128 / 128 "
+                         "(round 3) / 256 frames)")
     args = ap.parse_args()
 
     import torch
@@ -510,6 +511,7 @@ def main():
             "frame_ms_device": round(timing["totalMs"] / frames_timed, 4),
         }
         if not args.no_cpu_baseline and world == 1:
+            tracer.close()  # (its path state is not needed any more; the parity leg's tracer may want as much again)
             result["cpu_baseline"], result["parity"] = cpu_baseline_and_parity(scene, w, W, H, F, args.cpu_seconds, lambda: make_tracer(False, partition=False), params)
         # Next to the default line (helmet, 1080p), on the same GPU: the Sponza-class atrium -- the workload the north-star target is
         # stated on -- with its own CPU baseline + full-size parity leg, and the helmet at 3840x2160 (the metric's "4K" half).
