@@ -164,6 +164,13 @@ struct MiPt
   MiPtFrameTiming         accTiming{};
   std::vector<hipEvent_t> eventPool;
   hipStream_t             lastStream = nullptr;
+  // Optional (MI_PT_GRAPH): the launch sequence of a small batch (frame-by-frame use: the reference's interactive loop, ~27 short
+  // launches per frame) captured into a hipGraph and replayed: captured anew every batch on a private stream
+  // (the launch code is the same as without a graph; kernel arguments such as the frame counters are baked in by the capture),
+  // folded into the instantiated graph with hipGraphExecUpdate (same topology: no re-instantiation) and launched on the caller's
+  // stream as ONE submission.
+  hipStream_t             captureStream = nullptr;
+  hipGraphExec_t          graphExec     = nullptr;
 
   ~MiPt()
   {
@@ -180,6 +187,10 @@ struct MiPt
         (void)hipEventDestroy(e);
     if(fcHost)
       (void)hipHostFree(fcHost);
+    if(graphExec)
+      (void)hipGraphExecDestroy(graphExec);
+    if(captureStream)
+      (void)hipStreamDestroy(captureStream);
   }
 };
 
@@ -985,9 +996,31 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   int iterations = 0, traceLaunches = 0, shadeLaunches = 0, shadowLaunches = 0;
   static const bool usePacket = getenv("MI_PT_NO_PACKET") == nullptr;
   static const bool debugSpans = getenv("MI_PT_TRACE_SPANS") != nullptr;
+  // hipGraph replay of small batches (MI_PT_GRAPH = largest batch that is captured; default 0 = never).  Not with per-launch timing,
+  // the synchronising diagnostics, or volume-scatter scenes (their loop polls the queue length on the host).  Measured in round 3
+  // (tools/graph_ab.py, 1080p, per-launch timing off): helmet frame by frame 1376 Msamples/s replayed against 1384 launched one by
+  // one, 1894 / 1915 at 2 frames, 2580 / 2592 at 4; atrium 178 / 179 -- the host already queues the ~27 launches of a frame faster
+  // than the device drains them, and what separates consecutive kernels is their dependency (ramp-up and tail of each persistent
+  // grid), which a graph does not remove.  Hence off by default; the images are identical either way.
+  const char* graphEnv   = getenv("MI_PT_GRAPH");
+  const int   graphUpTo  = graphEnv ? atoi(graphEnv) : 0;
+  bool        capturing  = numFrames <= graphUpTo && !pt->timingEnabled && !debugSpans && !pt->hasVolumeScatter;
+  if(capturing)
+  {
+    if(!pt->captureStream && hipStreamCreateWithFlags(&pt->captureStream, hipStreamNonBlocking) != hipSuccess)
+      capturing = false;
+    if(capturing && hipStreamBeginCapture(pt->captureStream, hipStreamCaptureModeThreadLocal) != hipSuccess)
+    {
+      (void)hipGetLastError();
+      capturing = false;
+    }
+    if(capturing)
+      c.stream = pt->captureStream;  // every launch helper below records into the capture
+  }
+  hipStream_t const launchStream = capturing ? pt->captureStream : stream;
   for(int s = 0; s < params->numSamples; ++s)
   {
-    pt::launchResetCounters(c.queues, stream);
+    pt::launchResetCounters(c.queues, launchStream);
     // 8-wide BVH: ONE kernel generates the camera rays, walks them as packets, finishes the paths that leave the scene and queues
     // the hits (k_trace_primary); BVH2 / MI_PT_NO_PACKET: k_generate writes the rays and the per-lane kernel walks them
     const bool fusedPrimary = c.wide && usePacket && !debugSpans;
@@ -1073,6 +1106,38 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   }
   if(params->flags & MI_PT_FIRST_FRAME)
     pt::launchSelection(c, pt->selection.ptr);
+  if(capturing)
+  {
+    hipGraph_t graph = nullptr;
+    HIP_TRY(hipStreamEndCapture(pt->captureStream, &graph));
+    bool ready = false;
+    if(pt->graphExec)
+    {
+      hipGraphNode_t           errorNode = nullptr;
+      hipGraphExecUpdateResult result    = hipGraphExecUpdateSuccess;
+      ready = hipGraphExecUpdate(pt->graphExec, graph, &errorNode, &result) == hipSuccess && result == hipGraphExecUpdateSuccess;
+      if(!ready)
+      {
+        (void)hipGetLastError();  // another launch sequence (first frame, other depth, other kernels): instantiate afresh
+        (void)hipGraphExecDestroy(pt->graphExec);
+        pt->graphExec = nullptr;
+      }
+    }
+    if(!ready)
+    {
+      const hipError_t e = hipGraphInstantiate(&pt->graphExec, graph, nullptr, nullptr, 0);
+      if(e != hipSuccess)
+      {
+        (void)hipGraphDestroy(graph);
+        pt->graphExec = nullptr;
+        return fail(MI_PT_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+      }
+    }
+    const hipError_t le = hipGraphLaunch(pt->graphExec, stream);
+    (void)hipGraphDestroy(graph);
+    if(le != hipSuccess)
+      return fail(MI_PT_ERR_HIP, std::string("hipGraphLaunch: ") + hipGetErrorString(le));
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(pt->fcDone[fcSlot], stream));
   if(pt->timingEnabled)
