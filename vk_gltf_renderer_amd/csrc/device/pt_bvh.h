@@ -14,7 +14,10 @@
 
 namespace pt {
 
-constexpr int BVH_STACK_LDS  = 24;  // entries per lane kept in LDS
+#ifndef MI_BVH8_STACK_LDS
+#define MI_BVH8_STACK_LDS 12
+#endif
+constexpr int BVH_STACK_LDS  = 2 * MI_BVH8_STACK_LDS;  // entries per lane kept in LDS (24)
 constexpr int BVH_STACK_PRIV = 72;  // overflow entries per lane (scratch; touched only by very deep LBVH paths)
 constexpr int BVH_EMPTY      = int(0x80000000u);
 

@@ -6,8 +6,8 @@
 
 namespace pt {
 
-constexpr int BVH8_STACK_LDS  = 12;  // node groups per lane in LDS (2 dwords each)
-constexpr int BVH8_STACK_PRIV = 52;  // overflow (scratch)
+constexpr int BVH8_STACK_LDS  = MI_BVH8_STACK_LDS;  // node groups per lane in LDS (2 dwords each): 12
+constexpr int BVH8_STACK_PRIV = 64 - MI_BVH8_STACK_LDS;  // overflow (scratch): 52
 
 struct NodeGroup
 {

@@ -20,8 +20,12 @@ namespace {
 // node array), next to the per-lane traversal stacks (96 KiB), the waves' triangle-round lists (8 KiB) and, in the kernels
 // that defer alpha tests, their alpha lists (16 KiB): 55 or 39 KiB of nodes of the CU's 160 KiB.
 constexpr int TRACE_BLOCK = 1024;
-constexpr int NODE_CACHE  = 712;  // BVH8 nodes (80 B each) resident in LDS
-constexpr int NODE_CACHE_ALPHA = 504;  // ... in the kernels that also keep a list of deferred alpha tests there (16 B x 1024)
+#ifndef NODE_CACHE_EXTRA
+#define NODE_CACHE_EXTRA 0  // (A/B: LDS given back by a shallower LDS stack, MI_BVH8_STACK_LDS.  Measured in round 3: 10 / 8 node groups per
+                            //  lane in LDS with 200 / 400 more cached nodes: within +-0.5 % on all four workloads; 6 + 600: street -2 %)
+#endif
+constexpr int NODE_CACHE  = 712 + NODE_CACHE_EXTRA;  // BVH8 nodes (80 B each) resident in LDS
+constexpr int NODE_CACHE_ALPHA = 504 + NODE_CACHE_EXTRA;  // ... in the kernels that also keep a list of deferred alpha tests there (16 B x 1024)
 constexpr int SEL_BLOCK   = 256;
 #ifndef TRACE_MIN_WAVES
 #define TRACE_MIN_WAVES 1
