@@ -23,7 +23,7 @@ struct DevTexture  // 80 B
 // a material): the shade kernel reaches the texels in two dependent loads (this record, the texels) instead of five
 // (table pointers, texture info, descriptor, mip offset, texels).  The mip chain is contiguous in the texel pool, so the
 // offset of a level is level0 + sum of the sizes of the levels before it.
-struct DevTexRef  // 48 B
+struct DevTexRef  // 44 B
 {
   float    uv[6];          // uvTransform (column-major 3x2)
   uint32_t level0;         // texel offset of mip 0
