@@ -81,7 +81,7 @@ def scene_path(name, rank):
     return path
 
 
-def kernel_table(all_b, first_b, timing, frames):
+def kernel_table(all_b, first_b, timing, frames, in_flight=0):
     """Per-kernel roofline entries.  all_b / first_b: counters PER FRAME of the whole path loop and of bounce 0 alone (a second
     counter pass with maxDepth = 1); timing: MiPtFrameTiming totals over `frames` frames.  A kernel's algorithmic work per launch
     is (work per frame) x (frames per launch); SURVEY §8(d) defines the bytes, hit/miss aware: a segment that leaves the scene
@@ -126,6 +126,10 @@ def kernel_table(all_b, first_b, timing, frames):
             "segments x (60 + 192) + surfaceHits x (192 + 480 + 76) + textureTaps x 48 B")
     add("trace_shadow", timing["traceShadowMs"], timing["traceShadowLaunches"], "valu", walk_ops(all_b["nodesShadow"], all_b["trisShadow"], False),
         "nodesShadow x 235 + trisShadow x 56 lane-ops")
+    if timing["accumulateMs"] > 0 and in_flight > 0:
+        # k_finish_sample (SURVEY 8(d) "pixel accumulate"): one 16-B path record per pixel and frame, the accumulator once per launch
+        add("finish_sample", timing["accumulateMs"], max(1, round(frames / in_flight)), "hbm", all_b["cameraPaths"] * (16.0 + 32.0 / in_flight),
+            "cameraPaths x (16 B path record + 32 B of accumulator per launch)")
     return rows
 
 
@@ -274,7 +278,7 @@ def secondary_line(name, args, device, width=0, height=0, steps=5, cpu_seconds=0
 
     per_frame, first = counter_pass(w["depth"]), counter_pass(1)
     frames = steps * frames_step
-    kernels = kernel_table(per_frame, first, timing, frames)
+    kernels = kernel_table(per_frame, first, timing, frames, F)
     dominant = max(kernels, key=lambda k: kernels[k]["avg_launch_ms"] * kernels[k]["launches"])
     keys = ("cameraPaths", "segments", "surfaceHits", "shadowRays", "nodesPrimary", "trisPrimary", "nodesClosest", "trisClosest", "nodesShadow", "trisShadow", "textureTaps")
     roof = dict(kernels[dominant], kernel=dominant)
@@ -484,7 +488,7 @@ def main():
         per_frame = counter_pass(w["depth"])
         first = counter_pass(1) if w["depth"] >= 1 else dict(per_frame)  # bounce 0 alone: paths end after their first shade
         # the timed frames belong to this rank's tiles: timing and counters are both rank 0's
-        kernels = kernel_table(per_frame, first, timing, frames_timed)
+        kernels = kernel_table(per_frame, first, timing, frames_timed, F)
         dominant = max(kernels, key=lambda k: kernels[k]["avg_launch_ms"] * kernels[k]["launches"])
         roof = dict(kernels[dominant])
         roof.update({"kernel": dominant})

@@ -1282,7 +1282,7 @@ __global__ void __launch_bounds__(256, PRIMARY_MIN_WAVES) k_trace_primary(DevSce
   {
     if(hasFlag(fc.pc.flags, MI_PT_FIRST_FRAME) && cp.frame == 0u)  // NDC depth input of a first frame (k_finish_sample)
       P.firstHit[slot] = make_float4(cp.direction.x, cp.direction.y, cp.direction.z, 0.0f);
-    P.radiance[slot] = make_float4(cp.direction.x, cp.direction.y, cp.direction.z, 0.0f);                                    // maxRoughness.x = 0
+    P.radiance[slot] = make_float4(cp.direction.x, cp.direction.y, cp.direction.z, __uint_as_float(RADW_PRIMARY_MISS));
     P.misc[slot]     = make_float4(0.0f, __uint_as_float(PF_NOT_SOLID | PF_PRIMARY_MISS), __uint_as_float(cp.seed), 0.0f);  // depth 0, not alive
   }
   if(COUNT)
@@ -1527,7 +1527,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
       float    coneWidth = misc4.w;
       f3       throughput = xyz(tp4), radiance = xyz(rad4);
       float    lastSamplePdf = tp4.w;
-      f2       maxRoughness  = mk2(rad4.w, misc4.x);
+      f2       maxRoughness  = mk2(fabsf(rad4.w), misc4.x);  // the sign of radiance.w is the path's !solid (PathSoA)
       uint32_t flags = __float_as_uint(misc4.y), seed = __float_as_uint(misc4.z);
       int      surfaceDepth   = int((flags >> PF_DEPTH_SHIFT) & 0xffu);
       int      scatterBounces = int((flags >> PF_SCATTER_SHIFT) & 0xffu);
@@ -1833,7 +1833,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
       alive = !done && surfaceDepth < maxDepth;
       flags = (isInside ? PF_INSIDE : 0u) | (solid ? 0u : PF_NOT_SOLID) | (alive ? PF_ALIVE : 0u) | (uint32_t(min(surfaceDepth, 255)) << PF_DEPTH_SHIFT)
               | (uint32_t(scatterBounces) << PF_SCATTER_SHIFT);
-      P.radiance[slot] = make_float4(radiance.x, radiance.y, radiance.z, maxRoughness.x);
+      P.radiance[slot] = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(__float_as_uint(maxRoughness.x) | (solid ? 0u : RADW_NOT_SOLID)));
       P.misc[slot]     = make_float4(maxRoughness.y, __uint_as_float(flags), __uint_as_float(seed), coneWidth);
       if(alive)
       {
@@ -2477,6 +2477,9 @@ __global__ void __launch_bounds__(256) k_shadow_resolve(const DevScene* __restri
 // k_finish_sample: firefly clamp + per-frame mean + running-mean accumulation + NDC depth
 // (gltf_pathtrace.slang:531-538, 596, 604-630)
 //================================================================================================================================
+#ifndef FINISH_AHEAD
+#define FINISH_AHEAD 4  // records fetched ahead of the fold (build switch for the A/B)
+#endif
 __global__ void __launch_bounds__(256) k_finish_sample(FrameConsts fc, const DevScene* __restrict__ scp, const FrameConsts* __restrict__ fcp, PathSoA P,
                                                        const uint32_t* ownedTiles, int sampleIndex, float4* accum, float* depth, float4* albedoOut,
                                                        float4* normalOut)
@@ -2496,29 +2499,28 @@ __global__ void __launch_bounds__(256) k_finish_sample(FrameConsts fc, const Dev
   // Four frames' records are fetched ahead of their (serial, in frame order) fold: with pixel-major slots a pixel's records are
   // consecutive -- the four share a 64-byte line, which a thread must ask for while it is hot, its neighbours' lines lying 16 x
   // numFrames bytes apart -- and in either layout the four gathers overlap instead of queueing behind one another.
-  for(int f0 = 0; f0 < fc.numFrames; f0 += 4)
+  for(int f0 = 0; f0 < fc.numFrames; f0 += FINISH_AHEAD)
   {
-   float4   radAhead[4];
-   uint32_t flagsAhead[4];
+   float4   radAhead[FINISH_AHEAD];
 #pragma unroll
-   for(int j = 0; j < 4; ++j)
+   for(int j = 0; j < FINISH_AHEAD; ++j)
      if(f0 + j < fc.numFrames)
      {
        const uint32_t sj = pathSlot(fc, pslot, uint32_t(f0 + j));
        radAhead[j]       = P.radiance[sj];
-       flagsAhead[j]     = __float_as_uint(P.misc[sj].y);
      }
 #pragma unroll
-   for(int j = 0; j < 4; ++j)
+   for(int j = 0; j < FINISH_AHEAD; ++j)
    {
     const int f = f0 + j;
     if(f >= fc.numFrames)
       break;
     const uint32_t slot  = pathSlot(fc, pslot, uint32_t(f));
     float4         rad4  = radAhead[j];
-    const uint32_t flags = flagsAhead[j];
-    const bool     solid = !(flags & PF_NOT_SOLID);
-    if(flags & PF_PRIMARY_MISS)
+    // what this kernel needs of the path's flags rides in radiance.w (PathSoA): one 16-byte record per path and frame, not two
+    const uint32_t radw  = __float_as_uint(rad4.w);
+    const bool     solid = !(radw & RADW_NOT_SOLID);
+    if(radw == RADW_PRIMARY_MISS)
     {
       // a camera ray that left the scene: rad4 is its direction (k_trace_primary); the shade kernel's miss branch for a first ray
       const f3 dir      = mk3(rad4.x, rad4.y, rad4.z);

@@ -224,11 +224,15 @@ enum : uint32_t
   PF_DEPTH_SHIFT   = 8,      // bits 8..15  surfaceDepth
   PF_SCATTER_SHIFT = 16,     // bits 16..23 scatterBounces (saturating)
 };
+// the two flags k_finish_sample needs, mirrored into PathSoA::radiance.w so that it reads one record per path, not two
+constexpr uint32_t RADW_NOT_SOLID    = 0x80000000u;  // sign bit of maxRoughness.x (which is >= 0)
+constexpr uint32_t RADW_PRIMARY_MISS = 0xffc00001u;  // a NaN no arithmetic produces (maxRoughness.x of such a path is 0 and never read)
 
 struct PathSoA
 {
   float4*   throughput;   // rgb, lastSamplePdf
-  float4*   radiance;     // rgb, maxRoughness.x
+  float4*   radiance;     // rgb, maxRoughness.x (>= 0) with the sign bit = !solid (RADW_NOT_SOLID); RADW_PRIMARY_MISS: rgb = the camera
+                          // ray's direction (k_trace_primary) -- k_finish_sample reads this record alone
   float4*   misc;         // maxRoughness.y, flags (uint bits), seed (uint bits), cone.width
   uint4*    medium;       // VolumeMedium as 7 halves packed
   float4*   firstHit;     // firstHitPos.xyz, unused
