@@ -1548,12 +1548,12 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
       const bool meshHit = triIdx >= 0;
       if(meshHit)
       {
-        const DevShadeTri S = sc.shadeTris[triIdx];
+        const DevShadeTri S = gat(sc.shadeTris, triIdx);
         rnodeID             = int(S.rnode);
         primitiveID         = int(S.prim);
         materialID          = S.materialID;
-        const MiGltfRenderNode& rn = sc.nodes[rnodeID];
-        const DevPrim           rp = sc.prims[S.renderPrimID];
+        const MiGltfRenderNode& rn = gat(sc.nodes, rnodeID);
+        const DevPrim           rp = gat(sc.prims, S.renderPrimID);
         hit = getHitState(rp, mk3(1.0f - hit4.z - hit4.w, hit4.z, hit4.w), rn.worldToObject, rn.objectToWorld, u3{S.i0, S.i1, S.i2}, rayDir);
       }
       else
@@ -1660,7 +1660,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
         }
         else
         {
-          const MiGltfShadeMaterial& mat = sc.materials[materialID];
+          const MiGltfShadeMaterial& mat = gat(sc.materials, materialID);
           MeshState                  mesh;
           mesh.N = hit.nrm; mesh.T = hit.tangent; mesh.B = hit.bitangent; mesh.Ng = hit.geonrm;
           mesh.tc0 = hit.uv0; mesh.tc1 = hit.uv1;

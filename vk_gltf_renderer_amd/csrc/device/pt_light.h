@@ -47,7 +47,7 @@ PT_DEV uint32_t texelIndex(uint32_t levelOffset, int w, int x, int y) { return l
 // `lut` = the 256-entry sRGB decode table to use (sc.srgbLut, or a copy of it that the caller staged in LDS)
 PT_DEV f4 fetchTexel(const DevScene& sc, const float* lut, const DevTexture& t, int level, int w, int x, int y)
 {
-  uchar4 p = sc.texels[texelIndex(t.levelOffset[level], w, x, y)];
+  uchar4 p = gat(sc.texels, texelIndex(t.levelOffset[level], w, x, y));
   if(t.srgb)
     return mk4(lut[p.x], lut[p.y], lut[p.z], float(p.w) * (1.0f / 255.0f));
   return mk4(float(p.x) * (1.0f / 255.0f), float(p.y) * (1.0f / 255.0f), float(p.z) * (1.0f / 255.0f), float(p.w) * (1.0f / 255.0f));
@@ -74,7 +74,7 @@ PT_DEV f4 sampleTexture(const DevScene& sc, const float* lut, int texIndex, f2 u
 {
   if(texIndex < 0 || texIndex >= sc.numTextures)
     return mk4(1.0f);
-  const DevTexture& t  = sc.textures[texIndex];  // by reference: a by-value copy would put levelOffset[] in scratch
+  const DevTexture& t  = gat(sc.textures, texIndex);  // by reference: a by-value copy would put levelOffset[] in scratch
   float             lod = 0.0f;
   if(useGrad)
   {
@@ -130,8 +130,9 @@ PT_DEV f4 sampleHdr(const DevScene& sc, f2 uv)
   float tx = fx - flx, ty = fy - fly;
   int   x0 = wrapCoord(int(flx), w, MI_WRAP_REPEAT), x1 = wrapCoord(int(flx) + 1, w, MI_WRAP_REPEAT);
   int   y0 = wrapCoord(int(fly), h, MI_WRAP_REPEAT), y1 = wrapCoord(int(fly) + 1, h, MI_WRAP_REPEAT);
-  f4    a = mk4(sc.envPixels[size_t(y0) * w + x0]), b = mk4(sc.envPixels[size_t(y0) * w + x1]);
-  f4    c = mk4(sc.envPixels[size_t(y1) * w + x0]), d = mk4(sc.envPixels[size_t(y1) * w + x1]);
+  const float4* env = sc.envPixels;
+  f4    a = mk4(gat(env, size_t(y0) * w + x0)), b = mk4(gat(env, size_t(y0) * w + x1));
+  f4    c = mk4(gat(env, size_t(y1) * w + x0)), d = mk4(gat(env, size_t(y1) * w + x1));
   return (a * (1.0f - tx) + b * tx) * (1.0f - ty) + (c * (1.0f - tx) + d * tx) * ty;
 }
 // Alias-table importance sampling of the lat-long map (reference call site: pathtrace_functions.h.slang:437)
@@ -139,7 +140,7 @@ PT_DEV f4 environmentSample(const DevScene& sc, f3 xi, f3& toLight)
 {
   uint32_t   width = uint32_t(sc.envWidth), height = uint32_t(sc.envHeight), size = width * height;
   uint32_t   idx = min(uint32_t(xi.x * float(size)), size - 1);
-  MiEnvAccel a   = sc.envAccel[idx];
+  MiEnvAccel a   = gat(sc.envAccel, idx);
   uint32_t   envIdx;
   if(xi.y < a.q)
   {

@@ -194,6 +194,26 @@ inline void divideMagic(uint32_t d, uint32_t& magic, uint32_t& shift)
   shift                      = k;
 }
 
+#if defined(__HIPCC__)
+// A pointer that a kernel reads out of a device-resident struct (DevScene behind `const DevScene*`, DevPrim, TexCtx) is a generic
+// ("flat") pointer to the compiler: its loads are flat_load, which count on BOTH memory counters, and since LDS operations return
+// out of order every use of such a load drains everything outstanding (s_waitcnt vmcnt(0) lgkmcnt(0)).  All of these tables live in
+// global memory; saying so turns them into global_load with counted waits.
+// gat(table, i) = table[i], read as global memory (the index is applied in the global address space, which is what keeps the
+// compiler's address-space inference from folding the cast away).
+template <class T, class I>
+__device__ __forceinline__ const T& gat(const T* table, I i)
+{
+  return *(const T*)((const __attribute__((address_space(1))) T*)table + i);
+}
+#else  // the device headers compiled for the host (tests/host_shim)
+template <class T, class I>
+inline const T& gat(const T* table, I i)
+{
+  return table[i];
+}
+#endif
+
 // slot <-> (pixel slot, frame) of the micro-tile-major layout (FrameConsts::numFrames)
 #if defined(__HIPCC__)
 __device__ __forceinline__ uint32_t pathSlot(const FrameConsts& fc, uint32_t pixelSlot, uint32_t frame)

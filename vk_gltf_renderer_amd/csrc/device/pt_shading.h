@@ -25,10 +25,10 @@ struct u3
 };
 PT_DEV u3 getTriangleIndices(const DevPrim& rp, int prim)
 {
-  const uint32_t* p = rp.indices + 3 * size_t(prim);
+  const uint32_t* p = &gat(rp.indices, 3 * size_t(prim));
   return u3{p[0], p[1], p[2]};
 }
-PT_DEV f3 getVertexPosition(const DevPrim& rp, uint32_t i) { return mk3(rp.positions + 3 * size_t(i)); }
+PT_DEV f3 getVertexPosition(const DevPrim& rp, uint32_t i) { return mk3(&gat(rp.positions, 3 * size_t(i))); }
 PT_DEV f4 unpackUnorm4x8(uint32_t p)
 {
   return mk4(float((p >> 0) & 0xFF) / 255.0f, float((p >> 8) & 0xFF) / 255.0f, float((p >> 16) & 0xFF) / 255.0f, float((p >> 24) & 0xFF) / 255.0f);
@@ -39,14 +39,14 @@ PT_DEV f2 getInterpolatedVertexTexCoord(const DevPrim& rp, int channel, u3 idx, 
   if(!tc)
     return mk2(0.0f, 0.0f);
   const float2* t2 = reinterpret_cast<const float2*>(tc);
-  float2        a = t2[idx.x], bb = t2[idx.y], c = t2[idx.z];
+  float2        a = gat(t2, idx.x), bb = gat(t2, idx.y), c = gat(t2, idx.z);
   return mk2(a.x, a.y) * b.x + mk2(bb.x, bb.y) * b.y + mk2(c.x, c.y) * b.z;
 }
 PT_DEV f4 getInterpolatedVertexColor(const DevPrim& rp, u3 idx, f3 b)
 {
   if(!rp.colors)
     return mk4(1.0f);
-  return unpackUnorm4x8(rp.colors[idx.x]) * b.x + unpackUnorm4x8(rp.colors[idx.y]) * b.y + unpackUnorm4x8(rp.colors[idx.z]) * b.z;
+  return unpackUnorm4x8(gat(rp.colors, idx.x)) * b.x + unpackUnorm4x8(gat(rp.colors, idx.y)) * b.y + unpackUnorm4x8(gat(rp.colors, idx.z)) * b.z;
 }
 
 // ---- get_hit.h.slang:26-173 -----------------------------------------------------------------------------------------------
@@ -77,7 +77,7 @@ PT_DEV HitState getHitState(const DevPrim& rp, f3 bary, const float* w2o, const 
 {
   HitState hit;
   // the three interleaved vertices (DevPrim::verts): 9 x 16 B in flight at once
-  const float4 *V0 = rp.verts + 3 * size_t(ti.x), *V1 = rp.verts + 3 * size_t(ti.y), *V2 = rp.verts + 3 * size_t(ti.z);
+  const float4 *V0 = &gat(rp.verts, 3 * size_t(ti.x)), *V1 = &gat(rp.verts, 3 * size_t(ti.y)), *V2 = &gat(rp.verts, 3 * size_t(ti.z));
   const float4 a0 = V0[0], a1 = V0[1], a2 = V0[2], b0 = V1[0], b1 = V1[1], b2 = V1[2], c0 = V2[0], c1 = V2[1], c2 = V2[2];
   f3 pos0 = mk3(a0.x, a0.y, a0.z), pos1 = mk3(b0.x, b0.y, b0.z), pos2 = mk3(c0.x, c0.y, c0.z);
   f3 position  = pos0 * bary.x + pos1 * bary.y + pos2 * bary.z;
@@ -156,7 +156,7 @@ PT_DEV bool isTexturePresent(uint16_t t) { return t > 0; }
 // sampleLevel -> fetchTexel (pt_light.h) with two dependent loads (record, texels) instead of five.
 PT_DEV f4 fetchTexelRef(const TexCtx& tc, const DevTexRef& R, uint32_t levelOffset, int w, int x, int y)
 {
-  uchar4 p = tc.texels[texelIndex(levelOffset, w, x, y)];
+  uchar4 p = gat(tc.texels, texelIndex(levelOffset, w, x, y));
   if(R.srgb)
     return mk4(tc.lut[p.x], tc.lut[p.y], tc.lut[p.z], float(p.w) * (1.0f / 255.0f));
   return mk4(float(p.x) * (1.0f / 255.0f), float(p.y) * (1.0f / 255.0f), float(p.z) * (1.0f / 255.0f), float(p.w) * (1.0f / 255.0f));
@@ -168,43 +168,127 @@ PT_DEV f4 decodeTexelRef(const TexCtx& tc, const DevTexRef& R, uint32_t p)  // f
     return mk4(tc.lut[r], tc.lut[g], tc.lut[b], float(a) * (1.0f / 255.0f));
   return mk4(float(r) * (1.0f / 255.0f), float(g) * (1.0f / 255.0f), float(b) * (1.0f / 255.0f), float(a) * (1.0f / 255.0f));
 }
-PT_DEV f4 sampleLevelRef(const TexCtx& tc, const DevTexRef& R, f2 uv, int level, int filter)
+// The two blends of a texture fetch with their operation order pinned (one multiply and one fma per weight pair): the fetch
+// exists in several shapes -- footprint records or four texels, levels one after the other or together -- and all of them must
+// return the same bits (test_texture_footprint_layout_is_bit_identical), which free contraction of `a * (1 - t) + b * t` inside
+// differently inlined bodies does not give.
+PT_DEV f4 bilinearBlend(f4 a, f4 b, f4 c, f4 d, float tx, float ty)
+{
+#pragma clang fp contract(off)
+  const float ux = 1.0f - tx, uy = 1.0f - ty;
+  auto        ch = [&](float p00, float p10, float p01, float p11) { return __fmaf_rn(__fmaf_rn(p11, tx, p01 * ux), ty, __fmaf_rn(p10, tx, p00 * ux) * uy); };
+  return mk4(ch(a.x, b.x, c.x, d.x), ch(a.y, b.y, c.y, d.y), ch(a.z, b.z, c.z, d.z), ch(a.w, b.w, c.w, d.w));
+}
+PT_DEV f4 levelBlend(f4 a, f4 b, float f)
+{
+#pragma clang fp contract(off)
+  const float u = 1.0f - f;
+  return mk4(__fmaf_rn(b.x, f, a.x * u), __fmaf_rn(b.y, f, a.y * u), __fmaf_rn(b.z, f, a.z * u), __fmaf_rn(b.w, f, a.w * u));
+}
+// One bilinear tap of a level in two halves, so that the two taps of a trilinear fetch can have their footprint records in flight
+// together: where the record lies and the weights (quadTap), and the arithmetic on the fetched record (quadFilter).
+struct QuadTap
+{
+  uint32_t index;  // footprint record (DevScene::texQuads)
+  float    tx, ty;
+  bool     dupX, dupY;  // CLAMP_TO_EDGE left of / above the image: both coordinates of the pair clamp to texel 0
+};
+PT_DEV bool hasQuadPath(const TexCtx& tc, const DevTexRef& R) { return tc.quads && R.wrapS != MI_WRAP_MIRRORED_REPEAT && R.wrapT != MI_WRAP_MIRRORED_REPEAT; }
+PT_DEV uint32_t levelOffsetRef(const DevTexRef& R, int level)
 {
   uint32_t off = R.level0;
   for(int l = 0; l < level; ++l)
     off += uint32_t(max(1, int(R.width) >> l)) * uint32_t(max(1, int(R.height) >> l));
-  int   w = max(1, int(R.width) >> level), h = max(1, int(R.height) >> level);
+  return off;
+}
+// first texel and weights of a bilinear footprint (shared by every shape of the fetch; products and differences stay what they are)
+PT_DEV void bilinearCoords(f2 uv, int w, int h, int& ix, int& iy, float& tx, float& ty)
+{
+#pragma clang fp contract(off)
   float fx = uv.x * float(w), fy = uv.y * float(h);
-  if(filter == MI_FILTER_NEAREST)
-    return fetchTexelRef(tc, R, off, w, wrapCoord(int(floorf(fx)), w, R.wrapS), wrapCoord(int(floorf(fy)), h, R.wrapT));
   fx -= 0.5f;
   fy -= 0.5f;
-  float flx = floorf(fx), fly = floorf(fy);
-  float tx = fx - flx, ty = fy - fly;
-  if(tc.quads && R.wrapS != MI_WRAP_MIRRORED_REPEAT && R.wrapT != MI_WRAP_MIRRORED_REPEAT)
+  const float flx = floorf(fx), fly = floorf(fy);
+  ix = int(flx);
+  iy = int(fly);
+  tx = fx - flx;
+  ty = fy - fly;
+}
+PT_DEV QuadTap quadTap(const DevTexRef& R, f2 uv, int level)
+{
+  const uint32_t off = levelOffsetRef(R, level);
+  const int      w = max(1, int(R.width) >> level), h = max(1, int(R.height) >> level);
+  int            ix, iy;
+  QuadTap        t;
+  bilinearCoords(uv, w, h, ix, iy, t.tx, t.ty);
+  t.index = texelIndex(off, w, wrapCoord(ix, w, R.wrapS), wrapCoord(iy, h, R.wrapT));
+  t.dupX  = R.wrapS == MI_WRAP_CLAMP_TO_EDGE && ix < 0;
+  t.dupY  = R.wrapT == MI_WRAP_CLAMP_TO_EDGE && iy < 0;
+  return t;
+}
+PT_DEV f4 quadFilter(const TexCtx& tc, const DevTexRef& R, const QuadTap& t, const uint4 q)
+{
+  const float tx = t.tx, ty = t.ty;
+  const f4    a = decodeTexelRef(tc, R, q.x), b = decodeTexelRef(tc, R, t.dupX ? q.x : q.y);
+  const f4    c = decodeTexelRef(tc, R, t.dupY ? q.x : q.z), d = decodeTexelRef(tc, R, t.dupY ? (t.dupX ? q.x : q.y) : (t.dupX ? q.z : q.w));
+  return bilinearBlend(a, b, c, d, tx, ty);
+}
+PT_DEV f4 sampleLevelRef(const TexCtx& tc, const DevTexRef& R, f2 uv, int level, int filter)
+{
+  if(filter != MI_FILTER_NEAREST && hasQuadPath(tc, R))
   {
     // the whole footprint in one 16-byte gather (DevScene::texQuads): same texels, same arithmetic, same result
-    const int   ix = int(flx), iy = int(fly);
-    const uint4 q  = tc.quads[texelIndex(off, w, wrapCoord(ix, w, R.wrapS), wrapCoord(iy, h, R.wrapT))];
-    // CLAMP_TO_EDGE left of / above the image: both coordinates of the pair clamp to texel 0 (wrapCoord(i) == wrapCoord(i + 1))
-    const bool dupX = R.wrapS == MI_WRAP_CLAMP_TO_EDGE && ix < 0, dupY = R.wrapT == MI_WRAP_CLAMP_TO_EDGE && iy < 0;
-    const f4   a = decodeTexelRef(tc, R, q.x), b = decodeTexelRef(tc, R, dupX ? q.x : q.y);
-    const f4   c = decodeTexelRef(tc, R, dupY ? q.x : q.z), d = decodeTexelRef(tc, R, dupY ? (dupX ? q.x : q.y) : (dupX ? q.z : q.w));
-    return (a * (1.0f - tx) + b * tx) * (1.0f - ty) + (c * (1.0f - tx) + d * tx) * ty;
+    const QuadTap t = quadTap(R, uv, level);
+    return quadFilter(tc, R, t, gat(tc.quads, t.index));
   }
-  int   x0, x1, y0, y1;
-  wrapCoordPair(int(flx), w, R.wrapS, x0, x1);
-  wrapCoordPair(int(fly), h, R.wrapT, y0, y1);
-  f4    a = fetchTexelRef(tc, R, off, w, x0, y0), b = fetchTexelRef(tc, R, off, w, x1, y0);
-  f4    c = fetchTexelRef(tc, R, off, w, x0, y1), d = fetchTexelRef(tc, R, off, w, x1, y1);
-  return (a * (1.0f - tx) + b * tx) * (1.0f - ty) + (c * (1.0f - tx) + d * tx) * ty;
+  const uint32_t off = levelOffsetRef(R, level);
+  int   w = max(1, int(R.width) >> level), h = max(1, int(R.height) >> level);
+  if(filter == MI_FILTER_NEAREST)
+  {
+    const float fx = uv.x * float(w), fy = uv.y * float(h);
+    return fetchTexelRef(tc, R, off, w, wrapCoord(int(floorf(fx)), w, R.wrapS), wrapCoord(int(floorf(fy)), h, R.wrapT));
+  }
+  int   ix, iy, x0, x1, y0, y1;
+  float tx, ty;
+  bilinearCoords(uv, w, h, ix, iy, tx, ty);
+  wrapCoordPair(ix, w, R.wrapS, x0, x1);
+  wrapCoordPair(iy, h, R.wrapT, y0, y1);
+  // the four texels in flight together, then decoded (fetchTexelRef's arithmetic)
+  const uint32_t* T   = reinterpret_cast<const uint32_t*>(tc.texels);
+  const uint32_t  p00 = gat(T, texelIndex(off, w, x0, y0)), p10 = gat(T, texelIndex(off, w, x1, y0));
+  const uint32_t  p01 = gat(T, texelIndex(off, w, x0, y1)), p11 = gat(T, texelIndex(off, w, x1, y1));
+  f4    a = decodeTexelRef(tc, R, p00), b = decodeTexelRef(tc, R, p10);
+  f4    c = decodeTexelRef(tc, R, p01), d = decodeTexelRef(tc, R, p11);
+  return bilinearBlend(a, b, c, d, tx, ty);
+}
+// The texture record of a slot in ONE round trip: the compiler would fetch `width` first (the early-out below tests it) and
+// the rest behind the branch -- two dependent loads at the head of every fetch.
+PT_DEV DevTexRef loadTexRef(const DevTexRef* refs, uint32_t slot)
+{
+#if !defined(__HIPCC__)
+  return refs[slot];
+#else
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+  const DevTexRef* p = refs + slot;
+  u32x4            a, b;
+  u32x3            c;
+  asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %3, off offset:16\n\tglobal_load_dwordx3 %2, %3, off offset:32\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(a), "=&v"(b), "=&v"(c)
+               : "v"(p)
+               : "memory");
+  DevTexRef R;
+  uint32_t* W = reinterpret_cast<uint32_t*>(&R);
+  W[0] = a[0]; W[1] = a[1]; W[2] = a[2]; W[3] = a[3]; W[4] = b[0]; W[5] = b[1]; W[6] = b[2]; W[7] = b[3]; W[8] = c[0]; W[9] = c[1]; W[10] = c[2];
+  return R;
+#endif
 }
 __device__ __noinline__ f4 getTextureRef(TexCtx tc, uint32_t slot, f2 tc0, f2 tc1, float texGrad)
 {
 #ifdef MI_PT_DIAG_NO_TEX  // cost-attribution build (tools/attribution.sh): wrong image, no texture filtering
   return mk4(0.5f + 1e-3f * (tc0.x + tc1.y + texGrad + float(slot)));
 #endif
-  const DevTexRef R  = tc.refs[slot];
+  const DevTexRef R  = loadTexRef(tc.refs, slot);
   f2              t  = R.texCoord == 0 ? tc0 : tc1;
   const float*    U  = R.uv;
   f2              uv = mk2(t.x * U[0] + t.y * U[2] + U[4], t.x * U[1] + t.y * U[3] + U[5]);
@@ -227,11 +311,19 @@ __device__ __noinline__ f4 getTextureRef(TexCtx tc, uint32_t slot, f2 tc0, f2 tc
     return sampleLevelRef(tc, R, uv, min(int(floorf(lod + 0.5f)), int(R.numLevels) - 1), R.minFilter);
   int   l0 = int(floorf(lod)), l1 = min(l0 + 1, int(R.numLevels) - 1);
   float f  = lod - float(l0);
+  if(R.minFilter != MI_FILTER_NEAREST && hasQuadPath(tc, R) && !(f == 0.0f || l1 == l0))
+  {
+    // trilinear: both levels' footprint records in flight together
+    const QuadTap t0 = quadTap(R, uv, l0), t1 = quadTap(R, uv, l1);
+    const uint4   q0 = gat(tc.quads, t0.index), q1 = gat(tc.quads, t1.index);
+    const f4      a = quadFilter(tc, R, t0, q0), b = quadFilter(tc, R, t1, q1);
+    return levelBlend(a, b, f);
+  }
   f4    a  = sampleLevelRef(tc, R, uv, l0, R.minFilter);
   if(f == 0.0f || l1 == l0)
     return a;
   f4 b = sampleLevelRef(tc, R, uv, l1, R.minFilter);
-  return a * (1.0f - f) + b * f;
+  return levelBlend(a, b, f);
 }
 PT_DEV f3 multiToSingleScatterAlbedo(f3 rho)  // :125-129
 {
@@ -566,12 +658,12 @@ PT_DEV DevAlphaTri makeAlphaRecord(const DevScene& sc, const DevTri& T)
 // getShadowTransmission, :244-343
 __device__ __noinline__ f3 getShadowTransmission(const DevScene& sc, int rnode, int triangleID, f3 bary, float hitT, f3 rayDir, bool& isInside)
 {
-  const MiGltfRenderNode&    rn  = sc.nodes[rnode];
-  const MiGltfShadeMaterial& mat = sc.materials[max(0, rn.materialID)];
+  const MiGltfRenderNode&    rn  = gat(sc.nodes, rnode);
+  const MiGltfShadeMaterial& mat = gat(sc.materials, max(0, rn.materialID));
   float                      tFactor = mat.transmissionFactor;
   if(tFactor <= MIN_TRANSMISSION)
     return mk3(0.0f);
-  const DevPrim rp = sc.prims[rn.renderPrimID];
+  const DevPrim rp = gat(sc.prims, rn.renderPrimID);
   u3            ti = getTriangleIndices(rp, triangleID);
   f3 v0 = getVertexPosition(rp, ti.x), v1 = getVertexPosition(rp, ti.y), v2 = getVertexPosition(rp, ti.z);
   f3 normal = normalize(cross(v1 - v0, v2 - v0));
@@ -597,7 +689,7 @@ __device__ __noinline__ f3 getShadowTransmission(const DevScene& sc, int rnode, 
   float roughness = mat.pbrRoughnessFactor, metallic = mat.pbrMetallicFactor;
   if(isTexturePresent(mat.pbrMetallicRoughnessTexture))
   {
-    const MiGltfTextureInfo info = sc.texInfos[mat.pbrMetallicRoughnessTexture];
+    const MiGltfTextureInfo info = gat(sc.texInfos, mat.pbrMetallicRoughnessTexture);
     f2                      uv   = getInterpolatedVertexTexCoord(rp, info.texCoord, ti, bary);
     f4                      mr   = sampleTexture(sc, info.index, uv, false, mk2(0, 0), mk2(0, 0));
     roughness *= mr.y;
@@ -644,7 +736,7 @@ __device__ __noinline__ void sampleLights(const DevScene& sc, const FrameConsts&
     int         numLights    = sc.numLights;
     float       selectionPdf = 1.0f / float(numLights);
     int         lightIndex   = min(int(rnd(seed) * float(numLights)), numLights - 1);
-    MiGltfLight light        = sc.lights[lightIndex];
+    MiGltfLight light        = gat(sc.lights, lightIndex);
     float       r1 = rnd(seed), r2 = rnd(seed);
     LightContrib contrib = singleLightContribution(light, pos, mk2(r1, r2));
     dl.direction         = -contrib.incidentVector;
