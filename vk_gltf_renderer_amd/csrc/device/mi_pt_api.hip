@@ -548,6 +548,8 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
     if(p.texCoords1) geomBytes += align16(size_t(p.vertexCount) * 8);
     geomBytes += align16(size_t(p.vertexCount) * 48);  // interleaved copy (DevPrim::verts)
   }
+  if(geomBytes / 16 >= (size_t(1) << 32))  // DevShadeTri addresses vertices as 32-bit float4 indices into this pool
+    return fail(MI_PT_ERR_ARGUMENT, "the geometry pool exceeds 64 GiB");
   HIP_TRY(pt->geometry.alloc(std::max<size_t>(geomBytes, 16)));
   std::vector<uint8_t>     staging(std::max<size_t>(geomBytes, 16));
   std::vector<pt::DevPrim> devPrims(size_t(sd->numRenderPrimitives));
@@ -704,6 +706,7 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
   pt::DevScene& S = pt->scene;
   S.materials = pt->materials.ptr; S.texInfos = pt->texInfos.ptr; S.nodes = pt->nodes.ptr; S.prims = pt->prims.ptr; S.lights = pt->lights.ptr;
   S.textures = pt->textures.ptr; S.texels = pt->texels.ptr; S.texQuads = pt->texQuads.ptr; S.envPixels = nullptr; S.envAccel = nullptr; S.bvhNodes = nullptr; S.bvh8Nodes = nullptr; S.bvh8Planes = nullptr; S.tris = nullptr;
+  S.geomPool = reinterpret_cast<const float4*>(pt->geometry.ptr);
   S.texRefs = pt->texRefs.ptr; S.alphaTris = nullptr; S.shadeTris = nullptr; S.srgbLut = pt->srgbLut.ptr; S.numMaterials = sd->numMaterials; S.numTextures = sd->numTextures;
   S.numLights = sd->numLights; S.numNodes = sd->numRenderNodes;
   S.envWidth = 0; S.envHeight = 0;

@@ -1553,8 +1553,16 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
         primitiveID         = int(S.prim);
         materialID          = S.materialID;
         const MiGltfRenderNode& rn = gat(sc.nodes, rnodeID);
-        const DevPrim           rp = gat(sc.prims, S.renderPrimID);
-        hit = getHitState(rp, mk3(1.0f - hit4.z - hit4.w, hit4.z, hit4.w), rn.worldToObject, rn.objectToWorld, u3{S.i0, S.i1, S.i2}, rayDir);
+        // record -> vertices directly; the primitive's stream table only for the attributes that are not interleaved (uv1, colours)
+        DevPrim rp{};
+        u3      ti{0u, 0u, 0u};
+        if(S.attrs & (SHADE_HAS_UV1 | SHADE_HAS_COLORS))
+        {
+          rp = gat(sc.prims, S.renderPrimID);
+          ti = getTriangleIndices(rp, int(S.prim));
+        }
+        hit = getHitState(&gat(sc.geomPool, S.v0), &gat(sc.geomPool, S.v1), &gat(sc.geomPool, S.v2), S.attrs, &rp, ti,
+                          mk3(1.0f - hit4.z - hit4.w, hit4.z, hit4.w), rn.worldToObject, rn.objectToWorld, rayDir);
       }
       else
         hitT = INFINITE_F;

@@ -96,14 +96,23 @@ enum : uint32_t
 // What the shade kernel needs to start fetching the hit's attributes, per triangle (same index as tris): without it the
 // chain is triangle -> render node -> primitive record -> indices -> vertices; with it record -> {node, primitive, material}
 // -> vertices.
+enum : uint32_t  // DevShadeTri::attrs: which vertex streams the triangle's primitive has
+{
+  SHADE_HAS_NORMALS  = 1u << 0,
+  SHADE_HAS_UV0      = 1u << 1,
+  SHADE_HAS_TANGENTS = 1u << 2,
+  SHADE_HAS_UV1      = 1u << 3,  // uv1 / colours are not part of the interleaved vertex: a hit that needs them fetches its DevPrim
+  SHADE_HAS_COLORS   = 1u << 4,
+};
 struct DevShadeTri  // 32 B
 {
-  uint32_t i0, i1, i2;    // vertex indices of the triangle inside its primitive
+  uint32_t v0, v1, v2;    // the triangle's three interleaved vertices (DevPrim::verts) as float4 indices into DevScene::geomPool: the
+                          // shade kernel goes from this record straight to the vertices, without the primitive's pointer table
   uint32_t rnode;         // GltfRenderNode index
   int32_t  renderPrimID;  // GltfRenderNode::renderPrimID
   int32_t  materialID;    // max(0, GltfRenderNode::materialID)
   uint32_t prim;          // triangle index inside the primitive (PrimitiveIndex())
-  uint32_t _pad;
+  uint32_t attrs;         // SHADE_HAS_*
 };
 
 struct DevScene
@@ -130,6 +139,7 @@ struct DevScene
   const DevTri*              tris;      // triangles in the order of the ACTIVE structure (hit records index this array)
   const DevTexRef*           texRefs;   // numTextureInfos entries
   const DevShadeTri*         shadeTris; // same indexing as tris
+  const float4*              geomPool;  // the geometry pool (every DevPrim stream is a 16-byte aligned piece of it)
   const DevAlphaTri*         alphaTris; // same indexing as tris; valid for triangles of non-FORCE_OPAQUE instances
   const float*               srgbLut;  // 256 floats
   int                        numMaterials, numTextures, numLights, numNodes;

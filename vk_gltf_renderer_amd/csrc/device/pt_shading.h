@@ -68,16 +68,13 @@ PT_DEV f3 pointOffset(f3 p, f3 p0, f3 p1, f3 p2, f3 n0, f3 n1, f3 n2, f3 bary)  
   tmpw -= n2 * dotw;
   return p + tmpu * bary.x + tmpv * bary.y + tmpw * bary.z;
 }
-PT_DEV HitState getHitState(const DevPrim& rp, f3 bary, const float* w2o, const float* o2w, u3 ti, f3 worldRayDir);
-PT_DEV HitState getHitState(const DevPrim& rp, f3 bary, const float* w2o, const float* o2w, int triangleID, f3 worldRayDir)
-{
-  return getHitState(rp, bary, w2o, o2w, getTriangleIndices(rp, triangleID), worldRayDir);
-}
-PT_DEV HitState getHitState(const DevPrim& rp, f3 bary, const float* w2o, const float* o2w, u3 ti, f3 worldRayDir)
+// V0..V2: the triangle's interleaved vertices (DevPrim::verts); attrs: SHADE_HAS_*; rp / ti are only read when the primitive has
+// uv1 or vertex colours (rp may be null otherwise).
+PT_DEV HitState getHitState(const float4* V0, const float4* V1, const float4* V2, uint32_t attrs, const DevPrim* rp, u3 ti, f3 bary, const float* w2o,
+                            const float* o2w, f3 worldRayDir)
 {
   HitState hit;
-  // the three interleaved vertices (DevPrim::verts): 9 x 16 B in flight at once
-  const float4 *V0 = &gat(rp.verts, 3 * size_t(ti.x)), *V1 = &gat(rp.verts, 3 * size_t(ti.y)), *V2 = &gat(rp.verts, 3 * size_t(ti.z));
+  // 9 x 16 B in flight at once
   const float4 a0 = V0[0], a1 = V0[1], a2 = V0[2], b0 = V1[0], b1 = V1[1], b2 = V1[2], c0 = V2[0], c1 = V2[1], c2 = V2[2];
   f3 pos0 = mk3(a0.x, a0.y, a0.z), pos1 = mk3(b0.x, b0.y, b0.z), pos2 = mk3(c0.x, c0.y, c0.z);
   f3 position  = pos0 * bary.x + pos1 * bary.y + pos2 * bary.z;
@@ -85,7 +82,7 @@ PT_DEV HitState getHitState(const DevPrim& rp, f3 bary, const float* w2o, const 
   f3 geoNormal = normalize(cross(pos1 - pos0, pos2 - pos0));
   hit.geonrm   = normalize(mulTransposed(w2o, geoNormal));
   f3 nrm0 = geoNormal, nrm1 = geoNormal, nrm2 = geoNormal, normal = geoNormal;
-  if(rp.normals)
+  if(attrs & SHADE_HAS_NORMALS)
   {
     nrm0   = mk3(a0.w, a1.x, a1.y);
     nrm1   = mk3(b0.w, b1.x, b1.y);
@@ -97,9 +94,9 @@ PT_DEV HitState getHitState(const DevPrim& rp, f3 bary, const float* w2o, const 
   float sideFlip  = frontFace ? 1.0f : -1.0f;
   f3    shadowPos = pointOffset(position, pos0, pos1, pos2, nrm0 * sideFlip, nrm1 * sideFlip, nrm2 * sideFlip, bary);
   hit.shadowPos   = mulPoint(o2w, shadowPos);
-  hit.uv0 = rp.texCoords0 ? mk2(a1.z, a1.w) * bary.x + mk2(b1.z, b1.w) * bary.y + mk2(c1.z, c1.w) * bary.z : mk2(0.0f, 0.0f);
-  hit.uv1 = getInterpolatedVertexTexCoord(rp, 1, ti, bary);
-  if(rp.texCoords0)
+  hit.uv0 = (attrs & SHADE_HAS_UV0) ? mk2(a1.z, a1.w) * bary.x + mk2(b1.z, b1.w) * bary.y + mk2(c1.z, c1.w) * bary.z : mk2(0.0f, 0.0f);
+  hit.uv1 = (attrs & SHADE_HAS_UV1) ? getInterpolatedVertexTexCoord(*rp, 1, ti, bary) : mk2(0.0f, 0.0f);
+  if(attrs & SHADE_HAS_UV0)
   {
     const float2 a = make_float2(a1.z, a1.w), b = make_float2(b1.z, b1.w), c = make_float2(c1.z, c1.w);
     // computeTexelDensity, get_hit.h.slang:44-56
@@ -111,9 +108,9 @@ PT_DEV HitState getHitState(const DevPrim& rp, f3 bary, const float* w2o, const 
   }
   else
     hit.texelDensity = 0.0f;
-  hit.color = getInterpolatedVertexColor(rp, ti, bary);
+  hit.color = (attrs & SHADE_HAS_COLORS) ? getInterpolatedVertexColor(*rp, ti, bary) : mk4(1.0f);
   f4 tng0, tng1, tng2;
-  if(rp.tangents)
+  if(attrs & SHADE_HAS_TANGENTS)
   {
     tng0 = mk4(a2);
     tng1 = mk4(b2);
@@ -601,12 +598,14 @@ PT_DEV DevShadeTri makeShadeRecord(const DevScene& sc, const DevTri& T)
   const MiGltfRenderNode& rn    = sc.nodes[rnode];
   const DevPrim           rp    = sc.prims[rn.renderPrimID];
   const u3                ti    = getTriangleIndices(rp, int(prim));
-  r.i0 = ti.x; r.i1 = ti.y; r.i2 = ti.z;
+  const uint32_t          base  = uint32_t(rp.verts - sc.geomPool);
+  r.v0 = base + 3u * ti.x; r.v1 = base + 3u * ti.y; r.v2 = base + 3u * ti.z;
   r.rnode        = rnode;
   r.renderPrimID = rn.renderPrimID;
   r.materialID   = max(0, rn.materialID);
   r.prim         = prim;
-  r._pad         = 0;
+  r.attrs        = (rp.normals ? SHADE_HAS_NORMALS : 0u) | (rp.texCoords0 ? SHADE_HAS_UV0 : 0u) | (rp.tangents ? SHADE_HAS_TANGENTS : 0u)
+            | (rp.texCoords1 ? SHADE_HAS_UV1 : 0u) | (rp.colors ? SHADE_HAS_COLORS : 0u);
   return r;
 }
 // Fills the record of one triangle (run once after the BVH build, for every triangle of the active order).
