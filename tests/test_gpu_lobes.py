@@ -34,8 +34,12 @@ def test_material_zoo(built, tmp_path, group):
     o, g = pu.render_oracle(s, 6), pu.render_gpu(s, 6)
     _check(o, g)
     assert o["stats"]["textureTaps"] > 0 or group in ("retroreflection",)
-    # frames in flight and both acceleration structures give the same bits for these materials too
-    assert (g["accum"] == pu.render_gpu(s, 6, in_flight=3, bvh=1, collect_counters=False)["accum"]).all()
+    # frames in flight and both acceleration structures give the same bits for these materials too -- compared like with like: the
+    # stat-collecting kernels (g above) are template instantiations of their own, in which the compiler is free to fuse multiplies
+    # and adds differently; against the plain kernels they may differ by rounding only
+    plain = pu.render_gpu(s, 6, collect_counters=False)["accum"]
+    assert (plain == pu.render_gpu(s, 6, in_flight=3, bvh=1, collect_counters=False)["accum"]).all()
+    assert pu.compare_images(plain, g["accum"])["rel_l2"] < 1e-5
 
 
 @pytest.mark.parametrize("group", ("clearcoat", "iridescence", "diffuse_transmission", "blend"))

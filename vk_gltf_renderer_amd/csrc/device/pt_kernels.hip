@@ -301,27 +301,46 @@ PT_DEV CameraPath generateCameraPath(const FrameConsts& fc, const PathSoA& P, co
 // environment, if anything.
 // (not inlined, like missEnvironment below: the bounce-0 kernel and the shade kernel must get the same bits out of it, and two
 //  inlined copies may be contracted into fused multiply-adds differently)
-__device__ __noinline__ bool primaryMissBackplate(const DevScene& sc, const FrameConsts& fc, f3 rayDir, f3& radiance)
+__device__ __noinline__ f4 primaryMissBackplateCall(const DevScene& scIn, const FrameConsts& fcIn, f3 rayDir)  // .w != 0: there is a backplate, .xyz
 {
+  const DevScene&    sc = uniformConst(scIn);
+  const FrameConsts& fc = uniformConst(fcIn);
   if(hasFlag(fc.frameInfo.flags, MI_SCENE_USE_SOLID_BACKGROUND))
   {
-    radiance = mk3(fc.frameInfo.backgroundColor);
-    return true;
+    const f3 c = mk3(fc.frameInfo.backgroundColor);
+    return mk4(c.x, c.y, c.z, 1.0f);
   }
   if(hasFlag(fc.frameInfo.flags, MI_SCENE_USE_HDR_ENVIRONMENT) && fc.frameInfo.envBlur > 0.0f)
   {
-    f3 dir   = rotateAxis(rayDir, mk3(0, 1, 0), -fc.frameInfo.envRotation);
-    radiance = smoothHDRBlur(sc, getSphericalUv(dir), fc.frameInfo.envBlur) * fc.frameInfo.envIntensity;
-    return true;
+    f3       dir = rotateAxis(rayDir, mk3(0, 1, 0), -fc.frameInfo.envRotation);
+    const f3 c   = smoothHDRBlur(sc, getSphericalUv(dir), fc.frameInfo.envBlur) * fc.frameInfo.envIntensity;
+    return mk4(c.x, c.y, c.z, 1.0f);
   }
-  return false;
+  return mk4(0.0f);
+}
+PT_DEV bool primaryMissBackplate(const DevScene& sc, const FrameConsts& fc, f3 rayDir, f3& radiance)
+{
+  const f4 r = primaryMissBackplateCall(sc, fc, rayDir);
+  if(r.w == 0.0f)
+    return false;
+  radiance = xyz(r);
+  return true;
 }
 // Environment seen by a ray that leaves the scene and its MIS weight against next-event estimation (gltf_pathtrace.slang:139-156).
-__device__ __noinline__ void missEnvironment(const DevScene& sc, const FrameConsts& fc, f3 rayDir, float lastSamplePdf, f3& envColor, float& mis)
+__device__ __noinline__ f4 missEnvironmentCall(const DevScene& scIn, const FrameConsts& fcIn, f3 rayDir, float lastSamplePdf)
 {
+  const DevScene&    sc = uniformConst(scIn);
+  const FrameConsts& fc = uniformConst(fcIn);
   float envPdf;
+  f3    envColor;
   sampleEnvironment(sc, fc, rayDir, envColor, envPdf);
-  mis = computeEnvHitMisWeight(sc, fc, lastSamplePdf, envPdf);
+  return mk4(envColor.x, envColor.y, envColor.z, computeEnvHitMisWeight(sc, fc, lastSamplePdf, envPdf));
+}
+PT_DEV void missEnvironment(const DevScene& sc, const FrameConsts& fc, f3 rayDir, float lastSamplePdf, f3& envColor, float& mis)
+{
+  const f4 r = missEnvironmentCall(sc, fc, rayDir, lastSamplePdf);  // by value: registers, not the caller's scratch
+  envColor   = xyz(r);
+  mis        = r.w;
 }
 // checkInfinitePlaneIntersection (pathtrace_functions.h.slang:556-585): distance along the ray, or a negative number.
 PT_DEV float infinitePlaneT(const FrameConsts& fc, f3 rayOrigin, f3 rayDir, float hitT)

@@ -223,8 +223,10 @@ PT_DEV SkyPrecomp makeSkyPrecomp(const MiSkyPhysicalParameters& s)
   return k;
 }
 // `gamma` = angleBetween(dir, sun direction): the caller has it from the pdf (samplePhysicalSkyPDF) -- one atan2 instead of two
-__device__ __noinline__ f3 evalPhysicalSky(const MiSkyPhysicalParameters& s, const SkyPrecomp& k, f3 dir, float gamma)
+__device__ __noinline__ f3 evalPhysicalSky(const MiSkyPhysicalParameters& sIn, const SkyPrecomp& kIn, f3 dir, float gamma)
 {
+  const MiSkyPhysicalParameters& s = uniformConst(sIn);
+  const SkyPrecomp&              k = uniformConst(kIn);
   if(s.multiplier <= 0.0f)
     return mk3(0.0f);
   f3    up     = skyUp(s);

@@ -216,11 +216,32 @@ __device__ __forceinline__ const T& gat(const T* table, I i)
 {
   return *(const T*)((const __attribute__((address_space(1))) T*)table + i);
 }
+// A descriptor (DevScene, FrameConsts, the sky tables) reaches a non-inlined helper as a reference in VECTOR registers: the helper
+// cannot know that every lane holds the same address, nor that nothing writes there, and reads each field with a flat vector load
+// (sampleLights: 37 of them, each an address-pipeline slot and most of them a full drain).  uniformConst() states both facts: the
+// address is made scalar (readfirstlane) and the memory constant, so the fields arrive through the scalar cache in SGPRs.
+template <class T>
+__device__ __forceinline__ const T& uniformConst(const T& r)
+{
+#ifdef MI_PT_DIAG_NO_UNIFORM_CONST  // diagnostics build: the descriptors through vector loads again
+  return r;
+#endif
+  const unsigned long long p = reinterpret_cast<unsigned long long>(&r);
+  // (the builtin returns int: widen through uint32_t, or a low half with bit 31 set sign-extends into the high half)
+  const uint32_t           lo = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(p)))), hi = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(p >> 32))));
+  const unsigned long long u  = (unsigned long long)lo | ((unsigned long long)hi << 32);
+  return *(const T*)(const __attribute__((address_space(4))) T*)u;
+}
 #else  // the device headers compiled for the host (tests/host_shim)
 template <class T, class I>
 inline const T& gat(const T* table, I i)
 {
   return table[i];
+}
+template <class T>
+inline const T& uniformConst(const T& r)
+{
+  return r;
 }
 #endif
 

@@ -655,7 +655,20 @@ PT_DEV DevAlphaTri makeAlphaRecord(const DevScene& sc, const DevTri& T)
 }
 
 // getShadowTransmission, :244-343
-__device__ __noinline__ f3 getShadowTransmission(const DevScene& sc, int rnode, int triangleID, f3 bary, float hitT, f3 rayDir, bool& isInside)
+PT_DEV f3 getShadowTransmissionBody(const DevScene& sc, int rnode, int triangleID, f3 bary, float hitT, f3 rayDir, bool& isInside);
+// .xyz = transmission, .w != 0: inside after the surface (by value, like sampleLightsCall)
+__device__ __noinline__ f4 getShadowTransmissionCall(const DevScene& scIn, int rnode, int triangleID, f3 bary, float hitT, f3 rayDir, bool isInside)
+{
+  const f3 T = getShadowTransmissionBody(uniformConst(scIn), rnode, triangleID, bary, hitT, rayDir, isInside);
+  return mk4(T.x, T.y, T.z, isInside ? 1.0f : 0.0f);
+}
+PT_DEV f3 getShadowTransmission(const DevScene& sc, int rnode, int triangleID, f3 bary, float hitT, f3 rayDir, bool& isInside)
+{
+  const f4 r = getShadowTransmissionCall(sc, rnode, triangleID, bary, hitT, rayDir, isInside);
+  isInside   = r.w != 0.0f;
+  return xyz(r);
+}
+PT_DEV f3 getShadowTransmissionBody(const DevScene& sc, int rnode, int triangleID, f3 bary, float hitT, f3 rayDir, bool& isInside)
 {
   const MiGltfRenderNode&    rn  = gat(sc.nodes, rnode);
   const MiGltfShadeMaterial& mat = gat(sc.materials, max(0, rn.materialID));
@@ -716,7 +729,28 @@ PT_DEV void getDirectLightingTechniqueProbabilities(const DevScene& sc, const Fr
     envWeight /= total;
   }
 }
-__device__ __noinline__ void sampleLights(const DevScene& sc, const FrameConsts& fc, f3 pos, uint32_t& seed, DirectLight& dl)  // :379-464
+// (results by value: a reference parameter of a non-inlined function is a pointer into the caller's scratch, written and read
+// back through flat memory instructions; nine floats come back in registers)
+struct LightSample
+{
+  DirectLight dl;
+  uint32_t    seed;
+};
+PT_DEV void sampleLightsBody(const DevScene& sc, const FrameConsts& fc, f3 pos, uint32_t& seed, DirectLight& dl);
+__device__ __noinline__ LightSample sampleLightsCall(const DevScene& scIn, const FrameConsts& fcIn, f3 pos, uint32_t seed)
+{
+  LightSample r;
+  r.seed = seed;
+  sampleLightsBody(uniformConst(scIn), uniformConst(fcIn), pos, r.seed, r.dl);
+  return r;
+}
+PT_DEV void sampleLights(const DevScene& sc, const FrameConsts& fc, f3 pos, uint32_t& seed, DirectLight& dl)  // :379-464
+{
+  const LightSample r = sampleLightsCall(sc, fc, pos, seed);
+  seed = r.seed;
+  dl   = r.dl;
+}
+PT_DEV void sampleLightsBody(const DevScene& sc, const FrameConsts& fc, f3 pos, uint32_t& seed, DirectLight& dl)
 {
   f3 radiance        = mk3(0.0f);
   dl.pdf             = 0.0f;
@@ -751,11 +785,11 @@ __device__ __noinline__ void sampleLights(const DevScene& sc, const FrameConsts&
       {
         float r1 = rnd(seed), r2 = rnd(seed);
         f3    skyRadiance;
-        samplePhysicalSky(fc.sky, *fc.skyPre, mk2(r1, r2), dl.direction, envPdf, skyRadiance);
+        samplePhysicalSky(fc.sky, uniformConst(*fc.skyPre), mk2(r1, r2), dl.direction, envPdf, skyRadiance);
         radiance = skyRadiance / (envPdf * envWeight);
       }
       else
-        envPdf = samplePhysicalSkyPDF(fc.sky, *fc.skyPre, skyGamma(*fc.skyPre, dl.direction));
+        envPdf = samplePhysicalSkyPDF(fc.sky, uniformConst(*fc.skyPre), skyGamma(uniformConst(*fc.skyPre), dl.direction));
     }
     else
     {
@@ -794,9 +828,10 @@ PT_DEV void sampleEnvironment(const DevScene& sc, const FrameConsts& fc, f3 dire
 {
   if(!hasFlag(fc.frameInfo.flags, MI_SCENE_USE_HDR_ENVIRONMENT))
   {
-    const float gamma = skyGamma(*fc.skyPre, direction);
-    envColor = evalPhysicalSky(fc.sky, *fc.skyPre, direction, gamma);
-    envPdf   = samplePhysicalSkyPDF(fc.sky, *fc.skyPre, gamma);
+    const SkyPrecomp& pre   = uniformConst(*fc.skyPre);
+    const float       gamma = skyGamma(pre, direction);
+    envColor = evalPhysicalSky(fc.sky, pre, direction, gamma);
+    envPdf   = samplePhysicalSkyPDF(fc.sky, pre, gamma);
   }
   else
   {
