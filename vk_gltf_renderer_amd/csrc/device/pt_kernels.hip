@@ -1406,7 +1406,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
   __shared__ float    s_srgb[256];  // sRGB decode table next to the ALU: 3 lookups per texel, up to 8 texels per tap
   // The window sort exists in the generic kernel (key: material) and in the later bounces of the SIMPLE kernel (key: next-event
   // technique); the bounce-0 launch of the SIMPLE kernel gets its hits packed by k_trace_primary and walks the queue as it is.
-  constexpr bool CAN_SORT = !SIMPLE || !FIRST;
+  constexpr bool CAN_SORT = !SIMPLE || !FIRST;  // (compiling the sort out of the SIMPLE kernel's later bounces measured neutral: round 3)
   __shared__ uint32_t s_order[CAN_SORT ? SORT_WINDOW : 1];                   // queue positions of the window's live entries, sorted by bin
   __shared__ uint16_t s_segCount[CAN_SORT ? SORT_SEGMENTS : 1][SORT_BINS];   // entries of a bin in one (round, wave) segment -> exclusive prefix inside the bin
   __shared__ uint32_t s_binBase[SORT_BINS + 1];                 // first sorted index of each bin; [SORT_BINS] = live entries of the window
@@ -2452,8 +2452,8 @@ __global__ void __launch_bounds__(256) k_shadow_resolve(const DevScene* __restri
           uint32_t       rnode = 0u, prim = 0u;
           if(tieLast || tieBest)  // exact ties only: coincident surfaces
           {
-            rnode = __float_as_uint(sc.tris[tri].a.w);
-            prim  = __float_as_uint(sc.tris[tri].b.w);
+            rnode = __float_as_uint(gat(sc.tris, tri).a.w);
+            prim  = __float_as_uint(gat(sc.tris, tri).b.w);
           }
           const bool afterLast  = !haveLast || c.x > lastT || (tieLast && (rnode > lastRnode || (rnode == lastRnode && prim > lastPrim)));
           bool       beforeBest = best == CAND_NIL || c.x < bC.x;
@@ -2462,8 +2462,8 @@ __global__ void __launch_bounds__(256) k_shadow_resolve(const DevScene* __restri
             if(!bIds)  // the best so far was taken without its ids
             {
               const uint32_t bt = __float_as_uint(bC.w);
-              bRnode = __float_as_uint(sc.tris[bt].a.w);
-              bPrim  = __float_as_uint(sc.tris[bt].b.w);
+              bRnode = __float_as_uint(gat(sc.tris, bt).a.w);
+              bPrim  = __float_as_uint(gat(sc.tris, bt).b.w);
               bIds   = true;
             }
             beforeBest = rnode < bRnode || (rnode == bRnode && prim < bPrim);
@@ -2476,7 +2476,7 @@ __global__ void __launch_bounds__(256) k_shadow_resolve(const DevScene* __restri
         if(best == CAND_NIL)
           break;
         const uint32_t tri = __float_as_uint(bC.w);
-        const uint32_t rnode = __float_as_uint(sc.tris[tri].a.w), prim = __float_as_uint(sc.tris[tri].b.w);
+        const uint32_t rnode = __float_as_uint(gat(sc.tris, tri).a.w), prim = __float_as_uint(gat(sc.tris, tri).b.w);
         haveLast = true; lastT = bC.x; lastRnode = rnode; lastPrim = prim;
         const f3    bary    = mk3(1.0f - bC.y - bC.z, bC.y, bC.z);
         const float opacity = getOpacityFast(sc, int(tri), bary);
