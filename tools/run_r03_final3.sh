@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 evidence run, third edition (after the shade-path round trips and the one-record finish): same contents as tools/run_r03_final.sh.
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/.."; ulimit -c 0
 O=$PWD/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -q > $O/r03_gputest_final.txt 2>&1; echo "GPUTEST rc=$? $(tail -1 $O/r03_gputest_final.txt)"
 for w in helmet atrium; do
@@ -18,4 +18,3 @@ timeout 300 python bench.py --workload glass --steps 3 --warmup 1 > $O/r03_bench
 timeout 300 python bench.py --workload glass --denoise --steps 3 --warmup 1 --no-cpu-baseline > $O/r03_bench_glass_denoise.json 2> $O/r03_bench_glass_denoise.err; cut -c1-200 $O/r03_bench_glass_denoise.json
 timeout 200 python bench.py --workload helmet --in-flight 1 --frames-per-step 64 --steps 3 --warmup 1 --no-cpu-baseline --also none > $O/r03_bench_helmet_f1.json 2>/dev/null; cut -c1-200 $O/r03_bench_helmet_f1.json
 timeout 200 python bench.py --workload helmet --in-flight 8 --frames-per-step 64 --steps 3 --warmup 1 --no-cpu-baseline --also none > $O/r03_bench_helmet_f8.json 2>/dev/null; cut -c1-200 $O/r03_bench_helmet_f8.json
-tools/kstats.sh r03_glass --workload glass --steps 1 --warmup 1 | head -12
