@@ -1399,8 +1399,10 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
   // The scene / frame descriptors reach the non-inlined helpers (getTexture, sampleLights, the sky) by reference.  As
   // by-value kernel arguments they would be copied to scratch (their address escapes) and every field read would become a
   // memory round trip; as device-resident structs they are read through one uniform pointer.
-  const DevScene&    sc = *scp;
-  const FrameConsts& fc = *fcp;
+  // ... and as CONSTANT memory (uniformConst): a read of `sc.` / `fc.` that follows a store or a call is otherwise a vector load of a
+  // uniform address -- the compiler must assume the store or the callee wrote there -- and the loop is full of both.
+  const DevScene&    sc = uniformConst(*scp);
+  const FrameConsts& fc = uniformConst(*fcp);
   __shared__ uint32_t s_prefix[NSUB + 1];
   __shared__ uint32_t s_push[4];
   __shared__ float    s_srgb[256];  // sRGB decode table next to the ALU: 3 lookups per texel, up to 8 texels per tap
@@ -2432,7 +2434,7 @@ __global__ void __launch_bounds__(256) k_shadow_resolve(const DevScene* __restri
     f3           total = mk3(1.0f);
     if(REC && !occluded && code != CAND_NIL)
     {
-      const DevScene& sc       = *scp;
+      const DevScene& sc       = uniformConst(*scp);
       const f3        dir      = xyz(d4);
       const uint32_t  seed0    = __float_as_uint(c4.w);
       bool            isInside = (__float_as_uint(d4.w) & 1u) != 0u, haveLast = false;
