@@ -2,6 +2,8 @@
 // restatement of shaders/get_hit.h.slang, shaders/gltf_material_eval.h.slang, shaders/gltf_vertex_access.h.slang and the
 // non-tracing parts of shaders/pathtrace_functions.h.slang.  Each function cites the lines it follows.
 #pragma once
+#include <cstddef>
+
 #include "pt_light.h"
 
 namespace pt {
@@ -353,6 +355,14 @@ PT_DEV PbrMaterial evaluateMaterial(const DevScene& sc, const MiGltfShadeMateria
 {
 #define TEX(slot) (++taps, getTextureRef(st.tex, slot, st.tc0, st.tc1, st.texGrad))
   PbrMaterial p = defaultPbrMaterial();
+  // the five core map slots in one load (they are adjacent, 8-byte aligned): read where they are used, each was a 2-byte load and a
+  // wait of its own in front of its texture fetch
+  static_assert(offsetof(MiGltfShadeMaterial, pbrBaseColorTexture) % 8 == 0 && offsetof(MiGltfShadeMaterial, occlusionTexture) == offsetof(MiGltfShadeMaterial, pbrBaseColorTexture) + 8,
+                "core texture slots: base colour, normal, metallic-roughness, emissive, occlusion");
+  const uint32_t* slotWords = reinterpret_cast<const uint32_t*>(&m.pbrBaseColorTexture);
+  const uint32_t  sw0 = slotWords[0], sw1 = slotWords[1], sw2 = slotWords[2];
+  const uint16_t  texBaseColor = uint16_t(sw0 & 0xffffu), texNormal = uint16_t(sw0 >> 16), texMetallicRoughness = uint16_t(sw1 & 0xffffu),
+                 texEmissive = uint16_t(sw1 >> 16), texOcclusion = uint16_t(sw2 & 0xffffu);
   if(m.pbrModel == MI_PBR_SPECULAR_GLOSSINESS)
   {
     f4    diffuse    = mk4(m.pbrDiffuseFactor[0], m.pbrDiffuseFactor[1], m.pbrDiffuseFactor[2], m.pbrDiffuseFactor[3]) * st.baseColorVertexMul;
@@ -372,14 +382,14 @@ PT_DEV PbrMaterial evaluateMaterial(const DevScene& sc, const MiGltfShadeMateria
   else
   {
     f4 baseColor = mk4(m.pbrBaseColorFactor[0], m.pbrBaseColorFactor[1], m.pbrBaseColorFactor[2], m.pbrBaseColorFactor[3]) * st.baseColorVertexMul;
-    if(isTexturePresent(m.pbrBaseColorTexture))
-      baseColor *= TEX(m.pbrBaseColorTexture);
+    if(isTexturePresent(texBaseColor))
+      baseColor *= TEX(texBaseColor);
     p.baseColor     = xyz(baseColor);
     p.opacity       = baseColor.w;
     float roughness = m.pbrRoughnessFactor, metallic = m.pbrMetallicFactor;
-    if(isTexturePresent(m.pbrMetallicRoughnessTexture))
+    if(isTexturePresent(texMetallicRoughness))
     {
-      f4 s = TEX(m.pbrMetallicRoughnessTexture);
+      f4 s = TEX(texMetallicRoughness);
       roughness *= s.y;
       metallic *= s.z;
     }
@@ -388,9 +398,9 @@ PT_DEV PbrMaterial evaluateMaterial(const DevScene& sc, const MiGltfShadeMateria
     p.metallic  = clampf(metallic, 0.0f, 1.0f);
   }
   p.occlusion = m.occlusionStrength;
-  if(isTexturePresent(m.occlusionTexture))
+  if(isTexturePresent(texOcclusion))
   {
-    float occ   = TEX(m.occlusionTexture).x;
+    float occ   = TEX(texOcclusion).x;
     p.occlusion = 1.0f + p.occlusion * (occ - 1.0f);
   }
   p.N  = st.N;
@@ -398,17 +408,17 @@ PT_DEV PbrMaterial evaluateMaterial(const DevScene& sc, const MiGltfShadeMateria
   p.B  = st.B;
   p.Ng = st.Ng;
   bool needsTangentUpdate = false;
-  if(isTexturePresent(m.normalTexture))
+  if(isTexturePresent(texNormal))
   {
-    f3 nv = xyz(TEX(m.normalTexture));
+    f3 nv = xyz(TEX(texNormal));
     nv    = nv * 2.0f - mk3(1.0f);
     nv *= mk3(m.normalTextureScale, m.normalTextureScale, 1.0f);
     p.N                = normalize(st.T * nv.x + st.B * nv.y + st.N * nv.z);
     needsTangentUpdate = true;
   }
   p.emissive = mk3(m.emissiveFactor);
-  if(isTexturePresent(m.emissiveTexture))
-    p.emissive *= xyz(TEX(m.emissiveTexture));
+  if(isTexturePresent(texEmissive))
+    p.emissive *= xyz(TEX(texEmissive));
   p.emissive            = max3(mk3(0.0f), p.emissive);
   if(!SIMPLE)
   {
