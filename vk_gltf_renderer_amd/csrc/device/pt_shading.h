@@ -213,9 +213,8 @@ PT_DEV void bilinearCoords(f2 uv, int w, int h, int& ix, int& iy, float& tx, flo
   tx = fx - flx;
   ty = fy - fly;
 }
-PT_DEV QuadTap quadTap(const DevTexRef& R, f2 uv, int level)
+PT_DEV QuadTap quadTap(const DevTexRef& R, f2 uv, int level, uint32_t off)  // off = levelOffsetRef(R, level)
 {
-  const uint32_t off = levelOffsetRef(R, level);
   const int      w = max(1, int(R.width) >> level), h = max(1, int(R.height) >> level);
   int            ix, iy;
   QuadTap        t;
@@ -237,7 +236,7 @@ PT_DEV f4 sampleLevelRef(const TexCtx& tc, const DevTexRef& R, f2 uv, int level,
   if(filter != MI_FILTER_NEAREST && hasQuadPath(tc, R))
   {
     // the whole footprint in one 16-byte gather (DevScene::texQuads): same texels, same arithmetic, same result
-    const QuadTap t = quadTap(R, uv, level);
+    const QuadTap t = quadTap(R, uv, level, levelOffsetRef(R, level));
     return quadFilter(tc, R, t, gat(tc.quads, t.index));
   }
   const uint32_t off = levelOffsetRef(R, level);
@@ -297,9 +296,10 @@ __device__ __noinline__ f4 getTextureRef(TexCtx tc, uint32_t slot, f2 tc0, f2 tc
   if(texGrad > 0.0f)
   {
     f2    ddx = mk2(U[0] * texGrad, U[1] * texGrad), ddy = mk2(U[2] * texGrad, U[3] * texGrad);
-    float rx  = sqrtf(sqr(ddx.x * float(R.width)) + sqr(ddx.y * float(R.height)));
-    float ry  = sqrtf(sqr(ddy.x * float(R.width)) + sqr(ddy.y * float(R.height)));
-    float rho = fmaxf(rx, ry);
+    // max(sqrt(a), sqrt(b)) as sqrt(max(a, b)): the same bits (a correctly rounded square root is monotone), one square root less
+    float rx2 = sqr(ddx.x * float(R.width)) + sqr(ddx.y * float(R.height));
+    float ry2 = sqr(ddy.x * float(R.width)) + sqr(ddy.y * float(R.height));
+    float rho = sqrtf(fmaxf(rx2, ry2));
     lod       = rho > 0.0f ? log2f(rho) : -126.0f;
   }
   if(lod <= 0.0f)
@@ -313,7 +313,9 @@ __device__ __noinline__ f4 getTextureRef(TexCtx tc, uint32_t slot, f2 tc0, f2 tc
   if(R.minFilter != MI_FILTER_NEAREST && hasQuadPath(tc, R) && !(f == 0.0f || l1 == l0))
   {
     // trilinear: both levels' footprint records in flight together
-    const QuadTap t0 = quadTap(R, uv, l0), t1 = quadTap(R, uv, l1);
+    // (l1 == l0 + 1 here: the coarser level starts where the finer one ends)
+    const uint32_t off0 = levelOffsetRef(R, l0), off1 = off0 + uint32_t(max(1, int(R.width) >> l0)) * uint32_t(max(1, int(R.height) >> l0));
+    const QuadTap  t0 = quadTap(R, uv, l0, off0), t1 = quadTap(R, uv, l1, off1);
     const uint4   q0 = gat(tc.quads, t0.index), q1 = gat(tc.quads, t1.index);
     const f4      a = quadFilter(tc, R, t0, q0), b = quadFilter(tc, R, t1, q1);
     return levelBlend(a, b, f);
