@@ -3,6 +3,7 @@
 // (oracle/oracle_pt.h: oracle_bsdf_eval / _sample, oracle_sky_*), so that tests/test_device_headers_on_host.py can diff the two
 // restatements lobe by lobe on the CPU.  This library is built by the test session only and is never loaded by the product.
 #include "pt_shading.h"
+#include "pt_packet.h"
 
 using namespace pt;
 
@@ -78,5 +79,79 @@ __attribute__((visibility("default"))) void dev_light_contribution(const MiGltfL
   LightContrib c = singleLightContribution(*light, mk3(pos), mk2(xi[0], xi[1]));
   out8[0] = c.incidentVector.x; out8[1] = c.incidentVector.y; out8[2] = c.incidentVector.z; out8[3] = c.distance;
   out8[4] = c.intensity.x; out8[5] = c.intensity.y; out8[6] = c.intensity.z; out8[7] = c.pdf;
+}
+
+// The packet walk's interval test (pt_packet.h) next to the per-ray test it stands in for (pt_bvh8.h: bvh8TestChildrenPlanes, whose
+// arithmetic is restated here -- that header is not host-compilable), on one node and one packet of up to 64 rays that all point
+// into one octant.  exactAny: children some ray's own test enters; interval: children the interval test enters.  Returns 0 when
+// the rays do not share an octant.
+__attribute__((visibility("default"))) int dev_packet_masks(const float* P, const float* s, const float* planes, int nrays, const float* org, const float* dir,
+                                                            const float* tmax, uint32_t* exactAny, uint32_t* interval)
+{
+  float        idir[64][3];
+  PacketBounds B;
+  uint32_t     negMask = 0;
+  float        tmaxPacket = -INFINITY;
+  for(int a = 0; a < 3; ++a)
+  {
+    B.omin[a] = B.imin[a] = INFINITY;
+    B.omax[a] = B.imax[a] = -INFINITY;
+  }
+  for(int r = 0; r < nrays; ++r)
+  {
+    for(int a = 0; a < 3; ++a)
+    {
+      const float d = dir[3 * r + a], eps = 1e-30f;  // makeRaySetup, pt_bvh.h
+      idir[r][a]    = 1.0f / (std::fabs(d) < eps ? std::copysign(eps, d) : d);
+      B.omin[a] = std::min(B.omin[a], org[3 * r + a]); B.omax[a] = std::max(B.omax[a], org[3 * r + a]);
+      B.imin[a] = std::min(B.imin[a], idir[r][a]);     B.imax[a] = std::max(B.imax[a], idir[r][a]);
+      const uint32_t neg = idir[r][a] < 0.0f ? 1u : 0u;
+      if(r == 0)
+        negMask |= neg << a;
+      else if(((negMask >> a) & 1u) != neg)
+        return 0;
+    }
+    tmaxPacket = std::max(tmaxPacket, tmax[r]);
+  }
+  // ---- per ray, as bvh8TestChildrenPlanes does it
+  uint32_t any = 0;
+  for(int r = 0; r < nrays; ++r)
+    for(int c = 0; c < 8; ++c)
+    {
+      float tn = 0.0f, tf = tmax[r];
+      for(int a = 0; a < 3; ++a)
+      {
+        const bool  neg = (negMask >> a) & 1u;
+        const float Pa = P[a] - org[3 * r + a], k = 4.76837158e-7f;
+        const float d  = std::fmaf(255.0f, s[a], std::fabs(Pa)) * k;
+        const float sg = neg ? 1.0f : -1.0f;
+        const float A  = s[a] * idir[r][a];
+        const float Bn = std::fmaf(sg, d, Pa) * idir[r][a], Bf = std::fmaf(-sg, d, Pa) * idir[r][a];
+        const float qn = planes[(2 * a + (neg ? 1 : 0)) * 8 + c], qf = planes[(2 * a + (neg ? 0 : 1)) * 8 + c];
+        tn = std::max(tn, std::fmaf(qn, A, Bn));
+        tf = std::min(tf, std::fmaf(qf, A, Bf));
+      }
+      if(!std::signbit(tf - tn))
+        any |= 1u << c;
+    }
+  // ---- the interval test, lane by lane
+  uint32_t iv = 0;
+  for(int c = 0; c < 8; ++c)
+  {
+    float tn = -INFINITY, tf = INFINITY;
+    for(int pl = 0; pl < 8; ++pl)
+    {
+      const PacketLane L = makePacketLane(uint32_t(c * 8 + pl), negMask, B);
+      if(!L.live)
+        continue;
+      const float t = packetPlaneTime(L, planes[L.planeOffset], P[L.axis], s[L.axis]);
+      if(L.entry) tn = std::max(tn, t); else tf = std::min(tf, t);
+    }
+    if(packetChildHit(tn, tf, tmaxPacket))
+      iv |= 1u << c;
+  }
+  *exactAny = any;
+  *interval = iv;
+  return 1;
 }
 }

@@ -236,6 +236,36 @@ def test_packet_walk_float_planes_are_bit_identical(built, tmp_path):
         assert np.array_equal(np.load(out), ref["accum"]) and np.array_equal(np.load(sel), ref["selection"]), path
 
 
+def test_packet_interval_node_test_changes_no_bit(built, tmp_path):
+    """With pixel-major path slots (a multiple of 64 frames in flight) a camera-ray packet is 64 samples of one pixel, and the packet walk
+    tests a node's eight children against the packet's interval ray, one plane per lane (pt_packet.h), instead of every child in every
+    lane.  The interval test is conservative (tests/test_packet_interval.py): it may enter a child no ray needs, never miss one, and the
+    triangle tests stay per ray -- so image and selection ids equal those of the per-ray node test (MI_PT_PACKET_INTERVAL=0) bit for
+    bit, and it fetches at least as many and not many more records."""
+    import json
+    import subprocess
+    import sys
+    hdr = os.path.join(os.path.dirname(os.path.dirname(__file__)), "assets", "std_env.hdr")
+    scenes = [scenegen.scene_helmet_class(str(tmp_path / "helmet.glb"), seed=7, tess=48, tex_size=64),
+              scenegen.scene_atrium_class(str(tmp_path / "atrium.glb"), seed=5, detail=0.2, tex_size=64),
+              scenegen.scene_glass_class(str(tmp_path / "glass.glb"), seed=3, tess=16)]
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import parity_util as pu; s = pu.Setup(sys.argv[1], 200, 120, max_depth=3, hdr_path=%r); "
+            "g = pu.render_gpu(s, 64, in_flight=64); np.save(sys.argv[2], g['accum']); np.save(sys.argv[3], g['selection']); print(json.dumps(g['stats']))") % (
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), hdr)
+    for k, path in enumerate(scenes):
+        s = pu.Setup(path, 200, 120, max_depth=3, hdr_path=hdr)
+        ref = pu.render_gpu(s, 64, in_flight=64)
+        out, sel = str(tmp_path / f"perray{k}.npy"), str(tmp_path / f"perray_sel{k}.npy")
+        r = subprocess.run([sys.executable, "-c", code, path, out, sel], env=dict(os.environ, MI_PT_PACKET_INTERVAL="0"), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        other = json.loads(r.stdout.strip().splitlines()[-1])
+        assert np.array_equal(np.load(out), ref["accum"]) and np.array_equal(np.load(sel), ref["selection"]), path
+        for key in ("segments", "shadowRays", "surfaceHits"):
+            assert other[key] == ref["stats"][key], (key, other[key], ref["stats"][key])
+        assert other["nodesPrimary"] <= ref["stats"]["nodesPrimary"] <= 1.3 * other["nodesPrimary"], (other["nodesPrimary"], ref["stats"]["nodesPrimary"])
+        assert other["trisPrimary"] <= ref["stats"]["trisPrimary"] <= 1.5 * other["trisPrimary"], (other["trisPrimary"], ref["stats"]["trisPrimary"])
+
+
 def test_street_class_instancing(built, tmp_path):
     """BASELINE config 4 stand-in at test size: EXT_mesh_gpu_instancing (hundreds of render nodes from a few meshes), ~130
     materials, alpha-MASK trees, sun + sky."""

@@ -710,6 +710,10 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
   S.texRefs = pt->texRefs.ptr; S.alphaTris = nullptr; S.shadeTris = nullptr; S.srgbLut = pt->srgbLut.ptr; S.numMaterials = sd->numMaterials; S.numTextures = sd->numTextures;
   S.numLights = sd->numLights; S.numNodes = sd->numRenderNodes;
   S.envWidth = 0; S.envHeight = 0;
+  {
+    const char* e    = getenv("MI_PT_PACKET_INTERVAL");  // A/B switch: 0 = the per-ray node test in every packet
+    S.packetInterval = e ? atoi(e) : 1;
+  }
   if(int rc = buildAcceleration(pt.get()))
     return rc;
   phase("shade / alpha records");

@@ -10,6 +10,7 @@
 #include "pt_shading.h"
 #include "pt_bvh.h"
 #include "pt_bvh8.h"
+#include "pt_packet.h"
 #include "pt_feed.h"
 
 namespace pt {
@@ -1107,6 +1108,55 @@ PT_DEV void scalarLoadNodePlanes(const uint4* nodes, const float* planes, uint32
   n0 = make_uint4(a[0], a[1], a[2], a[3]);
   n1 = make_uint4(b[0], b[1], b[2], b[3]);
 }
+// the two header words of a node alone (origin, exponents, inner mask | child base, triangle base, leaf meta)
+PT_DEV void scalarLoadNodeHeader(const uint4* nodes, uint32_t index, uint4& n0, uint4& n1)
+{
+  const uint64_t addr = uint64_t(reinterpret_cast<uintptr_t>(nodes)) + uint64_t(index) * 80ull;
+  const uint64_t A    = (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(uint32_t(addr >> 32)))) << 32) | uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(uint32_t(addr))));
+  u32x4s         a, b;
+  asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x10\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(A) : "memory");
+  n0 = make_uint4(a[0], a[1], a[2], a[3]);
+  n1 = make_uint4(b[0], b[1], b[2], b[3]);
+}
+// ---- cross-lane pieces of the interval node test (pt_packet.h): lane = child * 8 + plane
+template <int CTRL>
+PT_DEV float dppMove(float v)  // every lane reads the lane CTRL names inside its row; all 64 lanes take part
+{
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// over the aligned group of eight lanes: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror
+PT_DEV float group8Max(float v)
+{
+  v = fmaxf(v, dppMove<0xB1>(v));
+  v = fmaxf(v, dppMove<0x4E>(v));
+  return fmaxf(v, dppMove<0x141>(v));
+}
+PT_DEV float group8Min(float v)
+{
+  v = fminf(v, dppMove<0xB1>(v));
+  v = fminf(v, dppMove<0x4E>(v));
+  return fminf(v, dppMove<0x141>(v));
+}
+PT_DEV float waveMax(float v)
+{
+#pragma unroll
+  for(int o = 32; o >= 1; o >>= 1)
+    v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+PT_DEV float waveMin(float v)
+{
+#pragma unroll
+  for(int o = 32; o >= 1; o >>= 1)
+    v = fminf(v, __shfl_xor(v, o));
+  return v;
+}
+// bits 0, 8, ..., 56 of a ballot -> bits 0..7
+PT_DEV uint32_t everyEighthBit(unsigned long long m)
+{
+  const uint32_t lo = uint32_t(m) & 0x01010101u, hi = uint32_t(m >> 32) & 0x01010101u;
+  return ((lo * 0x01020408u) >> 24) | (((hi * 0x01020408u) >> 24) << 4);
+}
 PT_DEV DevTri scalarLoadTri(const DevTri* tris, uint32_t index)
 {
   const uint64_t addr = uint64_t(reinterpret_cast<uintptr_t>(tris)) + uint64_t(index) * 48ull;
@@ -1180,6 +1230,27 @@ __global__ void __launch_bounds__(256, PRIMARY_MIN_WAVES) k_trace_primary(DevSce
     const uint32_t offNx = (oct & 1u) ? 32u : 0u, offFx = 32u - offNx, offNy = 64u + ((oct & 2u) ? 32u : 0u), offFy = 160u - offNy;
     const uint32_t offNz = 128u + ((oct & 4u) ? 32u : 0u), offFz = 288u - offNz;
     const float    sgnx = (oct & 1u) ? 1.0f : -1.0f, sgny = (oct & 2u) ? 1.0f : -1.0f, sgnz = (oct & 4u) ? 1.0f : -1.0f;
+    // Interval node test (pt_packet.h) for the packets it is tight for: 64 samples of one pixel (pixel-major slots) leaving one point
+    // (no lens) into one octant.  lane = child * 8 + plane tests one plane against the packet's interval ray; ~35 vector
+    // instructions per node instead of 174.  A child entered without need costs a visit and changes nothing.
+    bool       useInterval = false;
+    PacketLane PL{};
+    float      tmaxPacket = INFINITE_F;  // the largest distance any ray of the packet still accepts
+    if(oneOct && fc.slotLayout == 1 && sc.packetInterval != 0)
+    {
+      const float ox = __shfl(r.org.x, int(firstLane)), oy = __shfl(r.org.y, int(firstLane)), oz = __shfl(r.org.z, int(firstLane));
+      if(__ballot(active && (r.org.x != ox || r.org.y != oy || r.org.z != oz)) == 0ull)
+      {
+        const float  inf = __builtin_inff();
+        PacketBounds B;
+        B.omin[0] = B.omax[0] = ox; B.omin[1] = B.omax[1] = oy; B.omin[2] = B.omax[2] = oz;
+        B.imin[0] = waveMin(active ? r.idir.x : inf); B.imax[0] = waveMax(active ? r.idir.x : -inf);
+        B.imin[1] = waveMin(active ? r.idir.y : inf); B.imax[1] = waveMax(active ? r.idir.y : -inf);
+        B.imin[2] = waveMin(active ? r.idir.z : inf); B.imax[2] = waveMax(active ? r.idir.z : -inf);
+        PL          = makePacketLane(lane, oct, B);
+        useInterval = true;
+      }
+    }
     for(;;)
     {
       if((gBits >> 8) == 0u)
@@ -1212,8 +1283,24 @@ __global__ void __launch_bounds__(256, PRIMARY_MIN_WAVES) k_trace_primary(DevSce
           overflow = true;
       }
       uint4    n0, n1;
-      uint32_t hm = 0;
-      if(oneOct)
+      uint32_t hm = 0, hmU = 0;  // hm: children this lane's ray enters; hmU: children any ray of the packet enters
+      if(useInterval)
+      {
+        // this lane's plane of this lane's child: the node's 48 plane floats in one read, issued BEFORE the header's scalar loads
+        // (whose helper waits for them) so that the two latencies of this serial walk overlap
+        const float q  = PL.live ? sc.bvh8Planes[size_t(child) * 48u + PL.planeOffset] : 0.0f;
+        scalarLoadNodeHeader(sc.bvh8Nodes, child, n0, n1);
+        const float sx = __uint_as_float((n0.w & 0xffu) << 23), sy = __uint_as_float(((n0.w >> 8) & 0xffu) << 23), sz = __uint_as_float(((n0.w >> 16) & 0xffu) << 23);
+        const float sA = PL.axis == 0u ? sx : (PL.axis == 1u ? sy : sz);
+        const float pA = __uint_as_float(PL.axis == 0u ? n0.x : (PL.axis == 1u ? n0.y : n0.z));
+        const float cand = packetPlaneTime(PL, q, pA, sA);
+        const float inf  = __builtin_inff();
+        const float tn   = group8Max((PL.live && PL.entry) ? cand : -inf);
+        const float tf   = group8Min((PL.live && !PL.entry) ? cand : inf);
+        hmU = everyEighthBit(__ballot(packetChildHit(tn, tf, tmaxPacket) && (lane & 7u) == 0u));
+        hm  = active ? hmU : 0u;  // every ray of the packet tests the triangles of an entered leaf child
+      }
+      else if(oneOct)
       {
         f32x8s pnx, pny, pnz, pfx, pfy, pfz;
         scalarLoadNodePlanes(sc.bvh8Nodes, sc.bvh8Planes, child, offNx, offNy, offNz, offFx, offFy, offFz, n0, n1, pnx, pny, pnz, pfx, pfy, pfz);
@@ -1230,10 +1317,12 @@ __global__ void __launch_bounds__(256, PRIMARY_MIN_WAVES) k_trace_primary(DevSce
       }
       if(COUNT && lane == firstLane) ++nodes;  // counters = records FETCHED: one per wave here, one per lane in the per-lane kernels
       // a child is entered / its triangles are tested when any lane hits its box
-      uint32_t hmU = 0;
+      if(!useInterval)
+      {
 #pragma unroll
-      for(int i = 0; i < 8; ++i)
-        hmU |= (__ballot((hm >> i) & 1u) != 0ull) ? (1u << i) : 0u;
+        for(int i = 0; i < 8; ++i)
+          hmU |= (__ballot((hm >> i) & 1u) != 0ull) ? (1u << i) : 0u;
+      }
       const uint32_t imask = n0.w >> 24;
       uint32_t       hits  = hmU & imask;
       hits = (octinv & 1u) ? (((hits & 0x55u) << 1) | ((hits & 0xaau) >> 1)) : hits;
@@ -1241,7 +1330,8 @@ __global__ void __launch_bounds__(256, PRIMARY_MIN_WAVES) k_trace_primary(DevSce
       hits = (octinv & 4u) ? (((hits & 0x0fu) << 4) | ((hits & 0xf0u) >> 4)) : hits;
       gBase = n1.x;
       gBits = (hits << 8) | imask;
-      uint32_t leafU = hmU & ~imask;
+      uint32_t    leafU   = hmU & ~imask;
+      const float tBefore = best.t;
       while(leafU)
       {
         const int i = __ffs(int(leafU)) - 1;
@@ -1259,6 +1349,8 @@ __global__ void __launch_bounds__(256, PRIMARY_MIN_WAVES) k_trace_primary(DevSce
           }
         }
       }
+      if(useInterval && __ballot(active && best.t < tBefore) != 0ull)
+        tmaxPacket = waveMax(active ? best.t : -__builtin_inff());  // some ray found something nearer: the packet's bound may shrink
     }
     (void)overflow;  // PACKET_STACK covers any tree the builder emits for < 2^31 triangles at branching >= 2 per pending group
   }

@@ -147,6 +147,7 @@ struct DevScene
   int                        numTris;
   int                        bvh8NumNodes;
   int                        bvhRoot;  // node index, or ~tri for a single-triangle scene; INT_MIN when empty
+  int                        packetInterval;  // k_trace_primary: interval node test for one-pixel packets (pt_packet.h); 0 = per-ray test everywhere
 };
 
 // ---- per-frame constants (kernel argument, ~600 B) ---------------------------------------------------------------------
