@@ -23,3 +23,5 @@ for m in 1; do
   run street_iv$m python bench.py --workload street --steps 2 --warmup 1 $N
   run helmet4k_iv$m python bench.py --workload helmet --width 3840 --height 2160 --in-flight 64 --steps 3 --warmup 1 $N
 done
+unset MI_PT_PACKET_INTERVAL
+run helmet_f1 python bench.py --workload helmet --in-flight 1 --frames-per-step 64 --steps 3 --warmup 1 $N

@@ -1176,7 +1176,10 @@ PT_DEV DevTri scalarLoadTri(const DevTri* tris, uint32_t index)
 #ifndef PRIMARY_MIN_WAVES
 #define PRIMARY_MIN_WAVES 4
 #endif
-template <bool HAS_ALPHA, bool COUNT>
+// INTERVAL: the launch whose packets are one pixel's samples (pixel-major slots): eligible packets take the interval node test
+// (pt_packet.h), the others the per-ray byte path.  The per-ray plane path lives in the other instantiation only, so that neither
+// pays the other's registers.
+template <bool HAS_ALPHA, bool COUNT, bool INTERVAL>
 __global__ void __launch_bounds__(256, PRIMARY_MIN_WAVES) k_trace_primary(DevScene sc, FrameConsts fc, const DevScene* __restrict__ scp, const FrameConsts* __restrict__ fcp, PathSoA P,
                                                         Queues Q, const uint32_t* ownedTiles, int sampleIndex, uint32_t batchSlots, StatCounters* stats)
 {
@@ -1226,7 +1229,8 @@ __global__ void __launch_bounds__(256, PRIMARY_MIN_WAVES) k_trace_primary(DevSce
     bool           overflow = false;
     // one-octant packets (nearly all of them) test the nodes through the float planes in SGPRs (pt_bvh8.h)
     const uint32_t oct      = 7u ^ octinv;  // bit a set: direction component a is negative
-    const bool     oneOct   = sc.bvh8Planes != nullptr && __ballot(active && rayOctInv(r.idir) != octinv) == 0ull;
+    const bool     oneOctAny = sc.bvh8Planes != nullptr && __ballot(active && rayOctInv(r.idir) != octinv) == 0ull;
+    const bool     oneOct    = !INTERVAL && oneOctAny;  // the per-ray plane path
     const uint32_t offNx = (oct & 1u) ? 32u : 0u, offFx = 32u - offNx, offNy = 64u + ((oct & 2u) ? 32u : 0u), offFy = 160u - offNy;
     const uint32_t offNz = 128u + ((oct & 4u) ? 32u : 0u), offFz = 288u - offNz;
     const float    sgnx = (oct & 1u) ? 1.0f : -1.0f, sgny = (oct & 2u) ? 1.0f : -1.0f, sgnz = (oct & 4u) ? 1.0f : -1.0f;
@@ -1236,7 +1240,7 @@ __global__ void __launch_bounds__(256, PRIMARY_MIN_WAVES) k_trace_primary(DevSce
     bool       useInterval = false;
     PacketLane PL{};
     float      tmaxPacket = INFINITE_F;  // the largest distance any ray of the packet still accepts
-    if(oneOct && fc.slotLayout == 1 && sc.packetInterval != 0)
+    if(INTERVAL && oneOctAny)
     {
       const float ox = __shfl(r.org.x, int(firstLane)), oy = __shfl(r.org.y, int(firstLane)), oz = __shfl(r.org.z, int(firstLane));
       if(__ballot(active && (r.org.x != ox || r.org.y != oy || r.org.z != oz)) == 0ull)
@@ -1284,7 +1288,7 @@ __global__ void __launch_bounds__(256, PRIMARY_MIN_WAVES) k_trace_primary(DevSce
       }
       uint4    n0, n1;
       uint32_t hm = 0, hmU = 0;  // hm: children this lane's ray enters; hmU: children any ray of the packet enters
-      if(useInterval)
+      if(INTERVAL && useInterval)
       {
         // this lane's plane of this lane's child: the node's 48 plane floats in one read, issued BEFORE the header's scalar loads
         // (whose helper waits for them) so that the two latencies of this serial walk overlap
@@ -1300,7 +1304,7 @@ __global__ void __launch_bounds__(256, PRIMARY_MIN_WAVES) k_trace_primary(DevSce
         hmU = everyEighthBit(__ballot(packetChildHit(tn, tf, tmaxPacket) && (lane & 7u) == 0u));
         hm  = active ? hmU : 0u;  // every ray of the packet tests the triangles of an entered leaf child
       }
-      else if(oneOct)
+      else if(!INTERVAL && oneOct)
       {
         f32x8s pnx, pny, pnz, pfx, pfy, pfz;
         scalarLoadNodePlanes(sc.bvh8Nodes, sc.bvh8Planes, child, offNx, offNy, offNz, offFx, offFy, offFz, n0, n1, pnx, pny, pnz, pfx, pfy, pfz);
@@ -1317,7 +1321,7 @@ __global__ void __launch_bounds__(256, PRIMARY_MIN_WAVES) k_trace_primary(DevSce
       }
       if(COUNT && lane == firstLane) ++nodes;  // counters = records FETCHED: one per wave here, one per lane in the per-lane kernels
       // a child is entered / its triangles are tested when any lane hits its box
-      if(!useInterval)
+      if(!(INTERVAL && useInterval))
       {
 #pragma unroll
         for(int i = 0; i < 8; ++i)
@@ -1349,7 +1353,7 @@ __global__ void __launch_bounds__(256, PRIMARY_MIN_WAVES) k_trace_primary(DevSce
           }
         }
       }
-      if(useInterval && __ballot(active && best.t < tBefore) != 0ull)
+      if(INTERVAL && useInterval && __ballot(active && best.t < tBefore) != 0ull)
         tmaxPacket = waveMax(active ? best.t : -__builtin_inff());  // some ray found something nearer: the packet's bound may shrink
     }
     (void)overflow;  // PACKET_STACK covers any tree the builder emits for < 2^31 triangles at branching >= 2 per pending group
@@ -2911,8 +2915,16 @@ void launchTracePrimary(const LaunchCtx& c, int sampleIndex)
 {
   const uint32_t batchSlots = uint32_t(c.fc.numSlots) * uint32_t(c.fc.numFrames);
   dim3           grid(batchSlots / 256u), block(256);  // one workgroup per 256-slot chunk (numSlots is a multiple of 256)
-#define MI_LAUNCH_PRIMARY(A, C) \
-  hipLaunchKernelGGL((k_trace_primary<A, C>), grid, block, 0, c.stream, c.scene, c.fc, c.sceneDev, c.fcDev, c.paths, c.queues, c.ownedTiles, sampleIndex, batchSlots, c.stats)
+  // packets of one pixel's samples (pixel-major slots) take the interval node test: its own instantiation
+  const bool interval = c.fc.slotLayout == 1 && c.scene.packetInterval != 0 && c.scene.bvh8Planes != nullptr;
+#define MI_LAUNCH_PRIMARY(A, C)                                                                                                                   \
+  do                                                                                                                                              \
+  {                                                                                                                                               \
+    if(interval)                                                                                                                                  \
+      hipLaunchKernelGGL((k_trace_primary<A, C, true>), grid, block, 0, c.stream, c.scene, c.fc, c.sceneDev, c.fcDev, c.paths, c.queues, c.ownedTiles, sampleIndex, batchSlots, c.stats);  \
+    else                                                                                                                                          \
+      hipLaunchKernelGGL((k_trace_primary<A, C, false>), grid, block, 0, c.stream, c.scene, c.fc, c.sceneDev, c.fcDev, c.paths, c.queues, c.ownedTiles, sampleIndex, batchSlots, c.stats); \
+  } while(0)
   if(c.hasAlpha)
   {
     if(c.collectCounters) MI_LAUNCH_PRIMARY(true, true); else MI_LAUNCH_PRIMARY(true, false);
