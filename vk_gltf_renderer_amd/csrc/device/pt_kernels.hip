@@ -1179,8 +1179,11 @@ PT_DEV DevTri scalarLoadTri(const DevTri* tris, uint32_t index)
 // INTERVAL: the launch whose packets are one pixel's samples (pixel-major slots): eligible packets take the interval node test
 // (pt_packet.h), the others the per-ray byte path.  The per-ray plane path lives in the other instantiation only, so that neither
 // pays the other's registers.
+#ifndef PRIMARY_INTERVAL_MIN_WAVES
+#define PRIMARY_INTERVAL_MIN_WAVES PRIMARY_MIN_WAVES
+#endif
 template <bool HAS_ALPHA, bool COUNT, bool INTERVAL>
-__global__ void __launch_bounds__(256, PRIMARY_MIN_WAVES) k_trace_primary(DevScene sc, FrameConsts fc, const DevScene* __restrict__ scp, const FrameConsts* __restrict__ fcp, PathSoA P,
+__global__ void __launch_bounds__(256, INTERVAL ? PRIMARY_INTERVAL_MIN_WAVES : PRIMARY_MIN_WAVES) k_trace_primary(DevScene sc, FrameConsts fc, const DevScene* __restrict__ scp, const FrameConsts* __restrict__ fcp, PathSoA P,
                                                         Queues Q, const uint32_t* ownedTiles, int sampleIndex, uint32_t batchSlots, StatCounters* stats)
 {
   // `sc` / `fc` (kernel arguments, SGPRs) serve the inlined generation and walk; the non-inlined environment helpers of the miss
