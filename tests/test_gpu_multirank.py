@@ -34,6 +34,16 @@ if rank == 0:
     assert (t.numpy() == full).all(), "reduced tiles differ from the single-rank frame"
     np.save(os.environ["MI_OUT"], t.numpy())
 dist.barrier()
+# the same with 64 frames in flight: pixel-major path slots over the rank's own tiles, camera-ray packets of one pixel's samples
+# (interval node test) -- the layout bench.py --gpus N runs with
+part64 = pu.render_gpu(s, 64, collect_counters=False, tile=(rank, world, 32), in_flight=64)["accum"]
+t64 = torch.from_numpy(part64.copy())
+dist.barrier()
+dist.reduce(t64, dst=0, op=dist.ReduceOp.SUM)
+if rank == 0:
+    full64 = pu.render_gpu(s, 64, collect_counters=False, in_flight=64)["accum"]
+    assert (t64.numpy() == full64).all(), "64 frames in flight: reduced tiles differ from the single-rank frame"
+dist.barrier()
 dist.destroy_process_group()
 '''
 
