@@ -3,8 +3,8 @@
 
 A "step" is one pass of the hot path over one batch of synthetic input: `--frames-per-step` (default 256) consecutive frames
 per GPU, each ptSamples = 1 sample per pixel like the reference's headless run `--frames K --ptSamples 1`
-(docs/benchmarking.md:16-23), of the workload BASELINE.json's metric is quoted on and that fits one GPU: configs[1],
-DamagedHelmet-class + std_env.hdr, 1920x1080, depth 8 (the asset itself is not available offline;
+(docs/benchmarking.md:16-23).  The default workload is the one the north-star target is stated on and that fits one GPU:
+configs[2], Sponza-class atrium, 1920x1080, depth 12, NEE + MIS (the asset itself is not available offline;
 vk_gltf_renderer_amd.scenegen writes a seeded stand-in of the same class as a .glb).  The frames of a step are issued through
 mi_pt_render_frames in groups of `--in-flight` (default 128) that share every wavefront launch (bit-identical to rendering them
 one after the other; --in-flight 1 gives exactly that).  Metric = the reference's throughput_MSps (src/benchmarking.cpp:272-279):
@@ -13,16 +13,26 @@ W*H*spp / wall_s / 1e6 with spp = all samples of the timed region, inputs reside
 N > 1: the image is split into interleaved 32x32 tiles (--tile; tile % N == rank), every rank renders its tiles with no data-path
 collective, and ONE RCCL reduce(sum) of the RGBA32F accumulator over xGMI closes every step (inside the timed region).  A rank
 owns 1/N of every frame, so a step renders frames_per_step * N frames: the work per GPU is fixed as N grows -> "weak" scaling.
+`python bench.py --gpus N` without a launcher starts its own N ranks (torch.distributed.run on 127.0.0.1) and refuses to run when
+fewer than N devices are visible.
 
 Rank 0 prints ONE JSON line.  Besides the driver's fields it carries
-  roofline      the dominant kernel against the roof that bounds it ("hbm": algorithmic bytes per launch over the launch time vs
-                8 TB/s; "valu": useful vector-lane operations per launch over the launch time vs 78.6 Tlaneop/s), and under
-                "kernels" the same for every kernel of the step (DESIGN.md §4 states the byte / operation model);
-  also          measured right after the default helmet workload on the same GPU: "atrium", the Sponza-class workload (configs[2], the one the
-                north-star target is stated on) with its own cpu_baseline + parity, and "helmet_4k", the default workload at 3840x2160
-                (the metric's 4K half): value, per-kernel table, counters, 5 timed steps each;
+  north_star    the Sponza-class value again with the per-GPU rate the 8-GPU target needs;
+  roofline      the dominant kernel against the roof that bounds it, and under "kernels" the same for every kernel of the step.
+                "hbm" kernels: frac = bytes that CROSS THE MEMORY INTERFACE per launch (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this
+                command, calibrated, committed as profiles/pmc_latest_<workload>.json) / the launch time measured in THIS run / 8 TB/s --
+                it cannot pass 1; SURVEY 8(d)'s algorithmic bytes stand beside it as `algorithmic_frac` (which can: caches serve most of
+                them).  "valu" kernels (the BVH walks, bound by vector-instruction issue): frac = USEFUL vector-lane operations (slab and
+                triangle tests at 64 lanes, per-kernel instruction counts of the compiled code) per launch / launch time / 78.6 Tlaneop/s, with
+                the measured issue fraction (`issue_frac`: vector instructions x 4 cycles / SIMD cycles, from the committed SQ counter pass)
+                beside it.  DESIGN.md section 4 states both models;
+  also          the other configurations of BASELINE.json measured right after the headline on the same GPU, each with its own per-kernel
+                table: "helmet" (configs[1]), "helmet_4k" (the same at 3840x2160), "street" (configs[3], 3840x2160) and "glass_denoise"
+                (configs[4] with its a-trous pass), the ones with a different scene with their own cpu_baseline + parity leg;
   cpu_baseline  the CPU oracle timed on the host cores on a bounded sample of the same frames;
-  parity        the GPU accumulator against the oracle's on exactly those sample tiles (same frames, same seeds).
+  parity        the GPU accumulator against the oracle's on exactly those sample tiles (same frames, same seeds) after the configuration's
+                OWN sample count (256 spp for configs[2]), with the figure at a quarter and half of it (`by_spp`) so that the
+                1/sqrt(spp) fall of the difference is visible.
 """
 import argparse
 import ctypes as C
@@ -42,24 +52,37 @@ import numpy as np  # noqa: E402
 IN_FLIGHT_DEFAULT, FRAMES_PER_STEP_DEFAULT = 128, 256
 ALPHA_CUT_DEFAULT = 4  # measured (adaptive cut): atrium 462 -> 483 / 479 / 494 and street 455 -> 510 / 507 / 490 Msamples/s at 4 / 8 / 16
 WORKLOADS = {
-    # name: (BASELINE config, generator kwargs, width, height, maxDepth, env)
-    "helmet": dict(config="configs[1]: DamagedHelmet-class + std_env.hdr, 1920x1080, depth 8", gen="scene_helmet_class",
-                   kw=dict(seed=1234, tess=272, tex_size=2048), width=1920, height=1080, depth=8, hdr=True),
-    "atrium": dict(config="configs[2]: Sponza-class, 1920x1080, depth 12, NEE+MIS (directional light + sky)", gen="scene_atrium_class",
-                   kw=dict(seed=4321, detail=0.8, tex_size=512), width=1920, height=1080, depth=12, hdr=False),
-    "street": dict(config="configs[3]: BistroExterior-class (instanced street, ~2.8 M triangles, ~1000 render nodes, 130 materials), 3840x2160, depth 8",
-                   gen="scene_street_class", kw=dict(seed=777, detail=1.27, tex_size=256), width=3840, height=2160, depth=8, hdr=False),
-    "glass": dict(config="configs[4]: TransmissionTest-class, 1920x1080, depth 24", gen="scene_glass_class",
-                  kw=dict(seed=99, tess=96), width=1920, height=1080, depth=24, hdr=True, in_flight=256, frames_per_step=512),
-    "box": dict(config="configs[0]: resources/Box.glb, 256x256, depth 4", gen=None, kw={}, width=256, height=256, depth=4, hdr=True),
+    # name: BASELINE config, generator kwargs, width, height, maxDepth, env, spp = the configuration's OWN sample count (the parity leg's)
+    "helmet": dict(config="configs[1]: DamagedHelmet-class + std_env.hdr, 1920x1080, 64 spp, depth 8", gen="scene_helmet_class",
+                   kw=dict(seed=1234, tess=272, tex_size=2048), width=1920, height=1080, depth=8, hdr=True, spp=64),
+    "atrium": dict(config="configs[2]: Sponza-class, 1920x1080, 256 spp, depth 12, NEE+MIS (directional light + sky)", gen="scene_atrium_class",
+                   kw=dict(seed=4321, detail=0.8, tex_size=512), width=1920, height=1080, depth=12, hdr=False, spp=256),
+    "street": dict(config="configs[3]: BistroExterior-class (instanced street, ~2.8 M triangles, ~1000 render nodes, 130 materials), 3840x2160, 64 spp, depth 8",
+                   gen="scene_street_class", kw=dict(seed=777, detail=1.27, tex_size=256), width=3840, height=2160, depth=8, hdr=False, spp=64),
+    "glass": dict(config="configs[4]: TransmissionTest-class, 1920x1080, 512 spp, depth 24", gen="scene_glass_class",
+                  kw=dict(seed=99, tess=96), width=1920, height=1080, depth=24, hdr=True, in_flight=256, frames_per_step=512, spp=512),
+    "box": dict(config="configs[0]: resources/Box.glb, 256x256, 16 spp, depth 4", gen=None, kw={}, width=256, height=256, depth=4, hdr=True, spp=16),
 }
+# lines of the default run's "also": name -> (workload, width, height, denoise, parity leg)
+ALSO_LINES = {
+    "helmet": ("helmet", 0, 0, False, True),
+    "helmet_4k": ("helmet", 3840, 2160, False, False),  # the same scene as "helmet": no second parity leg
+    "atrium": ("atrium", 0, 0, False, True),
+    "street": ("street", 0, 0, False, True),
+    "glass": ("glass", 0, 0, False, True),
+    "glass_denoise": ("glass", 0, 0, True, True),
+}
+ALSO_DEFAULT = "helmet,helmet_4k,street,glass_denoise"
+NORTH_STAR = {"workload": "atrium", "target": ">= 2 Gsamples/s on Sponza 1080p at 8 x MI355X (BASELINE.json north_star)", "needs_per_gpu_Msamples_s": 250.0}
 # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy); 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T
-# vector-lane operations per second (a wave64 instruction issues over 2 cycles; x2 flops per fma = the 157.3 TFLOP/s fp32 peak)
+# vector-lane operations per second (x2 flops per fma = the 157.3 TFLOP/s fp32 vector peak)
 HBM_PEAK_GBS = 8000.0
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
-# Vector-ALU instructions of the two inner operations of the BVH walk, counted in the compiled code (tools/count_valu.sh):
-# one 8-wide node visit (decode + 8 slab tests + child order) and one triangle test (Moeller-Trumbore + candidate update).
-VALU_PER_NODE, VALU_PER_TRI = 235, 56
+# Vector-ALU instructions of the inner operations of the BVH walks, counted in the compiled code (tools/count_valu.sh): one 8-wide
+# node visit of the per-lane walk (decode + 8 slab tests + child order), one triangle test (Moeller-Trumbore + candidate update),
+# and one node of the packet walk's INTERVAL test (k_trace_primary with pixel-major slots: lane = child x 8 + plane tests one plane
+# of the node against the packet's interval ray -- all 64 lanes of ~50 instructions work on ONE node, pt_packet.h)
+VALU_PER_NODE, VALU_PER_TRI, VALU_PER_PACKET_NODE = 235, 56, 50
 # SURVEY §8(d) algorithmic bytes, per unit: ray + hit record, path state read + write, hit-attribute gather, instance +
 # primitive + material records, shadow-ray record, one texture tap, pixel accumulate
 B_RAYHIT, B_STATE, B_ATTR, B_RECORDS, B_SHADOW, B_TAP, B_PIXEL = 60, 192, 192, 480, 76, 48, 32
@@ -81,19 +104,43 @@ def scene_path(name, rank):
     return path
 
 
-def kernel_table(all_b, first_b, timing, frames, in_flight=0):
+def load_pmc(workload, F, W, H):
+    """The committed counter passes of this configuration (profiles/pmc_latest_<workload>[_4k].json, written by tools/make_pmc_latest.py
+    from separate rocprofv3 --pmc runs of this command), or None when no pass matches workload / resolution / frames in flight.
+    Never measured inside this run: counter collection serialises the kernels."""
+    tag = workload + ("_4k" if (workload == "helmet" and W == 3840) else "")
+    for f in (os.path.join(ROOT, "profiles", f"pmc_latest_{tag}.json"),):
+        try:
+            pmc = json.load(open(f))
+        except Exception:
+            continue
+        if pmc.get("workload") == workload and pmc.get("frames_in_flight") == F and pmc.get("resolution") == [W, H]:
+            pmc["_file"] = f"profiles/{os.path.basename(f)}"
+            return pmc
+    return None
+
+
+def kernel_table(all_b, first_b, timing, frames, in_flight=0, pmc=None):
     """Per-kernel roofline entries.  all_b / first_b: counters PER FRAME of the whole path loop and of bounce 0 alone (a second
-    counter pass with maxDepth = 1); timing: MiPtFrameTiming totals over `frames` frames.  A kernel's algorithmic work per launch
-    is (work per frame) x (frames per launch); SURVEY §8(d) defines the bytes, hit/miss aware: a segment that leaves the scene
-    carries its ray and path state only, the attribute / record / texture / shadow terms belong to the surface hits."""
+    counter pass with maxDepth = 1); timing: MiPtFrameTiming totals over `frames` frames; pmc: load_pmc() of this configuration.
+    "hbm" rows: achieved = bytes across the memory interface per launch (pmc) / THIS run's launch time, frac = achieved / 8 TB/s; the
+    SURVEY 8(d) bytes (hit/miss aware: a segment that leaves the scene carries its ray and path state only) / launch time are
+    `algorithmic_GBps`, `algorithmic_frac` -- a figure that can pass 1 because caches serve most of those bytes.
+    "valu" rows: achieved = useful vector-lane operations per launch / launch time, frac = achieved / 78.6 Tlaneop/s; `issue_frac`
+    (pmc) = vector instructions x 4 cycles / (1024 SIMDs x launch time x 2.4 GHz), `active_lanes` = lanes per vector instruction."""
     rest = {k: all_b[k] - first_b.get(k, 0) for k in all_b}
     fused = timing["tracePrimaryLaunches"] > 0
+    interval = in_flight >= 64 and in_flight % 64 == 0  # pixel-major slots: k_trace_primary tests nodes against the packet's interval ray
+    pk = (pmc or {}).get("kernels", {})
 
     def shade_bytes(c, shaded):
         return shaded * (B_RAYHIT + B_STATE) + c["surfaceHits"] * (B_ATTR + B_RECORDS + B_SHADOW) + c["textureTaps"] * B_TAP
 
-    def walk_ops(nodes, tris, per_wave):
-        return (nodes * VALU_PER_NODE + tris * VALU_PER_TRI) * (64 if per_wave else 1)
+    def walk_ops(nodes, tris):
+        return nodes * VALU_PER_NODE + tris * VALU_PER_TRI
+
+    def packet_ops(nodes, tris):  # every lane of the wave works on every record the wave fetches
+        return 64 * (nodes * (VALU_PER_PACKET_NODE if interval else VALU_PER_NODE) + tris * VALU_PER_TRI)
 
     rows = {}
 
@@ -102,35 +149,62 @@ def kernel_table(all_b, first_b, timing, frames, in_flight=0):
             return
         per_launch = work_per_frame * frames / launches
         avg_ms = ms / launches
+        p = pk.get(name)
+        row = {"bound": bound}
         if bound == "hbm":
-            achieved, peak, unit = per_launch / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+            alg = per_launch / (avg_ms * 1e-3) / 1e9
+            traffic = p["hbm_bytes_per_launch"] if p else None
+            achieved = traffic / (avg_ms * 1e-3) / 1e9 if traffic else None
+            row.update({"achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic,
+                        "algorithmic_GBps": round(alg, 1), "algorithmic_frac": round(alg / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": round(per_launch)})
         else:
-            achieved, peak, unit = per_launch / (avg_ms * 1e-3) / 1e12, VALU_PEAK_TLANEOPS, "Tlaneop/s"
-        rows[name] = {"bound": bound, "achieved": round(achieved, 3), "peak": round(peak, 2), "unit": unit, "frac": round(achieved / peak, 4),
-                      "avg_launch_ms": round(avg_ms, 5), "launches": launches, "ms_per_frame": round(ms / frames, 5),
-                      "work_per_launch": round(per_launch), "model": note}
+            achieved = per_launch / (avg_ms * 1e-3) / 1e12
+            row.update({"achieved": round(achieved, 3), "peak": round(VALU_PEAK_TLANEOPS, 2), "unit": "Tlaneop/s", "frac": round(achieved / VALU_PEAK_TLANEOPS, 4),
+                        "traffic": p["hbm_bytes_per_launch"] if p else None, "useful_laneops_per_launch": round(per_launch)})
+        if p:
+            for k in ("issue_frac", "active_lanes", "l2_hit_rate", "executed_valu_per_node_step"):
+                if p.get(k) is not None:
+                    row[k] = p[k]
+        row.update({"avg_launch_ms": round(avg_ms, 5), "launches": launches, "ms_per_frame": round(ms / frames, 5), "model": note})
+        rows[name] = row
 
     if fused:
-        add("trace_primary", timing["tracePrimaryMs"], timing["tracePrimaryLaunches"], "valu", walk_ops(all_b["nodesPrimary"], all_b["trisPrimary"], True),
-            "64 x (nodesPrimary x 235 + trisPrimary x 56) lane-ops (every lane of the wave tests every record the wave fetches)")
+        add("trace_primary", timing["tracePrimaryMs"], timing["tracePrimaryLaunches"], "valu", packet_ops(all_b["nodesPrimary"], all_b["trisPrimary"]),
+            f"64 x (nodesPrimary x {VALU_PER_PACKET_NODE if interval else VALU_PER_NODE} + trisPrimary x {VALU_PER_TRI}) lane-ops (packet walk: "
+            + ("interval node test, one plane per lane" if interval else "every lane tests every child") + ")")
         add("shade_first", timing["shadeFirstMs"], timing["shadeFirstLaunches"], "hbm", shade_bytes(first_b, first_b["surfaceHits"]),
-            "bounce 0: surfaceHits x (60 + 192 + 192 + 480 + 76) + textureTaps x 48 B (camera rays that leave the scene end in k_trace_primary)")
+            "algorithmic: bounce 0: surfaceHits x (60 + 192 + 192 + 480 + 76) + textureTaps x 48 B (camera rays that leave the scene end in k_trace_primary)")
         add("trace_closest", timing["traceClosestMs"] - timing["tracePrimaryMs"], timing["traceClosestLaunches"] - timing["tracePrimaryLaunches"], "valu",
-            walk_ops(all_b["nodesClosest"], all_b["trisClosest"], False), "nodesClosest x 235 + trisClosest x 56 lane-ops (bounces >= 1)")
+            walk_ops(all_b["nodesClosest"], all_b["trisClosest"]), f"nodesClosest x {VALU_PER_NODE} + trisClosest x {VALU_PER_TRI} lane-ops (bounces >= 1)")
         add("shade", timing["shadeMs"] - timing["shadeFirstMs"], timing["shadeLaunches"] - timing["shadeFirstLaunches"], "hbm", shade_bytes(rest, rest["segments"]),
-            "bounces >= 1: segments x (60 + 192) + surfaceHits x (192 + 480 + 76) + textureTaps x 48 B")
+            "algorithmic: bounces >= 1: segments x (60 + 192) + surfaceHits x (192 + 480 + 76) + textureTaps x 48 B")
     else:
-        add("trace_closest", timing["traceClosestMs"], timing["traceClosestLaunches"], "valu", walk_ops(all_b["nodesClosest"], all_b["trisClosest"], False),
-            "nodesClosest x 235 + trisClosest x 56 lane-ops")
+        add("trace_closest", timing["traceClosestMs"], timing["traceClosestLaunches"], "valu", walk_ops(all_b["nodesClosest"], all_b["trisClosest"]),
+            f"nodesClosest x {VALU_PER_NODE} + trisClosest x {VALU_PER_TRI} lane-ops")
         add("shade", timing["shadeMs"], timing["shadeLaunches"], "hbm", shade_bytes(all_b, all_b["segments"]),
-            "segments x (60 + 192) + surfaceHits x (192 + 480 + 76) + textureTaps x 48 B")
-    add("trace_shadow", timing["traceShadowMs"], timing["traceShadowLaunches"], "valu", walk_ops(all_b["nodesShadow"], all_b["trisShadow"], False),
-        "nodesShadow x 235 + trisShadow x 56 lane-ops")
+            "algorithmic: segments x (60 + 192) + surfaceHits x (192 + 480 + 76) + textureTaps x 48 B")
+    add("trace_shadow", timing["traceShadowMs"], timing["traceShadowLaunches"], "valu", walk_ops(all_b["nodesShadow"], all_b["trisShadow"]),
+        f"nodesShadow x {VALU_PER_NODE} + trisShadow x {VALU_PER_TRI} lane-ops")
     if timing["accumulateMs"] > 0 and in_flight > 0:
         # k_finish_sample (SURVEY 8(d) "pixel accumulate"): one 16-B path record per pixel and frame, the accumulator once per launch
         add("finish_sample", timing["accumulateMs"], max(1, round(frames / in_flight)), "hbm", all_b["cameraPaths"] * (16.0 + 32.0 / in_flight),
-            "cameraPaths x (16 B path record + 32 B of accumulator per launch)")
+            "algorithmic: cameraPaths x (16 B path record + 32 B of accumulator per launch)")
     return rows
+
+
+def roofline_of(kernels, pmc):
+    """The `roofline` object: the kernel with the largest share of the step, from the table above."""
+    dominant = max(kernels, key=lambda k: kernels[k]["avg_launch_ms"] * kernels[k]["launches"])
+    roof = dict(kernels[dominant], kernel=dominant)
+    if pmc is not None:
+        roof["traffic_source"] = (f"{pmc['_file']} ({pmc.get('command', 'rocprofv3 --pmc passes')}; round {pmc.get('round')}; FETCH_SIZE calibrated per access class, "
+                                  f"{pmc.get('fetch_size_calibration', '')}): counters of a separate run of this configuration, launch time of THIS run")
+        if roof.get("traffic"):
+            roof["traffic_GBps"] = round(roof["traffic"] / (roof["avg_launch_ms"] * 1e-3) / 1e9, 1)
+    else:
+        roof["traffic_source"] = None
+    return roof
 
 
 # path slots (frames in flight x pixels) per GPU: ~0.3 KB of path state and queue entries per slot, ~160 GB of the 288 -- enough for 64
@@ -152,29 +226,13 @@ def alpha_cut_note(subdivisions, triangles_loaded, dropped):
                     "(mi_scene_cut_alpha, the counterpart of the reference's opacity micro-map bake); the parity leg renders the scene AS LOADED (uncut) with the CPU oracle"}
 
 
-def pmc_traffic(workload, kernel, F, W, H, avg_launch_ms):
-    """HBM bytes per launch of `kernel` from the committed counter passes of this workload (profiles/pmc_latest_<workload>.json, written by
-    tools/make_pmc_latest.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command), or nulls when no pass matches the
-    configuration.  Never measured inside this run: counter collection serialises the kernels."""
-    for f in (os.path.join(ROOT, "profiles", f"pmc_latest_{workload}.json"), os.path.join(ROOT, "profiles", "pmc_latest.json")):
-        try:
-            pmc = json.load(open(f))
-        except Exception:
-            continue
-        if pmc.get("workload") == workload and pmc.get("frames_in_flight") == F and pmc.get("resolution") == [W, H]:
-            traffic = pmc.get("bench_kernel_traffic", {}).get(kernel)
-            if traffic is not None:
-                src = (f"profiles/{os.path.basename(f)} ({pmc.get('command', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes')}; round {pmc.get('round')}; "
-                       f"FETCH_SIZE factor {pmc.get('fetch_size_factor', 2.0)} from {pmc.get('fetch_size_calibration', 'the guide (wide streaming reads)')}): not measured in this run")
-                return {"traffic": traffic, "traffic_source": src, "traffic_GBps": round(traffic / (avg_launch_ms * 1e-3) / 1e9, 1)}
-    return {"traffic": None, "traffic_source": None, "traffic_GBps": None}
-
-
-def cpu_baseline_and_parity(scene, w, W, H, F, cpu_seconds, make_gpu_tracer, gpu_params):
-    """The CPU oracle timed on the host cores on a bounded sample of the workload -- every 16th 64x64 tile of the same frames (same
-    scene bytes, seeds, depth), as many frames as fit `cpu_seconds` -- and the GPU accumulator of exactly those frames compared with
-    the oracle's on exactly those tiles.  The oracle is used here only as the timed CPU baseline and as the checker of the GPU image
-    (it renders the scene AS LOADED: no alpha cut)."""
+def cpu_baseline_and_parity(scene, w, W, H, F, cpu_seconds, make_gpu_tracer, gpu_params, parity_spp=0):
+    """The CPU oracle on the host cores over a bounded sample of the workload -- every 16th 64x64 tile of the same frames (same scene
+    bytes, seeds, depth) -- and the GPU accumulator of exactly those frames compared with the oracle's on exactly those tiles.
+    Frames = the configuration's own sample count (`parity_spp`, default WORKLOADS[..]["spp"]: 256 for configs[2]); the difference is
+    also taken at a quarter and at half of it.  The CPU baseline figure is the oracle's rate over the first `cpu_seconds` of that run.
+    The oracle is used here only as the timed CPU baseline and as the checker of the GPU image (it renders the scene AS LOADED:
+    no alpha cut)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import parity_util as pu
     import oracle_lib
@@ -195,36 +253,47 @@ def cpu_baseline_and_parity(scene, w, W, H, F, cpu_seconds, make_gpu_tracer, gpu
     O.oracle_pt_set_tile_partition(o, 0, part, 64)
     owned = [t for t in range(tiles_total) if t % part == 0]
     px_owned = sum(min(64, W - (t % tx) * 64) * min(64, H - (t // tx) * 64) for t in owned)
-    done_px, frames_done, t_cpu0 = 0, 0, time.perf_counter()
-    while time.perf_counter() - t_cpu0 < cpu_seconds and frames_done < 4096:
-        p = setup.frame_params(frames_done, frames_done)
-        O.oracle_pt_render_frame(o, C.byref(p), cores)
-        frames_done += 1
-        done_px += px_owned
-    t_cpu = time.perf_counter() - t_cpu0
-    cpu_img = np.ctypeslib.as_array(O.oracle_pt_accum(o), shape=(H, W, 4)).copy()
-    O.oracle_pt_destroy(o)
-    cpu = {"value": round(done_px / t_cpu / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-           "sample": f"{frames_done} frame(s) x {len(owned)}/{tiles_total} tiles (every {part}th 64x64 tile) of the same workload, {t_cpu:.1f} s"}
-    # parity at the FULL configuration: the same frames on the GPU, compared on the tiles the oracle rendered
-    chk = make_gpu_tracer()
-    ptmod.HeadlessRenderer(chk, gpu_params).render(frames_done, in_flight=min(F, frames_done))
-    gpu_img = chk.read_accum()
-    chk.close()
     mask = np.zeros((H, W), bool)
     for t in owned:
         mask[(t // tx) * 64:(t // tx) * 64 + 64, (t % tx) * 64:(t % tx) * 64 + 64] = True
-    m = pu.compare_images(cpu_img[mask][None], gpu_img[mask][None])
-    parity = {"rel_l2": float(f"{m['rel_l2']:.3e}"), "frac_within_1e-2": round(m["frac_within_1e-2"], 5), "frac_within_1e-4": round(m["frac_within_1e-4"], 5),
-              "frac_exact": round(m["frac_exact"], 5), "tiles": len(owned), "pixels": int(mask.sum()), "frames": frames_done,
-              "resolution": [W, H], "reference": "CPU oracle (oracle/oracle_pt.cpp), same scene bytes (as loaded: no alpha cut), seeds and frame indices"}
+    spp = int(parity_spp or w.get("spp", 64))
+    marks = sorted({max(1, spp // 4), max(1, spp // 2), spp})
+    cpu_imgs, timed = {}, None
+    t_cpu0 = time.perf_counter()
+    for f in range(spp):
+        p = setup.frame_params(f, f)
+        O.oracle_pt_render_frame(o, C.byref(p), cores)
+        if timed is None and (time.perf_counter() - t_cpu0 >= cpu_seconds or f + 1 == spp):
+            timed = (f + 1, time.perf_counter() - t_cpu0)
+        if f + 1 in marks:
+            cpu_imgs[f + 1] = np.ctypeslib.as_array(O.oracle_pt_accum(o), shape=(H, W, 4))[mask].copy()
+    t_cpu = time.perf_counter() - t_cpu0
+    O.oracle_pt_destroy(o)
+    cpu = {"value": round(timed[0] * px_owned / timed[1] / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+           "sample": f"the first {timed[0]} frame(s) x {len(owned)}/{tiles_total} tiles (every {part}th 64x64 tile) of the same workload, {timed[1]:.1f} s "
+                     f"(the parity leg went on to {spp} frames: {t_cpu:.1f} s)"}
+    # parity at the FULL configuration: the same frames on the GPU, compared on the tiles the oracle rendered
+    chk = make_gpu_tracer()
+    runner, done, by_spp = ptmod.HeadlessRenderer(chk, gpu_params), 0, {}
+    for m_ in marks:
+        runner.render(m_ - done, in_flight=min(F, m_ - done))
+        done = m_
+        m = pu.compare_images(cpu_imgs[m_][None], chk.read_accum()[mask][None])
+        by_spp[str(m_)] = {"rel_l2": float(f"{m['rel_l2']:.3e}"), "frac_within_1e-2": round(m["frac_within_1e-2"], 5), "frac_within_1e-4": round(m["frac_within_1e-4"], 5),
+                           "frac_exact": round(m["frac_exact"], 5), "mean_rel_bias": float(f"{m['mean_rel_bias']:.2e}")}
+    chk.close()
+    parity = dict(by_spp[str(spp)])
+    parity.update({"spp": spp, "frames": spp, "by_spp": by_spp, "tiles": len(owned), "pixels": int(mask.sum()), "resolution": [W, H], "tolerance_rel_l2": 1e-3,
+                   "within_tolerance": bool(parity["rel_l2"] <= 1e-3),
+                   "reference": "CPU oracle (oracle/oracle_pt.cpp), same scene bytes (as loaded: no alpha cut), seeds and frame indices"})
     return cpu, parity
 
 
-def secondary_line(name, args, device, width=0, height=0, steps=5, cpu_seconds=0.0):
+def secondary_line(name, args, device, width=0, height=0, steps=5, parity=True, denoise=False):
     """Throughput + per-kernel roofline table of another workload (or the same one at another resolution) on this GPU: the same
-    step definition as the headline (frames in flight x 2 frames per step, `steps` steps timed after one warm-up batch), and with
-    `cpu_seconds` > 0 the same CPU-oracle baseline + full-size parity leg as the headline."""
+    step definition as the headline (frames in flight x 2 frames per step, `steps` steps timed after one warm-up batch; with `denoise`
+    one variance-guided a-trous pass closes every step inside the timed region, configs[4]), and with `parity` the same CPU-oracle
+    baseline + full-size parity leg as the headline."""
     import torch
     from vk_gltf_renderer_amd import _capi as capi
     from vk_gltf_renderer_amd import pathtracer as ptmod
@@ -238,9 +307,11 @@ def secondary_line(name, args, device, width=0, height=0, steps=5, cpu_seconds=0
     if hdr is not None:
         frame_info.flags |= capi.MI_SCENE_USE_HDR_ENVIRONMENT
 
-    def params(depth):
+    def params(depth, guides=False):
         p = ptmod.default_params()
         p.maxDepth, p.numSamples, p.pixelAngle, p.focalDistance = depth, 1, pixel_angle, focal
+        if guides:
+            p.flags |= capi.MI_PT_USE_OPTIX_DENOISER
         return p
 
     def tracer(counters):
@@ -255,16 +326,25 @@ def secondary_line(name, args, device, width=0, height=0, steps=5, cpu_seconds=0
     F = frames_in_flight(w.get("in_flight", IN_FLIGHT_DEFAULT), W, H)
     frames_step = 2 * F
     t = tracer(False)
-    r = ptmod.HeadlessRenderer(t, params(w["depth"]))
+    r = ptmod.HeadlessRenderer(t, params(w["depth"], denoise))
+
+    def step():
+        r.render(frames_step, in_flight=F)
+        if denoise:
+            t.denoise_svgf(iterations=5, read=False)
+
     r.render(F, in_flight=F)  # warm-up
+    if denoise:
+        t.denoise_svgf(iterations=5, read=False)
     t.synchronize()
     r.reset_frame()
     t.enable_timing(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        r.render(frames_step, in_flight=F)
+        step()
     t.synchronize()
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timing = t.frame_timing()
     t.close()
@@ -278,21 +358,43 @@ def secondary_line(name, args, device, width=0, height=0, steps=5, cpu_seconds=0
 
     per_frame, first = counter_pass(w["depth"]), counter_pass(1)
     frames = steps * frames_step
-    kernels = kernel_table(per_frame, first, timing, frames, F)
-    dominant = max(kernels, key=lambda k: kernels[k]["avg_launch_ms"] * kernels[k]["launches"])
+    pmc = load_pmc(name, F, W, H)
+    kernels = kernel_table(per_frame, first, timing, frames, F, pmc)
     keys = ("cameraPaths", "segments", "surfaceHits", "shadowRays", "nodesPrimary", "trisPrimary", "nodesClosest", "trisClosest", "nodesShadow", "trisShadow", "textureTaps")
-    roof = dict(kernels[dominant], kernel=dominant)
-    roof.update(pmc_traffic(name, dominant, F, W, H, roof["avg_launch_ms"]))
     line = {"value": round(float(W) * H * frames / elapsed / 1e6, 3), "unit": "Msamples/s", "ms_per_frame": round(elapsed / frames * 1e3, 5),
-            "config": {"workload": w["config"] + " (seeded synthetic stand-in)", "scene_triangles": scene.num_triangles,
+            "config": {"workload": w["config"].replace("1920x1080", f"{W}x{H}") + " (seeded synthetic stand-in)", "scene_triangles": scene.num_triangles,
                        "alpha_cut": alpha_cut_note(args.alpha_cut, triangles_loaded, dropped), "resolution": [W, H],
-                       "frames_in_flight": F, "max_depth": w["depth"], "frames_timed": frames, "steps": steps}, "timed_region_s": round(elapsed, 3),
-            "roofline": roof, "kernels": kernels, "per_frame": {k: round(per_frame[k], 1) for k in keys},
+                       "frames_in_flight": F, "max_depth": w["depth"], "frames_timed": frames, "steps": steps,
+                       "denoise": ("variance-guided a-trous (mi_pt_denoise_svgf, 5 iterations) once per step, inside the timed region" if denoise else None)},
+            "timed_region_s": round(elapsed, 3),
+            "roofline": roofline_of(kernels, pmc), "kernels": kernels, "per_frame": {k: round(per_frame[k], 1) for k in keys},
             "node_visits_per_secondary_ray": round(per_frame["nodesClosest"] / max(1.0, per_frame["segments"] - per_frame["cameraPaths"]), 2),
             "triangle_tests_per_secondary_ray": round(per_frame["trisClosest"] / max(1.0, per_frame["segments"] - per_frame["cameraPaths"]), 2)}
-    if cpu_seconds > 0:
-        line["cpu_baseline"], line["parity"] = cpu_baseline_and_parity(scene, w, W, H, F, cpu_seconds, lambda: tracer(False), params(w["depth"]))
+    if parity:
+        line["cpu_baseline"], line["parity"] = cpu_baseline_and_parity(scene, w, W, H, F, args.cpu_seconds, lambda: tracer(False), params(w["depth"]), args.parity_spp)
     return line
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this command under torch.distributed.run (one process per GPU,
+    rendezvous on 127.0.0.1) and become that launcher.  Refuses when fewer than N devices are visible -- unless BENCH_SHARE_GPU=1
+    (all ranks on device 0 over gloo: a functional check of the N > 1 code on a single-GPU box, not a measurement)."""
+    import socket
+    import torch
+    share = os.environ.get("BENCH_SHARE_GPU") == "1"
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n and not share:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible; refusing to report an {n}-GPU number from fewer devices "
+                         f"(BENCH_SHARE_GPU=1 BENCH_DIST_BACKEND=gloo runs the ranks on one device as a functional check)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
 
 
 def main():
@@ -300,7 +402,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="helmet", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=NORTH_STAR["workload"], choices=sorted(WORKLOADS),
+                    help="default: atrium = configs[2], the Sponza-class workload the north-star target is stated on")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -308,11 +411,13 @@ def main():
                     help="edge of the interleaved tiles the image is dealt out in (tile %% world == rank); 32 balances the 8 ranks of the "
                          "helmet workload to 4 %% (64: 19 %%, tools/check_rank_of_8.py)")
     ap.add_argument("--bvh", type=int, default=0, help="bit0: 0 = 8-wide compressed BVH (default), 1 = plain BVH2; bit1: 0 = PLOC topology (default), 1 = LBVH")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU baseline figure is the oracle's rate over the first this many seconds of the parity leg")
+    ap.add_argument("--parity-spp", type=int, default=0,
+                    help="frames (1 spp each) of the parity leg; 0 = the configuration's own sample count (atrium 256, helmet 64, street 64, glass 512)")
     ap.add_argument("--also", default=None,
-                    help="comma-separated workloads measured after the main one on a single GPU and reported under \"also\": by default "
-                         "`atrium,helmet_4k` next to the helmet (the Sponza-class workload the north-star target is stated on, with its own CPU "
-                         "baseline and parity leg, and the helmet at 3840x2160); `--also none` switches it off")
+                    help="comma-separated lines measured after the headline on a single GPU and reported under \"also\" (" + ", ".join(sorted(ALSO_LINES)) + "): by default `"
+                         + ALSO_DEFAULT + "` next to the atrium -- every other configuration of BASELINE.json, the ones with their own scene with a CPU baseline and parity leg; "
+                         "`--also none` switches it off")
     ap.add_argument("--denoise", action="store_true",
                     help="configs[4]'s denoise pass: the guide layers are captured with every frame and one variance-guided a-trous pass (mi_pt_denoise_svgf, "
                          "5 iterations) closes every step inside the timed region -- on rank 0, after the reduce, when N > 1")
@@ -328,6 +433,8 @@ def main():
                          "volume random walks leave a long tail of ~100 nearly empty bounce iterations per batch: 238 / 469 / 559 / 605 Msamples/s at 32 / 128 / 128 "
                          "(round 3) / 256 frames)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)  # does not return: this process becomes the launcher of N ranks of the same command
 
     import torch
     from vk_gltf_renderer_amd import _capi as capi
@@ -336,7 +443,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
@@ -488,12 +595,11 @@ def main():
         per_frame = counter_pass(w["depth"])
         first = counter_pass(1) if w["depth"] >= 1 else dict(per_frame)  # bounce 0 alone: paths end after their first shade
         # the timed frames belong to this rank's tiles: timing and counters are both rank 0's
-        kernels = kernel_table(per_frame, first, timing, frames_timed, F)
-        dominant = max(kernels, key=lambda k: kernels[k]["avg_launch_ms"] * kernels[k]["launches"])
-        roof = dict(kernels[dominant])
-        roof.update({"kernel": dominant})
-        roof.update(pmc_traffic(args.workload, dominant, F, W, H, roof["avg_launch_ms"]) if world == 1 else {"traffic": None, "traffic_source": None, "traffic_GBps": None})
+        pmc = load_pmc(args.workload, F, W, H) if world == 1 else None  # (the committed counter passes are single-GPU runs)
+        kernels = kernel_table(per_frame, first, timing, frames_timed, F, pmc)
+        roof = roofline_of(kernels, pmc)
         keys = ("cameraPaths", "segments", "surfaceHits", "shadowRays", "nodesPrimary", "trisPrimary", "nodesClosest", "trisClosest", "nodesShadow", "trisShadow", "textureTaps")
+        assert world == args.gpus
         result = {
             "metric": "Msamples/s (and ms/frame @ fixed spp) 1080p & 4K, 1/2/4/8 MI355X", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -513,22 +619,27 @@ def main():
             "per_frame": {k: round(per_frame[k], 1) for k in keys},
             "per_frame_bounce0": {k: round(first[k], 1) for k in keys},
             "frame_ms_device": round(timing["totalMs"] / frames_timed, 4),
+            "node_visits_per_secondary_ray": round(per_frame["nodesClosest"] / max(1.0, per_frame["segments"] - per_frame["cameraPaths"]), 2),
+            "triangle_tests_per_secondary_ray": round(per_frame["trisClosest"] / max(1.0, per_frame["segments"] - per_frame["cameraPaths"]), 2),
         }
+        if args.workload == NORTH_STAR["workload"] and not (args.width or args.height):
+            result["north_star"] = dict(NORTH_STAR, workload=result["config"]["workload"], value=result["value"], unit="Msamples/s", n_gpus=world,
+                                        value_per_gpu=round(value / world, 3), frac_of_needed_per_gpu=round(value / world / NORTH_STAR["needs_per_gpu_Msamples_s"], 3))
         if not args.no_cpu_baseline and world == 1:
             tracer.close()  # (its path state is not needed any more; the parity leg's tracer may want as much again)
-            result["cpu_baseline"], result["parity"] = cpu_baseline_and_parity(scene, w, W, H, F, args.cpu_seconds, lambda: make_tracer(False, partition=False), params)
-        # Next to the default line (helmet, 1080p), on the same GPU: the Sponza-class atrium -- the workload the north-star target is
-        # stated on -- with its own CPU baseline + full-size parity leg, and the helmet at 3840x2160 (the metric's "4K" half).
-        default_run = args.workload == "helmet" and not (args.width or args.height)
-        also = args.also if args.also is not None else ("atrium,helmet_4k" if default_run else "none")
+            result["cpu_baseline"], result["parity"] = cpu_baseline_and_parity(scene, w, W, H, F, args.cpu_seconds, lambda: make_tracer(False, partition=False), params,
+                                                                               args.parity_spp)
+        # Next to the default line (the Sponza-class atrium, configs[2]), on the same GPU: every other configuration of BASELINE.json --
+        # helmet (configs[1]) and the same at 3840x2160, street (configs[3], 4K), glass + denoise (configs[4]) -- each scene with its own CPU
+        # baseline + full-size parity leg.
+        default_run = args.workload == NORTH_STAR["workload"] and not (args.width or args.height or args.denoise)
+        also = args.also if args.also is not None else (ALSO_DEFAULT if default_run else "none")
         if also != "none" and world == 1:
-            tracer.close()  # (its ~40 GB of path state are not needed any more)
+            tracer.close()  # (its ~80 GB of path state are not needed any more)
             result["also"] = {}
             for name in also.split(","):
-                if name == "helmet_4k":
-                    result["also"][name] = secondary_line("helmet", args, local_rank, width=3840, height=2160, steps=5)
-                else:
-                    result["also"][name] = secondary_line(name, args, local_rank, steps=5, cpu_seconds=0.0 if args.no_cpu_baseline else args.cpu_seconds)
+                wl, aw, ah, den, par = ALSO_LINES[name]
+                result["also"][name] = secondary_line(wl, args, local_rank, width=aw, height=ah, steps=5, parity=par and not args.no_cpu_baseline, denoise=den)
         print(json.dumps(result), flush=True)
     tracer.close()
     if dist is not None:

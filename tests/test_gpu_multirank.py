@@ -71,17 +71,29 @@ def test_two_ranks_of_the_hip_renderer_reduce_to_the_single_rank_frame(built, tm
 
 
 def test_bench_two_ranks_on_one_gpu(built):
-    """bench.py's N = 2 code path (functional check; the numbers of a shared GPU mean nothing)."""
-    port = _free_port()
-    env = dict(os.environ, BENCH_SHARE_GPU="1", BENCH_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "box", "--frames-per-step", "8", "--in-flight", "4"]
+    """bench.py's N = 2 code path, started the way the driver may start it -- plain `python bench.py --gpus 2`, no launcher: bench.py
+    spawns its own ranks (functional check; the numbers of a shared GPU mean nothing)."""
+    env = dict(os.environ, BENCH_SHARE_GPU="1", BENCH_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "box", "--frames-per-step", "8", "--in-flight", "4"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["config"]["world_size_reported_by_backend"] == 2 and j["config"]["spp_per_step"] == 16 and j["value"] > 0
     assert j["config"]["reduce"].startswith("one RCCL reduce")
+
+
+def test_bench_refuses_more_gpus_than_visible(built):
+    """`bench.py --gpus N` must not print an N-GPU line from fewer devices (round-3 review: it silently ran one)."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0", "--workload", "box"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and "refusing" in (r.stdout + r.stderr)
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
 def test_bench_denoise_two_ranks_equals_one_rank(built, tmp_path):
