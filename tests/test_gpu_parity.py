@@ -451,7 +451,11 @@ def test_update_render_nodes_rebuilds_on_device(built, tmp_path):
     sa, sb = pu.Setup(make("a.glb", False), 160, 120, max_depth=4, hdr_path=hdr), pu.Setup(make("b.glb", True), 160, 120, max_depth=4, hdr_path=hdr)
     db = sb.scene.desc.contents
     assert db.numRenderNodes == sa.scene.desc.contents.numRenderNodes == 4
-    tr = ptmod.PathTracer(sa.scene)
+    os.environ["MI_PT_DIAG_FAIL_BUILD"] = "3"  # test hook, armed at creation: the third rebuild of THIS instance fails (see below)
+    try:
+        tr = ptmod.PathTracer(sa.scene)
+    finally:
+        del os.environ["MI_PT_DIAG_FAIL_BUILD"]
     tr.set_environment(sa.hdr); tr.resize(160, 120); tr.set_frame_info(sa.frame_info); tr.set_sky(sa.sky)
     tr.render_frame(sa.frame_params(0, 0))
     img_a = tr.read_accum()
@@ -474,12 +478,9 @@ def test_update_render_nodes_rebuilds_on_device(built, tmp_path):
     assert (sel != 3).all() and (sel == 2).any() and (sel == 4).any()
     # a rebuild that FAILS after the old structure has been released must leave an empty scene behind, not dangling pointers:
     # the call reports the error, the next frame renders the environment only, and a later good rebuild restores the scene
-    os.environ["MI_PT_DIAG_FAIL_BUILD"] = "1"
-    try:
-        with pytest.raises(ptmod.MiError):
-            tr.update_render_nodes(db.renderNodes, db.numRenderNodes)
-    finally:
-        del os.environ["MI_PT_DIAG_FAIL_BUILD"]
+    # (the instance was created with MI_PT_DIAG_FAIL_BUILD=3: its third rebuild -- this one -- fails; run-time switches are read once, at mi_pt_create)
+    with pytest.raises(ptmod.MiError):
+        tr.update_render_nodes(db.renderNodes, db.numRenderNodes)
     tr.render_frame(sb.frame_params(0, 0))
     assert (tr.read_selection() == 0).all() and np.isfinite(tr.read_accum()).all()
     tr.update_render_nodes(db.renderNodes, db.numRenderNodes)

@@ -28,6 +28,10 @@ print('atrium', j['value'], j.get('parity',{}).get('by_spp'), j.get('cpu_baselin
 for n,a in j.get('also',{}).items(): print(n, a['value'], a.get('parity',{}).get('by_spp'), a.get('cpu_baseline',{}).get('value'))
 PY
     ;;
+  second)  # cndmask variants of the VALU micro-benchmark; what eager triangle / alpha rounds do to the walks' counters; the GPU suite
+    timeout 200 tools/_scratch/mb_valu > $O/r04_mb_valu2.txt 2>&1; grep "waves/SIMD=4" $O/r04_mb_valu2.txt | cut -c1-20,80-160
+    ab r04b atrium
+    timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 ;;
   tests) timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ;;
   ab) shift; ab "$@" ;;
   *) echo "unknown step $1" ;;

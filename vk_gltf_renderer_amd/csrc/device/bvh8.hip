@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -532,6 +533,12 @@ bool buildBvh8(const BvhBuildOutput& b2, Bvh8Output& out, hipStream_t stream, st
       uint32_t maxLeaf = uint32_t(maxLeafTris());
       // MI_PT_COLLAPSE = sah | greedy: which BVH2 subtrees become the children of an 8-wide node (the images do not depend on it)
       const char* modeEnv = getenv("MI_PT_COLLAPSE");
+      if(modeEnv && strcmp(modeEnv, "sah") != 0 && strcmp(modeEnv, "greedy") != 0)
+      {
+        fprintf(stderr, "mi_pt: MI_PT_COLLAPSE=%s is neither \"sah\" nor \"greedy\"\n", modeEnv);  // (a typo must not silently select the other collapse)
+        ok = false;
+        break;
+      }
       const bool  sahDp   = modeEnv ? strcmp(modeEnv, "sah") == 0 : COLLAPSE_SAH_DEFAULT;
       if(sahDp)
       {

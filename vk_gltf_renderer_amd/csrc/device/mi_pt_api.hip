@@ -70,10 +70,56 @@ enum TimedKernel { TK_GENERATE, TK_TRACE, TK_SORT, TK_SHADE, TK_SHADOW, TK_ACCUM
 
 }  // namespace
 
+// Run-time switches (A/B and diagnostics; INTEGRATION.md lists them): read from the environment ONCE, in mi_pt_create, so that a
+// variable that appears or changes later cannot alter an instance's slot layout, kernels or scene in the middle of an accumulation.
+struct RunSwitches
+{
+  int    packetInterval = 1;       // MI_PT_PACKET_INTERVAL  0: per-ray node test in every camera-ray packet
+  bool   microtileSlots = false;   // MI_PT_MICROTILE_SLOTS  micro-tile-major path slots at any batch size
+  bool   ignoreAlpha    = false;   // MI_PT_DIAG_IGNORE_ALPHA  (wrong image: what the alpha tests cost)
+  bool   genericShade   = false;   // MI_PT_GENERIC_SHADE    the generic shade kernel for every scene
+  int    sortMode       = 2;       // MI_PT_SORT             window sort of the generic shade kernel: 0 | 1 | 2
+  int    sortModeSimple = 0;       // MI_PT_SORT_SIMPLE      ... of the SIMPLE kernel's later bounces: 0 | 1 | 3
+  bool   noPacket       = false;   // MI_PT_NO_PACKET        k_generate + per-lane walk instead of k_trace_primary
+  bool   traceSpans     = false;   // MI_PT_TRACE_SPANS      synchronising diagnostics
+  int    graphUpTo      = 0;       // MI_PT_GRAPH            batches up to this many frames replay a hipGraph
+  bool   noPlanes       = false;   // MI_PT_DIAG_NO_PLANES   no float planes for the packet walk
+  bool   noOpaqueTris   = false;   // MI_PT_DIAG_NO_OPAQUE_TRIS  alpha-test the OPAQUE class of the alpha cut too
+  bool   noQuads        = false;   // MI_PT_DIAG_NO_QUADS    four texel gathers per bilinear tap instead of one footprint
+  int    failBuildAt    = 0;       // MI_PT_DIAG_FAIL_BUILD=N  test hook: the N-th acceleration REbuild of the instance fails after the old structure is gone
+  bool   candPoolSet    = false;   // MI_PT_DIAG_CAND_POOL   entries of the transmissive-candidate pool (tests of the overflow path)
+  size_t candPool       = 0;
+  void   read()
+  {
+    auto flag = [](const char* n) { const char* e = getenv(n); return e != nullptr; };
+    auto num  = [](const char* n, int d) { const char* e = getenv(n); return e ? atoi(e) : d; };
+    packetInterval = num("MI_PT_PACKET_INTERVAL", 1);
+    microtileSlots = flag("MI_PT_MICROTILE_SLOTS");
+    ignoreAlpha    = flag("MI_PT_DIAG_IGNORE_ALPHA");
+    genericShade   = flag("MI_PT_GENERIC_SHADE");
+    sortMode       = num("MI_PT_SORT", 2);
+    sortModeSimple = num("MI_PT_SORT_SIMPLE", 0);
+    noPacket       = flag("MI_PT_NO_PACKET");
+    traceSpans     = flag("MI_PT_TRACE_SPANS");
+    graphUpTo      = num("MI_PT_GRAPH", 0);
+    noPlanes       = flag("MI_PT_DIAG_NO_PLANES");
+    noOpaqueTris   = flag("MI_PT_DIAG_NO_OPAQUE_TRIS");
+    noQuads        = flag("MI_PT_DIAG_NO_QUADS");
+    failBuildAt    = num("MI_PT_DIAG_FAIL_BUILD", 0);
+    if(const char* e = getenv("MI_PT_DIAG_CAND_POOL"))
+    {
+      candPoolSet = true;
+      candPool    = size_t(strtoull(e, nullptr, 10));
+    }
+  }
+};
+
 struct MiPt
 {
   int device = 0;
   int numCUs = 256;
+  RunSwitches sw;
+  int accelBuilds = 0;  // acceleration-structure builds of this instance so far (0 while the first one runs)
   // scene
   DevBuf<MiGltfShadeMaterial> materials;
   DevBuf<MiGltfTextureInfo>   texInfos;
@@ -234,8 +280,8 @@ int allocPathResources(MiPt* pt, int frames)
   pt->queues.candPool = nullptr; pt->queues.candNext = nullptr; pt->queues.overflow = nullptr;
   pt->queues.candCap  = 0;
   size_t candCap = qsize * 2;
-  if(const char* e = getenv("MI_PT_DIAG_CAND_POOL"))
-    candCap = size_t(strtoull(e, nullptr, 10));
+  if(pt->sw.candPoolSet)
+    candCap = pt->sw.candPool;
   if(pt->hasTransmissive && pt->wide && candCap > 0)
   {
     candCap = std::min(candCap, size_t(0x7fffffff));
@@ -374,9 +420,8 @@ int buildAccelerationUnguarded(MiPt* pt)
   if(pt->bvhTris) (void)hipFree(pt->bvhTris);
   if(pt->bvh8Nodes) (void)hipFree(pt->bvh8Nodes);
   pt->bvhNodes = nullptr; pt->bvhTris = nullptr; pt->bvh8Nodes = nullptr;
-  if(const char* e = getenv("MI_PT_DIAG_FAIL_BUILD"))  // test hook: a rebuild that fails after the old structure is gone
-    if(atoi(e) != 0)
-      return fail(MI_PT_ERR_HIP, "BVH build failed: MI_PT_DIAG_FAIL_BUILD");
+  if(pt->accelBuilds++ == pt->sw.failBuildAt && pt->sw.failBuildAt > 0)  // test hook (armed at mi_pt_create): this REbuild fails after the old structure is gone
+    return fail(MI_PT_ERR_HIP, "BVH build failed: MI_PT_DIAG_FAIL_BUILD");
   {
     DevBuf<uint32_t> dOffset;
     DevBuf<int32_t>  dEntry;
@@ -422,7 +467,7 @@ int buildAccelerationUnguarded(MiPt* pt)
       pt->scene.bvh8NumNodes = int(b8.numNodes);
       pt->staticStats.bvhNodeCount = b8.numNodes;
       pt->staticStats.bvhNodeBytes = 80;
-      if(getenv("MI_PT_DIAG_NO_PLANES") == nullptr)  // A/B switch of the packet walk's float planes
+      if(!pt->sw.noPlanes)  // A/B switch of the packet walk's float planes
       {
         HIP_TRY(pt->bvh8Planes.alloc(size_t(b8.numNodes) * 48));
         pt::launchBvh8Planes(b8.nodes, b8.numNodes, pt->bvh8Planes.ptr, nullptr);
@@ -525,6 +570,7 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
   };
 
   std::unique_ptr<MiPt> pt(new MiPt());
+  pt->sw.read();
   pt->device          = device;
   pt->numCUs          = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   pt->collectCounters = options && options->collectCounters;
@@ -574,7 +620,7 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
       d.tangents   = reinterpret_cast<const float*>(put(p.tangents, size_t(p.vertexCount) * 16));
       d.texCoords0 = reinterpret_cast<const float*>(put(p.texCoords0, size_t(p.vertexCount) * 8));
       d.texCoords1 = reinterpret_cast<const float*>(put(p.texCoords1, size_t(p.vertexCount) * 8));
-      d.opaqueTriangles = getenv("MI_PT_DIAG_NO_OPAQUE_TRIS") ? 0u : std::min(p.opaqueTriangleCount, p.triangleCount);  // (A/B switch: alpha-test them all)
+      d.opaqueTriangles = pt->sw.noOpaqueTris ? 0u : std::min(p.opaqueTriangleCount, p.triangleCount);  // (A/B switch: alpha-test them all)
       d._pad            = 0;
       {
         std::vector<float> iv(size_t(p.vertexCount) * 12, 0.0f);
@@ -665,7 +711,7 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
     HIP_TRY(pt->textures.upload(dt.data(), dt.size()));
     HIP_TRY(pt->texels.upload(pool.data(), pool.size()));
     // bilinear footprints (pt_scene.h: texQuads), built on the device from the pool just uploaded; MI_PT_DIAG_NO_QUADS=1: A/B switch
-    if(totalTexels > 0 && getenv("MI_PT_DIAG_NO_QUADS") == nullptr)
+    if(totalTexels > 0 && !pt->sw.noQuads)
     {
       HIP_TRY(pt->texQuads.alloc(pool.size()));
       for(const pt::DevTexture& d : dt)
@@ -710,10 +756,7 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
   S.texRefs = pt->texRefs.ptr; S.alphaTris = nullptr; S.shadeTris = nullptr; S.srgbLut = pt->srgbLut.ptr; S.numMaterials = sd->numMaterials; S.numTextures = sd->numTextures;
   S.numLights = sd->numLights; S.numNodes = sd->numRenderNodes;
   S.envWidth = 0; S.envHeight = 0;
-  {
-    const char* e    = getenv("MI_PT_PACKET_INTERVAL");  // A/B switch: 0 = the per-ray node test in every packet
-    S.packetInterval = e ? atoi(e) : 1;
-  }
+  S.packetInterval = pt->sw.packetInterval;  // A/B switch: 0 = the per-ray node test in every packet
   if(int rc = buildAcceleration(pt.get()))
     return rc;
   phase("shade / alpha records");
@@ -919,7 +962,7 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   c.fc.numSlots  = pt->numSlots;
   c.fc.numFrames = numFrames;
   pt::divideMagic(uint32_t(std::max(numFrames, 2)), c.fc.framesMagic, c.fc.framesShift);
-  c.fc.slotLayout = (numFrames % 64 == 0 && getenv("MI_PT_MICROTILE_SLOTS") == nullptr) ? 1 : 0;  // (A/B switch: micro-tile major at any batch size)
+  c.fc.slotLayout = (numFrames % 64 == 0 && !pt->sw.microtileSlots) ? 1 : 0;  // (A/B switch: micro-tile major at any batch size)
   c.paths        = pt->paths;
   pt->accumFrames   = float(params->totalSamples) / float(params->numSamples) + float(numFrames);
   const bool guides = (params->flags & MI_PT_USE_OPTIX_DENOISER) != 0;
@@ -938,9 +981,9 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   c.stats            = pt->stats.ptr;
   c.stream           = stream;
   c.persistentBlocks = unsigned(pt->numCUs) * 8u;
-  c.hasAlpha         = pt->hasAlpha && getenv("MI_PT_DIAG_IGNORE_ALPHA") == nullptr;  // diagnostics: what the alpha tests cost (wrong image)
+  c.hasAlpha         = pt->hasAlpha && !pt->sw.ignoreAlpha;  // diagnostics: what the alpha tests cost (wrong image)
   c.hasTransmissive  = pt->hasTransmissive;
-  c.simpleMaterials  = pt->simpleMaterials && getenv("MI_PT_GENERIC_SHADE") == nullptr;
+  c.simpleMaterials  = pt->simpleMaterials && !pt->sw.genericShade;
   c.wide             = pt->wide;
   c.collectCounters  = pt->collectCounters;
   {
@@ -948,16 +991,14 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
     // through the BSDF (glass workload: generic shade kernel -11 %); where every material runs the same code (the SIMPLE
     // kernel, which therefore has no sort at all) it only cost (helmet +4 %, atrium +12 %, street +4 % of the shade kernel).
     // MI_PT_SORT = 0 | 1 | 2 is the A/B switch of the generic kernel.
-    static const char* sortEnv = getenv("MI_PT_SORT");
-    c.sortMode = sortEnv ? atoi(sortEnv) : 2;
+    c.sortMode = pt->sw.sortMode;
     // The SIMPLE kernel's later bounces (MI_PT_SORT_SIMPLE = 0 | 1 | 3, default 0 = the queue as it is).  Mode 3 keys the window by
     // next-event technique -- the coin sampleLights() flips between the punctual lights and the environment -- and does what it was
     // built for: on the atrium the later-bounce shade kernel executes 15 % fewer vector instructions and 32.8 instead of 27.3 of 64
     // lanes per instruction (PMC, round 3).  It is still 10 % SLOWER (1.30 against 1.18 ms per frame; street 3.79 against 3.57): the
     // kernel waits on its dependent gathers, not on instruction issue, and the window's three extra gathers + two barriers add to
     // exactly that.  Mode 1 (hits / misses) is within noise on the atrium and costs the helmet's later bounces 11 %.
-    const char* sortSimpleEnv = getenv("MI_PT_SORT_SIMPLE");  // (read per batch: the GPU test flips it inside one process)
-    c.sortModeSimple          = sortSimpleEnv ? atoi(sortSimpleEnv) : 0;
+    c.sortModeSimple = pt->sw.sortModeSimple;  // (read at mi_pt_create: the GPU test that flips it creates an instance per setting)
   }
   // descriptor copies for the kernels that read them through a pointer
   if(pt->sceneDevDirty)
@@ -1001,16 +1042,15 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
     (void)hipEventRecord(frameA, stream);
   }
   int iterations = 0, traceLaunches = 0, shadeLaunches = 0, shadowLaunches = 0;
-  static const bool usePacket = getenv("MI_PT_NO_PACKET") == nullptr;
-  static const bool debugSpans = getenv("MI_PT_TRACE_SPANS") != nullptr;
+  const bool usePacket = !pt->sw.noPacket;
+  const bool debugSpans = pt->sw.traceSpans;
   // hipGraph replay of small batches (MI_PT_GRAPH = largest batch that is captured; default 0 = never).  Not with per-launch timing,
   // the synchronising diagnostics, or volume-scatter scenes (their loop polls the queue length on the host).  Measured in round 3
   // (tools/graph_ab.py, 1080p, per-launch timing off): helmet frame by frame 1376 Msamples/s replayed against 1384 launched one by
   // one, 1894 / 1915 at 2 frames, 2580 / 2592 at 4; atrium 178 / 179 -- the host already queues the ~27 launches of a frame faster
   // than the device drains them, and what separates consecutive kernels is their dependency (ramp-up and tail of each persistent
   // grid), which a graph does not remove.  Hence off by default; the images are identical either way.
-  const char* graphEnv   = getenv("MI_PT_GRAPH");
-  const int   graphUpTo  = graphEnv ? atoi(graphEnv) : 0;
+  const int   graphUpTo  = pt->sw.graphUpTo;
   bool        capturing  = numFrames <= graphUpTo && !pt->timingEnabled && !debugSpans && !pt->hasVolumeScatter;
   if(capturing)
   {
@@ -1115,10 +1155,15 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
     pt::launchSelection(c, pt->selection.ptr);
   if(capturing)
   {
-    hipGraph_t graph = nullptr;
-    HIP_TRY(hipStreamEndCapture(pt->captureStream, &graph));
-    bool ready = false;
-    if(pt->graphExec)
+    // Any failure from here on (end of capture, instantiation, launch) must not leave the instance out of step with its accumulator:
+    // nothing of this batch has run yet (it was only recorded), so the graph objects are dropped, the capture stream -- which a failed
+    // capture leaves invalidated -- is recreated on demand, graphs are switched off for this instance, and the batch is issued
+    // again the ordinary way.  (What this function advanced before the capture -- accumFrames, momentFrames, the ring slot of the frame
+    // constants -- is a function of `params` alone or harmless to take twice.)
+    hipGraph_t graph  = nullptr;
+    bool       failed = hipStreamEndCapture(pt->captureStream, &graph) != hipSuccess || graph == nullptr;
+    bool       ready  = false;
+    if(!failed && pt->graphExec)
     {
       hipGraphNode_t           errorNode = nullptr;
       hipGraphExecUpdateResult result    = hipGraphExecUpdateSuccess;
@@ -1130,20 +1175,23 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
         pt->graphExec = nullptr;
       }
     }
-    if(!ready)
+    if(!failed && !ready)
+      failed = hipGraphInstantiate(&pt->graphExec, graph, nullptr, nullptr, 0) != hipSuccess;
+    if(!failed)
+      failed = hipGraphLaunch(pt->graphExec, stream) != hipSuccess;
+    if(graph)
+      (void)hipGraphDestroy(graph);
+    if(failed)
     {
-      const hipError_t e = hipGraphInstantiate(&pt->graphExec, graph, nullptr, nullptr, 0);
-      if(e != hipSuccess)
-      {
-        (void)hipGraphDestroy(graph);
-        pt->graphExec = nullptr;
-        return fail(MI_PT_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
-      }
+      (void)hipGetLastError();
+      if(pt->graphExec)
+        (void)hipGraphExecDestroy(pt->graphExec);
+      pt->graphExec = nullptr;
+      (void)hipStreamDestroy(pt->captureStream);
+      pt->captureStream = nullptr;
+      pt->sw.graphUpTo  = 0;
+      return mi_pt_render_frames(pt, params, numFrames, hipStream);
     }
-    const hipError_t le = hipGraphLaunch(pt->graphExec, stream);
-    (void)hipGraphDestroy(graph);
-    if(le != hipSuccess)
-      return fail(MI_PT_ERR_HIP, std::string("hipGraphLaunch: ") + hipGetErrorString(le));
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(pt->fcDone[fcSlot], stream));

@@ -1961,7 +1961,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
       alive = !done && surfaceDepth < maxDepth;
       flags = (isInside ? PF_INSIDE : 0u) | (solid ? 0u : PF_NOT_SOLID) | (alive ? PF_ALIVE : 0u) | (uint32_t(min(surfaceDepth, 255)) << PF_DEPTH_SHIFT)
               | (uint32_t(scatterBounces) << PF_SCATTER_SHIFT);
-      P.radiance[slot] = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(__float_as_uint(maxRoughness.x) | (solid ? 0u : RADW_NOT_SOLID)));
+      // (fmaxf: a NaN or negative maxRoughness.x from degenerate material input must not collide with RADW_PRIMARY_MISS or the flag bit)
+      P.radiance[slot] = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(__float_as_uint(fmaxf(maxRoughness.x, 0.0f)) | (solid ? 0u : RADW_NOT_SOLID)));
       P.misc[slot]     = make_float4(maxRoughness.y, __uint_as_float(flags), __uint_as_float(seed), coneWidth);
       if(alive)
       {

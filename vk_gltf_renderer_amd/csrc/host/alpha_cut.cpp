@@ -163,7 +163,14 @@ uint64_t GltfScene::cutAlphaMasked(int subdivisions)
         break;
     }
     PassTable* F = nullptr;  // "this texel may FAIL the cutoff" (none when no byte is sure to pass: nothing can be marked opaque)
-    if(sure <= 255)
+    // The OPAQUE class is for plain MASK materials only.  An opaque triangle is flagged like FORCE_OPAQUE geometry on the device, and a
+    // shadow ray that meets one is occluded outright; a MASK material that also transmits (transmissionFactor above MIN_TRANSMISSION:
+    // translucent foliage) must instead go through the ordered transmissive pass, which tints the shadow with getShadowTransmission
+    // (raytracer_interface.h.slang:160-178).  Such materials -- and diffuse transmission, which clears FORCE_OPAQUE in the reference's
+    // getInstanceFlag (src/gltf_scene_rtx.cpp:271-295) -- keep the alpha test on every surviving piece; only the pieces that cannot
+    // pass are dropped.
+    const bool plainMask = !(mat.transmissionFactor > 0.0f) && !(mat.diffuseTransmissionFactor > 0.0f);
+    if(sure <= 255 && plainMask)
     {
       F = &failTables[{info.index, sure}];
       if(F->sat.empty())
