@@ -276,7 +276,9 @@ def test_gpu_translucent_mask_card_casts_the_same_tinted_shadow_with_the_cut(bui
     # the card's shadow on the floor is lit through the card: compare with the opaque-card version of the scene
     opaque = pu.Setup(_translucent_card_scene(str(tmp_path / "opaque.glb"), img, 0.0), 160, 120, max_depth=4, alpha_cut=8)
     g2 = pu.render_gpu(opaque, 8)
-    assert g1["accum"][..., :3].sum() > 1.01 * g2["accum"][..., :3].sum()
+    lum_opaque, lum_translucent = g2["accum"][..., :3].mean(-1), g1["accum"][..., :3].mean(-1)
+    dark = lum_opaque <= np.quantile(lum_opaque, 0.1)  # the opaque card's shadow (the oracle gives 0.0078 there against 0.0109 through the translucent card)
+    assert lum_translucent[dark].mean() > 1.15 * lum_opaque[dark].mean(), (lum_translucent[dark].mean(), lum_opaque[dark].mean())
 
 
 def test_cracks_of_the_adaptive_cut_stay_below_a_stated_measure(built, tmp_path):

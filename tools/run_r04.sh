@@ -32,6 +32,9 @@ PY
     timeout 200 tools/_scratch/mb_valu > $O/r04_mb_valu2.txt 2>&1; grep "waves/SIMD=4" $O/r04_mb_valu2.txt | cut -c1-20,80-160
     ab r04b atrium
     timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 ;;
+  third)  # the leaf word (node visit 235 -> 205 vector instructions): GPU suite, then A/B against the previous commit's library
+    timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -8
+    ab r04c atrium helmet glass street ;;
   tests) timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ;;
   ab) shift; ab "$@" ;;
   *) echo "unknown step $1" ;;

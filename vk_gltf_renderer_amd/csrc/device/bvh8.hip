@@ -7,12 +7,15 @@
 //
 // Node (5 x uint4):
 //   [0] p.x p.y p.z (float bits) | ex | ey<<8 | ez<<16 | imask<<24      quantisation frame: lo corner + per-axis 2^e
-//   [1] childBase | triBase | meta[0..3] | meta[4..7]                    meta: 0 empty, 0xff internal, else count<<5 | offset
+//   [1] childBase | triBase | valid16 | 0             valid16: bit 2s = leaf child in slot s has a triangle, bit 2s + 1 = it has two
+//       (a leaf child's triangles follow those of the leaf children in lower slots: index = triBase + popcount(valid16 below its bit);
+//        an inner child is a bit of imask, an empty slot is neither)
 //   [2] qlo.x[0..7] qlo.y[0..7]   [3] qlo.z[0..7] qhi.x[0..7]   [4] qhi.y[0..7] qhi.z[0..7]
 // Child boxes decode as fmaf(q, 2^e, p) — the builder checks with the same fmaf that every decoded box CONTAINS the true
 // box, so the structure is conservative and the image cannot depend on it (parity contract).
 // Internal children of a node are stored contiguously from childBase in slot order; the triangles of its leaf children
-// are stored contiguously from triBase (<= 3 per child, <= 24 per node).  Children sit in octant-ordered slots so that
+// are stored contiguously from triBase in slot order (<= 2 per child, <= 16 per node: the walk turns its 8-bit child hit mask into
+// triangle bits with one bit-doubling spread and one AND, pt_bvh8.h).  Children sit in octant-ordered slots so that
 // `slot ^ (7 ^ rayOctant)` is a front-to-back priority.
 //
 // The collapse runs ON THE DEVICE, level by level over the BVH2 the builder left in HBM (no download): one thread per 8-wide node of
@@ -48,26 +51,29 @@ struct Node8  // 80 bytes, see header
   uint8_t  imask;
   uint32_t childBase;
   uint32_t triBase;
-  uint8_t  meta[8];
+  uint16_t valid;      // two bits per slot: triangles of its leaf child (see header)
+  uint16_t reserved16;
+  uint32_t reserved32;
   uint8_t  qlo[3][8];
   uint8_t  qhi[3][8];
 };
 static_assert(sizeof(Node8) == 80, "Node8 must be 80 bytes");
 
-// Largest leaf child.  A node addresses its triangles through a 31-bit mask, so eight children of 3 always fit; with 4 a node
-// whose leaves would hold more than 31 falls back to 3 (MI_PT_LEAF_TRIS: tuning knob, the images do not depend on it).
+// Largest leaf child: 2 (MI_PT_LEAF_TRIS=1 selects one; the images do not depend on it).  Two bits of the node's 16-bit valid mask belong to
+// a slot, so a leaf child holds one or two triangles -- which is also what measured best when the mask had room for three and four
+// (round 2: 2 beats 1, 3 and 4 on the helmet, atrium and street workloads, +0.4 .. +2.5 % over 3).
 // SAH-optimal collapse by default: against the greedy one (MI_PT_COLLAPSE=greedy) 40 % fewer, fuller nodes (atrium 68.8 k -> 44 k),
 // node visits per secondary ray 19.74 -> 19.27 (atrium), 28.66 -> 27.55 (street), 8.01 -> 7.91 (helmet), and
 // atrium 482 -> 490, street 512 -> 518, helmet 3799 -> 3878, glass 537 -> 551 Msamples/s (round 3)
 constexpr bool COLLAPSE_SAH_DEFAULT = true;
-constexpr int MAX_LEAF_TRIS_DEFAULT = 2;  // measured: 2 beats 1, 3 and 4 on the helmet, atrium and street workloads (+0.4 .. +2.5 % over 3)
+constexpr int MAX_LEAF_TRIS_DEFAULT = 2;
 
 static int maxLeafTris()
 {
   static const int v = [] {
     const char* e = getenv("MI_PT_LEAF_TRIS");
     const int   n = e ? atoi(e) : MAX_LEAF_TRIS_DEFAULT;
-    return n < 1 ? 1 : (n > 4 ? 4 : n);
+    return n < 1 ? 1 : (n > 2 ? 2 : n);
   }();
   return v;
 }
@@ -411,7 +417,7 @@ __global__ void k_collapse_emit(int numItems, const int* items, const float4* no
   for(int sl = 0; sl < 8; ++sl)
     for(int a = 0; a < 3; ++a)
     {
-      N.qlo[a][sl] = 255;  // empty slot: inverted box (and meta == 0)
+      N.qlo[a][sl] = 255;  // empty slot: inverted box (and no valid bit)
       N.qhi[a][sl] = 0;
     }
   for(int a = 0; a < 3; ++a)
@@ -457,13 +463,12 @@ __global__ void k_collapse_emit(int numItems, const int* items, const float4* no
     if(d_isInner(nodes2, dp, c.ref, ml))
     {
       N.imask |= uint8_t(1u << sl);
-      N.meta[sl]                          = 0xff;
       nextItems[childAt - nextLevelStart] = c.ref;
       ++childAt;
     }
     else
     {
-      N.meta[sl] = uint8_t((tc << 5) | (triAt - N.triBase));
+      N.valid |= uint16_t((tc >= 2u ? 3u : 1u) << (2 * sl));  // (tc <= 2: d_isInner opens anything larger)
       // the (at most 4) triangles below c.ref, left to right
       int stack[8], sp = 0;
       stack[sp++] = c.ref;
@@ -811,7 +816,7 @@ bool buildBvh8(const BvhBuildOutput& b2, Bvh8Output& out, hipStream_t stream, st
     for(int s = 0; s < 8; ++s)
       for(int a = 0; a < 3; ++a)
       {
-        N.qlo[a][s] = 255;  // empty slot: inverted box (and meta == 0)
+        N.qlo[a][s] = 255;  // empty slot: inverted box (and no valid bit)
         N.qhi[a][s] = 0;
       }
     for(int a = 0; a < 3; ++a)
@@ -854,7 +859,6 @@ bool buildBvh8(const BvhBuildOutput& b2, Bvh8Output& out, hipStream_t stream, st
       if(c.ref >= 0 && triCount(c.ref) > MAX_LEAF_TRIS)
       {
         N.imask |= uint8_t(1u << s);
-        N.meta[s] = 0xff;
         Work w;
         w.node8 = uint32_t(nodes8.size());
         for(int k = 0; k < 2; ++k)
@@ -869,9 +873,8 @@ bool buildBvh8(const BvhBuildOutput& b2, Bvh8Output& out, hipStream_t stream, st
       }
       else
       {
-        uint32_t count  = triCount(c.ref);
-        uint32_t offset = uint32_t(perm.size()) - N.triBase;
-        N.meta[s]       = uint8_t((count << 5) | offset);
+        const uint32_t count = triCount(c.ref);  // <= MAX_LEAF_TRIS <= 2
+        N.valid |= uint16_t((count >= 2u ? 3u : 1u) << (2 * s));
         collectTris(c.ref, perm);
       }
     }

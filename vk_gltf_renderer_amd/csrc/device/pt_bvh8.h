@@ -1,6 +1,6 @@
 // Traversal of the 8-wide compressed BVH (layout: bvh8.hip).  One call = one node visit: decode 8 quantised child boxes,
-// slab-test them, and return (a) the group of hit INNER children as a front-to-back priority mask and (b) the mask of
-// triangles of hit LEAF children.  Traversal state per lane = current node group + an LDS stack of node groups.
+// slab-test them, and return (a) the group of hit INNER children as a front-to-back priority mask and (b) the triangles of hit
+// LEAF children as a "leaf word" (below).  Traversal state per lane = current node group + an LDS stack of node groups.
 #pragma once
 #include "pt_bvh.h"
 
@@ -81,10 +81,26 @@ PT_DEV uint32_t groupPopChild(NodeGroup& g, uint32_t octinv)
 
 PT_DEV float byteF(uint32_t w, int i) { return float((w >> (8 * i)) & 0xffu); }  // v_cvt_f32_ubyteN
 
-// Slab test of the 8 children of a loaded node: bit i of `hm` = child slot i is hit (inner or leaf), `tmask` = triangles of
-// the hit LEAF children (bit 31 is garbage from inner children and must be masked by the caller).
+// ---- leaf word: the triangles a node visit found, in ONE register.  A node owns up to 16 triangle bits, two per child slot
+// (bvh8.hip: valid16); the low half of the word is the node's valid16, the high half the PENDING triangles (bit 16 + 2s + k = triangle k
+// of the leaf child in slot s, hit and not yet handed to a test).  Triangles are stored compactly in slot order, so the index of a
+// pending bit is triBase + (valid bits below it).  "Nothing pending" is `word <= 0xffff` -- a comparison with a constant, like the
+// `mask != 0` it replaces -- so the walks' bookkeeping costs what it did when the word was a plain 24-bit mask of a node's triangles,
+// and the node visit no longer builds that mask child by child (6 of its 29 vector instructions per child, round 4).
+PT_DEV bool     leafPending(uint32_t w) { return w > 0xffffu; }
+PT_DEV uint32_t leafCount(uint32_t w) { return uint32_t(__popc(w >> 16)); }
+// removes the lowest pending triangle of the word and returns its index
+PT_DEV uint32_t leafPop(uint32_t& w, uint32_t triBase)
+{
+  const uint32_t bit = uint32_t(__ffs(int(w & 0xffff0000u))) - 1u;  // 16 .. 31
+  w &= ~(1u << bit);
+  return triBase + uint32_t(__popc(w & ((1u << (bit - 16u)) - 1u)));  // (bits below bit - 16 lie in the valid half: untouched by the clear)
+}
+
+// Slab test of the 8 children of a loaded node: bit i of `hm` = child slot i is hit (inner or leaf), `leafOut` = the leaf word of the
+// hit LEAF children (inner children own no valid bit, so their hits fall out in the AND).
 PT_DEV void bvh8TestChildren(const uint4& n0, const uint4& n1, const uint4& n2, const uint4& n3, const uint4& n4, const RaySetup& r, float tmax,
-                             uint32_t& hmOut, uint32_t& tmaskOut)
+                             uint32_t& hmOut, uint32_t& leafOut)
 {
   const float  sx = __uint_as_float((n0.w & 0xffu) << 23), sy = __uint_as_float(((n0.w >> 8) & 0xffu) << 23), sz = __uint_as_float(((n0.w >> 16) & 0xffu) << 23);
   const float  Px = __uint_as_float(n0.x) - r.org.x, Py = __uint_as_float(n0.y) - r.org.y, Pz = __uint_as_float(n0.z) - r.org.z;
@@ -100,13 +116,12 @@ PT_DEV void bvh8TestChildren(const uint4& n0, const uint4& n1, const uint4& n2, 
   const uint32_t qnx[2] = {nx ? n3.z : n2.x, nx ? n3.w : n2.y}, qfx[2] = {nx ? n2.x : n3.z, nx ? n2.y : n3.w};
   const uint32_t qny[2] = {ny ? n4.x : n2.z, ny ? n4.y : n2.w}, qfy[2] = {ny ? n2.z : n4.x, ny ? n2.w : n4.y};
   const uint32_t qnz[2] = {nz ? n4.z : n3.x, nz ? n4.w : n3.y}, qfz[2] = {nz ? n3.x : n4.z, nz ? n3.y : n4.w};
-  const uint32_t meta[2] = {n1.z, n1.w};
   // The loop is VALU-bound (it is the traversal's inner loop), so it is written for instruction count: the near and far
   // plane of an axis go through one packed fma; a child's miss is the sign of tf - tn, shifted into the mask by one alignbit
-  // (empty slots hold inverted boxes and miss by themselves); a leaf child's triangle range is one bit-field mask.
+  // (empty slots hold inverted boxes and miss by themselves).
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   const f32x2 A2x = {Ax, Ax}, A2y = {Ay, Ay}, A2z = {Az, Az}, B2x = {Bnx, Bfx}, B2y = {Bny, Bfy}, B2z = {Bnz, Bfz};
-  uint32_t    miss = 0, tmiss = 0, tall = 0;
+  uint32_t    miss = 0;
 #pragma unroll
   for(int j = 0; j < 8; ++j)
   {
@@ -116,18 +131,18 @@ PT_DEV void bvh8TestChildren(const uint4& n0, const uint4& n1, const uint4& n2, 
     const f32x2 tz = __builtin_elementwise_fma(f32x2{byteF(qnz[w], b), byteF(qfz[w], b)}, A2z, B2z);
     const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, 0.0f));
     const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, tmax));
-    const uint32_t d = __float_as_uint(tf - tn);  // sign set: tn > tf, a miss
-    miss             = __builtin_amdgcn_alignbit(miss, d, 31);
-    // range = ((1 << count) - 1) << offset; v_bfm_b32 reads 5 bits of each operand (inner children: 7 / 31, masked out below)
-    const uint32_t cnt = (meta[w] >> (8 * b + 5)) & 7u, off = meta[w] >> (8 * b);
-    uint32_t       range;
-    asm("v_bfm_b32 %0, %1, %2" : "=v"(range) : "v"(cnt), "v"(off));
-    tall |= range;
-    tmiss |= range & uint32_t(int32_t(d) >> 31);
+    miss           = __builtin_amdgcn_alignbit(miss, __float_as_uint(tf - tn), 31);  // sign set: tn > tf, a miss
   }
-  const uint32_t hm = ~miss & 0xffu, tmask = tall & ~tmiss;
-  hmOut    = hm;
-  tmaskOut = tmask;
+  const uint32_t hm = ~miss & 0xffu;
+  // child hit bits -> triangle bits: every bit doubled (slot s -> bits 2s, 2s + 1), then the node's valid16 keeps the triangles that exist
+  uint32_t x = hm;
+  x = (x | (x << 4)) & 0x0f0fu;
+  x = (x | (x << 2)) & 0x3333u;
+  x = (x | (x << 1)) & 0x5555u;
+  x |= x << 1;
+  const uint32_t valid = n1.z & 0xffffu;
+  hmOut   = hm;
+  leafOut = ((x & valid) << 16) | valid;
 }
 
 // The same test for a PACKET whose rays all point into one octant (k_trace_primary): the node is wave-uniform, so the byte -> float
@@ -175,8 +190,9 @@ PT_DEV uint32_t bvh8TestChildrenPlanes(const uint4& n0, const f32x8s& pnx, const
 // bounds the accumulated rounding of p - org, of the two products and of the fma -- so the test stays conservative
 // without a multiplicative fudge, including the cancellation case of an origin inside the node.
 // Nodes below index `cached` are read from the workgroup's LDS copy (ldsNodes), the rest from global memory.
+// `triBase` / `leafWord`: the triangles of the hit leaf children (leaf word above; leafPending(leafWord) says whether there are any).
 PT_DEV void bvh8Visit(const DevScene& sc, const RaySetup& r, float tmax, uint32_t octinv, uint32_t nodeIndex, NodeGroup& outGroup, uint32_t& triBase,
-                      uint32_t& triMask, const uint4* ldsNodes, uint32_t cached)
+                      uint32_t& leafWord, const uint4* ldsNodes, uint32_t cached)
 {
   uint4 n0, n1, n2, n3, n4;
   if(nodeIndex < cached)
@@ -195,9 +211,8 @@ PT_DEV void bvh8Visit(const DevScene& sc, const RaySetup& r, float tmax, uint32_
     n0 = N[0]; n1 = N[1]; n2 = N[2]; n3 = N[3]; n4 = N[4];
   }
   const uint32_t imask = n0.w >> 24;
-  uint32_t       hm, tmask;
-  bvh8TestChildren(n0, n1, n2, n3, n4, r, tmax, hm, tmask);
-  // leaf children of this node own triangle bits [0, 24); inner ones produced garbage above bit 24 at most: 0xff -> 127 << 31
+  uint32_t       hm, leaf;
+  bvh8TestChildren(n0, n1, n2, n3, n4, r, tmax, hm, leaf);
   uint32_t hits = hm & imask;
   // slot space -> priority space: bit p = slot ^ octinv, a butterfly on the three index bits
   hits = (octinv & 1u) ? (((hits & 0x55u) << 1) | ((hits & 0xaau) >> 1)) : hits;
@@ -206,7 +221,7 @@ PT_DEV void bvh8Visit(const DevScene& sc, const RaySetup& r, float tmax, uint32_
   outGroup.base = n1.x;
   outGroup.bits = (hits << 8) | imask;
   triBase       = n1.y;
-  triMask       = tmask & 0x7fffffffu;
+  leafWord      = leaf;
 }
 
 }  // namespace pt

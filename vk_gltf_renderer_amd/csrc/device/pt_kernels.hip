@@ -523,7 +523,7 @@ PT_DEV void triRoundPublish(const DevScene& sc, bool active, uint32_t& pBase, ui
 {
   const uint32_t lane = laneId();
   // how many triangles each lane hands in, and where (exclusive prefix over the lanes from the count's bit planes)
-  const uint32_t c = active ? min(uint32_t(__popc(pMask) + __popc(qMask)), uint32_t(TRI_ROUND_LANE_CAP)) : 0u;
+  const uint32_t c = active ? min(leafCount(pMask) + leafCount(qMask), uint32_t(TRI_ROUND_LANE_CAP)) : 0u;  // (p / q: leaf words, pt_bvh8.h)
   const unsigned long long b0 = __ballot((c & 1u) != 0u), b1 = __ballot((c & 2u) != 0u), b2 = __ballot((c & 4u) != 0u);
   const uint32_t off   = laneCountBelow(b0) + 2u * laneCountBelow(b1) + 4u * laneCountBelow(b2);
   const uint32_t total = min(64u, uint32_t(__popcll(b0)) + 2u * uint32_t(__popcll(b1)) + 4u * uint32_t(__popcll(b2)));
@@ -532,13 +532,11 @@ PT_DEV void triRoundPublish(const DevScene& sc, bool active, uint32_t& pBase, ui
   {
     if(k < n)
     {
-      if(pMask == 0u) { pBase = qBase; pMask = qMask; qMask = 0u; }
-      const uint32_t bit = uint32_t(__ffs(int(pMask)) - 1);
-      pMask &= pMask - 1u;
-      waveItems[off + k] = (pBase + bit) | (lane << 26);
+      if(!leafPending(pMask)) { pBase = qBase; pMask = qMask; qMask = 0u; }
+      waveItems[off + k] = leafPop(pMask, pBase) | (lane << 26);
     }
   }
-  if(pMask == 0u) { pBase = qBase; pMask = qMask; qMask = 0u; }
+  if(!leafPending(pMask)) { pBase = qBase; pMask = qMask; qMask = 0u; }
   __builtin_amdgcn_wave_barrier();
   tr.off  = off;
   tr.n    = n;
@@ -838,7 +836,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
   int         node = BVH_EMPTY;
   NodeGroup   G{0, 0};
   uint32_t    octinv = 0;
-  uint32_t    pBase = 0, pMask = 0, qBase = 0, qMask = 0;  // parked leaf hits (8-wide walk): triangle base + bit mask
+  uint32_t    pBase = 0, pMask = 0, qBase = 0, qMask = 0;  // parked leaf hits (8-wide walk): triangle base + leaf word (pt_bvh8.h)
   int         lastVisiting = 64;                           // lanes that visited a node in the previous step
   uint32_t    aCount   = 0;                                // deferred alpha tests on this wave's list (wave-uniform)
   bool        aPending = false;                            // ... some of them this lane's
@@ -926,11 +924,11 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
         const unsigned long long tTri0 = PROF_T();
         TriRound           tr;
         bool               round = false;
-        unsigned long long pend  = __ballot(active && pMask != 0u);
+        unsigned long long pend  = __ballot(active && leafPending(pMask));
         if(pend != 0ull)
         {
           const bool drain = lastVisiting < TRI_PHASE_LANES;  // few lanes left walking: nothing to wait for
-          round            = drain || __popcll(pend) >= TRI_ROUND_LANES || __popcll(__ballot(active && qMask != 0u)) >= TRI_ROUND_BLOCKED;
+          round            = drain || __popcll(pend) >= TRI_ROUND_LANES || __popcll(__ballot(active && leafPending(qMask))) >= TRI_ROUND_BLOCKED;
           if(round)
           {
             PROF_CNT(2, 1);
@@ -945,7 +943,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
         // straight after a node visit only a few lanes have triangles.  The hits are parked (two records per lane) and
         // tested in a dense phase once enough lanes have some; the closest hit does not depend on the test order.
         bool visited = false;
-        if(active && qMask == 0u)
+        if(active && !leafPending(qMask))
         {
           if((G.bits >> 8) == 0u && st2.sp > 0)
             G = st2.pop();
@@ -958,17 +956,17 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
             bvh8Visit(sc, r, best.t, octinv, child, G, tBase, tMask, s_nodes, cachedNodes);
             if(COUNT) ++nodes;
             visited = true;
-            if(tMask)
+            if(leafPending(tMask))
             {
-              if(pMask == 0u) { pBase = tBase; pMask = tMask; }
-              else            { qBase = tBase; qMask = tMask; }
+              if(!leafPending(pMask)) { pBase = tBase; pMask = tMask; }
+              else                    { qBase = tBase; qMask = tMask; }
             }
           }
         }
         PROF_ADD(1, tNode);
         PROF_CNT(0, 1);
         PROF_CNT(1, __popcll(__ballot(visited)));
-        PROF_CNT(7, __popcll(__ballot(active && qMask != 0u)));
+        PROF_CNT(7, __popcll(__ballot(active && leafPending(qMask))));
         lastVisiting = __popcll(__ballot(visited));
         const unsigned long long tTri = PROF_T();
         if(round)
@@ -980,7 +978,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
         if(HAS_ALPHA && aCount != 0u)
         {
           // alpha round: the list is long enough, or the walk is running dry, or rays have nothing left to do but wait for it
-          const bool walked  = active && pMask == 0u && (G.bits >> 8) == 0u && st2.sp == 0;
+          const bool walked  = active && !leafPending(pMask) && (G.bits >> 8) == 0u && st2.sp == 0;
           const int  waiting = __popcll(__ballot(walked && aPending));
           if(aCount >= ALPHA_ROUND_MIN || lastVisiting < TRI_PHASE_LANES || waiting >= ALPHA_ROUND_WAITING)
           {
@@ -992,7 +990,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
           }
         }
         PROF_ADD(2, tTri);
-        if(active && pMask == 0u && (G.bits >> 8) == 0u && st2.sp == 0 && !(HAS_ALPHA && aPending))
+        if(active && !leafPending(pMask) && (G.bits >> 8) == 0u && st2.sp == 0 && !(HAS_ALPHA && aPending))
         {
           in.aux[pos] = make_float4(best.t, __int_as_float(best.tri), best.u, best.v);
           active      = false;
@@ -1108,7 +1106,7 @@ PT_DEV void scalarLoadNodePlanes(const uint4* nodes, const float* planes, uint32
   n0 = make_uint4(a[0], a[1], a[2], a[3]);
   n1 = make_uint4(b[0], b[1], b[2], b[3]);
 }
-// the two header words of a node alone (origin, exponents, inner mask | child base, triangle base, leaf meta)
+// the two header words of a node alone (origin, exponents, inner mask | child base, triangle base, valid16 of the leaf triangles)
 PT_DEV void scalarLoadNodeHeader(const uint4* nodes, uint32_t index, uint4& n0, uint4& n1)
 {
   const uint64_t addr = uint64_t(reinterpret_cast<uintptr_t>(nodes)) + uint64_t(index) * 80ull;
@@ -1343,8 +1341,9 @@ __global__ void __launch_bounds__(256, INTERVAL ? PRIMARY_INTERVAL_MIN_WAVES : P
       {
         const int i = __ffs(int(leafU)) - 1;
         leafU &= leafU - 1u;
-        const uint32_t m   = ((i < 4 ? n1.z : n1.w) >> (8 * (i & 3))) & 0xffu;
-        const uint32_t cnt = m >> 5, off = m & 31u;
+        // (valid16 of the node, bvh8.hip: two bits per slot; the child's triangles follow those of the leaf children in lower slots)
+        const uint32_t valid = n1.z & 0xffffu;
+        const uint32_t cnt = uint32_t(__popc((valid >> (2 * i)) & 3u)), off = uint32_t(__popc(valid & ((1u << (2 * i)) - 1u)));
         for(uint32_t k = 0; k < cnt; ++k)
         {
           const uint32_t triIndex = n1.y + off + k;
@@ -1466,10 +1465,9 @@ __global__ void __launch_bounds__(SEL_BLOCK) k_selection(DevScene sc, FrameConst
           st2.push(G);
         uint32_t tBase, tMask;
         bvh8Visit(sc, r, bestT, octinv, child, G, tBase, tMask, nullptr, 0u);
-        while(tMask)
+        while(leafPending(tMask))
         {
-          const int k = __ffs(int(tMask)) - 1;
-          tMask &= tMask - 1u;
+          const int k = int(leafPop(tMask, 0u));  // (offset from the node's first triangle)
           testTri(int(tBase) + k);
         }
       }
@@ -2284,7 +2282,7 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
       {
         // node step + dense triangle phase, as in k_trace_closest (any-hit and the phase-1 search are order independent)
         bool visited = false;
-        if(active && qMask == 0u && !(DEFER && occluded))  // (an occluded ray may still wait for its deferred alpha tests)
+        if(active && !leafPending(qMask) && !(DEFER && occluded))  // (an occluded ray may still wait for its deferred alpha tests)
         {
           const float walkTmax = (HAS_TRANS && phase == 1 && found) ? bT : tMax;
           if((G.bits >> 8) == 0u && st2.sp > 0)
@@ -2298,17 +2296,17 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
             bvh8Visit(sc, r, walkTmax, octinv, child, G, tBase, tMask, s_nodes, cachedNodes);
             if(COUNT) ++nodes;
             visited = true;
-            if(tMask)
+            if(leafPending(tMask))
             {
-              if(pMask == 0u) { pBase = tBase; pMask = tMask; }
-              else            { qBase = tBase; qMask = tMask; }
+              if(!leafPending(pMask)) { pBase = tBase; pMask = tMask; }
+              else                    { qBase = tBase; qMask = tMask; }
             }
           }
         }
         SPROF_ADD(1, tInner);
         SPROF_CNT(12, __popcll(__ballot(visited)));
         const unsigned long long tTri = PROF_T();
-        unsigned long long pend = __ballot(active && pMask != 0u);
+        unsigned long long pend = __ballot(active && leafPending(pMask));
         if(!HAS_TRANS)
         {
           // without transmissive instances a committing candidate simply decides its ray: the triangle tests are spread over
@@ -2317,7 +2315,7 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
           {
             const int  visiting = __popcll(__ballot(visited));
             const bool drain    = visiting < TRI_PHASE_LANES;
-            if(drain || __popcll(pend) >= TRI_ROUND_LANES || __popcll(__ballot(active && qMask != 0u)) >= TRI_ROUND_BLOCKED)
+            if(drain || __popcll(pend) >= TRI_ROUND_LANES || __popcll(__ballot(active && leafPending(qMask))) >= TRI_ROUND_BLOCKED)
             {
               do
               {
@@ -2325,7 +2323,7 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
                 triRoundPublish(sc, active, pBase, pMask, qBase, qMask, s_items + (threadIdx.x & ~63u), tr);
                 triRoundFinishShadow<HAS_ALPHA, COUNT, REC>(sc, r, tMax, seed0, tr, occluded, tris, waveAlpha, aCount, aPending, &rec);
                 if(occluded) { pMask = 0u; qMask = 0u; }
-                pend = __ballot(active && pMask != 0u);
+                pend = __ballot(active && leafPending(pMask));
               } while(pend != 0ull && (drain || __popcll(pend) >= TRI_ROUND_LANES));
             }
           }
@@ -2333,7 +2331,7 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
           const unsigned long long tAlpha = PROF_T();
           if(DEFER && aCount != 0u)
           {
-            const bool walked  = active && (occluded || ((G.bits >> 8) == 0u && st2.sp == 0 && pMask == 0u));
+            const bool walked  = active && (occluded || ((G.bits >> 8) == 0u && st2.sp == 0 && !leafPending(pMask)));
             const int  waiting = __popcll(__ballot(walked && aPending));
             if(aCount >= ALPHA_ROUND_MIN || __popcll(__ballot(visited)) < TRI_PHASE_LANES || waiting >= ALPHA_ROUND_WAITING)
             {
@@ -2350,31 +2348,28 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
         {
           const int  visiting = __popcll(__ballot(visited));
           const bool drain    = visiting < TRI_PHASE_LANES;
-          if(drain || __popcll(pend) >= TRI_PHASE_LANES || __ballot(active && qMask != 0u) != 0ull)
+          if(drain || __popcll(pend) >= TRI_PHASE_LANES || __ballot(active && leafPending(qMask)) != 0ull)
           {
             do
             {
-              if(active && pMask != 0u)
+              if(active && leafPending(pMask))
               {
                 // two triangles per round, both records in flight together (as in k_trace_closest)
-                const int k0 = __ffs(int(pMask)) - 1;
-                pMask &= pMask - 1u;
-                const bool two = pMask != 0u;
-                const int  k1  = two ? __ffs(int(pMask)) - 1 : k0;
-                if(two)
-                  pMask &= pMask - 1u;
-                const DevTri T0 = sc.tris[int(pBase) + k0], T1 = sc.tris[int(pBase) + k1];
-                testTriLoaded(T0, int(pBase) + k0);
+                const int  i0  = int(leafPop(pMask, pBase));
+                const bool two = leafPending(pMask);
+                const int  i1  = two ? int(leafPop(pMask, pBase)) : i0;
+                const DevTri T0 = sc.tris[i0], T1 = sc.tris[i1];
+                testTriLoaded(T0, i0);
                 if(two && !occluded)
-                  testTriLoaded(T1, int(pBase) + k1);
+                  testTriLoaded(T1, i1);
                 if(occluded) { pMask = 0u; qMask = 0u; }
-                else if(pMask == 0u) { pBase = qBase; pMask = qMask; qMask = 0u; }
+                else if(!leafPending(pMask)) { pBase = qBase; pMask = qMask; qMask = 0u; }
               }
-              pend = __ballot(active && pMask != 0u);
-            } while(pend != 0ull && (drain || __popcll(pend) >= TRI_PHASE_EXIT_LANES || __ballot(active && qMask != 0u) != 0ull));
+              pend = __ballot(active && leafPending(pMask));
+            } while(pend != 0ull && (drain || __popcll(pend) >= TRI_PHASE_EXIT_LANES || __ballot(active && leafPending(qMask)) != 0ull));
           }
         }
-        walkDone = active && !(DEFER && aPending) && (occluded || ((G.bits >> 8) == 0u && st2.sp == 0 && pMask == 0u));
+        walkDone = active && !(DEFER && aPending) && (occluded || ((G.bits >> 8) == 0u && st2.sp == 0 && !leafPending(pMask)));
       }
       else if(active)
       {
