@@ -52,7 +52,7 @@ pick = {"shade_first": lambda n: n.startswith("k_shade<false") and n.endswith("t
 out = {"round": int(sys.argv[4]) if len(sys.argv) > 4 else 2, "workload": workload, "frames_in_flight": frames, "resolution": res,
        "fetch_size_calibration": (os.path.join("profiles", os.path.basename(calib_path)) + " (tools/calib_fetch.hip: counter / true bytes measured for 16-B streams and 16 / 48 / 80-B gathers)") if calib else "the guide (wide streaming reads): FETCH_SIZE x 2",
        "fetch_size_factor": "per kernel, see kernels[*].fetch_counter_over_true" if calib else 2.0,
-       "command": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --workload {workload} --steps 3 --warmup 1 --no-cpu-baseline",
+       "command": f"rocprofv3 --pmc <one counter group per pass: FETCH_SIZE | WRITE_SIZE | SQ_* | TCC_*> -- python bench.py --workload {workload}" + (f" --width {res[0]} --height {res[1]}" if (workload == "helmet" and res[0] == 3840) else "") + (" --denoise" if os.environ.get("PMC_DENOISE") else "") + " --steps 3 --warmup 1 --no-cpu-baseline --also none",
        "note": "hbm_bytes_per_launch = FETCH_SIZE / (counter-over-true ratio of the kernel's access class) + WRITE_SIZE / (ratio of its writes); the raw counters and the bounds [raw, 2 x raw] are kept next to it", "kernels": {}}
 for key, match in pick.items():
     cands = sorted((n for n, k in summary.items() if match(n) and "FETCH_SIZE" in k and "WRITE_SIZE" in k),
@@ -66,6 +66,19 @@ for key, match in pick.items():
                                    "fetch_counter_over_true": round(rf, 4), "write_counter_over_true": round(rw, 4),
                                    "hbm_bytes_per_launch": round(fetch / rf + write / rw), "hbm_bytes_bounds": [round(fetch + write), round(2 * fetch + write)],
                                    "avg_us": round(k.get("avg_us", 0.0), 1)}
+            # from the SQ / TCC passes of the same command (tools/profile.sh): how much of the launch the 1024 SIMDs spend issuing vector
+            # instructions -- instructions x 4 cycles / (SIMDs x duration x 2.4 GHz); 4 cycles is what a wave64 instruction of the kind these
+            # kernels are made of (min / max, conversions, shifts, selects, compares) occupies a SIMD for, measured by tools/microbench_valu.hip;
+            # plain fma / mul / add / and take half of that -- the lanes active per vector instruction, and the L2 hit rate
+            if k.get("SQ_INSTS_VALU") and k.get("avg_us"):
+                out["kernels"][key]["issue_frac"] = round(k["SQ_INSTS_VALU"] / d * 4.0 / (1024.0 * k["avg_us"] * 1e-6 * 2.4e9), 3)
+                out["kernels"][key]["valu_insts_per_launch"] = round(k["SQ_INSTS_VALU"] / d)
+            if k.get("SQ_THREAD_CYCLES_VALU") and k.get("SQ_INSTS_VALU"):
+                out["kernels"][key]["active_lanes"] = round(k["SQ_THREAD_CYCLES_VALU"] / k["SQ_INSTS_VALU"], 1)
+            if k.get("l2_hit_rate") is not None:
+                out["kernels"][key]["l2_hit_rate"] = round(k["l2_hit_rate"], 3)
+            if k.get("frac_wait_any") is not None:
+                out["kernels"][key]["wave_time_waiting"] = round(k["frac_wait_any"], 3)
 K = out["kernels"]
 
 
@@ -75,5 +88,5 @@ def group(*keys):
 
 
 # keyed like bench.py's kernel table (one entry per kernel of the step)
-out["bench_kernel_traffic"] = {k: K[k]["hbm_bytes_per_launch"] for k in ("trace_primary", "shade_first", "trace_closest", "shade", "trace_shadow") if k in K}
+out["bench_kernel_traffic"] = {k: K[k]["hbm_bytes_per_launch"] for k in ("trace_primary", "shade_first", "trace_closest", "shade", "trace_shadow", "finish_sample") if k in K}
 print(json.dumps(out, indent=1))

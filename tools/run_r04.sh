@@ -35,6 +35,29 @@ PY
   third)  # the leaf word (node visit 235 -> 205 vector instructions): GPU suite, then A/B against the previous commit's library
     timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -8
     ab r04c atrium helmet glass street ;;
+  fourth)  # where the walks' time goes on the current build (section timers), what the alpha tests still cost, the new GPU test
+    timeout 300 python -m pytest tests/test_alpha_cut.py -m gpu -x -q 2>&1 | tail -3
+    B="--workload atrium --steps 3 --warmup 1 $N"
+    MI_PT_LIB=$PWD/vk_gltf_renderer_amd/lib/var_prof/libmi_pt.so timeout 150 python bench.py $B > $O/r04d_atrium_prof.json 2> $O/r04d_atrium_prof.err; grep "profile" $O/r04d_atrium_prof.err | tail -8
+    MI_PT_DIAG_IGNORE_ALPHA=1 timeout 150 python bench.py $B > $O/r04d_atrium_noalpha.json 2> /dev/null; val $O/r04d_atrium_noalpha.json atrium_ignore_alpha
+    timeout 150 python bench.py $B --alpha-cut 0 > $O/r04d_atrium_nocut.json 2> /dev/null; val $O/r04d_atrium_nocut.json atrium_no_cut
+    timeout 150 python bench.py $B > $O/r04d_atrium_base.json 2> /dev/null; val $O/r04d_atrium_base.json atrium_base ;;
+  fifth)  # own-lane pipelined triangle tests against the triangle rounds (var_rounds): parity suite, then the A/B
+    timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -8
+    ab r04e atrium helmet glass street ;;
+  sixth)  # the fixed cost of the alpha kernels (no alpha candidate at all) against their dynamic cost; the seed in the queue entry
+    timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+    B="--workload atrium --steps 3 --warmup 1 $N"
+    timeout 150 python bench.py $B > $O/r04f_atrium_base.json 2> /dev/null; val $O/r04f_atrium_base.json atrium_base
+    MI_PT_DIAG_ALL_OPAQUE_TRIS=1 timeout 150 python bench.py $B > $O/r04f_atrium_allopaque.json 2> /dev/null; val $O/r04f_atrium_allopaque.json atrium_all_opaque_tris
+    MI_PT_DIAG_IGNORE_ALPHA=1 timeout 150 python bench.py $B > $O/r04f_atrium_noalpha.json 2> /dev/null; val $O/r04f_atrium_noalpha.json atrium_ignore_alpha
+    timeout 150 python bench.py --workload street --steps 3 --warmup 1 $N > $O/r04f_street_base.json 2> /dev/null; val $O/r04f_street_base.json street_base ;;
+  seventh)  # path state in the queue entry against state by slot (MI_PT_STATE_BY_SLOT=1, same library)
+    timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+    for w in atrium helmet glass street; do
+      timeout 150 python bench.py --workload $w --steps 3 --warmup 1 $N > $O/r04g_${w}_queue.json 2> /dev/null; val $O/r04g_${w}_queue.json ${w}_state_in_queue
+      MI_PT_STATE_BY_SLOT=1 timeout 150 python bench.py --workload $w --steps 3 --warmup 1 $N > $O/r04g_${w}_slot.json 2> /dev/null; val $O/r04g_${w}_slot.json ${w}_state_by_slot
+    done ;;
   tests) timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ;;
   ab) shift; ab "$@" ;;
   *) echo "unknown step $1" ;;

@@ -81,10 +81,13 @@ struct RunSwitches
   int    sortMode       = 2;       // MI_PT_SORT             window sort of the generic shade kernel: 0 | 1 | 2
   int    sortModeSimple = 0;       // MI_PT_SORT_SIMPLE      ... of the SIMPLE kernel's later bounces: 0 | 1 | 3
   bool   noPacket       = false;   // MI_PT_NO_PACKET        k_generate + per-lane walk instead of k_trace_primary
+  bool   stateBySlot    = false;   // MI_PT_STATE_BY_SLOT    path state gathered by slot in every launch (rounds 1-3) instead of travelling in the queue entry
   bool   traceSpans     = false;   // MI_PT_TRACE_SPANS      synchronising diagnostics
   int    graphUpTo      = 0;       // MI_PT_GRAPH            batches up to this many frames replay a hipGraph
   bool   noPlanes       = false;   // MI_PT_DIAG_NO_PLANES   no float planes for the packet walk
   bool   noOpaqueTris   = false;   // MI_PT_DIAG_NO_OPAQUE_TRIS  alpha-test the OPAQUE class of the alpha cut too
+  bool   allOpaqueTris  = false;   // MI_PT_DIAG_ALL_OPAQUE_TRIS (wrong image) every triangle of an alpha-tested primitive in the OPAQUE class: the alpha
+                                   //                            kernels run without a single alpha candidate -- their fixed cost
   bool   noQuads        = false;   // MI_PT_DIAG_NO_QUADS    four texel gathers per bilinear tap instead of one footprint
   int    failBuildAt    = 0;       // MI_PT_DIAG_FAIL_BUILD=N  test hook: the N-th acceleration REbuild of the instance fails after the old structure is gone
   bool   candPoolSet    = false;   // MI_PT_DIAG_CAND_POOL   entries of the transmissive-candidate pool (tests of the overflow path)
@@ -100,10 +103,12 @@ struct RunSwitches
     sortMode       = num("MI_PT_SORT", 2);
     sortModeSimple = num("MI_PT_SORT_SIMPLE", 0);
     noPacket       = flag("MI_PT_NO_PACKET");
+    stateBySlot    = flag("MI_PT_STATE_BY_SLOT");
     traceSpans     = flag("MI_PT_TRACE_SPANS");
     graphUpTo      = num("MI_PT_GRAPH", 0);
     noPlanes       = flag("MI_PT_DIAG_NO_PLANES");
     noOpaqueTris   = flag("MI_PT_DIAG_NO_OPAQUE_TRIS");
+    allOpaqueTris  = flag("MI_PT_DIAG_ALL_OPAQUE_TRIS");
     noQuads        = flag("MI_PT_DIAG_NO_QUADS");
     failBuildAt    = num("MI_PT_DIAG_FAIL_BUILD", 0);
     if(const char* e = getenv("MI_PT_DIAG_CAND_POOL"))
@@ -262,7 +267,7 @@ int allocPathResources(MiPt* pt, int frames)
   const size_t subCap    = ((numChunks + pt::NSUB - 1) / pt::NSUB + 1) * pt::QCHUNK;
   const size_t qsize     = subCap * pt::NSUB;
   HIP_TRY(pt->queueMem.alloc(qsize * 3 + pt::QC_COUNT));
-  HIP_TRY(pt->queuePayload.alloc(qsize * 10));
+  HIP_TRY(pt->queuePayload.alloc(qsize * 16));
   pt::RayQueue* qs[3] = {&pt->queues.active[0], &pt->queues.active[1], &pt->queues.shadow};
   for(int i = 0; i < 3; ++i)
   {
@@ -271,8 +276,14 @@ int allocPathResources(MiPt* pt, int frames)
     qs[i]->dir  = pt->queuePayload.ptr + qsize * size_t(3 * i + 1);
     qs[i]->aux  = pt->queuePayload.ptr + qsize * size_t(3 * i + 2);
   }
-  pt->queues.active[0].aux2 = pt->queues.active[1].aux2 = nullptr;
   pt->queues.shadow.aux2    = pt->queuePayload.ptr + qsize * 9;
+  pt->queues.shadow.misc = pt->queues.shadow.rad = nullptr;
+  for(int i = 0; i < 2; ++i)  // the living paths' state, in queue order (pt_scene.h: RayQueue, FrameConsts::stateInQueue)
+  {
+    qs[i]->aux2 = pt->queuePayload.ptr + qsize * size_t(10 + 3 * i + 0);
+    qs[i]->misc = pt->queuePayload.ptr + qsize * size_t(10 + 3 * i + 1);
+    qs[i]->rad  = pt->queuePayload.ptr + qsize * size_t(10 + 3 * i + 2);
+  }
   pt->queues.counters = pt->queueMem.ptr + 3 * qsize;
   pt->queues.subCap   = uint32_t(subCap);
   // recorded transmissive shadow candidates (pt_scene.h): two pool entries per shadow-queue entry, and an overflow list as long as
@@ -620,7 +631,7 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
       d.tangents   = reinterpret_cast<const float*>(put(p.tangents, size_t(p.vertexCount) * 16));
       d.texCoords0 = reinterpret_cast<const float*>(put(p.texCoords0, size_t(p.vertexCount) * 8));
       d.texCoords1 = reinterpret_cast<const float*>(put(p.texCoords1, size_t(p.vertexCount) * 8));
-      d.opaqueTriangles = pt->sw.noOpaqueTris ? 0u : std::min(p.opaqueTriangleCount, p.triangleCount);  // (A/B switch: alpha-test them all)
+      d.opaqueTriangles = pt->sw.allOpaqueTris ? p.triangleCount : (pt->sw.noOpaqueTris ? 0u : std::min(p.opaqueTriangleCount, p.triangleCount));  // (A/B switch: alpha-test them all)
       d._pad            = 0;
       {
         std::vector<float> iv(size_t(p.vertexCount) * 12, 0.0f);
@@ -963,6 +974,7 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   c.fc.numFrames = numFrames;
   pt::divideMagic(uint32_t(std::max(numFrames, 2)), c.fc.framesMagic, c.fc.framesShift);
   c.fc.slotLayout = (numFrames % 64 == 0 && !pt->sw.microtileSlots) ? 1 : 0;  // (A/B switch: micro-tile major at any batch size)
+  c.fc.stateInQueue = (!pt->sw.stateBySlot && !(pt->frameInfo.flags & MI_SCENE_INFINITE_PLANE_SHADOW_CATCHER)) ? 1 : 0;
   c.paths        = pt->paths;
   pt->accumFrames   = float(params->totalSamples) / float(params->numSamples) + float(numFrames);
   const bool guides = (params->flags & MI_PT_USE_OPTIX_DENOISER) != 0;

@@ -385,7 +385,9 @@ __global__ void __launch_bounds__(256) k_generate(DevScene sc, FrameConsts fc, P
     if(cp.valid)
     {
       Q.active[0].org[pos] = make_float4(cp.origin.x, cp.origin.y, cp.origin.z, 0.0f);
-      Q.active[0].dir[pos] = make_float4(cp.direction.x, cp.direction.y, cp.direction.z, 0.0f);
+      Q.active[0].dir[pos] = make_float4(cp.direction.x, cp.direction.y, cp.direction.z, __uint_as_float(cp.seed));  // .w: the path's seed (alpha draws of the walk)
+      if(fc.stateInQueue)
+        Q.active[0].misc[pos] = make_float4(0.0f, __uint_as_float(PF_ALIVE), __uint_as_float(cp.seed), 0.0f);  // the state travels with the ray (pt_scene.h)
     }
   }
   if(blockIdx.x == 0 && threadIdx.x < NSUB)
@@ -869,14 +871,13 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
         pos        = pPos;
         r          = makeRaySetup(xyz(pO), xyz(pD));
         best       = ClosestBest{INFINITE_F, 0.0f, 0.0f, -1, 0xffffffffu, 0xffffffffu};  // t = ray.TMax
-        seedLoaded = false;
+        seed0      = __float_as_uint(pD.w);  // the alpha draws of this ray: the path's seed travels in the queue entry (dir.w)
+        seedLoaded = true;
         if(WIDE)
         {
           octinv = rayOctInv(r.idir);
           G      = rootGroup(octinv);
           st2.sp = 0;
-          if(HAS_ALPHA)
-            seed0 = __float_as_uint(P.misc[slot].z);  // the alpha draws of this ray (first used in a triangle round)
         }
         else
         {
@@ -1384,9 +1385,13 @@ __global__ void __launch_bounds__(256, INTERVAL ? PRIMARY_INTERVAL_MIN_WAVES : P
     const uint32_t pos   = pos0 + before + laneCountBelow(shadeMask);
     Q.active[0].slot[pos] = slot;
     Q.active[0].org[pos]  = make_float4(cp.origin.x, cp.origin.y, cp.origin.z, 0.0f);
-    Q.active[0].dir[pos]  = make_float4(cp.direction.x, cp.direction.y, cp.direction.z, 0.0f);
+    Q.active[0].dir[pos]  = make_float4(cp.direction.x, cp.direction.y, cp.direction.z, __uint_as_float(cp.seed));
     Q.active[0].aux[pos]  = make_float4(best.t, __int_as_float(best.tri), best.u, best.v);
-    P.misc[slot]          = make_float4(0.0f, __uint_as_float(PF_ALIVE), __uint_as_float(cp.seed), 0.0f);  // cone.width = 0
+    const float4 misc0    = make_float4(0.0f, __uint_as_float(PF_ALIVE), __uint_as_float(cp.seed), 0.0f);  // cone.width = 0
+    if(fc.stateInQueue)
+      Q.active[0].misc[pos] = misc0;  // the state travels with the ray (pt_scene.h: RayQueue)
+    else
+      P.misc[slot] = misc0;
   }
   if(threadIdx.x >= total)
     Q.active[0].slot[pos0 + threadIdx.x] = QUEUE_DEAD;
@@ -1500,6 +1505,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
   // uniform address -- the compiler must assume the store or the callee wrote there -- and the loop is full of both.
   const DevScene&    sc = uniformConst(*scp);
   const FrameConsts& fc = uniformConst(*fcp);
+  const bool         stateInQueue = fc.stateInQueue != 0;  // misc / throughput / radiance of a living path ride in its queue entry (pt_scene.h: RayQueue)
   __shared__ uint32_t s_prefix[NSUB + 1];
   __shared__ uint32_t s_push[4];
   __shared__ float    s_srgb[256];  // sRGB decode table next to the ALU: 3 lookups per texel, up to 8 texels per tap
@@ -1569,7 +1575,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
             bin = SORT_BIN_MISS;
           else if(sortMode == 3)
           {
-            uint32_t seedPeek = __float_as_uint(P.misc[slot].z);
+            uint32_t seedPeek = __float_as_uint((fc.stateInQueue ? Q.active[cur].misc[myPos[k]] : P.misc[slot]).z);
             bin               = rnd(seedPeek) < lightWeight ? 0u : 1u;
           }
           else
@@ -1633,14 +1639,16 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
     bool           alive = false, pushShadow = false;
     unsigned       taps = 0;
     float4         nextOrg = make_float4(0, 0, 0, 0), nextDir = make_float4(0, 0, 0, 0);
+    float4         nextRad = make_float4(0, 0, 0, 0), nextMisc = make_float4(0, 0, 0, 0), nextThr = make_float4(0, 0, 0, 0);  // state of a path that goes on
     float4         shOrg = make_float4(0, 0, 0, 0), shDir = make_float4(0, 0, 0, 0), shCon = make_float4(0, 0, 0, 0), shCon2 = make_float4(0, 0, 0, 0);
     bool           catcher = false;
     if(inRange && slot != QUEUE_DEAD)
     {
       const float4 hit4 = Q.active[cur].aux[inPos], o4 = Q.active[cur].org[inPos], d4 = Q.active[cur].dir[inPos];
-      const float4 misc4 = P.misc[slot];
-      const float4 tp4   = FIRST ? make_float4(1.0f, 1.0f, 1.0f, DIRAC) : P.throughput[slot];
-      const float4 rad4  = FIRST ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : P.radiance[slot];
+      // the path's state: records of its queue entry (unit stride, like the ray), or -- catcher frames / MI_PT_STATE_BY_SLOT -- gathered by slot
+      const float4 misc4 = stateInQueue ? Q.active[cur].misc[inPos] : P.misc[slot];
+      const float4 tp4   = FIRST ? make_float4(1.0f, 1.0f, 1.0f, DIRAC) : (stateInQueue ? Q.active[cur].aux2[inPos] : P.throughput[slot]);
+      const float4 rad4  = FIRST ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : (stateInQueue ? Q.active[cur].rad[inPos] : P.radiance[slot]);
       f3       rayOrigin = xyz(o4), rayDir = xyz(d4);
       float    coneWidth = misc4.w;
       f3       throughput = xyz(tp4), radiance = xyz(rad4);
@@ -1960,13 +1968,22 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
       flags = (isInside ? PF_INSIDE : 0u) | (solid ? 0u : PF_NOT_SOLID) | (alive ? PF_ALIVE : 0u) | (uint32_t(min(surfaceDepth, 255)) << PF_DEPTH_SHIFT)
               | (uint32_t(scatterBounces) << PF_SCATTER_SHIFT);
       // (fmaxf: a NaN or negative maxRoughness.x from degenerate material input must not collide with RADW_PRIMARY_MISS or the flag bit)
-      P.radiance[slot] = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(__float_as_uint(fmaxf(maxRoughness.x, 0.0f)) | (solid ? 0u : RADW_NOT_SOLID)));
-      P.misc[slot]     = make_float4(maxRoughness.y, __uint_as_float(flags), __uint_as_float(seed), coneWidth);
+      nextRad  = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(__float_as_uint(fmaxf(maxRoughness.x, 0.0f)) | (solid ? 0u : RADW_NOT_SOLID)));
+      nextMisc = make_float4(maxRoughness.y, __uint_as_float(flags), __uint_as_float(seed), coneWidth);
+      // A path that ends here leaves its radiance where k_finish_sample reads it and its seed where the next sample of a multi-sample
+      // frame picks it up; one that goes on takes its state along in its queue entry (below, once the entry's position is known).
+      if(!stateInQueue || !alive)
+      {
+        P.radiance[slot] = nextRad;
+        P.misc[slot]     = nextMisc;
+      }
       if(alive)
       {
-        nextOrg            = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, 0.0f);
-        nextDir            = make_float4(rayDir.x, rayDir.y, rayDir.z, 0.0f);
-        P.throughput[slot] = make_float4(throughput.x, throughput.y, throughput.z, lastSamplePdf);
+        nextOrg = make_float4(rayOrigin.x, rayOrigin.y, rayOrigin.z, 0.0f);
+        nextDir = make_float4(rayDir.x, rayDir.y, rayDir.z, __uint_as_float(seed));  // .w: the path's seed -- the walk's alpha draws start from it
+        nextThr = make_float4(throughput.x, throughput.y, throughput.z, lastSamplePdf);
+        if(!stateInQueue)
+          P.throughput[slot] = nextThr;
       }
       if(COUNT && taps)
         atomicAdd(&stats->textureTaps, (unsigned long long)taps);
@@ -1980,10 +1997,17 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
       Q.active[nxt].slot[posNext] = slot;
       Q.active[nxt].org[posNext]  = nextOrg;
       Q.active[nxt].dir[posNext]  = nextDir;
+      if(stateInQueue)
+      {
+        Q.active[nxt].rad[posNext]  = nextRad;
+        Q.active[nxt].misc[posNext] = nextMisc;
+        Q.active[nxt].aux2[posNext] = nextThr;
+      }
     }
     if(pushShadow)
     {
-      Q.shadow.slot[posShadow] = slot;
+      // where k_shadow_resolve adds this ray's term: the path's next queue entry while it lives, PathSoA::radiance once it has ended
+      Q.shadow.slot[posShadow] = (stateInQueue && alive) ? (posNext | SHADOW_TARGET_QUEUE) : slot;
       Q.shadow.org[posShadow]  = shOrg;
       Q.shadow.dir[posShadow]  = shDir;
       Q.shadow.aux[posShadow]  = shCon;
@@ -2025,11 +2049,13 @@ PT_DEV void shadowDeposit(const PathSoA& P, const Queues& Q, int nxt, uint32_t s
   {
     if(!occ)
     {
-      float4 rad = P.radiance[slot];
+      // `slot` is the entry's target (pt_scene.h: SHADOW_TARGET_QUEUE): the living path's record in the next active queue, or its slot
+      float4* const target = (slot & SHADOW_TARGET_QUEUE) ? &Q.active[nxt].rad[slot & ~SHADOW_TARGET_QUEUE] : &P.radiance[slot];
+      float4        rad    = *target;
       rad.x += contrib.x * total.x;
       rad.y += contrib.y * total.y;
       rad.z += contrib.z * total.z;
-      P.radiance[slot] = rad;
+      *target = rad;
     }
     return;
   }

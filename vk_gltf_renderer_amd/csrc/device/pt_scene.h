@@ -184,6 +184,10 @@ struct FrameConsts
   int                     numFrames;
   uint32_t                framesMagic, framesShift;  // w / numFrames == mulhi(w, framesMagic) >> framesShift for w < 2^31 (divideMagic; numFrames >= 2)
   int                     slotLayout;                // 0: micro-tile major, 1: pixel major (numFrames % 64 == 0)
+  // 1: misc / throughput / radiance of a living path are records of its queue entry (RayQueue::misc / aux2 / rad); PathSoA::radiance and
+  // ::misc are written once, when the path ends.  0: by path slot, as in rounds 1-3 -- frames with the shadow-catcher plane, whose
+  // resolve pass ends a path from outside the shade kernel (pathtrace_functions.h.slang:520-534), and MI_PT_STATE_BY_SLOT=1 (A/B).
+  int                     stateInQueue;
 };
 
 // Exact division of a 31-bit number by d >= 2 as multiply-high + shift: with k = floor(log2 d) and m = ceil(2^(32+k) / d) (< 2^32
@@ -310,9 +314,19 @@ struct RayQueue
   float4*   dir;   // direction.xyz, (closest: unused | shadow: uint bits, bit0 = initialInside)
   float4*   aux;   // closest: hit record written by k_trace_closest (t, triangle index bits or -1, u, v)
                    // shadow : contribution.rgb, seed bits (input of k_trace_shadow)
-  float4*   aux2;  // shadow queue only, shadow-catcher entries only (dir.w bit1): unshadowed term.rgb, position of the path's
-                   // continuation entry in the next active queue (or 0xffffffff)
+  float4*   aux2;  // shadow queue: shadow-catcher entries only (dir.w bit1): unshadowed term.rgb, position of the path's
+                   // continuation entry in the next active queue (or 0xffffffff).  Active queues: the path's throughput.rgb + lastSamplePdf
+  // Active queues only -- the path's state TRAVELS WITH ITS RAY (FrameConsts::stateInQueue, round 4): what PathSoA::misc / ::radiance hold by
+  // slot, written by the shade launch that appends the entry and read by the next one as a unit-stride stream.  By the later bounces
+  // the surviving paths are sparse in slot space: three 16-byte gathers by slot touched up to three cache lines per path (and three
+  // scattered stores), where the entry's records now arrive in the order the wave processes them.
+  float4*   misc;  // maxRoughness.y, flags (uint bits), seed (uint bits), cone.width
+  float4*   rad;   // radiance so far .rgb, maxRoughness.x | RADW_NOT_SOLID -- k_shadow_resolve adds a shadow ray's term HERE while the path lives
 };
+// slot field of a SHADOW queue entry when the path's state is in the queue: where k_shadow_resolve adds the ray's term -- bit 31 set:
+// entry (slot & 0x7fffffff) of the NEXT active queue's `rad` (the path goes on); clear: PathSoA::radiance[slot] (the path ended with
+// this bounce, its radiance already lies where k_finish_sample reads it)
+constexpr uint32_t SHADOW_TARGET_QUEUE = 0x80000000u;
 struct Queues
 {
   RayQueue  active[2];  // paths to trace/shade this iteration, ping-pong
