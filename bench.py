@@ -82,7 +82,7 @@ VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 # node visit of the per-lane walk (decode + 8 slab tests + child order), one triangle test (Moeller-Trumbore + candidate update),
 # and one node of the packet walk's INTERVAL test (k_trace_primary with pixel-major slots: lane = child x 8 + plane tests one plane
 # of the node against the packet's interval ray -- all 64 lanes of ~50 instructions work on ONE node, pt_packet.h)
-VALU_PER_NODE, VALU_PER_TRI, VALU_PER_PACKET_NODE = 235, 56, 50
+VALU_PER_NODE, VALU_PER_TRI, VALU_PER_PACKET_NODE = 205, 56, 50  # (node visit: 235 until round 4's leaf word)
 # SURVEY §8(d) algorithmic bytes, per unit: ray + hit record, path state read + write, hit-attribute gather, instance +
 # primitive + material records, shadow-ray record, one texture tap, pixel accumulate
 B_RAYHIT, B_STATE, B_ATTR, B_RECORDS, B_SHADOW, B_TAP, B_PIXEL = 60, 192, 192, 480, 76, 48, 32
@@ -347,6 +347,7 @@ def secondary_line(name, args, device, width=0, height=0, steps=5, parity=True, 
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timing = t.frame_timing()
+    mem = t.memory()
     t.close()
 
     def counter_pass(depth):
@@ -367,6 +368,7 @@ def secondary_line(name, args, device, width=0, height=0, steps=5, parity=True, 
                        "frames_in_flight": F, "max_depth": w["depth"], "frames_timed": frames, "steps": steps,
                        "denoise": ("variance-guided a-trous (mi_pt_denoise_svgf, 5 iterations) once per step, inside the timed region" if denoise else None)},
             "timed_region_s": round(elapsed, 3),
+            "device_memory_GB": {"scene": round(mem["sceneBytes"] / 1e9, 3), "path_state_queues_images": round(mem["rendererBytes"] / 1e9, 3)},
             "roofline": roofline_of(kernels, pmc), "kernels": kernels, "per_frame": {k: round(per_frame[k], 1) for k in keys},
             "node_visits_per_secondary_ray": round(per_frame["nodesClosest"] / max(1.0, per_frame["segments"] - per_frame["cameraPaths"]), 2),
             "triangle_tests_per_secondary_ray": round(per_frame["trisClosest"] / max(1.0, per_frame["segments"] - per_frame["cameraPaths"]), 2)}
@@ -564,6 +566,7 @@ def main():
         elapsed = float(t.item())
     timing = tracer.frame_timing()
     tracer.enable_timing(False)
+    mem = tracer.memory()
     frames_timed = args.steps * frames_step
     samples = float(W) * float(H) * float(frames_timed)
     value = samples / elapsed / 1e6
@@ -619,6 +622,7 @@ def main():
             "per_frame": {k: round(per_frame[k], 1) for k in keys},
             "per_frame_bounce0": {k: round(first[k], 1) for k in keys},
             "frame_ms_device": round(timing["totalMs"] / frames_timed, 4),
+            "device_memory_GB": {"scene": round(mem["sceneBytes"] / 1e9, 3), "path_state_queues_images": round(mem["rendererBytes"] / 1e9, 3)},
             "node_visits_per_secondary_ray": round(per_frame["nodesClosest"] / max(1.0, per_frame["segments"] - per_frame["cameraPaths"]), 2),
             "triangle_tests_per_secondary_ray": round(per_frame["trisClosest"] / max(1.0, per_frame["segments"] - per_frame["cameraPaths"]), 2),
         }

@@ -58,6 +58,46 @@ PY
       timeout 150 python bench.py --workload $w --steps 3 --warmup 1 $N > $O/r04g_${w}_queue.json 2> /dev/null; val $O/r04g_${w}_queue.json ${w}_state_in_queue
       MI_PT_STATE_BY_SLOT=1 timeout 150 python bench.py --workload $w --steps 3 --warmup 1 $N > $O/r04g_${w}_slot.json 2> /dev/null; val $O/r04g_${w}_slot.json ${w}_state_by_slot
     done ;;
+  eighth)  # with the state in the queue entry: the technique-keyed window sort of the SIMPLE kernel's later bounces, once more
+    for m in 0 1 3; do
+      for w in atrium street; do
+        MI_PT_SORT_SIMPLE=$m timeout 150 python bench.py --workload $w --steps 3 --warmup 1 $N > $O/r04h_${w}_sort$m.json 2> /dev/null; val $O/r04h_${w}_sort$m.json ${w}_sort_simple_$m
+      done
+    done ;;
+  evidence)  # tools/run_r04.sh evidence <tag> <bench args...>: kernel-trace stats + counter passes of ONE configuration; leaves
+             # gpurun_out/r04_<tag>_kernel_stats.csv, r04_<tag>_pmc_summary.json and pmc_latest_<tag>.json (to be copied to profiles/)
+    shift; tag=$1; shift
+    tools/profile.sh r04_$tag "$@" --steps 2 --warmup 1 > /dev/null 2>&1
+    python tools/summarize_pmc.py $O/prof_r04_$tag $O/r04_${tag}_pmc_summary.json > /dev/null
+    cp "$(find $O/prof_r04_$tag/stats -name '*kernel_stats.csv' | head -1)" $O/r04_${tag}_kernel_stats.csv
+    python3 - $tag <<'PY'
+import json, subprocess, sys
+tag = sys.argv[1]
+line = [l for l in open(f"gpurun_out/prof_r04_{tag}/stats.log") if l.startswith("{")][-1]
+j = json.loads(line); c = j["config"]
+wl = [w for w in ("helmet", "atrium", "street", "glass", "box") if w in tag][0]
+out = subprocess.run([sys.executable, "tools/make_pmc_latest.py", f"gpurun_out/r04_{tag}_pmc_summary.json", wl, str(c["frames_in_flight"]), "4",
+                      "profiles/r03_fetch_calibration.json", str(c["resolution"][0]), str(c["resolution"][1])], capture_output=True, text=True)
+open(f"gpurun_out/pmc_latest_{tag}.json", "w").write(out.stdout)
+k = json.loads(out.stdout)["kernels"]
+print("EVIDENCE", tag, j["value"], {n: (v.get("issue_frac"), v.get("active_lanes"), round(v["hbm_bytes_per_launch"] / 1e9, 2)) for n, v in k.items()}, out.stderr[-300:])
+PY
+    ;;
+  sweep)  # frames in flight 1 / 8 / 64 / 128 at 1080p and 4K: what a maintainer gets per onRender batch size, and the memory it takes
+    for w in helmet atrium; do for f in 1 8 64 128; do
+      timeout 200 python bench.py --workload $w --in-flight $f --frames-per-step $((f * 2)) --steps 4 --warmup 1 $N > $O/r04_sweep_${w}_f$f.json 2> /dev/null
+      python3 -c "
+import json; j=json.loads(open('$O/r04_sweep_${w}_f$f.json').read().strip().splitlines()[-1]); print('SWEEP ${w} 1080p in_flight', j['config']['frames_in_flight'], j['value'], j['device_memory_GB'])"
+    done; done
+    for f in 1 8 64; do
+      timeout 200 python bench.py --workload helmet --width 3840 --height 2160 --in-flight $f --frames-per-step $((f * 2)) --steps 4 --warmup 1 $N > $O/r04_sweep_helmet4k_f$f.json 2> /dev/null
+      python3 -c "
+import json; j=json.loads(open('$O/r04_sweep_helmet4k_f$f.json').read().strip().splitlines()[-1]); print('SWEEP helmet 4K in_flight', j['config']['frames_in_flight'], j['value'], j['device_memory_GB'])"
+    done ;;
+  ninth)  # octant table in LDS + sign-free slab offsets (node visit 205 -> ~183 vector instructions) against the previous commit
+    timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+    ab r04i atrium helmet glass street ;;
+  tenth) ab r04j atrium helmet glass street ;;
   tests) timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ;;
   ab) shift; ab "$@" ;;
   *) echo "unknown step $1" ;;

@@ -81,6 +81,27 @@ PT_DEV uint32_t groupPopChild(NodeGroup& g, uint32_t octinv)
 
 PT_DEV float byteF(uint32_t w, int i) { return float((w >> (8 * i)) & 0xffu); }  // v_cvt_f32_ubyteN
 
+// Child masks live in PRIORITY space on the stack (bit p = slot ^ octinv: the highest set bit is the nearest child): a node visit turns
+// its 8-bit hit mask from slot space into that order -- a butterfly on the three index bits, 16 vector instructions -- or, in the
+// per-lane walks, looks it up: the 8 x 256 results as bytes in the workgroup's LDS (fillOctLut), one address add and one ds_read_u8.
+PT_DEV uint32_t octPermute(uint32_t hits, uint32_t octinv)
+{
+  hits = (octinv & 1u) ? (((hits & 0x55u) << 1) | ((hits & 0xaau) >> 1)) : hits;
+  hits = (octinv & 2u) ? (((hits & 0x33u) << 2) | ((hits & 0xccu) >> 2)) : hits;
+  hits = (octinv & 4u) ? (((hits & 0x0fu) << 4) | ((hits & 0xf0u) >> 4)) : hits;
+  return hits;
+}
+constexpr int OCT_LUT_BYTES = 8 * 256;
+#ifndef MI_PT_OCT_LUT
+#define MI_PT_OCT_LUT 1  // (A/B: 0 = the butterfly in every node visit)
+#endif
+// whole block; the caller's next barrier (fillNodeCache ends with one) publishes the table
+PT_DEV void fillOctLut(uint8_t* lut)
+{
+  for(uint32_t i = threadIdx.x; i < uint32_t(OCT_LUT_BYTES); i += blockDim.x)
+    lut[i] = uint8_t(octPermute(i & 255u, i >> 8));
+}
+
 // ---- leaf word: the triangles a node visit found, in ONE register.  A node owns up to 16 triangle bits, two per child slot
 // (bvh8.hip: valid16); the low half of the word is the node's valid16, the high half the PENDING triangles (bit 16 + 2s + k = triangle k
 // of the leaf child in slot s, hit and not yet handed to a test).  Triangles are stored compactly in slot order, so the index of a
@@ -97,6 +118,21 @@ PT_DEV uint32_t leafPop(uint32_t& w, uint32_t triBase)
   return triBase + uint32_t(__popc(w & ((1u << (bit - 16u)) - 1u)));  // (bits below bit - 16 lie in the valid half: untouched by the clear)
 }
 
+// Per node and axis: a child plane q (0..255) is crossed at t = q * A + B with A = 2^e / dir and B = (p - org) / dir; the walk wants a
+// LOWER bound for the planes a ray enters through and an UPPER bound for those it leaves through.  Bn = t0 - e and Bf = t0 + e with
+// t0 = fl(P * idir) and e = 2^-21 (255 |A| + |t0|): the roundings of P = p - org, of t0, of t0 -+ e and of the fma that adds q * A
+// (q * A itself is exact) sum to less than 4 x 2^-24 (255 |A| + |t0|), half of e -- conservative without a multiplicative fudge,
+// including the cancellation case of an origin inside the node.  The same expression whatever the direction's sign (round 4: before,
+// the pad went onto P before the multiplication and was added or subtracted by sign: two selects and a multiply more per axis); the
+// individual operations are pinned so that the byte and the float-plane form of the test stay bit-identical.
+PT_DEV void slabOffsets(float P, float idir, float A, float& Bn, float& Bf)
+{
+  const float t0 = __fmul_rn(P, idir);
+  const float e  = __fmul_rn(4.76837158e-7f, __fmaf_rn(255.0f, fabsf(A), fabsf(t0)));  // 2^-21 (...)
+  Bn             = __fsub_rn(t0, e);
+  Bf             = __fadd_rn(t0, e);
+}
+
 // Slab test of the 8 children of a loaded node: bit i of `hm` = child slot i is hit (inner or leaf), `leafOut` = the leaf word of the
 // hit LEAF children (inner children own no valid bit, so their hits fall out in the AND).
 PT_DEV void bvh8TestChildren(const uint4& n0, const uint4& n1, const uint4& n2, const uint4& n3, const uint4& n4, const RaySetup& r, float tmax,
@@ -104,14 +140,13 @@ PT_DEV void bvh8TestChildren(const uint4& n0, const uint4& n1, const uint4& n2, 
 {
   const float  sx = __uint_as_float((n0.w & 0xffu) << 23), sy = __uint_as_float(((n0.w >> 8) & 0xffu) << 23), sz = __uint_as_float(((n0.w >> 16) & 0xffu) << 23);
   const float  Px = __uint_as_float(n0.x) - r.org.x, Py = __uint_as_float(n0.y) - r.org.y, Pz = __uint_as_float(n0.z) - r.org.z;
-  const float  k  = 4.76837158e-7f;  // 2^-21
-  const float  dx = __fmaf_rn(255.0f, sx, fabsf(Px)) * k, dy = __fmaf_rn(255.0f, sy, fabsf(Py)) * k, dz = __fmaf_rn(255.0f, sz, fabsf(Pz)) * k;
   // a negative direction enters through the upper plane (the sign is idir's: it is well defined for -0.0 as well)
   const bool   nx = r.idir.x < 0.0f, ny = r.idir.y < 0.0f, nz = r.idir.z < 0.0f;
   const float  Ax = sx * r.idir.x, Ay = sy * r.idir.y, Az = sz * r.idir.z;
-  const float  Bnx = (nx ? Px + dx : Px - dx) * r.idir.x, Bfx = (nx ? Px - dx : Px + dx) * r.idir.x;
-  const float  Bny = (ny ? Py + dy : Py - dy) * r.idir.y, Bfy = (ny ? Py - dy : Py + dy) * r.idir.y;
-  const float  Bnz = (nz ? Pz + dz : Pz - dz) * r.idir.z, Bfz = (nz ? Pz - dz : Pz + dz) * r.idir.z;
+  float        Bnx, Bfx, Bny, Bfy, Bnz, Bfz;
+  slabOffsets(Px, r.idir.x, Ax, Bnx, Bfx);
+  slabOffsets(Py, r.idir.y, Ay, Bny, Bfy);
+  slabOffsets(Pz, r.idir.z, Az, Bnz, Bfz);
   // near / far byte planes per axis (4 children per word), chosen once per node by the direction sign
   const uint32_t qnx[2] = {nx ? n3.z : n2.x, nx ? n3.w : n2.y}, qfx[2] = {nx ? n2.x : n3.z, nx ? n2.y : n3.w};
   const uint32_t qny[2] = {ny ? n4.x : n2.z, ny ? n4.y : n2.w}, qfy[2] = {ny ? n2.z : n4.x, ny ? n2.w : n4.y};
@@ -159,12 +194,12 @@ PT_DEV uint32_t bvh8TestChildrenPlanes(const uint4& n0, const f32x8s& pnx, const
 {
   const float sx = __uint_as_float((n0.w & 0xffu) << 23), sy = __uint_as_float(((n0.w >> 8) & 0xffu) << 23), sz = __uint_as_float(((n0.w >> 16) & 0xffu) << 23);
   const float Px = __uint_as_float(n0.x) - r.org.x, Py = __uint_as_float(n0.y) - r.org.y, Pz = __uint_as_float(n0.z) - r.org.z;
-  const float k  = 4.76837158e-7f;  // 2^-21
-  const float dx = __fmaf_rn(255.0f, sx, fabsf(Px)) * k, dy = __fmaf_rn(255.0f, sy, fabsf(Py)) * k, dz = __fmaf_rn(255.0f, sz, fabsf(Pz)) * k;
   const float Ax = sx * r.idir.x, Ay = sy * r.idir.y, Az = sz * r.idir.z;
-  const float Bnx = __fmaf_rn(sgnx, dx, Px) * r.idir.x, Bfx = __fmaf_rn(-sgnx, dx, Px) * r.idir.x;
-  const float Bny = __fmaf_rn(sgny, dy, Py) * r.idir.y, Bfy = __fmaf_rn(-sgny, dy, Py) * r.idir.y;
-  const float Bnz = __fmaf_rn(sgnz, dz, Pz) * r.idir.z, Bfz = __fmaf_rn(-sgnz, dz, Pz) * r.idir.z;
+  float       Bnx, Bfx, Bny, Bfy, Bnz, Bfz;
+  (void)sgnx; (void)sgny; (void)sgnz;  // (the offsets no longer depend on the direction's sign: slabOffsets)
+  slabOffsets(Px, r.idir.x, Ax, Bnx, Bfx);
+  slabOffsets(Py, r.idir.y, Ay, Bny, Bfy);
+  slabOffsets(Pz, r.idir.z, Az, Bnz, Bfz);
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   const f32x2 A2x = {Ax, Ax}, A2y = {Ay, Ay}, A2z = {Az, Az};
   const f32x2 Bn2x = {Bnx, Bnx}, Bn2y = {Bny, Bny}, Bn2z = {Bnz, Bnz}, Bf2x = {Bfx, Bfx}, Bf2y = {Bfy, Bfy}, Bf2z = {Bfz, Bfz};
@@ -185,14 +220,12 @@ PT_DEV uint32_t bvh8TestChildrenPlanes(const uint4& n0, const f32x8s& pnx, const
 }
 
 // One node visit.  The builder guarantees that the decoded boxes fmaf(q, 2^e, p) contain their triangles.  Here every slab
-// plane costs ONE fma: t = q * A + B with A = 2^e / dir and B = (p - org -/+ delta) / dir per axis and per node, the near
-// planes pulled towards the ray's origin and the far planes pushed away by delta = 2^-21 (|p - org| + 255 * 2^e), which
-// bounds the accumulated rounding of p - org, of the two products and of the fma -- so the test stays conservative
-// without a multiplicative fudge, including the cancellation case of an origin inside the node.
+// plane costs ONE fma: t = q * A + B with A = 2^e / dir and B = (p - org) / dir -+ pad per axis and per node (slabOffsets): the
+// near planes pulled towards the ray's origin and the far planes pushed away by what bounds the accumulated rounding.
 // Nodes below index `cached` are read from the workgroup's LDS copy (ldsNodes), the rest from global memory.
 // `triBase` / `leafWord`: the triangles of the hit leaf children (leaf word above; leafPending(leafWord) says whether there are any).
 PT_DEV void bvh8Visit(const DevScene& sc, const RaySetup& r, float tmax, uint32_t octinv, uint32_t nodeIndex, NodeGroup& outGroup, uint32_t& triBase,
-                      uint32_t& leafWord, const uint4* ldsNodes, uint32_t cached)
+                      uint32_t& leafWord, const uint4* ldsNodes, uint32_t cached, const uint8_t* octLut = nullptr)
 {
   uint4 n0, n1, n2, n3, n4;
   if(nodeIndex < cached)
@@ -214,10 +247,14 @@ PT_DEV void bvh8Visit(const DevScene& sc, const RaySetup& r, float tmax, uint32_
   uint32_t       hm, leaf;
   bvh8TestChildren(n0, n1, n2, n3, n4, r, tmax, hm, leaf);
   uint32_t hits = hm & imask;
-  // slot space -> priority space: bit p = slot ^ octinv, a butterfly on the three index bits
-  hits = (octinv & 1u) ? (((hits & 0x55u) << 1) | ((hits & 0xaau) >> 1)) : hits;
-  hits = (octinv & 2u) ? (((hits & 0x33u) << 2) | ((hits & 0xccu) >> 2)) : hits;
-  hits = (octinv & 4u) ? (((hits & 0x0fu) << 4) | ((hits & 0xf0u) >> 4)) : hits;
+  // slot space -> priority space: bit p = slot ^ octinv
+  if(MI_PT_OCT_LUT && octLut)
+  {
+    typedef const __attribute__((address_space(3))) uint8_t* LdsBytePtr;  // (explicit LDS address space: a generic pointer would be a flat load)
+    hits = uint32_t(((LdsBytePtr)octLut)[(octinv << 8) | hits]);
+  }
+  else
+    hits = octPermute(hits, octinv);
   outGroup.base = n1.x;
   outGroup.bits = (hits << 8) | imask;
   triBase       = n1.y;

@@ -26,7 +26,11 @@ constexpr int TRACE_BLOCK = 1024;
                             //  lane in LDS with 200 / 400 more cached nodes: within +-0.5 % on all four workloads; 6 + 600: street -2 %)
 #endif
 constexpr int NODE_CACHE  = 712 + NODE_CACHE_EXTRA;  // BVH8 nodes (80 B each) resident in LDS
-constexpr int NODE_CACHE_ALPHA = 504 + NODE_CACHE_EXTRA;  // ... in the kernels that also keep a list of deferred alpha tests there (16 B x 1024)
+constexpr int NODE_CACHE_ALPHA = 504 + NODE_CACHE_EXTRA;
+// The any-hit walk also keeps the 2-KiB octant table of pt_bvh8.h there (it has the room: no triangle-round result slots): measured in
+// round 4 on both walks -- shadow walk -1.5 ... -3 % on every workload; closest-hit walk -2 % on the helmet but +1.5 ... +2.3 % on atrium,
+// glass and street (its node step then waits for one more LDS round trip where the butterfly's 16 instructions were hidden by the
+// other waves, and the table took the room of 26 cached nodes), so that kernel keeps the butterfly.  // ... in the kernels that also keep a list of deferred alpha tests there (16 B x 1024)
 constexpr int SEL_BLOCK   = 256;
 #ifndef TRACE_MIN_WAVES
 #define TRACE_MIN_WAVES 1
@@ -2094,6 +2098,7 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
   __shared__ uint32_t s_items[(WIDE && !HAS_TRANS) ? SBLOCK : 1];  // triangle rounds (see triRoundPublish)
   __shared__ uint4    s_alpha[(WIDE && DEFER) ? SBLOCK : 1];       // deferred alpha tests (see alphaRound)
   __shared__ uint32_t s_head[REC ? SBLOCK : 1], s_ovf[REC ? SBLOCK : 1];  // per ray in flight: recorded-candidate list head, overflow flag
+  __shared__ uint8_t  s_octLut[(WIDE && MI_PT_OCT_LUT) ? OCT_LUT_BYTES : 1];  // child mask -> front-to-back order per octant (pt_bvh8.h: octPermute)
   queuePrefix(&Q.counters[(nxt ? QC_PAIR1 : QC_PAIR0) + 1], s_prefix);  // the shadow tails written next to active queue `nxt`
   const RayQueue in = Q.shadow;
   const bool     subset = MODE == 2 && overflowOnly != 0;  // only the rays k_trace_shadow<MODE 3> listed in Q.overflow
@@ -2102,6 +2107,8 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
   feedInit(feed, subset ? Q.counters[QC_OVERFLOW] : s_prefix[NSUB]);
   if(!feedBlockHasWork(feed))
     return;
+  if(WIDE && MI_PT_OCT_LUT)
+    fillOctLut(s_octLut);
   const uint32_t cachedNodes = WIDE ? fillNodeCache(sc, s_nodes, uint32_t(ShadowCfg<MODE>::CACHE)) : 0u;
   LaneStack  st;
   LaneStack2 st2;
@@ -2319,7 +2326,7 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
             if(G.bits >> 8)
               st2.push(G);
             uint32_t tBase, tMask;
-            bvh8Visit(sc, r, walkTmax, octinv, child, G, tBase, tMask, s_nodes, cachedNodes);
+            bvh8Visit(sc, r, walkTmax, octinv, child, G, tBase, tMask, s_nodes, cachedNodes, s_octLut);
             if(COUNT) ++nodes;
             visited = true;
             if(leafPending(tMask))

@@ -267,6 +267,12 @@ class PathTracer:
         _check_pt(self._l.mi_pt_get_stats(self._p, C.byref(st)))
         return {n: int(getattr(st, n)) for n, _ in st._fields_}
 
+    def memory(self):
+        """mi_pt_get_memory: bytes of the scene (geometry, textures, acceleration structure), of the renderer (path state, queues, images) and of the device."""
+        m = capi.MiPtMemory()
+        _check_pt(self._l.mi_pt_get_memory(self._p, C.byref(m)))
+        return {n: int(getattr(m, n)) for n, _ in m._fields_}
+
     def reset_stats(self):
         _check_pt(self._l.mi_pt_reset_stats(self._p))
 
