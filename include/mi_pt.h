@@ -9,6 +9,11 @@
  * Conventions: every function returns 0 on success, a negative MiPtStatus on failure, never throws; the caller owns
  * all memory it passes in (it may be freed as soon as the call returns), the library owns all device memory.
  * Not thread-safe per instance (like BaseRenderer::onRender, which runs on the app thread only).
+ *
+ * Environment: the library's behaviour does not depend on the environment in production.  A set of MI_PT_* variables selects A/B
+ * variants and diagnostics ("Run-time switches (all of them)", lists every one with its default); they are read ONCE,
+ * in mi_pt_create, into the instance -- a variable that appears or changes later cannot alter a live instance's slot layout, kernels
+ * or scene.
  */
 #ifndef MI_PT_H
 #define MI_PT_H

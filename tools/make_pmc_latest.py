@@ -8,6 +8,10 @@ usage: tools/make_pmc_latest.py <summary.json> <workload> <frames in flight> [ro
 import json, os, sys
 
 summary, workload, frames = json.load(open(sys.argv[1]))["kernels"], sys.argv[2], int(sys.argv[3])
+try:
+    MIX = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_valu_mix.json")))["kernels"]
+except Exception:
+    MIX = {}
 calib_path = sys.argv[5] if len(sys.argv) > 5 else None
 calib = json.load(open(calib_path))["factors"] if calib_path else None
 res = [int(sys.argv[6]), int(sys.argv[7])] if len(sys.argv) > 7 else [1920, 1080]
@@ -29,8 +33,9 @@ if calib:
     def mix(s_wide, wide=r_wide):
         return 1.0 / (s_wide / wide + (1.0 - s_wide) / r_line)
 
-    r_fetch = {"shade_first": mix(52.0 / 980.0),    # per hit: queue entry 52 B as a stream; misc 16 + shade record / attributes 192 + records 480 + ~5 taps x 48 as gathers
-               "shade": mix(52.0 / 1012.0),           # + throughput / radiance 32 B by slot
+    r_fetch = {"shade_first": mix(68.0 / 980.0),    # per hit: queue entry 52 B + the path's misc record 16 B (round 4: in the entry) as streams; shade record /
+                                                     # attributes 192 + records 480 + ~5 taps x 48 as gathers
+               "shade": mix(100.0 / 1012.0),          # entry 52 B + misc / throughput / radiance 48 B as streams (round 4: the state travels in the queue entry)
                "trace_closest": mix(0.8, r_node),     # ~80 % of the bytes are 80-B node records (20 visits x 80 B against 8 triangles x 48 B)
                "trace_shadow": mix(0.8, r_node),
                "trace_primary": r_line,               # nodes and triangles through the scalar cache: 64-B lines
@@ -67,14 +72,21 @@ for key, match in pick.items():
                                    "hbm_bytes_per_launch": round(fetch / rf + write / rw), "hbm_bytes_bounds": [round(fetch + write), round(2 * fetch + write)],
                                    "avg_us": round(k.get("avg_us", 0.0), 1)}
             # from the SQ / TCC passes of the same command (tools/profile.sh): how much of the launch the 1024 SIMDs spend issuing vector
-            # instructions -- instructions x 4 cycles / (SIMDs x duration x 2.4 GHz); 4 cycles is what a wave64 instruction of the kind these
-            # kernels are made of (min / max, conversions, shifts, selects, compares) occupies a SIMD for, measured by tools/microbench_valu.hip;
-            # plain fma / mul / add / and take half of that -- the lanes active per vector instruction, and the L2 hit rate
+            # instructions -- instructions x (cycles per wave64 instruction) / (SIMDs x duration x 2.4 GHz).  The cycles come from the kernel's
+            # static class mix (profiles/r04_valu_mix.json, tools/valu_mix.py): 2 for the full-rate class (f32 fma / mul / add, and / or / xor,
+            # integer add, mov), 4 for the rest (min / max, conversions, shifts, selects, compares, packed f32), 8 for transcendentals -- classes
+            # timed by tools/microbench_valu.hip.  A model (the dynamic mix of the hot loop may differ); the bounds at 2 and at 4 cycles for every
+            # instruction stand beside it -- also the lanes active per vector instruction, and the L2 hit rate
             if k.get("SQ_INSTS_VALU") and k.get("avg_us"):
-                out["kernels"][key]["issue_frac"] = round(k["SQ_INSTS_VALU"] / d * 4.0 / (1024.0 * k["avg_us"] * 1e-6 * 2.4e9), 3)
+                per2 = k["SQ_INSTS_VALU"] / d * 2.0 / (1024.0 * k["avg_us"] * 1e-6 * 2.4e9)
+                mixk = MIX.get(name)
+                if mixk:
+                    out["kernels"][key]["issue_frac"] = round(min(1.0, per2 * mixk["avg_cycles"] / 2.0), 3)
+                    out["kernels"][key]["issue_cycles_per_instruction"] = mixk["avg_cycles"]
+                out["kernels"][key]["issue_frac_bounds"] = [round(per2, 3), round(min(1.0, 2.0 * per2), 3)]
                 out["kernels"][key]["valu_insts_per_launch"] = round(k["SQ_INSTS_VALU"] / d)
             if k.get("SQ_THREAD_CYCLES_VALU") and k.get("SQ_INSTS_VALU"):
-                out["kernels"][key]["active_lanes"] = round(k["SQ_THREAD_CYCLES_VALU"] / k["SQ_INSTS_VALU"], 1)
+                out["kernels"][key]["active_lanes"] = round(min(64.0, k["SQ_THREAD_CYCLES_VALU"] / k["SQ_INSTS_VALU"]), 1)  # (the counter runs a few per cent high: a dense kernel reads 64-67)
             if k.get("l2_hit_rate") is not None:
                 out["kernels"][key]["l2_hit_rate"] = round(k["l2_hit_rate"], 3)
             if k.get("frac_wait_any") is not None:

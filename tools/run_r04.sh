@@ -82,6 +82,7 @@ open(f"gpurun_out/pmc_latest_{tag}.json", "w").write(out.stdout)
 k = json.loads(out.stdout)["kernels"]
 print("EVIDENCE", tag, j["value"], {n: (v.get("issue_frac"), v.get("active_lanes"), round(v["hbm_bytes_per_launch"] / 1e9, 2)) for n, v in k.items()}, out.stderr[-300:])
 PY
+    rm -rf $O/prof_r04_$tag  # (the per-dispatch counter CSVs are tens of MB per configuration; gpurun copies back at most 64 MiB)
     ;;
   sweep)  # frames in flight 1 / 8 / 64 / 128 at 1080p and 4K: what a maintainer gets per onRender batch size, and the memory it takes
     for w in helmet atrium; do for f in 1 8 64 128; do
