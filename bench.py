@@ -163,7 +163,7 @@ def kernel_table(all_b, first_b, timing, frames, in_flight=0, pmc=None):
             row.update({"achieved": round(achieved, 3), "peak": round(VALU_PEAK_TLANEOPS, 2), "unit": "Tlaneop/s", "frac": round(achieved / VALU_PEAK_TLANEOPS, 4),
                         "traffic": p["hbm_bytes_per_launch"] if p else None, "useful_laneops_per_launch": round(per_launch)})
         if p:
-            for k in ("issue_frac", "active_lanes", "l2_hit_rate", "executed_valu_per_node_step"):
+            for k in ("issue_frac", "issue_frac_bounds", "issue_cycles_per_instruction", "active_lanes", "l2_hit_rate", "wave_time_waiting"):
                 if p.get(k) is not None:
                     row[k] = p[k]
         row.update({"avg_launch_ms": round(avg_ms, 5), "launches": launches, "ms_per_frame": round(ms / frames, 5), "model": note})
