@@ -631,8 +631,11 @@ def main():
                                         value_per_gpu=round(value / world, 3), frac_of_needed_per_gpu=round(value / world / NORTH_STAR["needs_per_gpu_Msamples_s"], 3))
         if not args.no_cpu_baseline and world == 1:
             tracer.close()  # (its path state is not needed any more; the parity leg's tracer may want as much again)
-            result["cpu_baseline"], result["parity"] = cpu_baseline_and_parity(scene, w, W, H, F, args.cpu_seconds, lambda: make_tracer(False, partition=False), params,
-                                                                               args.parity_spp)
+            try:
+                result["cpu_baseline"], result["parity"] = cpu_baseline_and_parity(scene, w, W, H, F, args.cpu_seconds, lambda: make_tracer(False, partition=False), params,
+                                                                                   args.parity_spp)
+            except Exception as e:  # noqa: BLE001  (the measured line stands even if the checker's leg cannot run)
+                result["cpu_baseline"] = result["parity"] = {"error": f"{type(e).__name__}: {e}"}
         # Next to the default line (the Sponza-class atrium, configs[2]), on the same GPU: every other configuration of BASELINE.json --
         # helmet (configs[1]) and the same at 3840x2160, street (configs[3], 4K), glass + denoise (configs[4]) -- each scene with its own CPU
         # baseline + full-size parity leg.
@@ -643,7 +646,13 @@ def main():
             result["also"] = {}
             for name in also.split(","):
                 wl, aw, ah, den, par = ALSO_LINES[name]
-                result["also"][name] = secondary_line(wl, args, local_rank, width=aw, height=ah, steps=5, parity=par and not args.no_cpu_baseline, denoise=den)
+                try:  # (a secondary line that fails -- e.g. out of device memory next to another tenant -- must not take the headline with it)
+                    result["also"][name] = secondary_line(wl, args, local_rank, width=aw, height=ah, steps=5, parity=par and not args.no_cpu_baseline, denoise=den)
+                except Exception as e:  # noqa: BLE001
+                    result["also"][name] = {"error": f"{type(e).__name__}: {e}"}
+                    import gc
+                    gc.collect()
+                    torch.cuda.empty_cache()
         print(json.dumps(result), flush=True)
     tracer.close()
     if dist is not None:

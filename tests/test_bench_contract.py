@@ -1,0 +1,88 @@
+"""bench.py's reporting contract, checked without a GPU: the roofline table cannot print a fraction above 1 (round-3 review: the algorithmic
+byte model printed 1.05 / 1.10 / 1.27), every configuration of the default run finds its committed counter passes, the rank launcher
+refuses what it cannot run, and the committed round-4 line obeys all of it."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def _timing(ms=10.0):
+    return {"tracePrimaryMs": ms, "tracePrimaryLaunches": 1, "shadeFirstMs": ms, "shadeFirstLaunches": 1, "traceClosestMs": 3 * ms, "traceClosestLaunches": 3,
+            "shadeMs": 3 * ms, "shadeLaunches": 3, "traceShadowMs": 2 * ms, "traceShadowLaunches": 2, "accumulateMs": 1.0, "totalMs": 9 * ms}
+
+
+def _counters(scale=1.0):
+    return {"cameraPaths": 2.0e6 * scale, "segments": 7.0e6 * scale, "surfaceHits": 6.5e6 * scale, "shadowRays": 3.5e6 * scale, "nodesPrimary": 9.0e5 * scale,
+            "trisPrimary": 6.0e5 * scale, "nodesClosest": 1.0e8 * scale, "trisClosest": 4.0e7 * scale, "nodesShadow": 4.5e7 * scale, "trisShadow": 2.0e7 * scale,
+            "textureTaps": 7.0e6 * scale}
+
+
+def test_every_default_configuration_finds_its_counter_passes():
+    """profiles/pmc_latest_<workload>.json must match the frames in flight and the resolution bench.py actually runs: a changed default
+    without new counter passes would silently print traffic: null."""
+    for name, (wl, w, h, _den, _par) in list(bench.ALSO_LINES.items()) + [("headline", (bench.NORTH_STAR["workload"], 0, 0, False, True))]:
+        cfg = bench.WORKLOADS[wl]
+        W, H = w or cfg["width"], h or cfg["height"]
+        F = bench.frames_in_flight(cfg.get("in_flight", bench.IN_FLIGHT_DEFAULT), W, H)
+        pmc = bench.load_pmc(wl, F, W, H)
+        assert pmc is not None, (name, wl, F, W, H)
+        for k in ("trace_primary", "shade_first", "trace_closest", "shade", "trace_shadow"):
+            e = pmc["kernels"][k]
+            assert e["hbm_bytes_per_launch"] > 0 and 0.0 < e["issue_frac"] <= 1.0 and e["issue_frac_bounds"][0] <= e["issue_frac"] <= e["issue_frac_bounds"][1] + 1e-9, (name, k, e)
+            assert 1.0 <= e["active_lanes"] <= 64.0
+
+
+def test_kernel_table_fractions_are_fractions():
+    """hbm rows: frac = counter traffic / launch time / 8 TB/s (None without counters), the algorithmic figure stands beside it under its own
+    name; valu rows: useful lane-operations against the vector peak, with the per-kernel instruction counts."""
+    per_frame, first = _counters(), {k: v * (0.3 if k != "cameraPaths" else 1.0) for k, v in _counters().items()}
+    pmc = bench.load_pmc("atrium", 128, 1920, 1080)
+    rows = bench.kernel_table(per_frame, first, _timing(), frames=128, in_flight=128, pmc=pmc)
+    for name, r in rows.items():
+        assert r["frac"] is None or 0.0 <= r["frac"], name
+        if r["bound"] == "hbm" and r["traffic"]:
+            assert r["frac"] == pytest.approx(r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9 / bench.HBM_PEAK_GBS, rel=1e-3)
+            assert "algorithmic_frac" in r and "algorithmic_GBps" in r
+        if r["bound"] == "valu":
+            assert r["peak"] == pytest.approx(78.64, abs=0.01) and 0.0 < r["issue_frac"] <= 1.0
+    # the packet walk is charged its interval test (50 instructions of all 64 lanes per node), not the per-ray test's count
+    tp = rows["trace_primary"]
+    assert tp["useful_laneops_per_launch"] == round(64 * (per_frame["nodesPrimary"] * bench.VALU_PER_PACKET_NODE + per_frame["trisPrimary"] * bench.VALU_PER_TRI) * 128)
+    # no counters (another resolution / batch size): no invented fraction for the memory-bound kernels
+    rows = bench.kernel_table(per_frame, first, _timing(), frames=128, in_flight=96, pmc=None)
+    assert rows["shade"]["frac"] is None and rows["shade"]["traffic"] is None and rows["shade"]["algorithmic_frac"] > 0
+    assert rows["trace_closest"]["frac"] > 0  # (useful work needs no counters)
+
+
+def test_committed_round4_line_obeys_the_contract():
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench_default.json")).read().strip().splitlines()[-1])
+    assert line["unit"] == "Msamples/s" and line["n_gpus"] == 1 and line["config"]["workload"].startswith("configs[2]") and line["north_star"]["value"] == line["value"]
+    lines = {"headline": line, **line["also"]}
+    assert set(line["also"]) == set(bench.ALSO_DEFAULT.split(","))
+    for name, ln in lines.items():
+        assert ln["roofline"]["traffic"] is not None, name  # no line without its counter passes
+        for k, r in ln["kernels"].items():
+            assert r["frac"] is not None and 0.0 < r["frac"] <= 1.0, (name, k, r["frac"])
+            if "issue_frac" in r:
+                assert 0.0 < r["issue_frac"] <= 1.0, (name, k)
+        if name != "helmet_4k":  # (the same scene as "helmet": one parity leg)
+            p = ln["parity"]
+            assert p["spp"] == bench.WORKLOADS[bench.ALSO_LINES[name][0] if name in bench.ALSO_LINES else "atrium"]["spp"]
+            assert p["rel_l2"] <= 1e-3 and p["within_tolerance"], (name, p["rel_l2"])
+            assert ln["cpu_baseline"]["kind"] == "port" and ln["cpu_baseline"]["cores"] >= 1
+
+
+def test_more_ranks_than_devices_is_refused_before_anything_runs():
+    """`python bench.py --gpus N` starts its own ranks -- and on a box with fewer devices (here: none) it must exit non-zero without a JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0", "--workload", "box"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and "refusing" in (r.stdout + r.stderr)
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
