@@ -266,6 +266,11 @@ int allocPathResources(MiPt* pt, int frames)
   const size_t numChunks = (n + pt::QCHUNK - 1) / pt::QCHUNK;
   const size_t subCap    = ((numChunks + pt::NSUB - 1) / pt::NSUB + 1) * pt::QCHUNK;
   const size_t qsize     = subCap * pt::NSUB;
+  // path slots and queue positions are 31-bit: bit 31 of a shadow entry's slot field tells the two apart (pt_scene.h: SHADOW_TARGET_QUEUE),
+  // 0xffffffff is QUEUE_DEAD, and the frame index of a slot is a 31-bit multiply-high (FrameConsts::framesMagic)
+  if(qsize >= (size_t(1) << 31))
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_render_frames: " + std::to_string(frames) + " frames in flight x " + std::to_string(pt->numSlots)
+                                        + " pixel slots exceed 2^31 path slots");
   HIP_TRY(pt->queueMem.alloc(qsize * 3 + pt::QC_COUNT));
   HIP_TRY(pt->queuePayload.alloc(qsize * 16));
   pt::RayQueue* qs[3] = {&pt->queues.active[0], &pt->queues.active[1], &pt->queues.shadow};
