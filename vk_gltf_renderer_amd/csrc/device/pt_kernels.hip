@@ -437,7 +437,11 @@ constexpr int TRI_PHASE_EXIT_LANES = 10;
 #ifndef TRI_ROUND_BLOCKED
 #define TRI_ROUND_BLOCKED 4  // ... or this many lanes have both of their park records in use
 #endif
-constexpr int TRI_ROUND_LANE_CAP = 7;
+#ifndef TRI_ROUND_LANE_CAP_N
+#define TRI_ROUND_LANE_CAP_N 4  // (7 until round 4.  The publish loop runs as many passes as the busiest lane hands in: 2 / 3 / 4 / 5 / 6 / 7 measured
+                                //  576 / 590 / 607 / 606 / 603 / 600 Msamples/s on the atrium, 593 / 609 / 627 / 626 / 624 / 624 on the street)
+#endif
+constexpr int TRI_ROUND_LANE_CAP = TRI_ROUND_LANE_CAP_N;
 // Deferred alpha tests (alphaRound*): flush the wave's list at this many entries, or once this many lanes wait for it.
 #ifndef ALPHA_ROUND_MIN
 #define ALPHA_ROUND_MIN 32
