@@ -427,7 +427,10 @@ __device__ unsigned long long g_shadowProf[16];  // the same for k_trace_shadow 
 #define REFILL_IDLE_LANES 16
 #endif
 // Dense triangle phase of the 8-wide walk: start once this many lanes have parked triangles, leave below the exit count.
-constexpr int TRI_PHASE_LANES      = 24;
+#ifndef TRI_PHASE_LANES_N
+#define TRI_PHASE_LANES_N 24
+#endif
+constexpr int TRI_PHASE_LANES      = TRI_PHASE_LANES_N;
 constexpr int TRI_PHASE_EXIT_LANES = 10;
 // Triangle rounds of the closest-hit walk (triRoundClosest): start one once this many lanes have parked triangles, and let
 // a lane hand in at most this many triangles per round.
