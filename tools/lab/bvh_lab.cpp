@@ -320,7 +320,7 @@ struct Bvh8
   double             sah = 0;
 };
 
-struct CollapseCfg { int maxLeaf = 2; bool sahdp = false; bool quantise = true; float cLeafTri = 0.24f; int width = 8; bool optimalSlots = false; };
+struct CollapseCfg { int scaleMantissaBits = 0; int maxLeaf = 2; bool sahdp = false; bool quantise = true; float cLeafTri = 0.24f; int width = 8; bool optimalSlots = false; };
 
 // optimal (SAH, dynamic programming) collapse after Ylitie et al. 2017, section 3: cost(n, i) = cheapest way to represent subtree n as
 // at most i roots of 8-wide (sub)trees; cLeaf per triangle and 1 per inner node, weighted by area.
@@ -498,6 +498,13 @@ static Bvh8 collapse(const Bvh2& B, const CollapseCfg& cfg)
         float ext = nb.hi[a] - nb.lo[a];
         int   e   = ext > 0 ? int(std::ceil(std::log2(double(ext) / 255.0))) : -126;
         scale[a]  = std::ldexp(1.0f, e);
+        if(cfg.scaleMantissaBits > 0 && ext > 0)  // scale = m * 2^e with an m of that many bits (device: a bf16-like scale per axis instead of an exponent byte)
+        {
+          const double want = double(ext) / 255.0;
+          int          e2   = int(std::floor(std::log2(want)));
+          const double unit = std::ldexp(1.0, e2 - cfg.scaleMantissaBits);
+          scale[a]          = float(std::ceil(want / unit) * unit);
+        }
       }
       for(int sl = 0; sl < 8; ++sl)
       {
@@ -755,6 +762,7 @@ int main(int argc, char** argv)
   cfg.sahdp    = get("collapse", "greedy") == "sahdp";
   cfg.cLeafTri = std::stof(get("ctri", "0.24"));
   cfg.quantise = get("quantise", "1") == "1";
+  cfg.scaleMantissaBits = std::stoi(get("scalebits", "0"));
   cfg.width    = std::stoi(get("width", "8"));
   cfg.optimalSlots = get("slots", "greedy") == "optimal";
   Bvh8 W = collapse(B, cfg);
