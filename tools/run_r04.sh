@@ -64,6 +64,12 @@ import json; j=json.loads(open('$O/r04_sweep_${w}_f$f.json').read().strip().spli
       python3 -c "
 import json; j=json.loads(open('$O/r04_sweep_helmet4k_f$f.json').read().strip().splitlines()[-1]); print('SWEEP helmet 4K in_flight', j['config']['frames_in_flight'], j['value'], j['device_memory_GB'])"
     done ;;
+  overlap)  # MI_PT_OVERLAP: the shadow stage of small batches on a second stream -- on (default 16 frames) against off, 1 / 4 / 8 / 16 frames in flight
+    for w in ${OVERLAP_WORKLOADS:-helmet atrium}; do for f in ${OVERLAP_FRAMES:-1 4 8 16}; do for o in 0 1024; do
+      MI_PT_OVERLAP=$o timeout 200 python bench.py --workload $w --in-flight $f --frames-per-step $((f * 4 > 256 ? 256 : f * 4)) --steps 4 --warmup 1 $N > $O/r04_overlap_${w}_f${f}_o$o.json 2> /dev/null
+      python3 -c "
+import json; j=json.loads(open('$O/r04_overlap_${w}_f${f}_o$o.json').read().strip().splitlines()[-1]); print('OVERLAP ${w} in_flight $f overlap_up_to $o', j['value'])"
+    done; done; done ;;
   mbvalu) timeout 200 tools/_scratch/mb_valu > $O/r04_mb_valu.txt 2>&1; grep "waves/SIMD=4" $O/r04_mb_valu.txt | cut -c1-20,80-160 ;;
   tests) timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ;;
   ab) shift; ab "$@" ;;

@@ -84,6 +84,9 @@ struct RunSwitches
   bool   stateBySlot    = false;   // MI_PT_STATE_BY_SLOT    path state gathered by slot in every launch (rounds 1-3) instead of travelling in the queue entry
   bool   traceSpans     = false;   // MI_PT_TRACE_SPANS      synchronising diagnostics
   int    graphUpTo      = 0;       // MI_PT_GRAPH            batches up to this many frames replay a hipGraph
+  int    overlapUpTo    = 32;      // MI_PT_OVERLAP          batches up to this many frames run a bounce's shadow stage on a second stream, next to the
+                                   //                        following bounce's closest-hit walk (0 = one stream, as in rounds 1-3); same image
+  int    overlapMinTris = 200000;  // MI_PT_OVERLAP_MIN_TRIS ... in scenes of at least this many (flattened) triangles
   bool   noPlanes       = false;   // MI_PT_DIAG_NO_PLANES   no float planes for the packet walk
   bool   noOpaqueTris   = false;   // MI_PT_DIAG_NO_OPAQUE_TRIS  alpha-test the OPAQUE class of the alpha cut too
   bool   allOpaqueTris  = false;   // MI_PT_DIAG_ALL_OPAQUE_TRIS (wrong image) every triangle of an alpha-tested primitive in the OPAQUE class: the alpha
@@ -106,6 +109,8 @@ struct RunSwitches
     stateBySlot    = flag("MI_PT_STATE_BY_SLOT");
     traceSpans     = flag("MI_PT_TRACE_SPANS");
     graphUpTo      = num("MI_PT_GRAPH", 0);
+    overlapUpTo    = num("MI_PT_OVERLAP", 32);
+    overlapMinTris = num("MI_PT_OVERLAP_MIN_TRIS", 200000);
     noPlanes       = flag("MI_PT_DIAG_NO_PLANES");
     noOpaqueTris   = flag("MI_PT_DIAG_NO_OPAQUE_TRIS");
     allOpaqueTris  = flag("MI_PT_DIAG_ALL_OPAQUE_TRIS");
@@ -221,6 +226,8 @@ struct MiPt
   // folded into the instantiated graph with hipGraphExecUpdate (same topology: no re-instantiation) and launched on the caller's
   // stream as ONE submission.
   hipStream_t             captureStream = nullptr;
+  hipStream_t             sideStream = nullptr;                    // the shadow stage of small batches (RunSwitches::overlapUpTo)
+  hipEvent_t              evShaded = nullptr, evShadowed = nullptr;  // main -> side after a shade launch, side -> main after the shadow stage
   hipGraphExec_t          graphExec     = nullptr;
 
   ~MiPt()
@@ -242,6 +249,12 @@ struct MiPt
       (void)hipGraphExecDestroy(graphExec);
     if(captureStream)
       (void)hipStreamDestroy(captureStream);
+    if(sideStream)
+      (void)hipStreamDestroy(sideStream);
+    if(evShaded)
+      (void)hipEventDestroy(evShaded);
+    if(evShadowed)
+      (void)hipEventDestroy(evShadowed);
   }
 };
 
@@ -1039,18 +1052,19 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   c.sceneDev = pt->sceneDev.ptr;
   c.fcDev    = pt->fcRing.ptr + fcSlot;
 
-  auto timed = [&](int kind, auto&& launch) {
+  auto timedOn = [&](hipStream_t on, int kind, auto&& launch) {
     if(pt->timingEnabled)
     {
       hipEvent_t a = getEvent(pt, pt->evCursor), b = getEvent(pt, pt->evCursor);
-      (void)hipEventRecord(a, stream);
+      (void)hipEventRecord(a, on);
       launch();
-      (void)hipEventRecord(b, stream);
+      (void)hipEventRecord(b, on);
       pt->pendingSpans.push_back({kind, a, b});
     }
     else
       launch();
   };
+  auto timed = [&](int kind, auto&& launch) { timedOn(stream, kind, launch); };
   hipEvent_t frameA = nullptr, frameB = nullptr;
   if(pt->timingEnabled)
   {
@@ -1082,6 +1096,23 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
       c.stream = pt->captureStream;  // every launch helper below records into the capture
   }
   hipStream_t const launchStream = capturing ? pt->captureStream : stream;
+  // Small batches: a bounce's shadow stage (any-hit walk + resolve) on a second stream, next to the NEXT bounce's closest-hit walk.  The two
+  // are independent -- the walk reads the continuation rays the shade launch wrote, the shadow stage adds into radiance records that only
+  // the next SHADE launch reads (which therefore waits for it) -- and with few frames in flight neither fills the 256 CUs: most
+  // workgroups of a persistent grid find no work and leave, so the other kernel's find room.  Needs the state in the queue entry (on
+  // catcher frames the resolve pass may end a path the walk is about to trace), no host-side polling of queue lengths, no capture.
+  // ... and launches long enough to be worth two cross-stream hand-overs per bounce: measured (round 4, frames in flight 1 / 4 / 8 / 16 / 32 / 64 / 128)
+  // atrium-class (406 k triangles, depth 12) +15 / +8 / +6 / +3.5 / +1.7 / +1.0 / +0.3 %, street-class 4K +8 % at 1, +1.6 % at 8, +0.3 % from 32;
+  // helmet-class (74 k, 60 % of the camera paths leave at bounce 0) -6.5 / -0.4 / -0.8 / -0.6 %: scenes below 2e5 triangles keep one stream.
+  // Default up to 32 frames: the interactive range, where it pays; larger batches fill the device by themselves, and their per-launch times
+  // (bench.py's kernel table) stay those of kernels that have the device to themselves.
+  bool overlap = numFrames <= pt->sw.overlapUpTo && pt->scene.numTris >= pt->sw.overlapMinTris && c.fc.stateInQueue != 0 && !capturing && !debugSpans
+                 && !pt->hasVolumeScatter;
+  if(overlap && !pt->sideStream)
+    overlap = hipStreamCreateWithFlags(&pt->sideStream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&pt->evShaded, hipEventDisableTiming) == hipSuccess
+              && hipEventCreateWithFlags(&pt->evShadowed, hipEventDisableTiming) == hipSuccess;
+  pt::LaunchCtx cSide = c;
+  cSide.stream        = pt->sideStream;
   for(int s = 0; s < params->numSamples; ++s)
   {
     pt::launchResetCounters(c.queues, launchStream);
@@ -1156,14 +1187,26 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
       {
         if(!(it == 0 && fusedPrimary))
           timed(TK_TRACE, [&] { pt::launchTraceClosest(c, cur); });
+        if(overlap && it > 0)
+          (void)hipStreamWaitEvent(stream, pt->evShadowed, 0);  // the previous bounce's shadow terms are in before this shade launch reads them
         timed(it == 0 ? TK_SHADE_FIRST : TK_SHADE, [&] { pt::launchShade(c, cur, it == 0); });
         if(it == 0 && pt->timingEnabled)
           ++pt->accTiming.shadeFirstLaunches;
-        timed(TK_SHADOW, [&] { pt::launchTraceShadow(c, cur ^ 1); });
+        if(overlap)
+        {
+          (void)hipEventRecord(pt->evShaded, stream);
+          (void)hipStreamWaitEvent(pt->sideStream, pt->evShaded, 0);
+          timedOn(pt->sideStream, TK_SHADOW, [&] { pt::launchTraceShadow(cSide, cur ^ 1); });
+          (void)hipEventRecord(pt->evShadowed, pt->sideStream);
+        }
+        else
+          timed(TK_SHADOW, [&] { pt::launchTraceShadow(c, cur ^ 1); });
       }
       ++iterations; ++traceLaunches; ++shadeLaunches; ++shadowLaunches;
       cur ^= 1;
     }
+    if(overlap && iterations > 0)
+      (void)hipStreamWaitEvent(stream, pt->evShadowed, 0);  // the last bounce's shadow terms, before the sample is folded
     timed(TK_ACCUM, [&] {
       pt::launchFinishSample(c, s, pt->accum, pt->depthImg(), guides ? pt->albedoImg() : nullptr, guides ? pt->normalImg() : nullptr);
     });

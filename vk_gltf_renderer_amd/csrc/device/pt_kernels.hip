@@ -820,15 +820,11 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
   if(blockIdx.x == 0 && threadIdx.x < NSUB)
   {
     // the shade kernel of this iteration appends to these; zero them here (the kernel boundary orders the writes)
+    // (the counters of the SHADOW stage -- its feed heads, the candidate pool, the overflow list -- are zeroed by k_shade, the launch
+    //  between the previous iteration's shadow stage and this one's: with frames in flight below MI_PT_OVERLAP that stage runs on a
+    //  second stream next to THIS kernel, which therefore must not touch them)
     Q.counters[(cur ? QC_PAIR0 : QC_PAIR1) + 2 * threadIdx.x]     = 0;
     Q.counters[(cur ? QC_PAIR0 : QC_PAIR1) + 2 * threadIdx.x + 1] = 0;
-    if(threadIdx.x < 8)
-    {
-      Q.counters[QC_HEADS_SHADOW + threadIdx.x]   = 0;
-      Q.counters[QC_HEADS_OVERFLOW + threadIdx.x] = 0;
-    }
-    if(threadIdx.x == 0)
-      Q.counters[QC_CAND_POOL] = Q.counters[QC_RESOLVE] = Q.counters[QC_OVERFLOW] = 0;
   }
   const RayQueue in = Q.active[cur];
   queuePrefix(&Q.counters[cur ? QC_PAIR1 : QC_PAIR0], s_prefix);
@@ -1209,13 +1205,7 @@ __global__ void __launch_bounds__(256, INTERVAL ? PRIMARY_INTERVAL_MIN_WAVES : P
     Q.counters[QC_PAIR1 + 2 * threadIdx.x]     = 0;
     Q.counters[QC_PAIR1 + 2 * threadIdx.x + 1] = 0;
     if(threadIdx.x < 8)
-    {
-      Q.counters[QC_HEADS_TRACE + threadIdx.x]  = 0;
-      Q.counters[QC_HEADS_SHADOW + threadIdx.x] = 0;
-      Q.counters[QC_HEADS_OVERFLOW + threadIdx.x] = 0;
-    }
-    if(threadIdx.x == 0)
-      Q.counters[QC_CAND_POOL] = Q.counters[QC_RESOLVE] = Q.counters[QC_OVERFLOW] = 0;
+      Q.counters[QC_HEADS_TRACE + threadIdx.x] = 0;
   }
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const uint32_t chunk = blockIdx.x;                 // 256 consecutive path slots = 4 micro-tiles (batchSlots is a multiple of 256)
@@ -1528,7 +1518,15 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
   __shared__ uint32_t s_binBase[SORT_BINS + 1];                 // first sorted index of each bin; [SORT_BINS] = live entries of the window
   static_assert(SHADE_BLOCK == 256, "one table entry per thread");
   if(blockIdx.x == 0 && threadIdx.x < 8)
+  {
     Q.counters[QC_HEADS_TRACE + threadIdx.x] = 0;  // for the next iteration's k_trace_closest
+    // ... and for this iteration's shadow stage (k_trace_shadow / k_shadow_resolve run after this launch and, the previous iteration's,
+    // before it -- also when that stage runs on its own stream next to the following k_trace_closest)
+    Q.counters[QC_HEADS_SHADOW + threadIdx.x]   = 0;
+    Q.counters[QC_HEADS_OVERFLOW + threadIdx.x] = 0;
+    if(threadIdx.x == 0)
+      Q.counters[QC_CAND_POOL] = Q.counters[QC_RESOLVE] = Q.counters[QC_OVERFLOW] = 0;
+  }
   queuePrefix(&Q.counters[cur ? QC_PAIR1 : QC_PAIR0], s_prefix);
   const uint32_t count      = s_prefix[NSUB];
   const int      nxt        = cur ^ 1;
