@@ -364,6 +364,41 @@ def test_frames_in_flight_bit_identical(built, assets, tmp_path):
             assert seq["stats"][k] == bat["stats"][k], (f, k)
 
 
+def test_shadow_stage_on_a_second_stream_changes_no_bit(built, assets, tmp_path):
+    """MI_PT_OVERLAP: batches of up to n frames run a bounce's any-hit walk + resolve on a second stream, next to the following bounce's
+    closest-hit walk (off below MI_PT_OVERLAP_MIN_TRIS triangles: forced on here).  Same frames as on one stream, bit for bit, with
+    the path counters: frame by frame, batches, multi-sample frames, alpha-tested foliage under sun + sky, transmissive spheres
+    (recording shadow walk; volume-scatter scenes keep one stream by themselves), and a catcher frame (which must fall back)."""
+    import ctypes as C  # noqa: F401
+    from vk_gltf_renderer_amd import _capi as capi
+    hdr = os.path.join(assets, "std_env.hdr")
+    atrium = scenegen.scene_atrium_class(str(tmp_path / "atrium.glb"), seed=5, detail=0.2, tex_size=64)
+    glass = scenegen.scene_glass_class(str(tmp_path / "glass.glb"), seed=9, tess=16)
+
+    def catcher(fi):
+        fi.flags |= capi.MI_SCENE_USE_INFINITE_PLANE | capi.MI_SCENE_INFINITE_PLANE_SHADOW_CATCHER
+        fi.infinitePlaneDistance = -0.6
+
+    cases = [(pu.Setup(atrium, 160, 96, max_depth=8), 6, 1), (pu.Setup(atrium, 160, 96, max_depth=8, alpha_cut=4), 8, 4),
+             (pu.Setup(os.path.join(assets, "shader_ball.gltf"), 160, 96, max_depth=6, spp_per_frame=3, hdr_path=hdr), 4, 2),
+             (pu.Setup(glass, 128, 80, max_depth=10, hdr_path=hdr), 4, 4),
+             (pu.Setup(os.path.join(assets, "Box.glb"), 128, 96, max_depth=5, hdr_path=hdr, frame_info_edit=catcher), 4, 2)]
+    # (path-level counters: the walks' node / triangle counts depend on which rays a persistent wave happens to pick up together)
+    keys = ("cameraPaths", "segments", "surfaceHits", "shadowRays", "textureTaps")
+    for setup, frames, in_flight in cases:
+        out = {}
+        for mode in ("0", "64"):
+            os.environ["MI_PT_OVERLAP"], os.environ["MI_PT_OVERLAP_MIN_TRIS"] = mode, "0"
+            try:
+                out[mode] = pu.render_gpu(setup, frames, in_flight=in_flight)
+            finally:
+                del os.environ["MI_PT_OVERLAP"], os.environ["MI_PT_OVERLAP_MIN_TRIS"]
+        a, b = out["0"], out["64"]
+        assert (a["accum"] == b["accum"]).all() and (a["selection"] == b["selection"]).all() and (a["depth"] == b["depth"]).all()
+        for k in keys:
+            assert a["stats"][k] == b["stats"][k], k
+
+
 def test_furnace_on_gpu(built, tmp_path):
     """The analytic furnace KAT on the device itself: white Lambert sphere in a uniform environment is invisible."""
     path = scenegen.scene_sphere(str(tmp_path / "s.glb"), scenegen.lambert_material((1, 1, 1)), 48, 24)
