@@ -584,9 +584,9 @@ static void walk(const Bvh8& W, const std::vector<Tri>& tris, const std::vector<
   V3 idir{1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
   const uint32_t octinv = 7u ^ ((idir.x < 0 ? 1u : 0u) | (idir.y < 0 ? 2u : 0u) | (idir.z < 0 ? 4u : 0u));
   float tmax = FLT_MAX;
-  struct Entry { int node; float tn; };
+  struct Entry { int node; float tn; float gmin; };  // gmin: smallest entry distance among the hit children of the node that pushed this entry
   std::vector<Entry> stack;
-  stack.push_back({0, 0});
+  stack.push_back({0, 0, 0});
   struct Parked { int base, cnt, due; };
   std::vector<Parked> parked;
   int visits = 0;
@@ -611,6 +611,7 @@ static void walk(const Bvh8& W, const std::vector<Tri>& tris, const std::vector<
   {
     Entry e = stack.back(); stack.pop_back();
     if((mode == 1 || mode == 3) && e.tn > tmax) continue;  // mode 3: octant order, but a child whose entry distance lies beyond the current hit is dropped when popped
+    if(mode == 4 && e.gmin > tmax) continue;                 // mode 4: ... only when its whole GROUP lies beyond the hit (one distance per stack entry on the device)
     const Node8& N = W.nodes[e.node];
     S.nodes += 1; ++visits;
     // due parked leaves
@@ -637,7 +638,9 @@ static void walk(const Bvh8& W, const std::vector<Tri>& tris, const std::vector<
     // push in reverse priority so that the nearest is popped first
     if(mode == 1) std::sort(hit, hit + nh, [](const H& a, const H& b) { return a.tn > b.tn; });
     else std::sort(hit, hit + nh, [&](const H& a, const H& b) { return (uint32_t(a.slot) ^ octinv) < (uint32_t(b.slot) ^ octinv); });
-    for(int k = 0; k < nh; ++k) stack.push_back({N.child[hit[k].slot], hit[k].tn});
+    float gmin = FLT_MAX;
+    for(int k = 0; k < nh; ++k) gmin = std::min(gmin, hit[k].tn);
+    for(int k = 0; k < nh; ++k) stack.push_back({N.child[hit[k].slot], hit[k].tn, gmin});
     S.maxStack = std::max(S.maxStack, double(stack.size()));
     if(mode == 2 && stack.empty())
     {
@@ -795,7 +798,7 @@ int main(int argc, char** argv)
     V3 d = tx * (rr * std::cos(ph)) + ty * (rr * std::sin(ph)) + nrm * std::sqrt(std::max(0.0f, 1 - u1));
     rays[i] = {p + nrm * 1e-3f, normalize(d)};
   }
-  for(int mode : {0, 2, 3, 1})
+  for(int mode : {0, 2, 3, 4, 1})
   {
     WalkStats S;
     const int defer = std::stoi(get("defer", "3"));
@@ -809,7 +812,7 @@ int main(int argc, char** argv)
     }
     const double cnode = 59 + 22 * cfg.width;
     printf("walk %-28s: %.2f node visits + %.2f triangle tests per ray  (cost (59+22w)n+56t = %.0f; hit rate %.3f, max stack %.0f)\n",
-           mode == 0 ? "octant order, immediate" : (mode == 1 ? "distance order, immediate" : (mode == 3 ? "octant order + cull at pop" : "octant order, deferred")), S.nodes / S.rays, S.tris / S.rays,
+           mode == 0 ? "octant order, immediate" : (mode == 1 ? "distance order, immediate" : (mode == 3 ? "octant order + cull at pop" : (mode == 4 ? "octant order + group cull" : "octant order, deferred"))), S.nodes / S.rays, S.tris / S.rays,
            (cnode * S.nodes + 56 * S.tris) / S.rays, S.hits / S.rays, S.maxStack);
   }
   // shadow rays: from the same surface points, half towards a fixed sun direction (through the skylight), half uniform over the sphere
