@@ -123,10 +123,11 @@ __attribute__((visibility("default"))) int dev_packet_masks(const float* P, cons
       {
         const bool  neg = (negMask >> a) & 1u;
         const float Pa = P[a] - org[3 * r + a], k = 4.76837158e-7f;
-        const float d  = std::fmaf(255.0f, s[a], std::fabs(Pa)) * k;
-        const float sg = neg ? 1.0f : -1.0f;
         const float A  = s[a] * idir[r][a];
-        const float Bn = std::fmaf(sg, d, Pa) * idir[r][a], Bf = std::fmaf(-sg, d, Pa) * idir[r][a];
+        // slabOffsets (pt_bvh8.h, round 4): the pad goes onto the plane TIME, the same expression whatever the direction's sign
+        const float t0 = Pa * idir[r][a];
+        const float e  = k * std::fmaf(255.0f, std::fabs(A), std::fabs(t0));
+        const float Bn = t0 - e, Bf = t0 + e;
         const float qn = planes[(2 * a + (neg ? 1 : 0)) * 8 + c], qf = planes[(2 * a + (neg ? 0 : 1)) * 8 + c];
         tn = std::max(tn, std::fmaf(qn, A, Bn));
         tf = std::min(tf, std::fmaf(qf, A, Bf));
