@@ -1100,14 +1100,17 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   // are independent -- the walk reads the continuation rays the shade launch wrote, the shadow stage adds into radiance records that only
   // the next SHADE launch reads (which therefore waits for it) -- and with few frames in flight neither fills the 256 CUs: most
   // workgroups of a persistent grid find no work and leave, so the other kernel's find room.  Needs the state in the queue entry (on
-  // catcher frames the resolve pass may end a path the walk is about to trace), no host-side polling of queue lengths, no capture.
+  // catcher frames the resolve pass may end a path the walk is about to trace) and no capture.
   // ... and launches long enough to be worth two cross-stream hand-overs per bounce: measured (round 4, frames in flight 1 / 4 / 8 / 16 / 32 / 64 / 128)
   // atrium-class (406 k triangles, depth 12) +15 / +8 / +6 / +3.5 / +1.7 / +1.0 / +0.3 %, street-class 4K +8 % at 1, +1.6 % at 8, +0.3 % from 32;
   // helmet-class (74 k, 60 % of the camera paths leave at bounce 0) -6.5 / -0.4 / -0.8 / -0.6 %: scenes below 2e5 triangles keep one stream.
   // Default up to 32 frames: the interactive range, where it pays; larger batches fill the device by themselves, and their per-launch times
   // (bench.py's kernel table) stay those of kernels that have the device to themselves.
-  bool overlap = numFrames <= pt->sw.overlapUpTo && pt->scene.numTris >= pt->sw.overlapMinTris && c.fc.stateInQueue != 0 && !capturing && !debugSpans
-                 && !pt->hasVolumeScatter;
+  // Volume-scatter scenes run it at every batch size and triangle count: their random walks leave ~100 bounce iterations of a few thousand paths per
+  // batch, three dependent launches each, and taking the shadow stage off that chain measured +31 % for a single frame, +8.7 % at 32 and +2.2 % at 256
+  // frames in flight on the glass-class workload (the host's poll of the queue length every eighth iteration only waits for the main stream).
+  bool overlap = pt->sw.overlapUpTo > 0 && ((numFrames <= pt->sw.overlapUpTo && pt->scene.numTris >= pt->sw.overlapMinTris) || pt->hasVolumeScatter)
+                 && c.fc.stateInQueue != 0 && !capturing && !debugSpans;
   if(overlap && !pt->sideStream)
     overlap = hipStreamCreateWithFlags(&pt->sideStream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&pt->evShaded, hipEventDisableTiming) == hipSuccess
               && hipEventCreateWithFlags(&pt->evShadowed, hipEventDisableTiming) == hipSuccess;
