@@ -193,6 +193,18 @@ def kernel_table(all_b, first_b, timing, frames, in_flight=0, pmc=None):
     return rows
 
 
+def overlap_note(kernels, ms_per_frame):
+    """Sum of the per-kernel device times over the frame time.  ~1 when the launches of a frame run one after the other; clearly above 1 when
+    the library runs a bounce's shadow stage on a second stream next to the following closest-hit walk (small batches, and every batch of a
+    volume-scatter scene: DESIGN.md section 2) -- per-kernel times and fractions are then those of kernels that SHARE the device."""
+    ratio = sum(k["ms_per_frame"] for k in kernels.values()) / max(ms_per_frame, 1e-9)
+    out = {"kernel_time_sum_over_frame_time": round(ratio, 3)}
+    if ratio > 1.1:
+        out["note"] = ("two streams: the shadow stage of a bounce runs next to the following bounce's closest-hit walk (MI_PT_OVERLAP); the per-kernel times and "
+                       "fractions of trace_closest / trace_shadow are those of kernels sharing the device, not the sum that makes the frame")
+    return out
+
+
 def roofline_of(kernels, pmc):
     """The `roofline` object: the kernel with the largest share of the step, from the table above."""
     dominant = max(kernels, key=lambda k: kernels[k]["avg_launch_ms"] * kernels[k]["launches"])
@@ -369,7 +381,8 @@ def secondary_line(name, args, device, width=0, height=0, steps=5, parity=True, 
                        "denoise": ("variance-guided a-trous (mi_pt_denoise_svgf, 5 iterations) once per step, inside the timed region" if denoise else None)},
             "timed_region_s": round(elapsed, 3),
             "device_memory_GB": {"scene": round(mem["sceneBytes"] / 1e9, 3), "path_state_queues_images": round(mem["rendererBytes"] / 1e9, 3)},
-            "roofline": roofline_of(kernels, pmc), "kernels": kernels, "per_frame": {k: round(per_frame[k], 1) for k in keys},
+            "roofline": roofline_of(kernels, pmc), "kernels": kernels, "streams": overlap_note(kernels, elapsed / frames * 1e3),
+            "per_frame": {k: round(per_frame[k], 1) for k in keys},
             "node_visits_per_secondary_ray": round(per_frame["nodesClosest"] / max(1.0, per_frame["segments"] - per_frame["cameraPaths"]), 2),
             "triangle_tests_per_secondary_ray": round(per_frame["trisClosest"] / max(1.0, per_frame["segments"] - per_frame["cameraPaths"]), 2)}
     if parity:
@@ -619,6 +632,7 @@ def main():
             "timed_region_s": round(elapsed, 3), "scene_build_s": round(create_s, 3),
             "roofline": roof,
             "kernels": kernels,
+            "streams": overlap_note(kernels, elapsed / frames_timed * 1e3),
             "per_frame": {k: round(per_frame[k], 1) for k in keys},
             "per_frame_bounce0": {k: round(first[k], 1) for k in keys},
             "frame_ms_device": round(timing["totalMs"] / frames_timed, 4),
