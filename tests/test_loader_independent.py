@@ -227,3 +227,81 @@ def test_strided_and_normalised_accessors_against_an_independent_reader(built, t
         f.write(struct.pack("<4sII", b"glTF", 2, 12 + 8 + len(js) + 8 + len(blob)))
         f.write(struct.pack("<I4s", len(js), b"JSON") + js + struct.pack("<I4s", len(blob), b"BIN\0") + blob)
     assert _check_scene(path) == (1, 2)
+
+
+def _world_of_node(g, target):
+    found = {}
+
+    def visit(ni, parent):
+        world = parent @ MiniGltf.local_matrix(g.doc["nodes"][ni])
+        found[ni] = world
+        for c in g.doc["nodes"][ni].get("children", []):
+            visit(c, world)
+
+    for root in g.doc["scenes"][g.doc.get("scene", 0)]["nodes"]:
+        visit(root, np.eye(4))
+    return found[target]
+
+
+def test_lights_cameras_and_texture_transforms_against_the_specifications(built, tmp_path):
+    """KHR_lights_punctual (a light shines down its node's -Z; spot cone angles; range -> 1 / range; the reference's conversion
+    src/gltf_scene_vk.cpp:1354-1392), the camera of a node (eye = origin of the node, looking down -Z, yfov), and KHR_texture_transform
+    (uv' = offset + R(rotation) * (scale * uv), checked where the specification and the reference's packing agree: no rotation, or a
+    uniform scale) -- decoded independently from the file and compared with the loader's tables."""
+    b = scenegen.GlbBuilder()
+    img = np.full((4, 4, 4), 200, np.uint8)
+    tex = b.texture(b.image(img))
+    transforms = [dict(offset=[0.25, -0.5], scale=[2.0, 3.0]), dict(offset=[0.1, 0.2], rotation=0.7, scale=[1.5, 1.5]), dict(rotation=-1.1)]
+    mats = [b.material({"pbrMetallicRoughness": {"baseColorTexture": {"index": tex, "texCoord": k % 2, "extensions": {"KHR_texture_transform": t}}}})
+            for k, t in enumerate(transforms)]
+    b.ext_used.add("KHR_texture_transform")
+    pos, nrm, uv, idx = scenegen.grid(1, 1, (1.0, 1.0), "y")
+    for m in mats:
+        b.node(mesh=b.mesh([b.primitive(pos, idx, nrm, uv, uv1=uv * 0.5, material=m)]))
+    lights = [{"type": "spot", "color": [1.0, 0.5, 0.25], "intensity": 7.0, "range": 4.0, "spot": {"innerConeAngle": 0.2, "outerConeAngle": 0.6}},
+              {"type": "point", "intensity": 3.0, "extras": {"radius": 0.05}}, {"type": "directional", "color": [0.9, 0.9, 1.0], "intensity": 2.5}]
+    light_nodes = []
+    parent = b.node(translation=[1.0, 2.0, 3.0], rotation=[0.0, 0.38268343, 0.0, 0.92387953], children=[])
+    for k, li in enumerate(lights):
+        n = b.node(root=False, extensions={"KHR_lights_punctual": {"light": b.light(li)}}, translation=[0.5 * k, 1.0, -0.25 * k],
+                   rotation=[float(np.sin(0.3 + 0.2 * k)), 0.0, 0.0, float(np.cos(0.3 + 0.2 * k))])
+        b.doc["nodes"][parent]["children"].append(n)
+        light_nodes.append(n)
+    cam_node = b.camera_node((2.0, 1.5, 4.0), (0.0, 0.25, 0.0), yfov=0.6)
+    path = b.save(str(tmp_path / "lights.glb"))
+    g = MiniGltf(path)
+    sc = ptmod.Scene(path)
+    d = sc.desc.contents
+    # ---- lights
+    assert d.numLights == 3
+    for k, (li, node) in enumerate(zip(lights, light_nodes)):
+        L = d.lights[k]
+        world = _world_of_node(g, node)
+        assert np.allclose(list(L.position), world[:3, 3], atol=1e-5)
+        assert np.allclose(list(L.direction), (world @ np.array([0, 0, -1.0, 0]))[:3], atol=1e-5)  # down the node's -Z
+        assert L.type == {"directional": 1, "spot": 2, "point": 3}[li["type"]]
+        assert np.allclose(list(L.color), li.get("color", [1, 1, 1])) and L.intensity == pytest.approx(li["intensity"])
+        if li["type"] == "spot":
+            assert L.innerAngle == pytest.approx(0.2) and L.outerAngle == pytest.approx(0.6)
+        if li["type"] != "directional":
+            assert L.angularSizeOrInvRange == pytest.approx(1.0 / li["range"] if "range" in li else 0.0)
+        assert L.radius == pytest.approx(li.get("extras", {}).get("radius", 0.0))
+    # ---- camera: eye at the node's origin, looking down its -Z, vertical field of view
+    cam = sc.camera(0)
+    world = _world_of_node(g, cam_node)
+    eye, fwd = np.array(list(cam.eye)), np.array(list(cam.center)) - np.array(list(cam.eye))
+    assert np.allclose(eye, world[:3, 3], atol=1e-5)
+    assert np.allclose(fwd / np.linalg.norm(fwd), (world @ np.array([0, 0, -1.0, 0]))[:3], atol=1e-4)
+    assert cam.fovDegrees == pytest.approx(np.degrees(0.6), abs=1e-3)
+    # ---- texture transforms: the packed float3x2 applied as the shader applies it, against the specification's offset + R * (scale * uv)
+    uvs = np.random.default_rng(1).uniform(-1, 2, (50, 2))
+    for k, t in enumerate(transforms):
+        mat = d.materials[k]
+        ti = d.textureInfos[mat.pbrBaseColorTexture]
+        assert ti.index == tex and ti.texCoord == k % 2
+        m = np.array(list(ti.uvTransform), np.float64)
+        got = np.stack([uvs[:, 0] * m[0] + uvs[:, 1] * m[2] + m[4], uvs[:, 0] * m[1] + uvs[:, 1] * m[3] + m[5]], 1)
+        r, (sx, sy), (ox, oy) = t.get("rotation", 0.0), t.get("scale", [1.0, 1.0]), t.get("offset", [0.0, 0.0])
+        su, sv = uvs[:, 0] * sx, uvs[:, 1] * sy
+        want = np.stack([np.cos(r) * su + np.sin(r) * sv + ox, -np.sin(r) * su + np.cos(r) * sv + oy], 1)
+        assert np.allclose(got, want, atol=1e-6), k
