@@ -82,7 +82,7 @@ VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 # node visit of the per-lane walk (decode + 8 slab tests + child order), one triangle test (Moeller-Trumbore + candidate update),
 # and one node of the packet walk's INTERVAL test (k_trace_primary with pixel-major slots: lane = child x 8 + plane tests one plane
 # of the node against the packet's interval ray -- all 64 lanes of ~50 instructions work on ONE node, pt_packet.h)
-VALU_PER_NODE, VALU_PER_TRI, VALU_PER_PACKET_NODE = 205, 56, 50  # (node visit: 235 until round 4's leaf word)
+VALU_PER_NODE, VALU_PER_TRI, VALU_PER_PACKET_NODE = 196, 56, 50  # (node visit: 235 until round 4's leaf word, 205 until its sign-free offsets)
 # SURVEY §8(d) algorithmic bytes, per unit: ray + hit record, path state read + write, hit-attribute gather, instance +
 # primitive + material records, shadow-ray record, one texture tap, pixel accumulate
 B_RAYHIT, B_STATE, B_ATTR, B_RECORDS, B_SHADOW, B_TAP, B_PIXEL = 60, 192, 192, 480, 76, 48, 32
