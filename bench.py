@@ -268,8 +268,8 @@ def alpha_cut_note(subdivisions, triangles_loaded, dropped):
 
 
 def cpu_baseline_and_parity(scene, w, W, H, F, cpu_seconds, make_gpu_tracer, gpu_params, parity_spp=0):
-    """The CPU oracle on the host cores over a bounded sample of the workload -- every 16th 64x64 tile of the same frames (same scene
-    bytes, seeds, depth) -- and the GPU accumulator of exactly those frames compared with the oracle's on exactly those tiles.
+    """The CPU oracle on the host cores over a bounded sample of the workload -- every 16th 64x64 tile of the same frames at 1080p, every
+    64th at 4K: about 32 tiles spread over the image (same scene bytes, seeds, depth) -- and the GPU accumulator of exactly those frames compared with the oracle's on exactly those tiles.
     Frames = the configuration's own sample count (`parity_spp`, default WORKLOADS[..]["spp"]: 256 for configs[2]); the difference is
     also taken at a quarter and at half of it.  The CPU baseline figure is the oracle's rate over the first `cpu_seconds` of that run.
     The oracle is used here only as the timed CPU baseline and as the checker of the GPU image (it renders the scene AS LOADED:
@@ -290,7 +290,7 @@ def cpu_baseline_and_parity(scene, w, W, H, F, cpu_seconds, make_gpu_tracer, gpu
     O.oracle_pt_set_sky(o, C.byref(setup.sky))
     tx, ty = (W + 63) // 64, (H + 63) // 64
     tiles_total = tx * ty
-    part = 16
+    part = 16 * max(1, round(tiles_total / 510))  # ~32 tiles whatever the resolution (4K: every 64th tile), so that the leg's CPU time follows spp, not pixels
     O.oracle_pt_set_tile_partition(o, 0, part, 64)
     owned = [t for t in range(tiles_total) if t % part == 0]
     px_owned = sum(min(64, W - (t % tx) * 64) * min(64, H - (t // tx) * 64) for t in owned)
