@@ -40,3 +40,16 @@ static inline float    __int_as_float(int u) { float f; std::memcpy(&f, &u, 4); 
 static inline uint32_t __umul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 static inline int      __ffs(int v) { return __builtin_ffs(v); }
 static inline int      __popc(uint32_t v) { return __builtin_popcount(v); }
+
+// ---- for bvh_reinsert.h (tests/host_shim/reinsert_on_host.cpp): single roundings and the two atomics the phases use
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
+static inline void  __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+static inline unsigned int atomicAdd(unsigned int* p, unsigned int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v)
+{
+  unsigned long long old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+  while(old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+  return old;
+}

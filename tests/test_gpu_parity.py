@@ -328,6 +328,32 @@ def test_image_independent_of_acceleration_structure(built, tmp_path):
     assert (pu.render_gpu(s, 2, bvh=0)["accum"] == pu.render_gpu(s, 2, bvh=1)["accum"]).all()
 
 
+@pytest.mark.skipif(os.environ.get("MI_PT_TEST_REINSERT") != "1", reason="the reinsertion passes of the device builder were written and checked on the CPU "
+                    "(tests/test_bvh_reinsert.py) after the round's GPU time was spent: their kernels have not run on a GPU yet and stay off by default; "
+                    "MI_PT_TEST_REINSERT=1 runs this check first thing next round")
+def test_reinsertion_changes_the_tree_not_the_image(built, tmp_path):
+    """MI_PT_REINSERT=n (bvh_reinsert.h: n searches over the BVH2, each followed by lock / move rounds and a refit, before the 8-wide collapse):
+    another tree, the same image bit for bit, fewer node visits."""
+    path = scenegen.scene_atrium_class(str(tmp_path / "atrium.glb"), seed=5, detail=0.12, tex_size=64)
+    s = pu.Setup(path, 160, 96, max_depth=8)
+    plain = pu.render_gpu(s, 2, bvh=0)
+    for passes, bvh in ((2, 0), (12, 0), (12, 1)):  # (bvh = 1: the BVH2 walk reads the reinserted records themselves)
+        os.environ["MI_PT_REINSERT"] = str(passes)
+        try:
+            r = pu.render_gpu(s, 2, bvh=bvh)
+        finally:
+            del os.environ["MI_PT_REINSERT"]
+        assert (r["accum"] == plain["accum"]).all() and (r["selection"] == plain["selection"]).all() and (r["depth"] == plain["depth"]).all(), (passes, bvh)
+        for k in ("segments", "shadowRays", "textureTaps"):
+            assert r["stats"][k] == plain["stats"][k]
+        if bvh == 0:
+            print("reinsertion passes", passes, ": 8-wide nodes", plain["stats"]["bvhNodeCount"], "->", r["stats"]["bvhNodeCount"], ", node visits (closest)",
+                  plain["stats"]["nodesClosest"], "->", r["stats"]["nodesClosest"], ", (shadow)", plain["stats"]["nodesShadow"], "->", r["stats"]["nodesShadow"])
+            assert r["stats"]["bvhNodeCount"] != plain["stats"]["bvhNodeCount"]
+            if passes >= 12:
+                assert r["stats"]["nodesClosest"] < 0.97 * plain["stats"]["nodesClosest"]
+
+
 def test_frames_in_flight_bit_identical(built, assets, tmp_path):
     """mi_pt_render_frames(F) == F successive mi_pt_render_frame calls, bit for bit (accumulator, depth, selection,
     counters): ragged batches, multi-sample frames, a tile partition, an alpha/light scene."""

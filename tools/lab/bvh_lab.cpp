@@ -4,9 +4,9 @@
 // seeded incoherent rays (cosine-distributed bounce rays leaving random surface points).  It decides which builder changes are
 // worth a GPU run; the numbers the design quotes are the device's own counters (MiPtStats).
 //
-//   g++ -O2 -std=c++17 -fopenmp -o /tmp/lab/bvh_lab tools/lab/bvh_lab.cpp
+//   g++ -O2 -std=c++17 -fopenmp -Itests/host_shim -Ivk_gltf_renderer_amd/csrc/device -o /tmp/lab/bvh_lab tools/lab/bvh_lab.cpp tests/host_shim/reinsert_on_host.cpp
 //   /tmp/lab/bvh_lab /tmp/lab/atrium.bin [options]      (input: tools/lab/dump_tris.py)
-// options: builder=ploc|sah|lbvh  radius=16  leaf=2  collapse=greedy|sahdp  reinsert=N  rays=200000  order=octant|dist  split=F
+// options: builder=ploc|sah|lbvh  radius=16  leaf=2  collapse=greedy|sahdp  reinsert=N  preinsert=N (the device's parallel passes)  rays=200000  order=octant|dist  split=F
 #include <algorithm>
 #include <cassert>
 #include <cfloat>
@@ -22,6 +22,8 @@
 #include <random>
 #include <string>
 #include <vector>
+
+extern "C" long long dev_reinsert(float* nodes, int numInner, int root, int passes, int rounds, int threads, int* movesPerPass, int* wantedPerPass);  // tests/host_shim/reinsert_on_host.cpp
 
 struct V3
 {
@@ -759,6 +761,43 @@ int main(int argc, char** argv)
       reinsertPass(B, std::stod(get("fraction", "0.02")), leafParent);
       printf("  reinsertion pass %d: SAH %.2f\n", p + 1, sahCost2(B));
     }
+  }
+  const int ppasses = std::stoi(get("preinsert", "0"));  // the DEVICE's parallel reinsertion (csrc/device/bvh_reinsert.h through tests/host_shim)
+  if(ppasses > 0)
+  {
+    const int ni = int(B.nodes.size());
+    std::vector<float> rec(size_t(ni) * 16);
+    for(int i = 0; i < ni; ++i)
+    {
+      const Node2& N = B.nodes[i];
+      float* f = &rec[size_t(i) * 16];
+      for(int k = 0; k < 2; ++k)
+      {
+        f[4 * k + 0] = N.b[k].lo.x; f[4 * k + 1] = N.b[k].hi.x; f[4 * k + 2] = N.b[k].lo.y; f[4 * k + 3] = N.b[k].hi.y;
+        f[8 + 2 * k] = N.b[k].lo.z; f[9 + 2 * k] = N.b[k].hi.z;
+        memcpy(&f[12 + k], &N.c[k], 4);
+      }
+      memcpy(&f[14], &N.cnt, 4);
+    }
+    std::vector<int> done(ppasses, 0), wanted(ppasses, 0);
+    const long long total = dev_reinsert(rec.data(), ni, B.root, ppasses, std::stoi(get("rounds", "8")), std::stoi(get("threads", "0")), done.data(), wanted.data());
+    for(int i = 0; i < ni; ++i)
+    {
+      Node2& N = B.nodes[i];
+      const float* f = &rec[size_t(i) * 16];
+      for(int k = 0; k < 2; ++k)
+      {
+        N.b[k].lo = V3{f[4 * k + 0], f[4 * k + 2], f[8 + 2 * k]};
+        N.b[k].hi = V3{f[4 * k + 1], f[4 * k + 3], f[9 + 2 * k]};
+        memcpy(&N.c[k], &f[12 + k], 4);
+      }
+      memcpy(&N.cnt, &f[14], 4);
+    }
+    B.nodes[B.root].parent = -1;
+    for(int i = 0; i < ni; ++i) for(int k = 0; k < 2; ++k) if(B.nodes[i].c[k] >= 0) B.nodes[B.nodes[i].c[k]].parent = i;
+    printf("  parallel reinsertion: %lld moves;", total);
+    for(int q = 0; q < ppasses; ++q) printf(" %d/%d", done[q], wanted[q]);
+    printf("  -> SAH %.2f\n", sahCost2(B));
   }
   CollapseCfg cfg;
   cfg.maxLeaf  = std::stoi(get("leaf", "2"));

@@ -13,6 +13,7 @@
 
 #include <cfloat>
 
+#include "bvh_reinsert.h"
 #include "pt_build.h"
 #include "pt_bvh.h"
 
@@ -385,6 +386,44 @@ __global__ void k_emit_tris(int n, const uint32_t* vals, const DevTri* tris, Dev
     outTris[i] = tris[vals[i]];
 }
 
+// ---- reinsertion passes over the finished BVH2 (bvh_reinsert.h holds the work of one thread of each phase) ---------------------------
+__global__ void k_re_parents(Bvh2Tree T)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < T.numInner)
+    reinsertParents(T, i);
+}
+__global__ void k_re_search(Bvh2Tree T, int ids, ReinsertMove* moves)
+{
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if(id < ids)
+    moves[id] = reinsertSearch(T, id);
+}
+__global__ void k_re_lock(Bvh2Tree T, int ids, ReinsertMove* moves, unsigned long long* locks)
+{
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if(id < ids)
+    reinsertLock(T, moves, locks, id);
+}
+__global__ void k_re_apply(Bvh2Tree T, int ids, ReinsertMove* moves, unsigned long long* locks, unsigned int* carriedOut)
+{
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if(id < ids && reinsertApply(T, moves, locks, id))
+    atomicAdd(carriedOut, 1u);
+}
+__global__ void k_re_unlock(int ids, unsigned long long* locks)
+{
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if(id < ids)
+    reinsertUnlock(locks, id);
+}
+__global__ void k_re_refit(Bvh2Tree T, unsigned int* arrive)
+{
+  const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
+  if(leaf <= T.numInner)
+    reinsertRefit(T, arrive, leaf);
+}
+
 #define BUILD_CHECK(x)                                                                                                  \
   do                                                                                                                    \
   {                                                                                                                     \
@@ -399,6 +438,59 @@ __global__ void k_emit_tris(int n, const uint32_t* vals, const DevTri* tris, Dev
 // NB: BUILD_CHECK `break`s out of the single do { } while(0) that wraps buildBvh's body.
 
 }  // namespace
+
+// `passes` searches, each followed by up to `rounds` lock / move rounds and one refit; stops early once a pass moves fewer than one node
+// in two thousand.  Leaves the records, the root index and the triangle counts in the form the collapse reads (bvh8.hip).
+static bool reinsertBvh2(float4* nodes, int numInner, int root, int passes, int rounds, hipStream_t stream, std::string& err, uint32_t* movesOut)
+{
+  if(movesOut)
+    *movesOut = 0;
+  if(passes <= 0 || numInner < 3)
+    return true;
+  const int           ids = 2 * numInner + 1, B = 256;
+  int *               parent = nullptr, *leafParent = nullptr;
+  ReinsertMove*       moves  = nullptr;
+  unsigned long long* locks  = nullptr;
+  unsigned int *      arrive = nullptr, *carried = nullptr;
+  bool                ok     = true;
+  do
+  {
+    BUILD_CHECK(hipMalloc(&parent, sizeof(int) * numInner));
+    BUILD_CHECK(hipMalloc(&leafParent, sizeof(int) * (numInner + 1)));
+    BUILD_CHECK(hipMalloc(&moves, sizeof(ReinsertMove) * ids));
+    BUILD_CHECK(hipMalloc(&locks, sizeof(unsigned long long) * ids));
+    BUILD_CHECK(hipMalloc(&arrive, sizeof(unsigned int) * numInner));
+    BUILD_CHECK(hipMalloc(&carried, sizeof(unsigned int)));
+    const Bvh2Tree T{nodes, parent, leafParent, numInner, root};
+    const dim3     gN((numInner + B - 1) / B), gI((ids + B - 1) / B), gL((numInner + 1 + B - 1) / B);
+    for(int pass = 0; pass < passes && ok; ++pass)
+    {
+      hipLaunchKernelGGL(k_re_parents, gN, dim3(B), 0, stream, T);
+      hipLaunchKernelGGL(k_re_search, gI, dim3(B), 0, stream, T, ids, moves);
+      BUILD_CHECK(hipMemsetAsync(locks, 0, sizeof(unsigned long long) * ids, stream));
+      BUILD_CHECK(hipMemsetAsync(carried, 0, sizeof(unsigned int), stream));
+      for(int round = 0; round < rounds; ++round)
+      {
+        hipLaunchKernelGGL(k_re_lock, gI, dim3(B), 0, stream, T, ids, moves, locks);
+        hipLaunchKernelGGL(k_re_apply, gI, dim3(B), 0, stream, T, ids, moves, locks, carried);
+        hipLaunchKernelGGL(k_re_unlock, gI, dim3(B), 0, stream, ids, locks);
+      }
+      hipLaunchKernelGGL(k_re_parents, gN, dim3(B), 0, stream, T);
+      BUILD_CHECK(hipMemsetAsync(arrive, 0, sizeof(unsigned int) * numInner, stream));
+      hipLaunchKernelGGL(k_re_refit, gL, dim3(B), 0, stream, T, arrive);
+      BUILD_CHECK(hipGetLastError());
+      unsigned int done = 0;
+      BUILD_CHECK(hipMemcpyAsync(&done, carried, sizeof(done), hipMemcpyDeviceToHost, stream));
+      BUILD_CHECK(hipStreamSynchronize(stream));
+      if(movesOut)
+        *movesOut += done;
+      if(done < unsigned(numInner / 2000 + 1))
+        break;
+    }
+  } while(0);
+  (void)hipFree(parent); (void)hipFree(leafParent); (void)hipFree(moves); (void)hipFree(locks); (void)hipFree(arrive); (void)hipFree(carried);
+  return ok;
+}
 
 bool buildBvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream, std::string& err)
 {
@@ -532,6 +624,11 @@ bool buildBvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream, 
     out.root     = 0;
     out.numNodes = n - 1;
     }
+  }
+  if(out.numNodes >= 3 && in.reinsertPasses > 0 && !reinsertBvh2(out.nodes, int(out.numNodes), out.root, in.reinsertPasses, in.reinsertRounds, stream, err, &out.reinsertMoves))
+  {
+    ok = false;
+    break;
   }
   BUILD_CHECK(hipMemcpy(hb, bounds, sizeof(hb), hipMemcpyDeviceToHost));
   } while(0);

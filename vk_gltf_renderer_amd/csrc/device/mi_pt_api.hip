@@ -92,6 +92,10 @@ struct RunSwitches
   bool   allOpaqueTris  = false;   // MI_PT_DIAG_ALL_OPAQUE_TRIS (wrong image) every triangle of an alpha-tested primitive in the OPAQUE class: the alpha
                                    //                            kernels run without a single alpha candidate -- their fixed cost
   bool   noQuads        = false;   // MI_PT_DIAG_NO_QUADS    four texel gathers per bilinear tap instead of one footprint
+  int    reinsert       = 0;       // MI_PT_REINSERT         reinsertion passes over the BVH2 before the 8-wide collapse at scene build (bvh_reinsert.h):
+                                   //                        about a tenth fewer node visits per ray in the CPU laboratory (tools/lab), not yet timed on a GPU -> off
+  int    reinsertUpdate = 0;       // MI_PT_REINSERT_UPDATE  ... at the rebuilds of mi_pt_update_render_nodes (a moving instance pays them every time)
+  int    reinsertRounds = 4;       // MI_PT_REINSERT_ROUNDS  lock / move rounds per pass
   int    failBuildAt    = 0;       // MI_PT_DIAG_FAIL_BUILD=N  test hook: the N-th acceleration REbuild of the instance fails after the old structure is gone
   bool   candPoolSet    = false;   // MI_PT_DIAG_CAND_POOL   entries of the transmissive-candidate pool (tests of the overflow path)
   size_t candPool       = 0;
@@ -115,6 +119,9 @@ struct RunSwitches
     noOpaqueTris   = flag("MI_PT_DIAG_NO_OPAQUE_TRIS");
     allOpaqueTris  = flag("MI_PT_DIAG_ALL_OPAQUE_TRIS");
     noQuads        = flag("MI_PT_DIAG_NO_QUADS");
+    reinsert       = num("MI_PT_REINSERT", 0);
+    reinsertUpdate = num("MI_PT_REINSERT_UPDATE", 0);
+    reinsertRounds = std::max(1, num("MI_PT_REINSERT_ROUNDS", 4));
     failBuildAt    = num("MI_PT_DIAG_FAIL_BUILD", 0);
     if(const char* e = getenv("MI_PT_DIAG_CAND_POOL"))
     {
@@ -458,6 +465,8 @@ int buildAccelerationUnguarded(MiPt* pt)
     HIP_TRY(dEntry.upload(entryNode.data(), entryNode.size()));
     pt::BvhBuildInput in{pt->nodes.ptr, pt->prims.ptr, pt->instFlags.ptr, dOffset.ptr, dEntry.ptr, int(entryNode.size()), uint32_t(totalTris)};
     in.karrasTopology = (pt->bvhBuilder & 2) != 0;
+    in.reinsertPasses = pt->accelBuilds == 1 ? pt->sw.reinsert : pt->sw.reinsertUpdate;  // (accelBuilds counts this build already)
+    in.reinsertRounds = pt->sw.reinsertRounds;
     pt::BvhBuildOutput bo;
     std::string        err;
     if(!pt::buildBvh(in, bo, nullptr, err))

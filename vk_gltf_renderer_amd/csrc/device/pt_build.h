@@ -18,6 +18,8 @@ struct BvhBuildInput
   int                     numEntries;
   uint32_t                numTris;
   bool                    karrasTopology = false;  // true: plain LBVH (Morton-prefix hierarchy); false: PLOC clustering
+  int                     reinsertPasses = 0;      // parallel reinsertion over the finished BVH2 (bvh_reinsert.h): searches ...
+  int                     reinsertRounds = 4;      // ... and lock / move rounds per search
 };
 struct BvhBuildOutput
 {
@@ -25,6 +27,7 @@ struct BvhBuildOutput
   DevTri*  tris     = nullptr;  // device, Morton order (leaf reference ~i = triangle i of this array)
   uint32_t numNodes = 0, numTris = 0;
   int      root     = 0;
+  uint32_t reinsertMoves = 0;   // subtrees the reinsertion passes moved
   float    centroidLo[3] = {0, 0, 0}, centroidHi[3] = {0, 0, 0};
 };
 bool buildBvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream, std::string& err);
