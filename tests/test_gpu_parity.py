@@ -328,9 +328,9 @@ def test_image_independent_of_acceleration_structure(built, tmp_path):
     assert (pu.render_gpu(s, 2, bvh=0)["accum"] == pu.render_gpu(s, 2, bvh=1)["accum"]).all()
 
 
-@pytest.mark.skipif(os.environ.get("MI_PT_TEST_REINSERT") != "1", reason="the reinsertion passes of the device builder were written and checked on the CPU "
-                    "(tests/test_bvh_reinsert.py) after the round's GPU time was spent: their kernels have not run on a GPU yet and stay off by default; "
-                    "MI_PT_TEST_REINSERT=1 runs this check first thing next round")
+@pytest.mark.skipif(os.environ.get("MI_PT_TEST_REINSERT") != "1", reason="the reinsertion passes of the device builder were written after the round's GPU time was all but spent: "
+                    "their kernels were checked on an MI355X by tools/test_reinsert_gpu.hip (records bit-identical to the host run, profiles/r04_reinsert_gpu_check.txt), "
+                    "this test through the renderer has not run yet and the passes stay off by default; MI_PT_TEST_REINSERT=1 runs it first thing next round")
 def test_reinsertion_changes_the_tree_not_the_image(built, tmp_path):
     """MI_PT_REINSERT=n (bvh_reinsert.h: n searches over the BVH2, each followed by lock / move rounds and a refit, before the 8-wide collapse):
     another tree, the same image bit for bit, fewer node visits."""

@@ -6,7 +6,7 @@
 //
 //   g++ -O2 -std=c++17 -fopenmp -Itests/host_shim -Ivk_gltf_renderer_amd/csrc/device -o /tmp/lab/bvh_lab tools/lab/bvh_lab.cpp tests/host_shim/reinsert_on_host.cpp
 //   /tmp/lab/bvh_lab /tmp/lab/atrium.bin [options]      (input: tools/lab/dump_tris.py)
-// options: builder=ploc|sah|lbvh  radius=16  leaf=2  collapse=greedy|sahdp  reinsert=N  preinsert=N (the device's parallel passes)  rays=200000  order=octant|dist  split=F
+// options: builder=ploc|sah|lbvh  radius=16  leaf=2  collapse=greedy|sahdp  reinsert=N  preinsert=N (the device's parallel passes; dump2=<prefix> writes the records before and after for tools/test_reinsert_gpu.hip)  rays=200000  order=octant|dist  split=F
 #include <algorithm>
 #include <cassert>
 #include <cfloat>
@@ -577,7 +577,7 @@ static bool slab(const Box& b, const Ray& r, V3 idir, float tmax, float& tn)
   return t0 <= t1;
 }
 
-struct WalkStats { double nodes = 0, tris = 0, rays = 0, hits = 0, maxStack = 0; };
+struct WalkStats { double nodes = 0, tris = 0, rays = 0, hits = 0, maxStack = 0, deep = 0, maxGroups = 0; };  // deep: visits made with more than 12 GROUPS (a node's pending children: the device's stack entry) waiting
 
 // mode 0: octant order, triangles tested immediately (the ideal of the device walk); 1: distance order; 2: octant order with the
 // device's deferral model: leaf hits are parked and tested only after `defer` further node visits (tmax tightens late)
@@ -586,9 +586,9 @@ static void walk(const Bvh8& W, const std::vector<Tri>& tris, const std::vector<
   V3 idir{1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
   const uint32_t octinv = 7u ^ ((idir.x < 0 ? 1u : 0u) | (idir.y < 0 ? 2u : 0u) | (idir.z < 0 ? 4u : 0u));
   float tmax = FLT_MAX;
-  struct Entry { int node; float tn; float gmin; };  // gmin: smallest entry distance among the hit children of the node that pushed this entry
+  struct Entry { int node; float tn; float gmin; int from; };  // from: the node that pushed it; gmin: smallest entry distance among the hit children of the node that pushed this entry
   std::vector<Entry> stack;
-  stack.push_back({0, 0, 0});
+  stack.push_back({0, 0, 0, -1});
   struct Parked { int base, cnt, due; };
   std::vector<Parked> parked;
   int visits = 0;
@@ -642,8 +642,14 @@ static void walk(const Bvh8& W, const std::vector<Tri>& tris, const std::vector<
     else std::sort(hit, hit + nh, [&](const H& a, const H& b) { return (uint32_t(a.slot) ^ octinv) < (uint32_t(b.slot) ^ octinv); });
     float gmin = FLT_MAX;
     for(int k = 0; k < nh; ++k) gmin = std::min(gmin, hit[k].tn);
-    for(int k = 0; k < nh; ++k) stack.push_back({N.child[hit[k].slot], hit[k].tn, gmin});
+    for(int k = 0; k < nh; ++k) stack.push_back({N.child[hit[k].slot], hit[k].tn, gmin, e.node});
     S.maxStack = std::max(S.maxStack, double(stack.size()));
+    {
+      int groups = 0;
+      for(size_t k = 0; k < stack.size(); ++k) groups += (k == 0 || stack[k].from != stack[k - 1].from) ? 1 : 0;
+      S.maxGroups = std::max(S.maxGroups, double(groups));
+      if(groups > 12) S.deep += 1;
+    }
     if(mode == 2 && stack.empty())
     {
       for(auto& p : parked) testLeaf(p.base, p.cnt);
@@ -779,6 +785,13 @@ int main(int argc, char** argv)
       }
       memcpy(&f[14], &N.cnt, 4);
     }
+    auto dump = [&](const std::string& path) {  // the records as the device holds them: int32 numInner, int32 root, numInner x 16 floats (tools/test_reinsert_gpu.hip)
+      FILE* o = fopen(path.c_str(), "wb");
+      if(!o) { perror("dump"); return; }
+      fwrite(&ni, 4, 1, o); fwrite(&B.root, 4, 1, o); fwrite(rec.data(), 4, rec.size(), o);
+      fclose(o);
+    };
+    if(opt.count("dump2")) dump(opt["dump2"] + ".in");
     std::vector<int> done(ppasses, 0), wanted(ppasses, 0);
     const long long total = dev_reinsert(rec.data(), ni, B.root, ppasses, std::stoi(get("rounds", "8")), std::stoi(get("threads", "0")), done.data(), wanted.data());
     for(int i = 0; i < ni; ++i)
@@ -793,6 +806,7 @@ int main(int argc, char** argv)
       }
       memcpy(&N.cnt, &f[14], 4);
     }
+    if(opt.count("dump2")) dump(opt["dump2"] + ".expected");
     B.nodes[B.root].parent = -1;
     for(int i = 0; i < ni; ++i) for(int k = 0; k < 2; ++k) if(B.nodes[i].c[k] >= 0) B.nodes[B.nodes[i].c[k]].parent = i;
     printf("  parallel reinsertion: %lld moves;", total);
@@ -808,6 +822,25 @@ int main(int argc, char** argv)
   cfg.width    = std::stoi(get("width", "8"));
   cfg.optimalSlots = get("slots", "greedy") == "optimal";
   Bvh8 W = collapse(B, cfg);
+  {  // depth: the device collapses level by level (two kernels, a scan and a host round trip per level of the 8-wide tree)
+    std::vector<std::pair<int, int>> st{{B.root, 1}};
+    int maxD2 = 0; double sumLeafD = 0, leaves = 0;
+    while(!st.empty())
+    {
+      auto [nd, d] = st.back(); st.pop_back();
+      maxD2 = std::max(maxD2, d);
+      for(int k = 0; k < 2; ++k) { if(B.nodes[nd].c[k] >= 0) st.push_back({B.nodes[nd].c[k], d + 1}); else { sumLeafD += d; leaves += 1; } }
+    }
+    std::vector<std::pair<int, int>> s8{{0, 1}};
+    int maxD8 = 0;
+    while(!s8.empty())
+    {
+      auto [nd, d] = s8.back(); s8.pop_back();
+      maxD8 = std::max(maxD8, d);
+      for(int sl = 0; sl < 8; ++sl) if(W.nodes[nd].child[sl] >= 0) s8.push_back({W.nodes[nd].child[sl], d + 1});
+    }
+    printf("depth: BVH2 max %d, mean leaf depth %.1f; 8-wide levels %d\n", maxD2, sumLeafD / leaves, maxD8);
+  }
   double leafChildren = 0, innerChildren = 0;
   for(const Node8& N : W.nodes) for(int s = 0; s < 8; ++s) { if(N.child[s] == -1) leafChildren++; else if(N.child[s] >= 0) innerChildren++; }
   printf("BVH8 (%s, leaf <= %d): %zu nodes, SAH(nodes) %.2f, fill %.2f children/node (%.2f leaf), %.2f tris/leaf\n", cfg.sahdp ? "sahdp" : "greedy", cfg.maxLeaf,
@@ -847,12 +880,12 @@ int main(int argc, char** argv)
 #pragma omp for schedule(dynamic, 256)
       for(int i = 0; i < nrays; ++i) walk(W, tris, alpha, rays[i], mode, defer, uint32_t(i) * 7919u + 17u, L);
 #pragma omp critical
-      { S.nodes += L.nodes; S.tris += L.tris; S.rays += L.rays; S.hits += L.hits; S.maxStack = std::max(S.maxStack, L.maxStack); }
+      { S.nodes += L.nodes; S.tris += L.tris; S.rays += L.rays; S.hits += L.hits; S.maxStack = std::max(S.maxStack, L.maxStack); S.deep += L.deep; S.maxGroups = std::max(S.maxGroups, L.maxGroups); }
     }
     const double cnode = 59 + 22 * cfg.width;
-    printf("walk %-28s: %.2f node visits + %.2f triangle tests per ray  (cost (59+22w)n+56t = %.0f; hit rate %.3f, max stack %.0f)\n",
+    printf("walk %-28s: %.2f node visits + %.2f triangle tests per ray  (cost (59+22w)n+56t = %.0f; hit rate %.3f, max stack %.0f; groups waiting: max %.0f, more than 12 at %.3f %% of the visits)\n",
            mode == 0 ? "octant order, immediate" : (mode == 1 ? "distance order, immediate" : (mode == 3 ? "octant order + cull at pop" : (mode == 4 ? "octant order + group cull" : "octant order, deferred"))), S.nodes / S.rays, S.tris / S.rays,
-           (cnode * S.nodes + 56 * S.tris) / S.rays, S.hits / S.rays, S.maxStack);
+           (cnode * S.nodes + 56 * S.tris) / S.rays, S.hits / S.rays, S.maxStack, S.maxGroups, 100.0 * S.deep / S.nodes);
   }
   // shadow rays: from the same surface points, half towards a fixed sun direction (through the skylight), half uniform over the sphere
   {

@@ -54,7 +54,8 @@ print("EVIDENCE", tag, j["value"], {n: (v.get("issue_frac"), v.get("active_lanes
 PY
     rm -rf $O/prof_r04_$tag  # (the per-dispatch counter CSVs are tens of MB per configuration; gpurun copies back at most 64 MiB)
     ;;
-  reinsert)  # MI_PT_REINSERT (bvh_reinsert.h): never run on a GPU when it was written -- the bit-identity check first, then what it buys and what the build costs
+  reinsert)  # MI_PT_REINSERT (bvh_reinsert.h; round 4 ran its kernels stand-alone and one native A/B, profiles/r04_reinsert_*): the check through the renderer first,
+             # then what the passes buy on every workload and what the build costs
     MI_PT_TEST_REINSERT=1 timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -s -k "reinsertion or independent_of_acceleration" 2>&1 | tail -8
     for w in atrium street helmet glass; do for p in 0 8 24; do
       MI_PT_REINSERT=$p timeout 300 python bench.py --workload $w --steps 3 --warmup 1 $N > $O/r05_reinsert_${w}_p$p.json 2> $O/r05_reinsert_${w}_p$p.err && val $O/r05_reinsert_${w}_p$p.json ${w}_reinsert$p || { echo "FAILED ${w} $p"; tail -3 $O/r05_reinsert_${w}_p$p.err; }

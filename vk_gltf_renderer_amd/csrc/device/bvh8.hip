@@ -119,7 +119,8 @@ __device__ __forceinline__ void d_childBox(const float4* nodes2, int node, int w
 __device__ __forceinline__ float d_area(const DCand& c)
 {
   const float ex = c.hi[0] - c.lo[0], ey = c.hi[1] - c.lo[1], ez = c.hi[2] - c.lo[2];
-  return __fadd_rn(__fadd_rn(__fmul_rn(ex, ey), __fmul_rn(ey, ez)), __fmul_rn(ez, ex));  // (no contraction: the host reference computes the same value)
+  return __fadd_rn(__fadd_rn(__fmul_rn(ex, ey), __fmul_rn(ey, ez)), __fmul_rn(ez, ex));  // (fixed association; NB __fmul_rn / __fadd_rn are a plain * and + in this
+                                                                                         //  ROCm and hipcc may still fuse them -- bvh_reinsert.h: r2Area, where the bits matter, uses the pragma)
 }
 // ---- SAH-optimal collapse (Ylitie, Karras, Laine 2017, section 3.2) ------------------------------------------------------------
 // cost[n][i], i = 1..7: the cheapest way to represent the BVH2 subtree n as AT MOST i children of some 8-wide node -- each such child

@@ -82,8 +82,14 @@ PT_DEV RBox r2Union(const RBox& a, const RBox& b)
 }
 PT_DEV float r2Area(const RBox& b)
 {
+  // Three products and two sums, each rounded once: hipcc fuses a * b + c into one fma by default -- also through __fmul_rn / __fadd_rn, which are a
+  // plain * and + in this ROCm -- and the host compiler of the CPU test tier does not; with the pragma the device's records equal the host's bit for
+  // bit (tools/test_reinsert_gpu.hip).  The only products of these phases are here.
+#ifdef __clang__
+#pragma clang fp contract(off)
+#endif
   const float ex = b.hi[0] - b.lo[0], ey = b.hi[1] - b.lo[1], ez = b.hi[2] - b.lo[2];
-  return __fadd_rn(__fadd_rn(__fmul_rn(ex, ey), __fmul_rn(ey, ez)), __fmul_rn(ez, ex));  // (no contraction: host and device agree)
+  return ex * ey + ey * ez + ez * ex;
 }
 PT_DEV int r2ParentOf(const Bvh2Tree& T, int ref) { return ref >= 0 ? T.parent[ref] : T.leafParent[~ref]; }
 PT_DEV int r2SlotOf(const Bvh2Tree& T, int parentNode, int ref) { return r2ChildRef(T.nodes, parentNode, 0) == ref ? 0 : 1; }

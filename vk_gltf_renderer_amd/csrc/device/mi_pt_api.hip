@@ -93,7 +93,9 @@ struct RunSwitches
                                    //                            kernels run without a single alpha candidate -- their fixed cost
   bool   noQuads        = false;   // MI_PT_DIAG_NO_QUADS    four texel gathers per bilinear tap instead of one footprint
   int    reinsert       = 0;       // MI_PT_REINSERT         reinsertion passes over the BVH2 before the 8-wide collapse at scene build (bvh_reinsert.h):
-                                   //                        about a tenth fewer node visits per ray in the CPU laboratory (tools/lab), not yet timed on a GPU -> off
+                                   //                        about a tenth fewer node visits per ray; on the device bit-identical to the host run of the same phase
+                                   //                        functions, 4 ms per pass at 0.4 M triangles; steady state atrium +4.8 %, street +9 % (native A/B,
+                                   //                        profiles/r04_reinsert_*).  Off until the GPU suite and the bench line have run with it.
   int    reinsertUpdate = 0;       // MI_PT_REINSERT_UPDATE  ... at the rebuilds of mi_pt_update_render_nodes (a moving instance pays them every time)
   int    reinsertRounds = 4;       // MI_PT_REINSERT_ROUNDS  lock / move rounds per pass
   int    failBuildAt    = 0;       // MI_PT_DIAG_FAIL_BUILD=N  test hook: the N-th acceleration REbuild of the instance fails after the old structure is gone
