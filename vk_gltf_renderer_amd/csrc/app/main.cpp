@@ -4,6 +4,7 @@
 // (docs/benchmarking.md:16-23).  Positional arguments ending in .gltf/.glb/.hdr are accepted like in the reference.
 #include <cstdio>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <vector>
 #include <cstring>
@@ -129,9 +130,27 @@ int main(int argc, char** argv)
   {
     const int batch = f == 0 ? 1 : std::max(1, std::min(framesInFlight, frames - f));
     const int before = app.resources().frameCount;
-    app.onRender(nullptr, true, uint32_t(frames), batch);
-    f += std::max(1, app.resources().frameCount - before);
+    const auto t0 = std::chrono::steady_clock::now();
+    app.onRender(nullptr, true, uint32_t(frames), batch);  // (headless: returns after the batch's device work)
+    const int done = std::max(1, app.resources().frameCount - before);
+    // (our own line) wall time of every batch: the steady state can be read off without the first batches' one-off costs (allocations, first touch)
+    printf("HEADLESS_BATCH first_frame=%d frames=%d ms=%.3f\n", f, done, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    f += done;
   }
   app.onLastHeadlessFrame(uint32_t(frames));
+  if(app.pathTracer().collectsCounters() && app.pathTracer().handle())
+  {
+    MiPtStats st{};
+    if(mi_pt_get_stats(app.pathTracer().handle(), &st) == MI_PT_OK)
+    {
+      const double secondary = double(st.segments) - double(st.cameraPaths);
+      printf("HEADLESS_COUNTERS camera_paths=%llu segments=%llu shadow_rays=%llu nodes_closest=%llu tris_closest=%llu nodes_shadow=%llu tris_shadow=%llu nodes_primary=%llu bvh_nodes=%llu "
+             "node_visits_per_secondary_ray=%.3f triangle_tests_per_secondary_ray=%.3f node_visits_per_shadow_ray=%.3f\n",
+             (unsigned long long)st.cameraPaths, (unsigned long long)st.segments, (unsigned long long)st.shadowRays, (unsigned long long)st.nodesClosest,
+             (unsigned long long)st.trisClosest, (unsigned long long)st.nodesShadow, (unsigned long long)st.trisShadow, (unsigned long long)st.nodesPrimary,
+             (unsigned long long)st.bvhNodeCount, secondary > 0 ? double(st.nodesClosest) / secondary : 0.0, secondary > 0 ? double(st.trisClosest) / secondary : 0.0,
+             st.shadowRays ? double(st.nodesShadow) / double(st.shadowRays) : 0.0);
+    }
+  }
   return 0;
 }

@@ -47,6 +47,8 @@ void PathTracer::registerParameters(ParameterRegistry* r)
   r->add("optixAutoDenoiseInterval", "Denoiser: auto-denoise interval (frames)", &m_denoiser.autoDenoiseInterval);
   r->add("denoiseMethod", "Denoiser: [a-trous:0, variance-guided:1]", &m_denoiser.method);
   r->add("ptPerformanceTarget", "Performance target [Interactive:0, Balanced:1, Quality:2, MaxQuality:3]", &m_performanceTarget);
+  // (our own) traversal / shading counters of the C-ABI: slower kernels, printed as HEADLESS_COUNTERS at the end of a headless run
+  r->add("ptCounters", "Collect traversal counters (MiPtStats; slower) and print them at the end of a headless run", &m_collectCounters);
 }
 
 void PathTracer::onAttach(Resources& res, void* profiler)
@@ -66,6 +68,7 @@ void PathTracer::onSceneInvalidated(Resources& res)
     return;
   MiPtCreateOptions opt{};
   opt.device = res.device;
+  opt.collectCounters = m_collectCounters ? 1 : 0;
   if(mi_pt_create(mi_scene_desc(res.scene), &opt, &m_pt) != MI_PT_OK)
   {
     m_error = mi_pt_last_error();

@@ -30,6 +30,7 @@ public:
   const std::string& lastError() const { return m_error; }
   MiPt* handle() const { return m_pt; }
   bool  adaptiveSampling() const { return m_adaptiveSampling; }
+  bool  collectsCounters() const { return m_collectCounters; }
   int   totalSamples() const { return m_totalSamplesAccumulated; }
 
   // The denoiser that takes the OptiX adapter's place (reference: OptiXDenoiser::Settings, src/optix_denoiser.hpp:134-140; same
@@ -71,6 +72,7 @@ private:
   bool        m_autoFocus{true};           // reference: src/renderer_pathtracer.hpp:89
   bool        m_adaptiveSampling{true};    // reference default: on, until --ptSamples is given (src/renderer_pathtracer.hpp:161)
   int         m_performanceTarget{1};      // Balanced
+  bool        m_collectCounters{false};    // --ptCounters (our own): MiPtCreateOptions::collectCounters
   double      m_lastFrameDeviceMs{0.0};
   int         m_totalSamplesAccumulated{0};
   int         m_framesThisCall{1}, m_framesLastCall{1};

@@ -12,6 +12,9 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cfloat>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 #include "bvh_reinsert.h"
 #include "pt_build.h"
@@ -447,6 +450,10 @@ static bool reinsertBvh2(float4* nodes, int numInner, int root, int passes, int 
     *movesOut = 0;
   if(passes <= 0 || numInner < 3)
     return true;
+  static const bool   timing = getenv("MI_PT_BUILD_TIMING") != nullptr;
+  const auto          t0     = std::chrono::steady_clock::now();
+  int                 passesRun = 0;
+  uint32_t            movesAll  = 0;
   const int           ids = 2 * numInner + 1, B = 256;
   int *               parent = nullptr, *leafParent = nullptr;
   ReinsertMove*       moves  = nullptr;
@@ -482,13 +489,18 @@ static bool reinsertBvh2(float4* nodes, int numInner, int root, int passes, int 
       unsigned int done = 0;
       BUILD_CHECK(hipMemcpyAsync(&done, carried, sizeof(done), hipMemcpyDeviceToHost, stream));
       BUILD_CHECK(hipStreamSynchronize(stream));
-      if(movesOut)
-        *movesOut += done;
+      ++passesRun;
+      movesAll += done;
       if(done < unsigned(numInner / 2000 + 1))
         break;
     }
   } while(0);
   (void)hipFree(parent); (void)hipFree(leafParent); (void)hipFree(moves); (void)hipFree(locks); (void)hipFree(arrive); (void)hipFree(carried);
+  if(movesOut)
+    *movesOut = movesAll;
+  if(timing)
+    fprintf(stderr, "[mi_pt build] reinsertion: %d of %d passes x %d rounds over %d nodes and leaves, %u subtrees moved, %.2f ms\n", passesRun, passes, rounds, ids, movesAll,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   return ok;
 }
 
