@@ -694,7 +694,7 @@ static void walkAny(const Bvh8& W, const std::vector<Tri>& tris, const std::vect
           }
         }
       }
-      else hit[nh++] = {sl, order == 1 ? N.box[sl].area() : (order == 2 ? -tn : float(uint32_t(sl) ^ octinv))};
+      else hit[nh++] = {sl, order == 1 ? N.box[sl].area() : (order == 2 ? -tn : (order == 3 ? float(sl) : (order == 4 ? -float(uint32_t(sl) ^ octinv) : (order == 5 ? -float(sl) : float(uint32_t(sl) ^ octinv)))))};
     }
     std::sort(hit, hit + nh, [](const H& a, const H& b) { return a.key < b.key; });  // highest key popped first
     for(int k = 0; k < nh; ++k) stack.push_back(N.child[hit[k].slot]);
@@ -898,18 +898,18 @@ int main(int argc, char** argv)
       else { float z = 1 - 2 * U(rng), rr = std::sqrt(std::max(0.0f, 1 - z * z)), ph = 6.2831853f * U(rng); d = V3{rr * std::cos(ph), z, rr * std::sin(ph)}; }
       sh[i] = {rays[i].o, d};
     }
-    for(int order : {0, 1, 2})
+    for(int half : {0, 1, 2}) for(int order : {0, 1, 2, 3, 4, 5})
     {
       WalkStats S;
 #pragma omp parallel
       {
         WalkStats L;
 #pragma omp for schedule(dynamic, 256)
-        for(int i = 0; i < nrays; ++i) walkAny(W, tris, alpha, sh[i], order, uint32_t(i) * 7919u + 17u, L);
+        for(int i = 0; i < nrays; ++i) if(half == 0 || (half == 1) == bool(i & 1)) walkAny(W, tris, alpha, sh[i], order, uint32_t(i) * 7919u + 17u, L);
 #pragma omp critical
         { S.nodes += L.nodes; S.tris += L.tris; S.rays += L.rays; S.hits += L.hits; }
       }
-      printf("any-hit %-24s: %.2f node visits + %.2f triangle tests per ray (occluded %.3f)\n", order == 0 ? "octant order" : (order == 1 ? "largest box first" : "nearest first"),
+      printf("any-hit %s %-24s: %.2f node visits + %.2f triangle tests per ray (occluded %.3f)\n", half == 0 ? "all rays " : (half == 1 ? "sun rays " : "any dir. "), order == 0 ? "octant order" : (order == 1 ? "largest box first" : (order == 2 ? "nearest first" : (order == 3 ? "slot order, 7 first" : (order == 4 ? "octant order reversed" : "slot order, 0 first")))),
              S.nodes / S.rays, S.tris / S.rays, S.hits / S.rays);
     }
   }

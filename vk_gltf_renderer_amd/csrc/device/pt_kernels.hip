@@ -2269,7 +2269,8 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
         haveLast = false;
         found    = false;
         prevHitT = 0.0f;
-        octinv   = rayOctInv(r.idir);
+        // any-hit is order independent: MI_PT_SHADOW_FAR_FIRST walks from the ray's far end (DevScene::shadowOctFlip); the ordered search of MODE 2 keeps near first
+        octinv   = rayOctInv(r.idir) ^ (MODE == 2 ? 0u : sc.shadowOctFlip);
         restartWalk();
         active = true;
         if(REC)

@@ -148,6 +148,7 @@ struct DevScene
   int                        bvh8NumNodes;
   int                        bvhRoot;  // node index, or ~tri for a single-triangle scene; INT_MIN when empty
   int                        packetInterval;  // k_trace_primary: interval node test for one-pixel packets (pt_packet.h); 0 = per-ray test everywhere
+  uint32_t                   shadowOctFlip;   // 7: the any-hit walks of k_trace_shadow (MODE 0 / 1 / 3: order independent) take a node's children far end first; 0: near end first
 };
 
 // ---- per-frame constants (kernel argument, ~600 B) ---------------------------------------------------------------------
