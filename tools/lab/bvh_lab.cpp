@@ -638,7 +638,7 @@ static void walk(const Bvh8& W, const std::vector<Tri>& tris, const std::vector<
       else hit[nh++] = {sl, tn};
     }
     // push in reverse priority so that the nearest is popped first
-    if(mode == 1) std::sort(hit, hit + nh, [](const H& a, const H& b) { return a.tn > b.tn; });
+    if(mode == 1 || mode == 5) std::sort(hit, hit + nh, [](const H& a, const H& b) { return a.tn > b.tn; });  // (mode 5: the order alone, nothing dropped when popped)
     else std::sort(hit, hit + nh, [&](const H& a, const H& b) { return (uint32_t(a.slot) ^ octinv) < (uint32_t(b.slot) ^ octinv); });
     float gmin = FLT_MAX;
     for(int k = 0; k < nh; ++k) gmin = std::min(gmin, hit[k].tn);
@@ -870,7 +870,7 @@ int main(int argc, char** argv)
     V3 d = tx * (rr * std::cos(ph)) + ty * (rr * std::sin(ph)) + nrm * std::sqrt(std::max(0.0f, 1 - u1));
     rays[i] = {p + nrm * 1e-3f, normalize(d)};
   }
-  for(int mode : {0, 2, 3, 4, 1})
+  for(int mode : {0, 2, 3, 4, 1, 5})
   {
     WalkStats S;
     const int defer = std::stoi(get("defer", "3"));
@@ -884,7 +884,7 @@ int main(int argc, char** argv)
     }
     const double cnode = 59 + 22 * cfg.width;
     printf("walk %-28s: %.2f node visits + %.2f triangle tests per ray  (cost (59+22w)n+56t = %.0f; hit rate %.3f, max stack %.0f; groups waiting: max %.0f, more than 12 at %.3f %% of the visits)\n",
-           mode == 0 ? "octant order, immediate" : (mode == 1 ? "distance order, immediate" : (mode == 3 ? "octant order + cull at pop" : (mode == 4 ? "octant order + group cull" : "octant order, deferred"))), S.nodes / S.rays, S.tris / S.rays,
+           mode == 0 ? "octant order, immediate" : (mode == 5 ? "distance order, no cull" : mode == 1 ? "distance order, immediate" : (mode == 3 ? "octant order + cull at pop" : (mode == 4 ? "octant order + group cull" : "octant order, deferred"))), S.nodes / S.rays, S.tris / S.rays,
            (cnode * S.nodes + 56 * S.tris) / S.rays, S.hits / S.rays, S.maxStack, S.maxGroups, 100.0 * S.deep / S.nodes);
   }
   // shadow rays: from the same surface points, half towards a fixed sun direction (through the skylight), half uniform over the sphere
