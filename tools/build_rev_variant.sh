@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds libmi_pt.so of another git revision next to the product library (vk_gltf_renderer_amd/lib/var_<name>/libmi_pt.so, selected at
-# run time with MI_PT_LIB=<path>), so that one GPU call can A/B the working tree against it (tools/run_r04.sh ab).
+# run time with MI_PT_LIB=<path>), so that one GPU call can A/B the working tree against it (tools/run_gpu.sh ab).
 # usage: tools/build_rev_variant.sh <name> <git revision>
 set -e
 name=$1; rev=$2

@@ -1,5 +1,5 @@
 #!/bin/bash
-# The round's GPU runner, one gpurun call per step:  gpurun -- 'tools/run_r04.sh <step> [args]'
+# The GPU runner (rounds 4 and 5), one gpurun call per step:  gpurun -- 'tools/run_gpu.sh <step> [args]'
 #   tests                      the GPU suite
 #   line                       the full default bench line
 #   ab <tag> <workloads...>    every vk_gltf_renderer_amd/lib/var_*/libmi_pt.so (tools/build_variant.sh, tools/build_rev_variant.sh) next to the product build
@@ -34,7 +34,7 @@ print('atrium', j['value'], j.get('parity',{}).get('by_spp'), j.get('cpu_baselin
 for n,a in j.get('also',{}).items(): print(n, a['value'], a.get('parity',{}).get('by_spp'), a.get('cpu_baseline',{}).get('value'))
 PY
     ;;
-  evidence)  # tools/run_r04.sh evidence <tag> <bench args...>: kernel-trace stats + counter passes of ONE configuration; leaves
+  evidence)  # tools/run_gpu.sh evidence <tag> <bench args...>: kernel-trace stats + counter passes of ONE configuration; leaves
              # gpurun_out/r04_<tag>_kernel_stats.csv, r04_<tag>_pmc_summary.json and pmc_latest_<tag>.json (to be copied to profiles/)
     shift; tag=$1; shift
     tools/profile.sh r04_$tag "$@" --steps 2 --warmup 1 > /dev/null 2>&1
