@@ -13,12 +13,14 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def lib(tmp_path_factory):
+@pytest.fixture(scope="module", params=["", "-DREINSERT_SOFT_LOCKS"], ids=["path-locks", "soft-locks"])
+def lib(request, tmp_path_factory):
+    """Both lock flavours of bvh_reinsert.h: the product build's (a move carried out keeps its whole path) and the -DREINSERT_SOFT_LOCKS experiment (only the
+    nodes whose links it rewrote; the rest of its chains may be crossed, not rewritten, by later moves of the pass)."""
     out = str(tmp_path_factory.mktemp("host_shim_reinsert") / "libreinsert_on_host.so")
     shim = os.path.join(ROOT, "tests", "host_shim")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-fopenmp", "-fPIC", "-shared", "-I" + shim, "-I" + os.path.join(ROOT, "vk_gltf_renderer_amd", "csrc", "device"),
-                    "-o", out, os.path.join(shim, "reinsert_on_host.cpp")], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fopenmp", "-fPIC", "-shared", *request.param.split(), "-I" + shim,
+                    "-I" + os.path.join(ROOT, "vk_gltf_renderer_amd", "csrc", "device"), "-o", out, os.path.join(shim, "reinsert_on_host.cpp")], check=True)
     L = C.CDLL(out)
     L.dev_reinsert.restype = C.c_longlong
     L.dev_reinsert.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]

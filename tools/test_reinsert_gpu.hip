@@ -5,6 +5,7 @@
 // the tree under a balanced top (the street workload's size without shipping its 425 MB of records).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Ivk_gltf_renderer_amd/csrc/device -Wno-unused-function -o tools/_scratch/test_reinsert_gpu tools/test_reinsert_gpu.hip
 //   tools/_scratch/test_reinsert_gpu <prefix> <passes> <rounds> [copies]
+// (the -DREINSERT_SOFT_LOCKS flavour: add the flag here AND to the laboratory's build, so that <prefix>.expected comes from the same flavour)
 #include "bvh_build.hip"
 
 #include <chrono>

@@ -195,22 +195,25 @@ PT_DEV ReinsertMove reinsertSearch(const Bvh2Tree& T, int id)
 // target up to (not including) the common ancestor.  Two moves whose sets are disjoint can be carried out in either order -- and cannot
 // close a cycle: a target inside another moved subtree has that subtree's root on its chain.
 PT_DEV unsigned long long r2Key(const ReinsertMove& m, int id) { return (static_cast<unsigned long long>(__float_as_uint(m.gain)) << 32) | static_cast<uint32_t>(id); }
+// f(node id, topo): topo = the move rewrites this node's links (x, its parent and grandparent, the target and the target's parent); the other nodes of
+// the two chains only have their boxes changed by it.
 template <typename F>
 PT_DEV void r2ForEachLocked(const Bvh2Tree& T, int id, const ReinsertMove& m, F f)
 {
   const int x = r2RefOf(T, id);
   const int p = r2ParentOf(T, x);
-  f(id);
-  f(T.parent[p]);
+  const int q = r2ParentOf(T, m.target);
+  f(id, true);
+  f(T.parent[p], true);
   for(int n = p;; n = T.parent[n])
   {
-    f(n);
+    f(n, n == p || n == q);
     if(n == m.lca)
       break;
   }
   for(int r = m.target;;)
   {
-    f(r2IdOf(T, r));
+    f(r2IdOf(T, r), r == m.target || r == q);
     const int up = r2ParentOf(T, r);
     if(up == m.lca)
       break;  // (below the sibling the chain ends at the sibling, higher up at the ancestor's other child)
@@ -221,25 +224,59 @@ PT_DEV bool r2Wanted(const ReinsertMove& m) { return m.lca >= 0 && m.gain > 0.0f
 // Several lock rounds per search: a move that loses a record to a better one gives way for this round only -- unless the better one is then
 // carried out (its records stay TAKEN until the next search), it tries again in the next round, so that one long path through the upper
 // tree does not cost a pass to everything it crosses.
-constexpr unsigned long long REINSERT_TAKEN = ~0ull;
+// -DREINSERT_SOFT_LOCKS (experiment: CPU tests and laboratory only so far -- 8 passes x 12 rounds reach what 24 x 4 reach with whole-path locks, atrium
+// area cost 61.98 against 61.75 -- one more kernel per round, k_re_mark; VARIANT_SRC=bvh_build tools/build_variant.sh soft -DREINSERT_SOFT_LOCKS): of a move carried out only the nodes whose LINKS it rewrote stay TAKEN; the other nodes
+// of its chains are CROSSED -- their boxes are stale, their links are not -- and a later move of the same pass may cross them with its own chains, but
+// not rewrite them: a target inside a moved subtree still has that subtree's root, TAKEN or CROSSED, among the nodes it would have to rewrite or cross.
+constexpr unsigned long long REINSERT_TAKEN   = ~0ull;
+constexpr unsigned long long REINSERT_CROSSED = ~0ull - 1ull;
+PT_DEV bool r2Blocked(unsigned long long lock, bool topo)
+{
+#ifdef REINSERT_SOFT_LOCKS
+  return lock == REINSERT_TAKEN || (topo && lock == REINSERT_CROSSED);
+#else
+  (void)topo;
+  return lock == REINSERT_TAKEN;
+#endif
+}
 PT_DEV void reinsertLock(const Bvh2Tree& T, ReinsertMove* moves, unsigned long long* locks, int id)
 {
   const ReinsertMove m = moves[id];
   if(!r2Wanted(m))
     return;
   bool taken = false;
-  r2ForEachLocked(T, id, m, [&](int n) { taken = taken || locks[n] == REINSERT_TAKEN; });
+  r2ForEachLocked(T, id, m, [&](int n, bool topo) { taken = taken || r2Blocked(locks[n], topo); });
   if(taken)
   {
     moves[id].lca = -1;  // one of its records belongs to a move already carried out: the next search decides again
     return;
   }
   const unsigned long long key = r2Key(m, id);
-  r2ForEachLocked(T, id, m, [&](int n) { atomicMax(&locks[n], key); });
+  r2ForEachLocked(T, id, m, [&](int n, bool) { atomicMax(&locks[n], key); });  // (a CROSSED node keeps its mark: no key is that large)
 }
+#ifdef REINSERT_SOFT_LOCKS
+// one thread per node and leaf, after reinsertApply and before reinsertUnlock: the moves this round carried out mark their paths
+PT_DEV void reinsertMark(const Bvh2Tree& T, ReinsertMove* moves, unsigned long long* locks, int id)
+{
+  const ReinsertMove m = moves[id];
+  if(!(m.lca >= 0 && m.gain == -1.0f))
+    return;
+  moves[id].lca = -1;
+  // (the chains are read from the parent links of the searched tree, like everywhere in a pass; two moves of one round may both write CROSSED to a node
+  //  they both cross, a TAKEN node is its move's alone)
+  r2ForEachLocked(T, id, m, [&](int n, bool topo) {
+    if(topo)
+      locks[n] = REINSERT_TAKEN;
+  });
+  r2ForEachLocked(T, id, m, [&](int n, bool topo) {
+    if(!topo && locks[n] != REINSERT_TAKEN)
+      locks[n] = REINSERT_CROSSED;
+  });
+}
+#endif
 PT_DEV void reinsertUnlock(unsigned long long* locks, int id)
 {
-  if(locks[id] != REINSERT_TAKEN)
+  if(locks[id] < REINSERT_CROSSED)
     locks[id] = 0ull;
 }
 // returns whether the move was carried out
@@ -250,7 +287,11 @@ PT_DEV bool reinsertApply(const Bvh2Tree& T, ReinsertMove* moves, unsigned long 
     return false;
   const unsigned long long key = r2Key(m, id);
   bool                     all = true;
-  r2ForEachLocked(T, id, m, [&](int n) { all = all && locks[n] == key; });
+#ifdef REINSERT_SOFT_LOCKS
+  r2ForEachLocked(T, id, m, [&](int n, bool topo) { all = all && (locks[n] == key || (!topo && locks[n] == REINSERT_CROSSED)); });
+#else
+  r2ForEachLocked(T, id, m, [&](int n, bool) { all = all && locks[n] == key; });
+#endif
   if(!all)
     return false;
   moves[id].lca = -1;
@@ -269,7 +310,12 @@ PT_DEV bool reinsertApply(const Bvh2Tree& T, ReinsertMove* moves, unsigned long 
   r2SetChildRef(T.nodes, q, qs, p);
   r2SetChildBox(T.nodes, q, qs, r2Union(yb, xb));
   // (the parent links stay those of the searched tree until the pass ends: the chains of the moves still waiting are read from them)
-  r2ForEachLocked(T, id, m, [&](int n) { locks[n] = REINSERT_TAKEN; });
+#ifdef REINSERT_SOFT_LOCKS
+  moves[id].lca  = m.lca;    // (kept for reinsertMark: the marks of this round must not be seen by the checks of this round -- whether a neighbour's
+  moves[id].gain = -1.0f;    //  chain node already reads CROSSED would depend on which thread came first)
+#else
+  r2ForEachLocked(T, id, m, [&](int n, bool) { locks[n] = REINSERT_TAKEN; });
+#endif
   return true;
 }
 
