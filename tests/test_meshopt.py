@@ -1,0 +1,327 @@
+"""EXT_meshopt_compression / KHR_meshopt_compression (csrc/host/meshopt_decoder.cpp; the reference hands these streams to meshoptimizer,
+src/gltf_scene.cpp:372-470).  No third-party codec exists in this image, so the decoders are round-tripped against encoders written from the same
+specification (tests/meshopt_codec.py), checked on hand-assembled streams whose bytes follow the specification's layout directly, hammered with
+truncated and corrupted streams (an error, never a crash or an out-of-bounds write), and exercised end to end through the glTF loader."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import meshopt_codec as mc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("meshopt_host") / "libmeshopt_on_host.so")
+    host = os.path.join(ROOT, "vk_gltf_renderer_amd", "csrc", "host")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I" + host, "-o", out,
+                    os.path.join(ROOT, "tests", "host_shim", "meshopt_on_host.cpp"), os.path.join(host, "meshopt_decoder.cpp")], check=True)
+    return out
+
+
+def _call(lib, fn, data, count, stride, guard=64):
+    """Runs one decoder in a child process (the library is built with AddressSanitizer, which cannot be loaded into this interpreter): returns
+    (ok, decoded bytes, message).  The destination is exactly count * stride bytes inside a guarded allocation."""
+    code = (
+        "import ctypes as C, sys\n"
+        "L = C.CDLL(%r)\n"
+        "data = bytes.fromhex(sys.stdin.readline().strip())\n"
+        "count, stride = %d, %d\n"
+        "dst = (C.c_ubyte * max(1, count * stride))()\n"
+        "err = C.create_string_buffer(256)\n"
+        "f = getattr(L, %r)\n"
+        "f.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p]\n"
+        "ok = f(dst, count, stride, data, len(data), err)\n"
+        "print(ok); print(bytes(dst)[:count * stride].hex()); print(err.value.decode())\n") % (lib, count, stride, fn)
+    env = dict(os.environ, LD_PRELOAD=subprocess.run(["g++", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip(),
+               ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run(["python3", "-c", code], input=data.hex() + "\n", capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.split("\n")
+    return lines[0] == "1", bytes.fromhex(lines[1]), lines[2]
+
+
+def _same_triangles(a, b):
+    a, b = np.asarray(a).reshape(-1, 3), np.asarray(b).reshape(-1, 3)
+    if a.shape != b.shape:
+        return False
+    return all(any(np.array_equal(np.roll(x, r), y) for r in range(3)) for x, y in zip(a, b))  # a corner rotation keeps the winding
+
+
+def test_hand_assembled_streams(lib):
+    """Bytes put together by hand from the layout in the specification (not by the encoder of this repo)."""
+    # ATTRIBUTES, stride 4, 3 vertices: byte plane 0 of the three vertices is 10, 11, 13 (differences +0 to the tail's 10, +1, +2 -> zigzag 0, 2, 4: a
+    # 4-bit group), planes 1-3 constant (all-zero groups).  One group per plane -> one header byte per plane.
+    tail = bytes(28) + bytes([10, 20, 30, 40])
+    plane0 = bytes([0b10]) + bytes([0x02, 0x40, 0, 0, 0, 0, 0, 0])   # header: group 0 in 4-bit mode; values 0, 2, 4, 0 ... packed high nibble first
+    stream = bytes([0xA0]) + plane0 + bytes([0]) * 3 + tail
+    ok, out, msg = _call(lib, "mo_vertices", stream, 3, 4)
+    assert ok, msg
+    assert list(out) == [10, 20, 30, 40, 11, 20, 30, 40, 13, 20, 30, 40]
+    # the same with an escape: difference +100 -> zigzag 200 does not fit 4 bits: nibble 15, the byte follows the packed part
+    plane0 = bytes([0b10]) + bytes([0x0F, 0, 0, 0, 0, 0, 0, 0]) + bytes([200])
+    ok, out, msg = _call(lib, "mo_vertices", bytes([0xA0]) + plane0 + bytes([0]) * 3 + tail, 2, 4)
+    assert ok and list(out) == [10, 20, 30, 40, 110, 20, 30, 40], msg
+    # INDICES: 5, 6, 4 against baseline 0: differences +5, +1, -2 -> zigzag 10, 2, 3 -> shifted left with the baseline bit 0
+    ok, out, msg = _call(lib, "mo_sequence", bytes([0xD1, 20, 4, 6]) + bytes(4), 3, 2)
+    assert ok and list(np.frombuffer(out, np.uint16)) == [5, 6, 4], msg
+    # TRIANGLES: (0, 1, 2) as three fresh corners through the table's entry 0 (pair 0x00), then (2, 1, 3): the edge (2, 1) was pushed second of
+    # the three -> one behind the newest -> high nibble 1, fresh corner -> low nibble 0
+    table = bytes([0x00]) + bytes(15)
+    ok, out, msg = _call(lib, "mo_triangles", bytes([0xE1, 0xF0, 0x10]) + table, 6, 2)
+    assert ok and list(np.frombuffer(out, np.uint16)) == [0, 1, 2, 2, 1, 3], msg
+
+
+def test_vertex_streams_round_trip(lib):
+    rng = np.random.default_rng(1)
+    for count, stride, kind in [(1, 4, "noise"), (15, 8, "smooth"), (16, 12, "smooth"), (17, 16, "noise"), (255, 4, "smooth"), (256, 4, "steps"), (257, 4, "smooth"),
+                                (1000, 12, "smooth"), (700, 32, "steps"), (40, 256, "noise"), (600, 20, "zero"), (0, 8, "zero")]:
+        if kind == "noise":
+            v = rng.integers(0, 256, (count, stride), dtype=np.uint8)
+        elif kind == "zero":
+            v = np.zeros((count, stride), np.uint8)
+        elif kind == "steps":
+            v = np.repeat(rng.integers(0, 256, (count // 50 + 1, stride), dtype=np.uint8), 50, 0)[:count]
+        else:  # slowly varying 16-bit fields with the odd jump: every group mode occurs
+            base = np.cumsum(rng.integers(-3, 4, (count, stride // 2)), 0) + rng.integers(0, 60000, (1, stride // 2))
+            base[rng.integers(0, max(count, 1), max(count // 20, 1)) if count else []] += 5000
+            v = (base & 0xFFFF).astype(np.uint16).view(np.uint8).reshape(count, stride)
+        stream = mc.encode_vertices(v)
+        ok, out, msg = _call(lib, "mo_vertices", stream, count, stride)
+        assert ok, (count, stride, kind, msg)
+        assert out == v.tobytes(), (count, stride, kind)
+        if kind == "smooth" and count >= 255:
+            assert len(stream) < 0.8 * v.size  # (the point of the codec; also: the encoder really used the packed modes)
+
+
+def test_index_streams_round_trip(lib):
+    rng = np.random.default_rng(2)
+    cases = []
+    n = 12
+    grid = np.array([[(y * n + x, y * n + x + 1, (y + 1) * n + x, (y + 1) * n + x, y * n + x + 1, (y + 1) * n + x + 1) for x in range(n - 1)] for y in range(n - 1)]).reshape(-1)
+    cases.append(("grid", grid))
+    cases.append(("strip", np.array([(i, i + 1, i + 2) if i % 2 == 0 else (i + 1, i, i + 2) for i in range(300)]).reshape(-1)))
+    cases.append(("fan", np.array([(0, i + 1, i + 2) for i in range(100)]).reshape(-1)))
+    cases.append(("random", rng.integers(0, 70000, 3 * 500)))
+    cases.append(("random small", rng.integers(0, 24, 3 * 500)))
+    cases.append(("restart", np.concatenate([grid[:60], np.array([0, 1, 2, 2, 1, 3]), grid[60:120]])))
+    cases.append(("huge", np.array([0, 1, 2, 4000000000, 5, 4000000001, 4000000001, 5, 123456789])))
+    cases.append(("empty", np.zeros(0, np.int64)))
+    for name, idx in cases:
+        for version in (0, 1):
+            stream = mc.encode_triangles(idx, version)
+            stride = 4 if (len(idx) and idx.max() > 65535) else 2
+            ok, out, msg = _call(lib, "mo_triangles", stream, len(idx), stride)
+            assert ok, (name, version, msg)
+            got = np.frombuffer(out, np.uint32 if stride == 4 else np.uint16)
+            assert _same_triangles(idx, got), (name, version)
+        if name == "grid":
+            assert len(stream) < 1.2 * len(idx) / 3 + 17 + 8  # about one byte per triangle of a regular grid
+        if name == "huge":
+            continue  # (the sequence codec packs the baseline bit next to a 32-bit zigzag difference: differences beyond 2^30 do not fit, by design)
+        for version in (0, 1):
+            seq = mc.encode_sequence(idx, version)
+            stride = 4 if (len(idx) and idx.max() > 65535) else 2
+            ok, out, msg = _call(lib, "mo_sequence", seq, len(idx), stride)
+            assert ok, (name, msg)
+            assert np.array_equal(np.frombuffer(out, np.uint32 if stride == 4 else np.uint16), idx.astype(np.uint32 if stride == 4 else np.uint16)), name
+
+
+def test_filters(lib):
+    rng = np.random.default_rng(3)
+    n = rng.normal(size=(500, 3))
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    n = np.concatenate([n, [[0, 0, 1], [0, 0, -1], [1, 0, 0], [0, -1, 0]]])
+    for stride, bits, tol in ((4, 8, 0.02), (8, 12, 1.5e-3), (8, 16, 1e-4)):  # (two quantisation steps of the octahedral grid)
+        q = mc.filter_oct_encode(np.concatenate([n, np.full((len(n), 1), 0.5)], 1), bits, stride)
+        code = ("import ctypes as C, sys\nL = C.CDLL(%r)\nd = bytearray(bytes.fromhex(sys.stdin.readline().strip()))\nb = (C.c_ubyte * len(d)).from_buffer(d)\n"
+                "e = C.create_string_buffer(256)\nL.mo_filter.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_char_p]\n"
+                "print(L.mo_filter(0, b, %d, %d, e)); print(bytes(d).hex())\n") % (lib, len(n), stride)
+        out = _filter(code, q.tobytes())
+        dec = np.frombuffer(out, np.int8 if stride == 4 else np.int16).reshape(-1, 4).astype(np.float64)
+        full = 127.0 if stride == 4 else 32767.0
+        assert np.abs(dec[:, :3] / full - n).max() < tol, (stride, bits, np.abs(dec[:, :3] / full - n).max())
+        assert np.array_equal(dec[:, 3], q[:, 3])  # the fourth component passes through
+    quat = rng.normal(size=(300, 4))
+    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    q = mc.filter_quat_encode(quat, 12)
+    code = ("import ctypes as C, sys\nL = C.CDLL(%r)\nd = bytearray(bytes.fromhex(sys.stdin.readline().strip()))\nb = (C.c_ubyte * len(d)).from_buffer(d)\n"
+            "e = C.create_string_buffer(256)\nL.mo_filter.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_char_p]\n"
+            "print(L.mo_filter(1, b, %d, 8, e)); print(bytes(d).hex())\n") % (lib, len(quat))
+    dec = np.frombuffer(_filter(code, q.tobytes()), np.int16).reshape(-1, 4) / 32767.0
+    same = np.minimum(np.abs(dec - quat).max(1), np.abs(dec + quat).max(1))  # q and -q are the same rotation
+    assert same.max() < 1.5e-3, same.max()
+    f = np.concatenate([rng.normal(size=(200, 3)) * 10.0 ** rng.integers(-6, 6, (200, 1)), [[0.0, 1.0, -1.0], [1e-30, -3.5, 65504.0]]]).astype(np.float32)
+    enc = mc.filter_exp_encode(f, 16)
+    code = ("import ctypes as C, sys\nL = C.CDLL(%r)\nd = bytearray(bytes.fromhex(sys.stdin.readline().strip()))\nb = (C.c_ubyte * len(d)).from_buffer(d)\n"
+            "e = C.create_string_buffer(256)\nL.mo_filter.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_char_p]\n"
+            "print(L.mo_filter(2, b, %d, 12, e)); print(bytes(d).hex())\n") % (lib, len(f))
+    dec = np.frombuffer(_filter(code, enc.tobytes()), np.float32).reshape(-1, 3)
+    assert np.all(np.abs(dec - f) <= np.abs(f) * 2.0 ** -14 + 1e-30)
+
+
+def _filter(code, payload):
+    env = dict(os.environ, LD_PRELOAD=subprocess.run(["g++", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip(), ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run(["python3", "-c", code], input=payload.hex() + "\n", capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0 and r.stdout.split("\n")[0] == "1", r.stderr[-1500:] + r.stdout[:200]
+    return bytes.fromhex(r.stdout.split("\n")[1])
+
+
+def test_corrupt_streams_are_errors_not_crashes(lib):
+    """Truncations, bit flips and wrong declared sizes of valid streams under AddressSanitizer: every outcome is a clean result -- mostly a refusal,
+    thanks to the end-of-stream checks; a flipped bit inside a payload byte may legitimately decode to other values."""
+    rng = np.random.default_rng(4)
+    v = (np.cumsum(rng.integers(-3, 4, (300, 6)), 0) & 0xFFFF).astype(np.uint16).view(np.uint8).reshape(300, 12)
+    vs = mc.encode_vertices(v)
+    idx = rng.integers(0, 500, 3 * 200)
+    ts, ss = mc.encode_triangles(idx, 1), mc.encode_sequence(idx, 1)
+    structural, flips = [], []
+    for fn, stream, count, stride in (("mo_vertices", vs, 300, 12), ("mo_triangles", ts, 600, 2), ("mo_sequence", ss, 600, 2)):
+        structural += [(fn, stream[:k], count, stride) for k in (0, 1, 2, len(stream) // 2, len(stream) - 1)]
+        structural += [(fn, stream, count + 16 * 3, stride), (fn, stream, max(count - 48, 0), stride), (fn, stream + b"\0", count, stride)]
+        for _ in range(12):
+            b = bytearray(stream)
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+            flips.append((fn, bytes(b), count, stride))
+    structural += [("mo_vertices", vs, 300, 16), ("mo_vertices", bytes([0xA1]) + vs[1:], 300, 12), ("mo_triangles", bytes([0xE2]) + ts[1:], 600, 2), ("mo_sequence", ts, 600, 2),
+                   ("mo_triangles", ts, 601, 2), ("mo_triangles", ts, 600, 3), ("mo_vertices", vs, 300, 10)]
+    for fn, stream, count, stride in structural:  # a stream cut short, one byte too long, or declared with another count / stride: refused, every time
+        ok, _, msg = _call(lib, fn, stream, count, stride)
+        assert not ok and msg.startswith("meshopt: "), (fn, len(stream), count, stride, msg)
+    refused = 0
+    for fn, stream, count, stride in flips:       # flipped bits: refused, or decoded to other values -- a clean result either way (AddressSanitizer watches)
+        ok, _, msg = _call(lib, fn, stream, count, stride)
+        assert ok or msg.startswith("meshopt: "), msg
+        refused += 0 if ok else 1
+    print("bit flips refused:", refused, "of", len(flips))
+    ok, _, msg = _call(lib, "mo_vertices", bytes([0xA1]) + vs[1:], 300, 12)
+    assert not ok and "version 1 is not supported" in msg
+
+
+# ---- end to end: a glTF whose geometry exists only as meshopt streams -------------------------------------------------------------------------
+def _pack_meshopt(builder, path, ext_name="EXT_meshopt_compression", index_version=1, required=True, corrupt=None, oct_normals=False):
+    """Rewrites a GlbBuilder scene so that every buffer view of mesh data lives in a data-less fallback buffer (1) and its bytes are a meshopt stream in
+    the GLB's binary chunk (buffer 0), like gltfpack -cc writes them.  Image buffer views stay plain.  oct_normals: NORMAL as normalised int8 x 4 behind the
+    OCTAHEDRAL filter (KHR_mesh_quantization)."""
+    import json
+    import struct
+    doc = json.loads(json.dumps(builder.doc))
+    old = bytes(builder.bin)
+    size = {5120: 1, 5121: 1, 5122: 2, 5123: 2, 5125: 4, 5126: 4}
+    comps = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4}
+    index_views, attr_views = set(), {}
+    for mesh in doc["meshes"]:
+        for prim in mesh["primitives"]:
+            if "indices" in prim:
+                index_views.add(doc["accessors"][prim["indices"]]["bufferView"])
+            for name, acc in prim["attributes"].items():
+                a = doc["accessors"][acc]
+                attr_views[a["bufferView"]] = (name, acc)
+    new_bin, fallback_len = bytearray(), 0
+
+    def put(data):
+        while len(new_bin) % 4:
+            new_bin.append(0)
+        off = len(new_bin)
+        new_bin.extend(data)
+        return off
+    for i, bv in enumerate(doc["bufferViews"]):
+        raw = old[bv.get("byteOffset", 0):bv.get("byteOffset", 0) + bv["byteLength"]]
+        if i in index_views:
+            acc = next(a for a in doc["accessors"] if a.get("bufferView") == i)
+            dt = {5123: np.uint16, 5125: np.uint32}[acc["componentType"]]
+            stream = mc.encode_triangles(np.frombuffer(raw, dt), index_version)
+            ext = {"mode": "TRIANGLES", "byteStride": size[acc["componentType"]], "count": acc["count"]}
+        elif i in attr_views:
+            name, ai = attr_views[i]
+            acc = doc["accessors"][ai]
+            stride = size[acc["componentType"]] * comps[acc["type"]]
+            data = np.frombuffer(raw, np.uint8).reshape(acc["count"], stride)
+            ext = {"mode": "ATTRIBUTES", "byteStride": stride, "count": acc["count"]}
+            if name == "NORMAL" and oct_normals:
+                q = mc.filter_oct_encode(np.frombuffer(raw, np.float32).reshape(-1, 3), 8, 4)
+                data, stride = q.view(np.uint8).reshape(acc["count"], 4), 4
+                acc.update({"componentType": 5120, "normalized": True})
+                bv["byteStride"] = 4
+                ext = {"mode": "ATTRIBUTES", "byteStride": 4, "count": acc["count"], "filter": "OCTAHEDRAL"}
+            stream = mc.encode_vertices(data)
+            bv["byteLength"] = acc["count"] * stride
+        else:
+            bv["byteOffset"] = put(raw)  # (images)
+            continue
+        if corrupt is not None and i == corrupt[0]:
+            stream = corrupt[1](stream)
+        ext.update({"buffer": 0, "byteOffset": put(stream), "byteLength": len(stream)})
+        fallback_len = (fallback_len + 3) & ~3
+        bv.update({"buffer": 1, "byteOffset": fallback_len, "extensions": {ext_name: ext}})
+        fallback_len += bv["byteLength"]
+    doc["buffers"] = [{"byteLength": len(new_bin)}, {"byteLength": fallback_len, "extensions": {ext_name: {"fallback": True}}}]
+    used = set(builder.ext_used) | {ext_name} | ({"KHR_mesh_quantization"} if oct_normals else set())
+    doc["extensionsUsed"] = sorted(used)
+    if required:
+        doc["extensionsRequired"] = sorted({ext_name} | ({"KHR_mesh_quantization"} if oct_normals else set()))
+    while len(new_bin) % 4:
+        new_bin.append(0)
+    js = json.dumps(doc, separators=(",", ":")).encode()
+    js += b" " * ((4 - len(js) % 4) % 4)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<4sII", b"glTF", 2, 12 + 8 + len(js) + 8 + len(new_bin)))
+        f.write(struct.pack("<I4s", len(js), b"JSON") + js)
+        f.write(struct.pack("<I4s", len(new_bin), b"BIN\0") + bytes(new_bin))
+    return path
+
+
+def _geometry(scene):
+    d = scene.desc.contents
+    out = []
+    for p in range(d.numRenderPrimitives):
+        rp = d.renderPrimitives[p]
+        nv, nt = rp.vertexCount, rp.triangleCount
+        pos = np.ctypeslib.as_array(rp.positions, shape=(nv * 3,)).reshape(-1, 3).copy()
+        nrm = np.ctypeslib.as_array(rp.normals, shape=(nv * 3,)).reshape(-1, 3).copy() if rp.normals else None
+        uv = np.ctypeslib.as_array(rp.texCoords0, shape=(nv * 2,)).reshape(-1, 2).copy() if rp.texCoords0 else None
+        idx = np.ctypeslib.as_array(rp.indices, shape=(nt * 3,)).copy()
+        out.append((pos, nrm, uv, idx))
+    return out
+
+
+def test_gltf_with_meshopt_compressed_geometry_loads_like_the_plain_file(built, tmp_path):
+    from vk_gltf_renderer_amd import pathtracer as ptmod
+    from vk_gltf_renderer_amd import scenegen
+
+    def build(big=False):
+        b = scenegen.GlbBuilder()
+        img = np.random.default_rng(7).integers(0, 255, (8, 8, 4), dtype=np.uint8)
+        mat = b.material({"pbrMetallicRoughness": {"baseColorTexture": {"index": b.texture(b.image(img))}}})
+        for k, (nx, ny) in enumerate(((9, 7), (40, 33), (262, 255) if big else (70, 60))):  # big: 67 k vertices, 32-bit indices, hundreds of vertex blocks
+            pos, nrm, uv, idx = scenegen.grid(nx, ny, (2.0 + k, 1.5), "y")
+            pos = pos + np.random.default_rng(k).normal(0, 0.01, pos.shape)
+            nrm = np.broadcast_to(nrm, pos.shape) + np.random.default_rng(k).normal(0, 0.2, pos.shape)
+            nrm = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+            b.node(mesh=b.mesh([b.primitive(pos, idx, nrm, uv, material=mat)]), translation=[3.0 * k, 0, 0])
+        return b
+    plains = {big: _geometry(ptmod.Scene(build(big).save(str(tmp_path / f"plain{int(big)}.glb")))) for big in (False, True)}
+    plain = plains[False]
+    for ext_name, version, big in (("EXT_meshopt_compression", 0, True), ("EXT_meshopt_compression", 1, False), ("KHR_meshopt_compression", 1, False)):
+        got = _geometry(ptmod.Scene(_pack_meshopt(build(big), str(tmp_path / f"{ext_name}_{version}.glb"), ext_name, version)))
+        assert len(got) == len(plains[big]) == 3
+        for (p0, n0, u0, i0), (p1, n1, u1, i1) in zip(plains[big], got):
+            assert np.array_equal(p0, p1) and np.array_equal(n0, n1) and np.array_equal(u0, u1)
+            assert _same_triangles(i0, i1)
+    # the file is a fraction of the plain one (the streams, not a copy, are what was read)
+    assert os.path.getsize(tmp_path / "EXT_meshopt_compression_0.glb") < 0.6 * os.path.getsize(tmp_path / "plain1.glb")
+    # normals as int8 behind the OCTAHEDRAL filter
+    got = _geometry(ptmod.Scene(_pack_meshopt(build(), str(tmp_path / "oct.glb"), oct_normals=True)))
+    for (p0, n0, u0, i0), (p1, n1, u1, i1) in zip(plain, got):
+        assert np.array_equal(p0, p1) and np.abs(n1 - n0).max() < 0.03 and np.abs(np.linalg.norm(n1, axis=1) - 1).max() < 0.02
+    # a damaged stream refuses the FILE, with the reference's message
+    for which, damage in ((0, lambda s: s[:-1]), (1, lambda s: s[:len(s) // 2]), (3, lambda s: bytes([s[0] ^ 0x40]) + s[1:])):
+        # (buffer view 0 is the image; 1 .. 4 are POSITION, NORMAL, TEXCOORD_0 and the indices of the first mesh)
+        with pytest.raises(Exception) as e:
+            ptmod.Scene(_pack_meshopt(build(), str(tmp_path / f"bad{which}.glb"), corrupt=(1 + which, damage)))
+        assert "meshopt_compression decompression failed" in str(e.value), str(e.value)

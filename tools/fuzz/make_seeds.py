@@ -38,4 +38,15 @@ scenegen.scene_animated(d + '/anim.glb')
 scenegen.scene_atrium_class(d + '/atrium.glb', seed=5, detail=0.05, tex_size=16)
 scenegen.scene_material_zoo(d + '/zoo.glb', 'texture_transform', tess=6, tex_size=8)
 scenegen.scene_helmet_class(d + '/helmet.glb', seed=1, tess=8, tex_size=16)
+# geometry that exists only as EXT / KHR_meshopt_compression streams (attributes, triangles with both codec versions, the octahedral filter)
+import test_meshopt as M
+def meshopt_scene():
+    b = scenegen.GlbBuilder()
+    for k, (nx, ny) in enumerate(((5, 4), (20, 17))):
+        pos, nrm, uv, idx = scenegen.grid(nx, ny, (2.0, 1.5), "y")
+        b.node(mesh=b.mesh([b.primitive(pos, idx, np.broadcast_to(nrm, pos.shape), uv, material=b.material({}))]), translation=[3.0 * k, 0, 0])
+    return b
+M._pack_meshopt(meshopt_scene(), d + '/meshopt_v0.glb', "EXT_meshopt_compression", 0)
+M._pack_meshopt(meshopt_scene(), d + '/meshopt_v1.glb', "KHR_meshopt_compression", 1)
+M._pack_meshopt(meshopt_scene(), d + '/meshopt_oct.glb', "EXT_meshopt_compression", 1, oct_normals=True)
 print(sorted(os.listdir(d)))

@@ -1,5 +1,6 @@
 // See gltf_scene.hpp for scope and reference citations.
 #include "gltf_scene.hpp"
+#include "meshopt_decoder.hpp"
 #include "mikktspace_tangents.hpp"
 
 #include <algorithm>
@@ -679,6 +680,36 @@ bool GltfScene::load(const std::string& filename)
     m_error = e.what();
     return false;
   }
+  // What the loader implements of the reference's list (src/gltf_scene.cpp:213-254, + EXT_texture_webp of src/renderer.cpp:783): a file that REQUIRES
+  // anything else is refused like there (SceneValidator::validateModelExtensions, src/gltf_scene_validator.cpp:295-322), a merely USED one gets a warning.
+  // Not implemented and therefore refused when required: KHR_draco_mesh_compression (a build option of the reference).  KHR_texture_basisu counts as
+  // supported: its KTX2 container is read (image_loader.cpp), a BasisLZ / UASTC payload inside is an undecodable IMAGE, not an unloadable file.
+  {
+    static const char* const supported[] = {
+        "EXT_mesh_gpu_instancing", "EXT_mesh_opacity_micromap", "EXT_meshopt_compression", "EXT_texture_webp", "KHR_animation_pointer", "KHR_interactivity", "KHR_lights_punctual",
+        "KHR_materials_anisotropy", "KHR_materials_clearcoat", "KHR_materials_diffuse_transmission", "KHR_materials_dispersion", "KHR_materials_displacement",
+        "KHR_materials_emissive_strength", "KHR_materials_ior", "KHR_materials_iridescence", "KHR_materials_pbrSpecularGlossiness", "KHR_materials_retroreflection",
+        "KHR_materials_sheen", "KHR_materials_specular", "KHR_materials_transmission", "KHR_materials_unlit", "KHR_materials_variants",
+        "KHR_materials_volume_scatter", "KHR_materials_volume", "KHR_mesh_quantization", "KHR_meshopt_compression", "KHR_node_hoverability", "KHR_node_selectability", "KHR_node_visibility",
+        "KHR_texture_basisu", "KHR_texture_transform", "MSFT_texture_dds", "NV_attributes_iray"};
+    auto isSupported = [&](const std::string& e) {
+      for(const char* s : supported)
+        if(e == s)
+          return true;
+      return false;
+    };
+    const Value& required = m_doc["extensionsRequired"];
+    for(size_t i = 0; i < required.size(); ++i)
+      if(required[i].isString() && !isSupported(required[i].str))
+      {
+        m_error = "Required extension unsupported : " + required[i].str;
+        return false;
+      }
+    const Value& used = m_doc["extensionsUsed"];
+    for(size_t i = 0; i < used.size(); ++i)
+      if(used[i].isString() && !isSupported(used[i].str))
+        fprintf(stderr, "[mihost] Used extension unsupported : %s\n", used[i].str.c_str());
+  }
   const std::string baseDir = dirOf(filename);
   m_buffers.clear();
   const Value& buffers = m_doc["buffers"];
@@ -698,7 +729,81 @@ bool GltfScene::load(const std::string& filename)
       data = glbBin;
     m_buffers.push_back(std::move(data));
   }
+  if(!decompressMeshopt())
+    return false;
   return parse(baseDir);
+}
+
+// EXT_meshopt_compression / KHR_meshopt_compression (reference: Scene::decompressMeshoptExtension, src/gltf_scene.cpp:372-470, which hands the streams
+// to meshoptimizer): every buffer view that carries the extension is decoded INTO the region of the buffer it nominally views -- the "fallback"
+// buffer, which in a compressed-only file has a length and no data -- and the accessors then read it like any other.  Sizes are untrusted.
+bool GltfScene::decompressMeshopt()
+{
+  const Value& views   = m_doc["bufferViews"];
+  const Value& buffers = m_doc["buffers"];
+  for(size_t i = 0; i < views.size(); ++i)
+  {
+    const Value* e = &ext(views[i], "KHR_meshopt_compression");
+    if(!e->isObject())
+      e = &ext(views[i], "EXT_meshopt_compression");
+    if(!e->isObject())
+      continue;
+    auto bad = [&](const std::string& what) {
+      m_error = "meshopt_compression decompression failed: bufferView " + std::to_string(i) + ": " + what;
+      return false;
+    };
+    const double srcBuffer = (*e)["buffer"].number(-1.0), srcOffset = (*e)["byteOffset"].number(0.0), srcLength = (*e)["byteLength"].number(-1.0);
+    const double stride = (*e)["byteStride"].number(-1.0), count = (*e)["count"].number(-1.0);
+    const double dstBuffer = views[i]["buffer"].number(-1.0), dstOffset = views[i]["byteOffset"].number(0.0), dstLength = views[i]["byteLength"].number(-1.0);
+    const double limit = 1.0e12;  // (well inside what a double counts exactly and a size_t holds)
+    if(!(srcBuffer >= 0 && srcBuffer < double(m_buffers.size()) && dstBuffer >= 0 && dstBuffer < double(m_buffers.size())))
+      return bad("buffer index out of range");
+    if(!(srcOffset >= 0 && srcLength >= 0 && srcOffset + srcLength <= double(m_buffers[size_t(srcBuffer)].size())))
+      return bad("the compressed bytes lie outside their buffer");
+    if(!(stride > 0 && stride <= 256 && count >= 0 && count < limit && dstOffset >= 0 && dstLength >= 0 && dstLength < limit && count * stride <= dstLength))
+      return bad("count x byteStride exceeds the buffer view");
+    std::vector<uint8_t>& dst = m_buffers[size_t(dstBuffer)];
+    if(dst.empty())
+    {
+      // a fallback buffer without data: give it its declared length (bounded: what the views into it can address)
+      const double declared = buffers[size_t(dstBuffer)]["byteLength"].number(0.0);
+      if(!(declared >= 0 && declared < limit))
+        return bad("fallback buffer length out of range");
+      dst.assign(size_t(declared), 0);
+    }
+    if(!(dstOffset + dstLength <= double(dst.size())))
+      return bad("the buffer view lies outside its buffer");
+    if(size_t(srcBuffer) == size_t(dstBuffer) && srcOffset < dstOffset + dstLength && dstOffset < srcOffset + srcLength)
+      return bad("the compressed bytes overlap the region they decode into");
+    const uint8_t* src = m_buffers[size_t(srcBuffer)].data() + size_t(srcOffset);
+    uint8_t*       out = dst.data() + size_t(dstOffset);
+    const size_t   n = size_t(count), st = size_t(stride);
+    const std::string mode = (*e)["mode"].isString() ? (*e)["mode"].str : std::string(), filter = (*e)["filter"].isString() ? (*e)["filter"].str : std::string("NONE");
+    std::string       err;
+    bool              ok = false;
+    if(mode == "ATTRIBUTES")
+      ok = meshopt::decodeVertexBuffer(out, n, st, src, size_t(srcLength), err);
+    else if(mode == "TRIANGLES")
+      ok = meshopt::decodeIndexBuffer(out, n, st, src, size_t(srcLength), err);
+    else if(mode == "INDICES")
+      ok = meshopt::decodeIndexSequence(out, n, st, src, size_t(srcLength), err);
+    else
+      err = "unknown mode \"" + mode + "\"";
+    if(ok && filter == "OCTAHEDRAL")
+      ok = meshopt::filterOctahedral(out, n, st, err);
+    else if(ok && filter == "QUATERNION")
+      ok = meshopt::filterQuaternion(out, n, st, err);
+    else if(ok && filter == "EXPONENTIAL")
+      ok = meshopt::filterExponential(out, n, st, err);
+    else if(ok && filter != "NONE")
+    {
+      ok  = false;
+      err = "unknown filter \"" + filter + "\"";
+    }
+    if(!ok)
+      return bad(err);
+  }
+  return true;
 }
 
 //----------------------------------------------------------------------------------------------------------------------

@@ -152,6 +152,7 @@ private:
   std::vector<uint8_t>          m_onPath;  // nodes on the current traversal path (cycle guard)
 
   mijson::Value                      m_doc;
+  bool decompressMeshopt();  // EXT / KHR_meshopt_compression buffer views -> their fallback regions (meshopt_decoder.hpp)
   std::vector<std::vector<uint8_t>>  m_buffers;
   std::string                        m_error;
   std::vector<MiGltfShadeMaterial>   m_materials;
