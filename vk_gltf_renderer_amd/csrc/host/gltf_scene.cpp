@@ -766,9 +766,14 @@ bool GltfScene::decompressMeshopt()
     if(dst.empty())
     {
       // a fallback buffer without data: give it its declared length (bounded: what the views into it can address)
+      // ... and by what the streams of this file can possibly expand to: the densest vertex stream spends 4 header bytes on a plane of 256 zero
+      // differences (64 : 1), an index stream at least one byte per 12-byte triangle
       const double declared = buffers[size_t(dstBuffer)]["byteLength"].number(0.0);
-      if(!(declared >= 0 && declared < limit))
-        return bad("fallback buffer length out of range");
+      double       loaded   = 0.0;
+      for(const std::vector<uint8_t>& b : m_buffers)
+        loaded += double(b.size());
+      if(!(declared >= 0 && declared <= 80.0 * loaded + 4096.0))
+        return bad("fallback buffer length out of proportion to the file");
       dst.assign(size_t(declared), 0);
     }
     if(!(dstOffset + dstLength <= double(dst.size())))
