@@ -577,7 +577,7 @@ static bool slab(const Box& b, const Ray& r, V3 idir, float tmax, float& tn)
   return t0 <= t1;
 }
 
-struct WalkStats { double nodes = 0, tris = 0, rays = 0, hits = 0, maxStack = 0, deep = 0, maxGroups = 0; };  // deep: visits made with more than 12 GROUPS (a node's pending children: the device's stack entry) waiting
+struct WalkStats { double nodes = 0, tris = 0, rays = 0, hits = 0, maxStack = 0, deep = 0, maxGroups = 0, coplanar = 0, behind = 0; };  // coplanar: tests of a triangle in whose plane the ray STARTS; behind: whose plane the ray never reaches (origin and direction on the same side)  // deep: visits made with more than 12 GROUPS (a node's pending children: the device's stack entry) waiting
 
 // mode 0: octant order, triangles tested immediately (the ideal of the device walk); 1: distance order; 2: octant order with the
 // device's deferral model: leaf hits are parked and tested only after `defer` further node visits (tmax tightens late)
@@ -598,6 +598,13 @@ static void walk(const Bvh8& W, const std::vector<Tri>& tris, const std::vector<
       int   ti = W.tris[base + k];
       float t;
       S.tris += 1;
+      {
+        const Tri& T  = tris[ti];
+        const V3   n  = cross(T.p1 - T.p0, T.p2 - T.p0);
+        const float nl = std::sqrt(dot(n, n)) + 1e-30f, dist = dot(n, r.o - T.p0) / nl, dn = dot(n, r.d) / nl;
+        if(std::fabs(dist) < 2e-3f) S.coplanar += 1;
+        else if(dist * dn >= 0) S.behind += 1;
+      }
       if(hitTri(tris[ti], r, tmax, t))
       {
         if(alpha[ti])
@@ -880,12 +887,12 @@ int main(int argc, char** argv)
 #pragma omp for schedule(dynamic, 256)
       for(int i = 0; i < nrays; ++i) walk(W, tris, alpha, rays[i], mode, defer, uint32_t(i) * 7919u + 17u, L);
 #pragma omp critical
-      { S.nodes += L.nodes; S.tris += L.tris; S.rays += L.rays; S.hits += L.hits; S.maxStack = std::max(S.maxStack, L.maxStack); S.deep += L.deep; S.maxGroups = std::max(S.maxGroups, L.maxGroups); }
+      { S.nodes += L.nodes; S.tris += L.tris; S.rays += L.rays; S.hits += L.hits; S.maxStack = std::max(S.maxStack, L.maxStack); S.deep += L.deep; S.maxGroups = std::max(S.maxGroups, L.maxGroups); S.coplanar += L.coplanar; S.behind += L.behind; }
     }
     const double cnode = 59 + 22 * cfg.width;
-    printf("walk %-28s: %.2f node visits + %.2f triangle tests per ray  (cost (59+22w)n+56t = %.0f; hit rate %.3f, max stack %.0f; groups waiting: max %.0f, more than 12 at %.3f %% of the visits)\n",
+    printf("walk %-28s: %.2f node visits + %.2f triangle tests per ray  (cost (59+22w)n+56t = %.0f; hit rate %.3f, max stack %.0f; groups waiting: max %.0f, more than 12 at %.3f %% of the visits; of the triangle tests %.1f %% start in the triangle's plane, %.1f %% face away from it)\n",
            mode == 0 ? "octant order, immediate" : (mode == 5 ? "distance order, no cull" : mode == 1 ? "distance order, immediate" : (mode == 3 ? "octant order + cull at pop" : (mode == 4 ? "octant order + group cull" : "octant order, deferred"))), S.nodes / S.rays, S.tris / S.rays,
-           (cnode * S.nodes + 56 * S.tris) / S.rays, S.hits / S.rays, S.maxStack, S.maxGroups, 100.0 * S.deep / S.nodes);
+           (cnode * S.nodes + 56 * S.tris) / S.rays, S.hits / S.rays, S.maxStack, S.maxGroups, 100.0 * S.deep / S.nodes, 100.0 * S.coplanar / std::max(S.tris, 1.0), 100.0 * S.behind / std::max(S.tris, 1.0));
   }
   // shadow rays: from the same surface points, half towards a fixed sun direction (through the skylight), half uniform over the sphere
   {
