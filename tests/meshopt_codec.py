@@ -57,6 +57,99 @@ def encode_vertices(v):
     return bytes(out)
 
 
+def _encode_plane(z, widths):
+    """z: zigzag values padded to a multiple of 16 -> (header bytes + body) with the group widths table `widths` (bits per value; 0 = zeros, 8 = plain)"""
+    header = bytearray((len(z) // 16 + 3) // 4)
+    body = bytearray()
+    for g in range(len(z) // 16):
+        grp = z[g * 16:(g + 1) * 16]
+        best = None
+        for i, bits in enumerate(widths):
+            if bits == 0:
+                if grp.any():
+                    continue
+                cost = 0
+            elif bits == 8:
+                cost = 16
+            else:
+                cost = 2 * bits + int((grp >= (1 << bits) - 1).sum())
+            if best is None or cost < best[0]:
+                best = (cost, i, bits)
+        _, i, bits = best
+        header[g // 4] |= i << ((g % 4) * 2)
+        if bits == 8:
+            body += bytes(int(x) for x in grp)
+        elif bits:
+            sentinel, per = (1 << bits) - 1, 8 // bits
+            packed, extra = bytearray(), bytearray()
+            for b in range(16 // per):
+                byte = 0
+                for x in grp[b * per:(b + 1) * per]:
+                    byte = (byte << bits) | (sentinel if x >= sentinel else int(x))
+                    if x >= sentinel:
+                        extra.append(int(x))
+                packed.append(byte)
+            body += packed + extra
+    return bytes(header) + bytes(body)
+
+
+def encode_vertices_v1(v, channels=None):
+    """Codec version 1 (KHR_meshopt_compression).  channels: one byte per 4-byte component -- low two bits 0 = byte differences, 1 = 16-bit differences,
+    2 = 32-bit XOR rotated left by the high nibble."""
+    v = np.ascontiguousarray(v, np.uint8)
+    count, stride = v.shape
+    assert stride % 4 == 0 and 0 < stride <= 256
+    channels = list(channels) if channels is not None else [0] * (stride // 4)
+    out = bytearray([0xA1])
+    block = min(256, (8192 // stride) & ~15)
+    first = v[0].copy() if count else np.zeros(stride, np.uint8)
+    last = first.copy()
+    for off in range(0, count, block):
+        blk = v[off:off + block].astype(np.int64)
+        n = len(blk)
+        aligned = (n + 15) & ~15
+        control, data = bytearray(stride // 4), bytearray()
+        for k in range(0, stride, 4):
+            ch = channels[k // 4]
+            mode, rot = ch & 3, ch >> 4
+            planes = np.zeros((4, n), np.int64)
+            if mode == 0:
+                for j in range(4):
+                    col = blk[:, k + j]
+                    prev = np.concatenate([[int(last[k + j])], col[:-1]])
+                    d = ((col - prev + 128) & 0xFF) - 128
+                    planes[j] = ((d << 1) ^ (d >> 63)) & 0xFF
+            elif mode == 1:
+                for h in (0, 2):
+                    col = blk[:, k + h] | (blk[:, k + h + 1] << 8)
+                    prev = np.concatenate([[int(last[k + h]) | (int(last[k + h + 1]) << 8)], col[:-1]])
+                    d = ((col - prev + 32768) & 0xFFFF) - 32768
+                    z = ((d << 1) ^ (d >> 63)) & 0xFFFF
+                    planes[h], planes[h + 1] = z & 0xFF, z >> 8
+            else:
+                col = blk[:, k] | (blk[:, k + 1] << 8) | (blk[:, k + 2] << 16) | (blk[:, k + 3] << 24)
+                l32 = int(last[k]) | (int(last[k + 1]) << 8) | (int(last[k + 2]) << 16) | (int(last[k + 3]) << 24)
+                prev = np.concatenate([[l32], col[:-1]])
+                x = (col ^ prev) & 0xFFFFFFFF
+                x = ((x << rot) | (x >> ((32 - rot) & 31))) & 0xFFFFFFFF if rot else x
+                for j in range(4):
+                    planes[j] = (x >> (8 * j)) & 0xFF
+            for j in range(4):
+                z = np.concatenate([planes[j], np.zeros(aligned - n, np.int64)])
+                if not z.any():
+                    ctrl, enc = 2, b""
+                else:
+                    options = [(len(e), c, e) for c, e in ((0, _encode_plane(z, (0, 1, 2, 4))), (1, _encode_plane(z, (1, 2, 4, 8))), (3, bytes(int(x) for x in planes[j])))]
+                    _, ctrl, enc = min(options, key=lambda o: (o[0], o[1]))
+                control[k // 4] |= ctrl << (j * 2)
+                data += enc
+        out += control + data
+        last = v[off + n - 1].copy()
+    used = stride + stride // 4
+    out += bytes(max(24, used) - used) + bytes(first) + bytes(channels)
+    return bytes(out)
+
+
 # ---- mode TRIANGLES ------------------------------------------------------------------------------------------------------------------------
 def _varint(v):
     out = bytearray()

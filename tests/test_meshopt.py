@@ -94,6 +94,14 @@ def test_vertex_streams_round_trip(lib):
         ok, out, msg = _call(lib, "mo_vertices", stream, count, stride)
         assert ok, (count, stride, kind, msg)
         assert out == v.tobytes(), (count, stride, kind)
+        # codec version 1: every channel mode (bytes, 16-bit halves, rotated 32-bit XOR), the plane codings chosen by size
+        if count <= 1000 and stride <= 32:
+            for channels in ([0] * (stride // 4), [1] * (stride // 4), [2 | (r << 4) for r in (0, 5, 15, 12, 9, 1, 8, 3)][:stride // 4],
+                             [(0, 1, 2 | (7 << 4))[c % 3] for c in range(stride // 4)]):
+                s1 = mc.encode_vertices_v1(v, channels)
+                ok, out, msg = _call(lib, "mo_vertices", s1, count, stride)
+                assert ok, (count, stride, kind, channels, msg)
+                assert out == v.tobytes(), (count, stride, kind, channels)
         if kind == "smooth" and count >= 255:
             assert len(stream) < 0.8 * v.size  # (the point of the codec; also: the encoder really used the packed modes)
 
@@ -177,10 +185,11 @@ def test_corrupt_streams_are_errors_not_crashes(lib):
     rng = np.random.default_rng(4)
     v = (np.cumsum(rng.integers(-3, 4, (300, 6)), 0) & 0xFFFF).astype(np.uint16).view(np.uint8).reshape(300, 12)
     vs = mc.encode_vertices(v)
+    vs1 = mc.encode_vertices_v1(v, [1, 2 | (4 << 4), 0])
     idx = rng.integers(0, 500, 3 * 200)
     ts, ss = mc.encode_triangles(idx, 1), mc.encode_sequence(idx, 1)
     structural, flips = [], []
-    for fn, stream, count, stride in (("mo_vertices", vs, 300, 12), ("mo_triangles", ts, 600, 2), ("mo_sequence", ss, 600, 2)):
+    for fn, stream, count, stride in (("mo_vertices", vs, 300, 12), ("mo_vertices", vs1, 300, 12), ("mo_triangles", ts, 600, 2), ("mo_sequence", ss, 600, 2)):
         structural += [(fn, stream[:k], count, stride) for k in (0, 1, 2, len(stream) // 2, len(stream) - 1)]
         structural += [(fn, stream, count + 16 * 3, stride), (fn, stream, max(count - 48, 0), stride), (fn, stream + b"\0", count, stride)]
         for _ in range(12):
@@ -199,12 +208,12 @@ def test_corrupt_streams_are_errors_not_crashes(lib):
         assert ok or msg.startswith("meshopt: "), msg
         refused += 0 if ok else 1
     print("bit flips refused:", refused, "of", len(flips))
-    ok, _, msg = _call(lib, "mo_vertices", bytes([0xA1]) + vs[1:], 300, 12)
-    assert not ok and "version 1 is not supported" in msg
+    ok, _, msg = _call(lib, "mo_vertices", bytes([0xA2]) + vs[1:], 300, 12)
+    assert not ok and "unknown vertex codec version" in msg
 
 
 # ---- end to end: a glTF whose geometry exists only as meshopt streams -------------------------------------------------------------------------
-def _pack_meshopt(builder, path, ext_name="EXT_meshopt_compression", index_version=1, required=True, corrupt=None, oct_normals=False):
+def _pack_meshopt(builder, path, ext_name="EXT_meshopt_compression", index_version=1, required=True, corrupt=None, oct_normals=False, vertex_version=0):
     """Rewrites a GlbBuilder scene so that every buffer view of mesh data lives in a data-less fallback buffer (1) and its bytes are a meshopt stream in
     the GLB's binary chunk (buffer 0), like gltfpack -cc writes them.  Image buffer views stay plain.  oct_normals: NORMAL as normalised int8 x 4 behind the
     OCTAHEDRAL filter (KHR_mesh_quantization)."""
@@ -249,7 +258,10 @@ def _pack_meshopt(builder, path, ext_name="EXT_meshopt_compression", index_versi
                 acc.update({"componentType": 5120, "normalized": True})
                 bv["byteStride"] = 4
                 ext = {"mode": "ATTRIBUTES", "byteStride": 4, "count": acc["count"], "filter": "OCTAHEDRAL"}
-            stream = mc.encode_vertices(data)
+            if vertex_version == 0:
+                stream = mc.encode_vertices(data)
+            else:  # float components: the rotated XOR suits them; the rest as 16-bit halves
+                stream = mc.encode_vertices_v1(data, [(2 | (8 << 4)) if acc["componentType"] == 5126 else 1] * (stride // 4))
             bv["byteLength"] = acc["count"] * stride
         else:
             bv["byteOffset"] = put(raw)  # (images)
@@ -308,7 +320,8 @@ def test_gltf_with_meshopt_compressed_geometry_loads_like_the_plain_file(built, 
     plains = {big: _geometry(ptmod.Scene(build(big).save(str(tmp_path / f"plain{int(big)}.glb")))) for big in (False, True)}
     plain = plains[False]
     for ext_name, version, big in (("EXT_meshopt_compression", 0, True), ("EXT_meshopt_compression", 1, False), ("KHR_meshopt_compression", 1, False)):
-        got = _geometry(ptmod.Scene(_pack_meshopt(build(big), str(tmp_path / f"{ext_name}_{version}.glb"), ext_name, version)))
+        got = _geometry(ptmod.Scene(_pack_meshopt(build(big), str(tmp_path / f"{ext_name}_{version}.glb"), ext_name, version,
+                                                  vertex_version=1 if ext_name.startswith("KHR") else 0)))
         assert len(got) == len(plains[big]) == 3
         for (p0, n0, u0, i0), (p1, n1, u1, i1) in zip(plains[big], got):
             assert np.array_equal(p0, p1) and np.array_equal(n0, n1) and np.array_equal(u0, u1)

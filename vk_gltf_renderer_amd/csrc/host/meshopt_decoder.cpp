@@ -1,7 +1,7 @@
 // EXT_meshopt_compression / KHR_meshopt_compression bitstream decoders (see meshopt_decoder.hpp).  The three stream layouts, as the extension
 // specifies them:
 //
-// ATTRIBUTES  [0xA0 | version] [blocks ...] [tail: max(32, stride) bytes, the FIRST vertex in its last `stride` bytes]
+// ATTRIBUTES  [0xA0 | version] [blocks ...] [tail: max(32, stride) bytes, the FIRST vertex in its last `stride` bytes]      (version 0; version 1: see decodeVertexBuffer)
 //   Vertices come in blocks of min(256, (8192 / stride) & ~15); inside a block the data is stored byte plane by byte plane (all vertices' byte 0,
 //   then byte 1, ...).  A plane is the zigzag-coded difference of every byte to the same byte of the previous vertex (the tail's vertex before the
 //   first one), cut into groups of 16: two header bits per group (packed four groups to a byte in front of the plane) say whether the group is all
@@ -31,7 +31,7 @@ bool fail(std::string& err, const char* what)
 // ---- ATTRIBUTES ---------------------------------------------------------------------------------------------------------------------
 constexpr size_t GROUP = 16, BLOCK_BYTES = 8192, BLOCK_MAX = 256, TAIL_MIN = 32;
 
-// one group of 16 values with `bits` = 2 or 4 per packed value, most significant value first; returns the position after the group or null
+// one group of 16 values with `bits` = 1, 2 or 4 per packed value, most significant value first; returns the position after the group or null
 const uint8_t* unpackGroup(const uint8_t* p, const uint8_t* end, uint8_t* out, int bits)
 {
   const size_t packed = GROUP * size_t(bits) / 8;
@@ -60,7 +60,8 @@ const uint8_t* unpackGroup(const uint8_t* p, const uint8_t* end, uint8_t* out, i
   return extra;
 }
 
-const uint8_t* decodePlane(const uint8_t* p, const uint8_t* end, uint8_t* out, size_t alignedCount)
+// a byte plane of `alignedCount` values in groups of 16; the two header bits of a group index `widths` (bits per value: 0 = all zero, 8 = plain bytes)
+const uint8_t* decodePlane(const uint8_t* p, const uint8_t* end, uint8_t* out, size_t alignedCount, const int widths[4])
 {
   const size_t groups      = alignedCount / GROUP;
   const size_t headerBytes = (groups + 3) / 4;
@@ -70,11 +71,11 @@ const uint8_t* decodePlane(const uint8_t* p, const uint8_t* end, uint8_t* out, s
   p += headerBytes;
   for(size_t g = 0; g < groups; ++g)
   {
-    const int mode = (header[g / 4] >> ((g % 4) * 2)) & 3;
+    const int bits = widths[(header[g / 4] >> ((g % 4) * 2)) & 3];
     uint8_t*  o    = out + g * GROUP;
-    if(mode == 0)
+    if(bits == 0)
       memset(o, 0, GROUP);
-    else if(mode == 3)
+    else if(bits == 8)
     {
       if(size_t(end - p) < GROUP)
         return nullptr;
@@ -83,7 +84,7 @@ const uint8_t* decodePlane(const uint8_t* p, const uint8_t* end, uint8_t* out, s
     }
     else
     {
-      p = unpackGroup(p, end, o, mode == 1 ? 2 : 4);
+      p = unpackGroup(p, end, o, bits);
       if(!p)
         return nullptr;
     }
@@ -150,36 +151,103 @@ bool decodeVertexBuffer(uint8_t* dst, size_t count, size_t stride, const uint8_t
 {
   if(stride == 0 || stride > 256 || stride % 4 != 0)
     return fail(err, "ATTRIBUTES: byteStride must be a multiple of 4 in [4, 256]");
-  const size_t tail = stride < TAIL_MIN ? TAIL_MIN : stride;
-  if(srcSize < 1 + tail)
-    return fail(err, "ATTRIBUTES: stream shorter than its header and tail");
+  if(srcSize < 1)
+    return fail(err, "ATTRIBUTES: empty stream");
   if((src[0] & 0xf0u) != 0xa0u)
     return fail(err, "ATTRIBUTES: not a vertex stream");
-  if((src[0] & 0x0fu) != 0)
-    return fail(err, "ATTRIBUTES: vertex codec version 1 is not supported (version 0 is)");
-  uint8_t previous[256];
-  memcpy(previous, src + srcSize - stride, stride);
+  const int version = src[0] & 0x0f;
+  if(version > 1)
+    return fail(err, "ATTRIBUTES: unknown vertex codec version");
+  // Version 1 (KHR_meshopt_compression) keeps the layout and adds, per 4-byte component of the vertex, a CHANNEL byte in the tail -- how its
+  // differences are formed: per byte, per 16-bit half, or as a rotated XOR of the 32-bit word -- and, at the head of every block, a CONTROL byte whose
+  // two bits per byte plane pick the plane's coding: group widths {0, 1, 2, 4} or {1, 2, 4, 8}, all zero, or plain bytes.
+  const size_t channelBytes = version == 0 ? 0 : stride / 4;
+  const size_t tailUsed = stride + channelBytes, tailMin = version == 0 ? 32 : 24;
+  const size_t tail     = tailUsed < tailMin ? tailMin : tailUsed;
+  if(srcSize < 1 + tail)
+    return fail(err, "ATTRIBUTES: stream shorter than its header and tail");
+  uint8_t        previous[256];
+  const uint8_t* channels = src + srcSize - channelBytes;
+  memcpy(previous, src + srcSize - tailUsed, stride);
+  for(size_t c = 0; c < channelBytes; ++c)
+    if((channels[c] & 3u) == 3u)
+      return fail(err, "ATTRIBUTES: unknown channel mode");
   size_t blockMax = (BLOCK_BYTES / stride) & ~(GROUP - 1);
   if(blockMax > BLOCK_MAX)
     blockMax = BLOCK_MAX;
+  static const int widthsV0[4] = {0, 2, 4, 8}, widthsV1[5] = {0, 1, 2, 4, 8};
   const uint8_t *p = src + 1, *end = src + srcSize;
-  uint8_t        plane[BLOCK_MAX];
+  uint8_t        planes[4][BLOCK_MAX];
   for(size_t first = 0; first < count; first += blockMax)
   {
     const size_t n       = count - first < blockMax ? count - first : blockMax;
     const size_t aligned = (n + GROUP - 1) & ~(GROUP - 1);
     uint8_t*     out     = dst + first * stride;
-    for(size_t k = 0; k < stride; ++k)
+    if(size_t(end - p) < channelBytes)
+      return fail(err, "ATTRIBUTES: stream ends inside a block");
+    const uint8_t* control = p;
+    p += channelBytes;
+    for(size_t k = 0; k < stride; k += 4)
     {
-      p = decodePlane(p, end, plane, aligned);
-      if(!p)
-        return fail(err, "ATTRIBUTES: stream ends inside a block");
-      uint8_t prev = previous[k];
-      for(size_t i = 0; i < n; ++i)
+      for(int j = 0; j < 4; ++j)
       {
-        const uint8_t z = plane[i];
-        prev            = uint8_t(uint8_t((z >> 1) ^ (0u - (z & 1u))) + prev);
-        out[i * stride + k] = prev;
+        const int ctrl = version == 0 ? 0 : (control[k / 4] >> (j * 2)) & 3;
+        if(version != 0 && ctrl == 3)
+        {
+          if(size_t(end - p) < n)
+            return fail(err, "ATTRIBUTES: stream ends inside a block");
+          memcpy(planes[j], p, n);
+          p += n;
+        }
+        else if(version != 0 && ctrl == 2)
+          memset(planes[j], 0, n);
+        else
+        {
+          p = decodePlane(p, end, planes[j], aligned, version == 0 ? widthsV0 : widthsV1 + ctrl);
+          if(!p)
+            return fail(err, "ATTRIBUTES: stream ends inside a block");
+        }
+      }
+      const unsigned channel = version == 0 ? 0u : channels[k / 4];
+      const unsigned mode    = channel & 3u;
+      if(mode == 0)
+      {
+        for(int j = 0; j < 4; ++j)
+        {
+          uint8_t prev = previous[k + size_t(j)];
+          for(size_t i = 0; i < n; ++i)
+          {
+            const uint8_t z = planes[j][i];
+            prev            = uint8_t(uint8_t((z >> 1) ^ (0u - (z & 1u))) + prev);
+            out[i * stride + k + size_t(j)] = prev;
+          }
+        }
+      }
+      else if(mode == 1)
+      {
+        for(int h = 0; h < 4; h += 2)
+        {
+          uint16_t prev = uint16_t(previous[k + size_t(h)] | (previous[k + size_t(h) + 1] << 8));
+          for(size_t i = 0; i < n; ++i)
+          {
+            const uint16_t z = uint16_t(planes[h][i] | (planes[h + 1][i] << 8));
+            prev             = uint16_t(uint16_t((z >> 1) ^ (0u - (z & 1u))) + prev);
+            out[i * stride + k + size_t(h)]     = uint8_t(prev);
+            out[i * stride + k + size_t(h) + 1] = uint8_t(prev >> 8);
+          }
+        }
+      }
+      else
+      {
+        const unsigned rot = (32u - (channel >> 4)) & 31u;  // the encoder rotated the XOR left by channel >> 4
+        uint32_t       prev = uint32_t(previous[k]) | (uint32_t(previous[k + 1]) << 8) | (uint32_t(previous[k + 2]) << 16) | (uint32_t(previous[k + 3]) << 24);
+        for(size_t i = 0; i < n; ++i)
+        {
+          const uint32_t d = uint32_t(planes[0][i]) | (uint32_t(planes[1][i]) << 8) | (uint32_t(planes[2][i]) << 16) | (uint32_t(planes[3][i]) << 24);
+          prev             = ((d << rot) | (d >> ((32u - rot) & 31u))) ^ prev;
+          for(int j = 0; j < 4; ++j)
+            out[i * stride + k + size_t(j)] = uint8_t(prev >> (8 * j));
+        }
       }
     }
     memcpy(previous, out + (n - 1) * stride, stride);

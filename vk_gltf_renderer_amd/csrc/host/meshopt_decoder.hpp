@@ -9,7 +9,7 @@
 
 namespace meshopt {
 
-// mode ATTRIBUTES: `count` vertices of `stride` bytes (a multiple of 4, at most 256).  Codec version 0; version 1 (KHR only) is refused.
+// mode ATTRIBUTES: `count` vertices of `stride` bytes (a multiple of 4, at most 256).  Codec versions 0 (EXT_meshopt_compression) and 1 (KHR_).
 bool decodeVertexBuffer(uint8_t* dst, size_t count, size_t stride, const uint8_t* src, size_t srcSize, std::string& err);
 // mode TRIANGLES: `count` indices (a multiple of 3) of `stride` = 2 or 4 bytes.  Codec versions 0 and 1.
 bool decodeIndexBuffer(uint8_t* dst, size_t count, size_t stride, const uint8_t* src, size_t srcSize, std::string& err);
