@@ -47,6 +47,6 @@ def meshopt_scene():
         b.node(mesh=b.mesh([b.primitive(pos, idx, np.broadcast_to(nrm, pos.shape), uv, material=b.material({}))]), translation=[3.0 * k, 0, 0])
     return b
 M._pack_meshopt(meshopt_scene(), d + '/meshopt_v0.glb', "EXT_meshopt_compression", 0)
-M._pack_meshopt(meshopt_scene(), d + '/meshopt_v1.glb', "KHR_meshopt_compression", 1)
+M._pack_meshopt(meshopt_scene(), d + '/meshopt_v1.glb', "KHR_meshopt_compression", 1, vertex_version=1)
 M._pack_meshopt(meshopt_scene(), d + '/meshopt_oct.glb', "EXT_meshopt_compression", 1, oct_normals=True)
 print(sorted(os.listdir(d)))
