@@ -601,3 +601,24 @@ def test_required_extensions_are_validated_like_the_reference(built, tmp_path):
     for ext in ("KHR_texture_basisu", "KHR_mesh_quantization", "EXT_texture_webp", "KHR_materials_volume_scatter", "MSFT_texture_dds", "EXT_meshopt_compression",
                 "KHR_meshopt_compression"):
         assert ptmod.Scene(scene(required=[ext])).num_triangles == 8
+
+
+def test_jpeg_colour_models_beyond_ycbcr(built, tmp_path):
+    """Four-component (Adobe CMYK, stored inverted) and untransformed RGB JPEGs, decided like stb_image decides them (component ids, the Adobe segment's
+    transform byte, the JFIF header): against libjpeg's own conversion through Pillow.  (YCCK follows stb_image's formula; Pillow cannot write one.)"""
+    PIL_Image = pytest.importorskip("PIL.Image")
+    import io
+    base = np.kron(np.random.default_rng(6).integers(0, 255, (4, 5, 3), dtype=np.uint8), np.ones((8, 8, 1), np.uint8))
+    blobs = []
+    buf = io.BytesIO()
+    PIL_Image.fromarray(base).convert("CMYK").save(buf, "JPEG", quality=95)
+    blobs.append(buf.getvalue())
+    buf = io.BytesIO()
+    try:
+        PIL_Image.fromarray(base).save(buf, "JPEG", quality=95, keep_rgb=True)
+        blobs.append(buf.getvalue())
+    except Exception:
+        pass  # (older Pillow: no keep_rgb)
+    for blob, got in zip(blobs, _scene_with_images(tmp_path, "cm.glb", blobs, "image/jpeg")):
+        ref = np.asarray(PIL_Image.open(io.BytesIO(blob)).convert("RGB")).astype(int)
+        assert got.shape[:2] == ref.shape[:2] and np.abs(got[..., :3].astype(int) - ref).max() <= 2

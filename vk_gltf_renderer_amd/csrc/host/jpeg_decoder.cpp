@@ -49,7 +49,7 @@ struct Decoder
   Huffman        dc[4], ac[4];
   int            width = 0, height = 0, ncomp = 0;
   bool           progressive = false;
-  Component      comp[3];
+  Component      comp[4];
   int            hmax = 1, vmax = 1, mcusX = 0, mcusY = 0;
   int            restartInterval = 0;
   // entropy-coded segment reader
@@ -185,8 +185,8 @@ struct Decoder
     // of `fileSize` bytes cannot describe more than some hundred pixels per byte)
     if(width <= 0 || height <= 0 || !saneImageSize(uint64_t(width), uint64_t(height)) || uint64_t(width) * uint64_t(height) > uint64_t(fileSize) * 512ull + 65536ull)
       return fail("bad dimensions");
-    if((ncomp != 1 && ncomp != 3) || len < 6 + 3 * ncomp)
-      return fail("only 1- or 3-component images are supported");
+    if((ncomp != 1 && ncomp != 3 && ncomp != 4) || len < 6 + 3 * ncomp)
+      return fail("only 1-, 3- or 4-component images are supported");
     progressive = prog;
     for(int i = 0; i < ncomp; ++i)
     {
@@ -619,15 +619,29 @@ struct Decoder
       out[i] = in[std::min(i * c.h / hmax, stride - 1)];
   }
 
+  // Colour model as stb_image decides it (the reference decodes JPEG through tinygltf's stb_image): three components are RGB as stored when their ids
+  // are 'R', 'G', 'B' or when an Adobe segment says "no transform" and there is no JFIF header, else YCbCr; four components are CMYK (Adobe
+  // transform 0: the values are stored inverted, so a channel is c * k / 255), YCCK (transform 2: YCbCr to RGB, then (255 - rgb) * k / 255), or
+  // YCbCr with a fourth channel that is ignored.
+  int  adobeTransform = -1;
+  bool jfif           = false;
+  static uint8_t mul8(int x, int y)
+  {
+    const unsigned t = unsigned(x) * unsigned(y) + 128u;
+    return uint8_t((t + (t >> 8)) >> 8);
+  }
   bool output(Image& img) const
   {
     img.width  = width;
     img.height = height;
     img.rgba.assign(size_t(width) * height * 4, 255);
-    std::vector<uint8_t> rows[3], tmp;
+    std::vector<uint8_t> rows[4], tmp;
     for(int i = 0; i < ncomp; ++i)
       rows[i].resize(size_t(width));
     auto fixed = [](double x) { return int(x * 4096.0 + 0.5) << 8; };
+    const bool plainRgb = ncomp == 3 && ((comp[0].id == 'R' && comp[1].id == 'G' && comp[2].id == 'B') || (adobeTransform == 0 && !jfif));
+    const bool cmyk     = ncomp == 4 && adobeTransform == 0;
+    const bool ycck     = ncomp == 4 && adobeTransform == 2;
     for(int y = 0; y < height; ++y)
     {
       for(int i = 0; i < ncomp; ++i)
@@ -639,6 +653,13 @@ struct Decoder
           o[4 * x] = o[4 * x + 1] = o[4 * x + 2] = rows[0][size_t(x)];
         continue;
       }
+      if(plainRgb || cmyk)
+      {
+        for(int x = 0; x < width; ++x)
+          for(int c = 0; c < 3; ++c)
+            o[4 * x + c] = cmyk ? mul8(rows[c][size_t(x)], rows[3][size_t(x)]) : rows[c][size_t(x)];
+        continue;
+      }
       for(int x = 0; x < width; ++x)
       {
         int yFixed = (int(rows[0][size_t(x)]) << 20) + (1 << 19);
@@ -648,6 +669,9 @@ struct Decoder
         int b = yFixed + cb * fixed(1.77200);
         r >>= 20; g >>= 20; b >>= 20;
         o[4 * x] = clamp8(r); o[4 * x + 1] = clamp8(g); o[4 * x + 2] = clamp8(b);
+        if(ycck)
+          for(int c = 0; c < 3; ++c)
+            o[4 * x + c] = mul8(255 - o[4 * x + c], rows[3][size_t(x)]);
       }
     }
     return true;
@@ -659,7 +683,6 @@ struct Decoder
       return fail("not a JPEG stream");
     p += 2;
     bool haveFrame = false, haveScan = false;
-    int  adobeTransform = -1;
     while(p + 4 <= end)
     {
       if(p[0] != 0xff)
@@ -707,6 +730,10 @@ struct Decoder
             return fail("bad DRI");
           restartInterval = (s[0] << 8) | s[1];
           break;
+        case 0xe0:
+          if(len >= 5 && std::memcmp(s, "JFIF", 5) == 0)
+            jfif = true;
+          break;
         case 0xee:
           if(len >= 12 && std::memcmp(s, "Adobe", 5) == 0)
             adobeTransform = s[11];
@@ -724,8 +751,6 @@ struct Decoder
     }
     if(!haveFrame || !haveScan)
       return fail("no image data");
-    if(ncomp == 3 && adobeTransform == 0)
-      return fail("Adobe RGB-coded (untransformed) JPEG is not supported");
     reconstruct();
     return output(img);
   }
