@@ -23,6 +23,8 @@ def scene(name, data, mime, ext=None):
 for prog in (False, True):
     buf = io.BytesIO(); Image.fromarray(rgba[..., :3]).save(buf, "JPEG", quality=80, progressive=prog)
     scene(f"jpeg{int(prog)}.glb", buf.getvalue(), "image/jpeg")
+buf = io.BytesIO(); Image.fromarray(rgba[..., :3]).convert("CMYK").save(buf, "JPEG", quality=80)
+scene("jpeg_cmyk.glb", buf.getvalue(), "image/jpeg")
 # png variants
 for mode in ("RGBA", "L", "P"):
     buf = io.BytesIO(); Image.fromarray(rgba).convert(mode).save(buf, "PNG")

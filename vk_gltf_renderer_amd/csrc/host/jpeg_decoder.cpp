@@ -367,7 +367,7 @@ struct Decoder
     int ns = len >= 1 ? s[0] : 0;
     if(ns < 1 || ns > ncomp || len < 1 + 2 * ns + 3)
       return fail("bad SOS");
-    Component* sc[3];
+    Component* sc[4];
     for(int i = 0; i < ns; ++i)
     {
       sc[i] = nullptr;
