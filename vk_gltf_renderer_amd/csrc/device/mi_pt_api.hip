@@ -94,7 +94,7 @@ struct RunSwitches
   bool   noQuads        = false;   // MI_PT_DIAG_NO_QUADS    four texel gathers per bilinear tap instead of one footprint
   bool   shadowFarFirst = false;   // MI_PT_SHADOW_FAR_FIRST any-hit shadow walks take a node's children from the ray's far end (the laboratory counts 18-26 % fewer node visits
                                    //                        and a third fewer triangle tests per shadow ray on the atrium and the street: a ray that starts on a surface wades
-                                   //                        through the boxes around its origin, its occluder is usually the large thing at the other end); not yet run on a GPU
+                                   //                        through the boxes around its origin, its occluder is usually the large thing at the other end); on a GPU only the round-4 smoke run so far (same 8-bit image), no suite, no timing
   int    reinsert       = 0;       // MI_PT_REINSERT         reinsertion passes over the BVH2 before the 8-wide collapse at scene build (bvh_reinsert.h):
                                    //                        about a tenth fewer node visits per ray; on the device bit-identical to the host run of the same phase
                                    //                        functions, 4 ms per pass at 0.4 M triangles; steady state atrium +4.8 %, street +9 % (native A/B,
