@@ -425,6 +425,86 @@ def secondary_line(name, args, device, width=0, height=0, steps=5, parity=True, 
     return line
 
 
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "hbm_frac", "algorithmic_frac", "issue_frac", "active_lanes", "l2_hit_rate",
+                 "avg_launch_ms", "launches", "traffic")
+FINAL_LINE_LIMIT = 6144  # bytes: the driver keeps the tail of stdout; round 4's single 33 KB line could not be parsed from it
+
+
+def compact_roofline(roof, full=True):
+    """The numbers of a `roofline` object (no prose).  `hbm_frac` = counter bytes across the memory interface per launch / launch time / 8 TB/s for
+    every kernel, whatever roof `frac` is taken against (for an "hbm" kernel the two are the same figure)."""
+    if not roof or "error" in roof:
+        return roof
+    r = dict(roof)
+    if r.get("traffic") and r.get("avg_launch_ms"):
+        r["hbm_frac"] = round(r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    keys = ROOFLINE_KEYS if full else ("kernel", "bound", "frac", "hbm_frac", "active_lanes")
+    return {k: r[k] for k in keys if r.get(k) is not None}
+
+
+def compact_line(result):
+    """The LAST stdout line of a run: the driver's contract fields, the dominant kernel's roofline as numbers, the CPU baseline, the parity
+    figure, and one short record per other configuration -- the shape of the reference's own one-line summary record
+    (src/benchmarking.cpp:281-303).  Kernel tables, per-frame counters and every prose field stay in the full record (bench_full.json, stderr)."""
+    c = result["config"]
+    out = {k: result[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    out["config"] = {k: c[k] for k in ("workload", "resolution", "spp_per_step", "frames_in_flight", "max_depth", "tile", "parallelism", "world_size_reported_by_backend",
+                                         "devices_visible", "reduce", "denoise", "library") if c.get(k) is not None}
+    out["ms_per_frame"] = result["ms_per_frame"]
+    out["roofline"] = compact_roofline(result.get("roofline"))
+
+    def cpu(b):
+        if not b or "error" in b:
+            return b
+        o = {k: b[k] for k in ("value", "unit", "cores", "kind", "flags") if k in b}
+        o["sample"] = b.get("sample", "")[:120]
+        return o
+
+    def par(p):
+        return p if (not p or "error" in p) else {k: p[k] for k in ("rel_l2", "spp", "tolerance_rel_l2", "within_tolerance", "pixels") if k in p}
+
+    if "cpu_baseline" in result:
+        out["cpu_baseline"], out["parity"] = cpu(result["cpu_baseline"]), par(result.get("parity"))
+    for k in ("node_visits_per_secondary_ray", "bytes_per_path_slot"):
+        if k in result:
+            out[k] = result[k]
+    if "device_memory_GB" in result:
+        out["device_memory_GB"] = result["device_memory_GB"]
+    if "north_star" in result:
+        out["north_star"] = {k: result["north_star"][k] for k in ("value", "n_gpus", "value_per_gpu", "needs_per_gpu_Msamples_s", "frac_of_needed_per_gpu")}
+    if "also" in result:
+        out["also"] = {}
+        for name, ln in result["also"].items():
+            if "error" in ln:
+                out["also"][name] = {"error": ln["error"][:160]}
+                continue
+            e = {"value": ln["value"], "ms_per_frame": ln["ms_per_frame"], "resolution": ln["config"]["resolution"], "roofline": compact_roofline(ln.get("roofline"), full=False)}
+            if ln.get("cpu_baseline") and "error" not in ln["cpu_baseline"]:
+                e["cpu_baseline"] = ln["cpu_baseline"]["value"]
+            if ln.get("parity") and "error" not in ln["parity"]:
+                e["parity_rel_l2"], e["parity_spp"] = ln["parity"]["rel_l2"], ln["parity"]["spp"]
+            elif ln.get("parity"):
+                e["parity_error"] = ln["parity"]["error"][:120]
+            out["also"][name] = e
+    out["full_record"] = "bench_full.json"
+    return out
+
+
+def emit(result):
+    """The full record -> bench_full.json (BENCH_FULL overrides the path) and stderr; the compact line -> stdout, last."""
+    full = json.dumps(result)
+    path = os.environ.get("BENCH_FULL", os.path.join(ROOT, "bench_full.json"))
+    try:
+        with open(path, "w") as f:
+            f.write(full + "\n")
+    except OSError as e:
+        print(f"bench.py: could not write {path}: {e}", file=sys.stderr)
+    print(full, file=sys.stderr, flush=True)
+    line = json.dumps(compact_line(result))
+    assert len(line) < FINAL_LINE_LIMIT, len(line)
+    print(line, flush=True)
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N ranks of this command under torch.distributed.run (one process per GPU,
     rendezvous on 127.0.0.1) and become that launcher.  Refuses when fewer than N devices are visible -- unless BENCH_SHARE_GPU=1
@@ -703,7 +783,7 @@ def main():
                     import gc
                     gc.collect()
                     torch.cuda.empty_cache()
-        print(json.dumps(result), flush=True)
+        emit(result)
     tracer.close()
     if dist is not None:
         dist.barrier()

@@ -79,6 +79,51 @@ def test_committed_round4_line_obeys_the_contract():
             assert ln["cpu_baseline"]["kind"] == "port" and ln["cpu_baseline"]["cores"] >= 1
 
 
+def _committed_full_records():
+    prof = os.path.join(ROOT, "profiles")
+    return sorted(f for f in os.listdir(prof) if f.endswith("_bench_default.json") or f.endswith("_bench_full.json"))
+
+
+@pytest.mark.parametrize("record", _committed_full_records())
+def test_final_line_is_compact(record):
+    """Round 4's default run printed ONE 33 KB line and the driver's record of it could not be parsed.  The last stdout line is now built by
+    compact_line() from the full record (which goes to bench_full.json and stderr): under 6 KB -- in practice under 4 -- with every field the
+    driver and the review read, numbers only in `roofline`, and one short record per other configuration."""
+    full = json.loads(open(os.path.join(ROOT, "profiles", record)).read().strip().splitlines()[-1])
+    line = bench.compact_line(full)
+    text = json.dumps(line)
+    assert len(text) < bench.FINAL_LINE_LIMIT and len(text) < 4096, len(text)
+    assert "\n" not in text
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "parity", "north_star", "also"):
+        assert k in line, k
+    for k in ("workload", "resolution", "spp_per_step", "frames_in_flight", "max_depth", "library"):
+        assert k in line["config"], k
+    roof = line["roofline"]
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "hbm_frac", "avg_launch_ms", "launches", "traffic"):
+        assert k in roof, k
+    assert all(not isinstance(v, str) or k in ("bound", "kernel", "unit") for k, v in roof.items())  # numbers only
+    assert 0.0 < roof["frac"] <= 1.0 and 0.0 < roof["hbm_frac"] <= 1.0
+    assert roof["hbm_frac"] == pytest.approx(roof["traffic"] / (roof["avg_launch_ms"] * 1e-3) / 1e9 / bench.HBM_PEAK_GBS, rel=1e-3)
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1 and line["cpu_baseline"]["value"] > 0
+    assert line["parity"]["within_tolerance"] and line["parity"]["rel_l2"] <= 1e-3
+    assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"]
+    for name, e in line["also"].items():
+        assert e["value"] == full["also"][name]["value"] and set(e["roofline"]) >= {"kernel", "bound", "frac"}, name
+
+
+def test_emit_prints_the_compact_line_last(tmp_path, capfd):
+    full = json.loads(open(os.path.join(ROOT, "profiles", _committed_full_records()[-1])).read().strip().splitlines()[-1])
+    os.environ["BENCH_FULL"] = str(tmp_path / "full.json")
+    try:
+        bench.emit(full)
+    finally:
+        del os.environ["BENCH_FULL"]
+    out, err = capfd.readouterr()
+    assert out.count("\n") == 1 and json.loads(out) == bench.compact_line(full)
+    assert json.loads(open(tmp_path / "full.json").read()) == full and json.loads(err.strip().splitlines()[-1]) == full
+
+
 def test_more_ranks_than_devices_is_refused_before_anything_runs():
     """`python bench.py --gpus N` starts its own ranks -- and on a box with fewer devices (here: none) it must exit non-zero without a JSON line."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "BENCH_SHARE_GPU")}

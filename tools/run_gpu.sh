@@ -12,7 +12,7 @@ O=$PWD/gpurun_out; mkdir -p $O
 N="--no-cpu-baseline --also none"
 val() { python3 -c "
 import json,sys
-j=json.loads(open('$1').read().strip().splitlines()[-1]); k=j['kernels']
+j=json.loads([l for l in open('$1'.replace('.json','.err')) if l.startswith('{')][-1]); k=j['kernels']  # (the full record goes to stderr; stdout ends with the compact line)
 print('RESULT $2', round(j['value'],1), ' '.join(f\"{n}={k[n]['ms_per_frame']:.4f}\" for n in k), 'visits', j.get('node_visits_per_secondary_ray'), 'tris', j.get('triangle_tests_per_secondary_ray'))"; }
 ab() { # ab <tag> <workloads...>: every lib/var_* build next to the product build, --steps 3
   tag=$1; shift
