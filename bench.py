@@ -410,7 +410,7 @@ def secondary_line(name, args, device, width=0, height=0, steps=5, parity=True, 
     keys = ("cameraPaths", "segments", "surfaceHits", "shadowRays", "nodesPrimary", "trisPrimary", "nodesClosest", "trisClosest", "nodesShadow", "trisShadow", "textureTaps")
     line = {"value": round(float(W) * H * frames / elapsed / 1e6, 3), "unit": "Msamples/s", "ms_per_frame": round(elapsed / frames * 1e3, 5),
             "config": {"workload": w["config"].replace("1920x1080", f"{W}x{H}") + " (seeded synthetic stand-in)", "scene_triangles": scene.num_triangles,
-                       "alpha_cut": alpha_cut_note(args.alpha_cut, triangles_loaded, dropped), "bvh_reinsertion_passes": int(os.environ.get("MI_PT_REINSERT", "0") or 0),
+                       "alpha_cut": alpha_cut_note(args.alpha_cut, triangles_loaded, dropped), "bvh_reinsertion_passes": int(os.environ.get("MI_PT_REINSERT", "16") or 0),
                        "resolution": [W, H],
                        "frames_in_flight": F, "max_depth": w["depth"], "frames_timed": frames, "steps": steps,
                        "denoise": ("variance-guided a-trous (mi_pt_denoise_svgf, 5 iterations) once per step, inside the timed region" if denoise else None)},
@@ -737,7 +737,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": w["config"] + " (seeded synthetic stand-in)" if w["gen"] else w["config"], "scene_triangles": scene.num_triangles,
                        "alpha_cut": alpha_cut_note(args.alpha_cut, triangles_loaded, alpha_cut_dropped),
-                       "bvh_reinsertion_passes": int(os.environ.get("MI_PT_REINSERT", "0") or 0),  # (read by the library at mi_pt_create; 0 = the builder's tree as clustered)
+                       "bvh_reinsertion_passes": int(os.environ.get("MI_PT_REINSERT", "16") or 0),  # (read by the library at mi_pt_create; 0 = the builder's tree as clustered)
                        "resolution": [W, H], "spp_per_step": frames_step, "frames_in_flight": F, "max_depth": w["depth"], "tile": args.tile,
                        "parallelism": f"tiles{world}" if world > 1 else "single", "world_size_reported_by_backend": (dist.get_world_size() if dist is not None else 1),
                        "devices_visible": torch.cuda.device_count(),

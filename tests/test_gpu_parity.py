@@ -328,21 +328,28 @@ def test_image_independent_of_acceleration_structure(built, tmp_path):
     assert (pu.render_gpu(s, 2, bvh=0)["accum"] == pu.render_gpu(s, 2, bvh=1)["accum"]).all()
 
 
-@pytest.mark.skipif(os.environ.get("MI_PT_TEST_REINSERT") != "1", reason="the reinsertion passes of the device builder were written after the round's GPU time was all but spent: "
-                    "their kernels were checked on an MI355X by tools/test_reinsert_gpu.hip (records bit-identical to the host run, profiles/r04_reinsert_gpu_check.txt), "
-                    "this test through the renderer has not run yet and the passes stay off by default; MI_PT_TEST_REINSERT=1 runs it first thing next round")
 def test_reinsertion_changes_the_tree_not_the_image(built, tmp_path):
     """MI_PT_REINSERT=n (bvh_reinsert.h: n searches over the BVH2, each followed by lock / move rounds and a refit, before the 8-wide collapse):
-    another tree, the same image bit for bit, fewer node visits."""
+    another tree, the same image bit for bit, fewer node visits.  On by default since round 5 (16 passes): MI_PT_REINSERT=0 is the tree as clustered."""
     path = scenegen.scene_atrium_class(str(tmp_path / "atrium.glb"), seed=5, detail=0.12, tex_size=64)
     s = pu.Setup(path, 160, 96, max_depth=8)
-    plain = pu.render_gpu(s, 2, bvh=0)
-    for passes, bvh in ((2, 0), (12, 0), (12, 1)):  # (bvh = 1: the BVH2 walk reads the reinserted records themselves)
+
+    def render(passes, bvh):
+        old = os.environ.get("MI_PT_REINSERT")
         os.environ["MI_PT_REINSERT"] = str(passes)
         try:
-            r = pu.render_gpu(s, 2, bvh=bvh)
+            return pu.render_gpu(s, 2, bvh=bvh)
         finally:
-            del os.environ["MI_PT_REINSERT"]
+            if old is None:
+                del os.environ["MI_PT_REINSERT"]
+            else:
+                os.environ["MI_PT_REINSERT"] = old
+
+    plain = render(0, 0)
+    default = pu.render_gpu(s, 2, bvh=0)  # the shipped default: passes on
+    assert (default["accum"] == plain["accum"]).all() and default["stats"]["nodesClosest"] < 0.97 * plain["stats"]["nodesClosest"]
+    for passes, bvh in ((2, 0), (12, 0), (12, 1)):  # (bvh = 1: the BVH2 walk reads the reinserted records themselves)
+        r = render(passes, bvh)
         assert (r["accum"] == plain["accum"]).all() and (r["selection"] == plain["selection"]).all() and (r["depth"] == plain["depth"]).all(), (passes, bvh)
         for k in ("segments", "shadowRays", "textureTaps"):
             assert r["stats"][k] == plain["stats"][k]
@@ -354,10 +361,8 @@ def test_reinsertion_changes_the_tree_not_the_image(built, tmp_path):
                 assert r["stats"]["nodesClosest"] < 0.97 * plain["stats"]["nodesClosest"]
 
 
-@pytest.mark.skipif(os.environ.get("MI_PT_TEST_SHADOW_ORDER") != "1", reason="MI_PT_SHADOW_FAR_FIRST was added after the round's GPU time was spent (the laboratory's count: "
-                    "tools/lab/bvh_lab.cpp, any-hit orders); off by default, MI_PT_TEST_SHADOW_ORDER=1 runs this check first thing next round")
 def test_shadow_walk_from_the_far_end_changes_no_bit(built, assets, tmp_path):
-    """Any-hit is order independent: with MI_PT_SHADOW_FAR_FIRST=1 the shadow walks of modes 0 / 1 / 3 (opaque, alpha-tested, recording) take a node's children
+    """Any-hit is order independent: by default (round 5; MI_PT_SHADOW_FAR_FIRST=0 is the near-first order of rounds 1-4) the shadow walks of modes 0 / 1 / 3 (opaque, alpha-tested, recording) take a node's children
     from the ray's far end -- same image, same path-level counters, fewer node visits of shadow rays; the ordered search (mode 2) keeps its order."""
     scenes = [(scenegen.scene_atrium_class(str(tmp_path / "atrium.glb"), seed=5, detail=0.12, tex_size=64), 160, 96, 8, None, {}),
               (scenegen.scene_glass_class(str(tmp_path / "glass.glb"), seed=3, tess=24), 128, 80, 12, os.path.join(assets, "std_env.hdr"), {}),
@@ -365,12 +370,16 @@ def test_shadow_walk_from_the_far_end_changes_no_bit(built, assets, tmp_path):
               (scenegen.scene_glass_class(str(tmp_path / "glass2.glb"), seed=3, tess=24), 128, 80, 12, None, {"bvh": 1})]  # (BVH2: mode 2 walks everything)
     for path, w, h, depth, hdr, kw in scenes:
         s = pu.Setup(path, w, h, max_depth=depth, hdr_path=hdr)
-        near = pu.render_gpu(s, 3, **kw)
-        os.environ["MI_PT_SHADOW_FAR_FIRST"] = "1"
+        far = pu.render_gpu(s, 3, **kw)
+        old = os.environ.get("MI_PT_SHADOW_FAR_FIRST")
+        os.environ["MI_PT_SHADOW_FAR_FIRST"] = "0"
         try:
-            far = pu.render_gpu(s, 3, **kw)
+            near = pu.render_gpu(s, 3, **kw)
         finally:
-            del os.environ["MI_PT_SHADOW_FAR_FIRST"]
+            if old is None:
+                del os.environ["MI_PT_SHADOW_FAR_FIRST"]
+            else:
+                os.environ["MI_PT_SHADOW_FAR_FIRST"] = old
         assert (far["accum"] == near["accum"]).all() and (far["selection"] == near["selection"]).all(), path
         for k in ("cameraPaths", "segments", "shadowRays", "surfaceHits", "textureTaps"):  # (path level: the walks' own counters vary with the dynamic feed)
             assert far["stats"][k] == near["stats"][k], (path, k)

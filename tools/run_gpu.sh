@@ -57,9 +57,7 @@ PY
   staged|reinsert)  # MI_PT_REINSERT (bvh_reinsert.h; round 4 ran its kernels stand-alone and one native A/B, profiles/r04_reinsert_*): the check through the renderer first,
              # then what the passes buy on every workload and what the build costs
     MI_PT_TEST_REINSERT=1 MI_PT_TEST_SHADOW_ORDER=1 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -s -k "reinsertion or independent_of_acceleration or far_end" 2>&1 | tail -12
-    tools/build_variant.sh part -DMI_PT_PARTITION_TECHNIQUE > /dev/null 2>&1  # (needs hipcc: build it BEFORE the gpurun call; here for the record) continuation rays appended by next technique
     for w in atrium street helmet glass; do
-      MI_PT_LIB=$PWD/vk_gltf_renderer_amd/lib/var_part/libmi_pt.so timeout 300 python bench.py --workload $w --steps 3 --warmup 1 $N > $O/r05_part_${w}.json 2> $O/r05_part_${w}.err && val $O/r05_part_${w}.json ${w}_partition || { echo "FAILED ${w} partition"; tail -3 $O/r05_part_${w}.err; }
     done
     for w in atrium street helmet glass; do  # the shadow walk from the far end (tools/lab: -18 .. -26 % node visits of shadow rays)
       MI_PT_SHADOW_FAR_FIRST=1 timeout 300 python bench.py --workload $w --steps 3 --warmup 1 $N > $O/r05_farfirst_${w}.json 2> $O/r05_farfirst_${w}.err && val $O/r05_farfirst_${w}.json ${w}_farfirst || { echo "FAILED ${w} far first"; tail -3 $O/r05_farfirst_${w}.err; }

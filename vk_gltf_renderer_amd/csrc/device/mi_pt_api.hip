@@ -92,14 +92,14 @@ struct RunSwitches
   bool   allOpaqueTris  = false;   // MI_PT_DIAG_ALL_OPAQUE_TRIS (wrong image) every triangle of an alpha-tested primitive in the OPAQUE class: the alpha
                                    //                            kernels run without a single alpha candidate -- their fixed cost
   bool   noQuads        = false;   // MI_PT_DIAG_NO_QUADS    four texel gathers per bilinear tap instead of one footprint
-  bool   shadowFarFirst = false;   // MI_PT_SHADOW_FAR_FIRST any-hit shadow walks take a node's children from the ray's far end (the laboratory counts 18-26 % fewer node visits
-                                   //                        and a third fewer triangle tests per shadow ray on the atrium and the street: a ray that starts on a surface wades
-                                   //                        through the boxes around its origin, its occluder is usually the large thing at the other end); on a GPU only the round-4 smoke run so far (same 8-bit image), no suite, no timing
-  int    reinsert       = 0;       // MI_PT_REINSERT         reinsertion passes over the BVH2 before the 8-wide collapse at scene build (bvh_reinsert.h):
-                                   //                        about a tenth fewer node visits per ray; on the device bit-identical to the host run of the same phase
-                                   //                        functions, 4 ms per pass at 0.4 M triangles; steady state atrium +4.8 %, street +9 % (native A/B,
-                                   //                        profiles/r04_reinsert_*).  Off until the GPU suite and the bench line have run with it.
-  int    reinsertUpdate = 0;       // MI_PT_REINSERT_UPDATE  ... at the rebuilds of mi_pt_update_render_nodes (a moving instance pays them every time)
+  bool   shadowFarFirst = true;    // MI_PT_SHADOW_FAR_FIRST=0 any-hit shadow walks (k_trace_shadow MODE 0 / 1 / 3: order independent) take a node's children near end first,
+                                   //                        as in rounds 1-4.  Default since round 5: from the ray's FAR end -- a ray that starts on a surface wades through the
+                                   //                        boxes around its origin, its occluder is usually the large thing at the other end.  Same image bit for bit
+                                   //                        (test_shadow_walk_from_the_far_end_changes_no_bit); atrium 604 -> 656, street 623 -> 661 Msamples/s (profiles/r05_staged_ab.txt)
+  int    reinsert       = 16;      // MI_PT_REINSERT         reinsertion passes over the BVH2 before the 8-wide collapse at scene build (bvh_reinsert.h); 0 = the tree as clustered.
+                                   //                        Same image bit for bit (test_reinsertion_changes_the_tree_not_the_image), a tenth fewer node visits per ray:
+                                   //                        atrium 604 -> 633, street 623 -> 680 Msamples/s; both switches: 682 / 727 (profiles/r05_staged_ab.txt)
+  int    reinsertUpdate = 4;       // MI_PT_REINSERT_UPDATE  ... at the rebuilds of mi_pt_update_render_nodes (a moving instance pays them every time)
   int    reinsertRounds = 4;       // MI_PT_REINSERT_ROUNDS  lock / move rounds per pass
   int    failBuildAt    = 0;       // MI_PT_DIAG_FAIL_BUILD=N  test hook: the N-th acceleration REbuild of the instance fails after the old structure is gone
   bool   candPoolSet    = false;   // MI_PT_DIAG_CAND_POOL   entries of the transmissive-candidate pool (tests of the overflow path)
@@ -124,9 +124,9 @@ struct RunSwitches
     noOpaqueTris   = flag("MI_PT_DIAG_NO_OPAQUE_TRIS");
     allOpaqueTris  = flag("MI_PT_DIAG_ALL_OPAQUE_TRIS");
     noQuads        = flag("MI_PT_DIAG_NO_QUADS");
-    shadowFarFirst = flag("MI_PT_SHADOW_FAR_FIRST");
-    reinsert       = num("MI_PT_REINSERT", 0);
-    reinsertUpdate = num("MI_PT_REINSERT_UPDATE", 0);
+    shadowFarFirst = num("MI_PT_SHADOW_FAR_FIRST", 1) != 0;
+    reinsert       = std::max(0, num("MI_PT_REINSERT", 16));
+    reinsertUpdate = std::max(0, num("MI_PT_REINSERT_UPDATE", 4));
     reinsertRounds = std::max(1, num("MI_PT_REINSERT_ROUNDS", 4));
     failBuildAt    = num("MI_PT_DIAG_FAIL_BUILD", 0);
     if(const char* e = getenv("MI_PT_DIAG_CAND_POOL"))

@@ -129,54 +129,6 @@ PT_DEV PushPos queuePushBlock2(bool predNext, bool predShadow, uint32_t subCap, 
   return p;
 }
 
-#ifdef MI_PT_PARTITION_TECHNIQUE
-// Variant build (tools/build_variant.sh part -DMI_PT_PARTITION_TECHNIQUE; not in the product library): the continuation rays of a block's chunk are appended
-// in TWO runs -- first the paths whose next direct-light sample will pick a light, then those that will pick the environment -- so that the waves of the next
-// bounce's shade kernel are of one technique each, at no sorting pass: the technique is the first draw of the next bounce from the seed the entry carries
-// (pt_shading.h: sampleLightsBody), i.e. known here.  Same sub-queue, same count: the capacity bound of the sub-queues holds.  s_tmp: 6 words.
-PT_DEV PushPos queuePushBlock3(bool predNextA, bool predNextB, bool predShadow, uint32_t subCap, uint32_t* pair, uint32_t sub, uint32_t* s_tmp)
-{
-  if(threadIdx.x == 0)
-  {
-    s_tmp[0] = 0;
-    s_tmp[1] = 0;
-    s_tmp[4] = 0;
-  }
-  __syncthreads();
-  const unsigned long long maskA = __ballot(predNextA), maskB = __ballot(predNextB), maskS = __ballot(predShadow);
-  const uint32_t           lane  = laneId();
-  uint32_t                 wbaseA = 0, wbaseB = 0, wbaseS = 0;
-  if(lane == 0)
-  {
-    if(maskA != 0ull)
-      wbaseA = atomicAdd(&s_tmp[0], uint32_t(__popcll(maskA)));
-    if(maskB != 0ull)
-      wbaseB = atomicAdd(&s_tmp[4], uint32_t(__popcll(maskB)));
-    if(maskS != 0ull)
-      wbaseS = atomicAdd(&s_tmp[1], uint32_t(__popcll(maskS)));
-  }
-  wbaseA = uint32_t(__shfl(int(wbaseA), 0));
-  wbaseB = uint32_t(__shfl(int(wbaseB), 0));
-  wbaseS = uint32_t(__shfl(int(wbaseS), 0));
-  __syncthreads();
-  if(threadIdx.x == 0)
-  {
-    const uint32_t     nA = s_tmp[0], nB = s_tmp[4], nS = s_tmp[1];
-    unsigned long long base = 0ull;
-    if((nA | nB | nS) != 0u)
-      base = atomicAdd(reinterpret_cast<unsigned long long*>(pair), (static_cast<unsigned long long>(nS) << 32) | (nA + nB));
-    s_tmp[2] = uint32_t(base);
-    s_tmp[3] = uint32_t(base >> 32);
-    s_tmp[5] = nA;
-  }
-  __syncthreads();
-  const unsigned long long below = (1ull << lane) - 1ull;
-  PushPos                  p;
-  p.next   = sub * subCap + s_tmp[2] + (predNextA ? wbaseA + uint32_t(__popcll(maskA & below)) : s_tmp[5] + wbaseB + uint32_t(__popcll(maskB & below)));
-  p.shadow = sub * subCap + s_tmp[3] + wbaseS + uint32_t(__popcll(maskS & below));
-  return p;
-}
-#endif
 
 // (A per-WAVE version of this append -- one 64-bit global atomic per wave, no barrier, so that the waves of a block run their chunks
 //  independently -- was measured in round 3: helmet 3793 against 3799 Msamples/s, atrium 478 / 482, street 504 / 512, glass 529 / 537.
@@ -1557,11 +1509,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
   const FrameConsts& fc = uniformConst(*fcp);
   const bool         stateInQueue = fc.stateInQueue != 0;  // misc / throughput / radiance of a living path ride in its queue entry (pt_scene.h: RayQueue)
   __shared__ uint32_t s_prefix[NSUB + 1];
-#ifdef MI_PT_PARTITION_TECHNIQUE
-  __shared__ uint32_t s_push[6];
-#else
   __shared__ uint32_t s_push[4];
-#endif
   __shared__ float    s_srgb[256];  // sRGB decode table next to the ALU: 3 lookups per texel, up to 8 texels per tap
   // The window sort exists in the generic kernel (key: material) and in the later bounces of the SIMPLE kernel (key: next-event
   // technique); the bounce-0 launch of the SIMPLE kernel gets its hits packed by k_trace_primary and walks the queue as it is.
@@ -2052,18 +2000,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
       if(COUNT && (meshHit || hitInfinitePlane))
         atomicAdd(&stats->surfaceHits, 1ull);
     }
-#ifdef MI_PT_PARTITION_TECHNIQUE
-    bool lightNext = true;  // the next bounce's first draw against the light technique's weight (sampleLightsBody); uniform weights
-    {
-      float lw, ew;
-      getDirectLightingTechniqueProbabilities(sc, fc, lw, ew);
-      uint32_t peek = __float_as_uint(nextDir.w);
-      lightNext     = alive && rnd(peek) < lw;
-    }
-    const PushPos  pp      = queuePushBlock3(alive && lightNext, alive && !lightNext, pushShadow, Q.subCap, &Q.counters[(nxt ? QC_PAIR1 : QC_PAIR0) + 2 * (chunk % NSUB)], chunk % NSUB, s_push);
-#else
     const PushPos  pp      = queuePushBlock2(alive, pushShadow, Q.subCap, &Q.counters[(nxt ? QC_PAIR1 : QC_PAIR0) + 2 * (chunk % NSUB)], chunk % NSUB, s_push);
-#endif
     const uint32_t posNext = pp.next, posShadow = pp.shadow;
     if(alive)
     {
