@@ -5,7 +5,6 @@
 #   ab <tag> <workloads...>    every vk_gltf_renderer_amd/lib/var_*/libmi_pt.so (tools/build_variant.sh, tools/build_rev_variant.sh) next to the product build
 #   evidence <tag> <args...>   kernel-trace stats + counter passes of one configuration -> pmc_latest_<tag>.json (copy to profiles/)
 #   sweep                      frames in flight 1 / 8 / 64 / 128 at 1080p and 4K with device memory
-#   staged                     (for round 5: MI_PT_REINSERT and MI_PT_SHADOW_FAR_FIRST) the BVH2 reinsertion passes of the builder: the GPU check first, then 0 / 8 / 24 passes on every workload
 #   mbvalu                     tools/microbench_valu.hip (build it first: hipcc --offload-arch=gfx950 -O3 tools/microbench_valu.hip -o tools/_scratch/mb_valu)
 cd "$(dirname "$0")/.."; ulimit -c 0
 O=$PWD/gpurun_out; mkdir -p $O
@@ -53,20 +52,6 @@ k = json.loads(out.stdout)["kernels"]
 print("EVIDENCE", tag, j["value"], {n: (v.get("issue_frac"), v.get("active_lanes"), round(v["hbm_bytes_per_launch"] / 1e9, 2)) for n, v in k.items()}, out.stderr[-300:])
 PY
     rm -rf $O/prof_r04_$tag  # (the per-dispatch counter CSVs are tens of MB per configuration; gpurun copies back at most 64 MiB)
-    ;;
-  staged|reinsert)  # MI_PT_REINSERT (bvh_reinsert.h; round 4 ran its kernels stand-alone and one native A/B, profiles/r04_reinsert_*): the check through the renderer first,
-             # then what the passes buy on every workload and what the build costs
-    MI_PT_TEST_REINSERT=1 MI_PT_TEST_SHADOW_ORDER=1 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -s -k "reinsertion or independent_of_acceleration or far_end" 2>&1 | tail -12
-    for w in atrium street helmet glass; do
-    done
-    for w in atrium street helmet glass; do  # the shadow walk from the far end (tools/lab: -18 .. -26 % node visits of shadow rays)
-      MI_PT_SHADOW_FAR_FIRST=1 timeout 300 python bench.py --workload $w --steps 3 --warmup 1 $N > $O/r05_farfirst_${w}.json 2> $O/r05_farfirst_${w}.err && val $O/r05_farfirst_${w}.json ${w}_farfirst || { echo "FAILED ${w} far first"; tail -3 $O/r05_farfirst_${w}.err; }
-    done
-    for w in atrium street helmet glass; do for p in 0 8 24; do
-      MI_PT_REINSERT=$p timeout 300 python bench.py --workload $w --steps 3 --warmup 1 $N > $O/r05_reinsert_${w}_p$p.json 2> $O/r05_reinsert_${w}_p$p.err && val $O/r05_reinsert_${w}_p$p.json ${w}_reinsert$p || { echo "FAILED ${w} $p"; tail -3 $O/r05_reinsert_${w}_p$p.err; }
-      python3 -c "
-import json; j=json.loads(open('$O/r05_reinsert_${w}_p$p.json').read().strip().splitlines()[-1]); print('  scene build', j.get('scene_build_s'), 's')"
-    done; done
     ;;
   sweep)  # frames in flight 1 / 8 / 64 / 128 at 1080p and 4K: what a maintainer gets per onRender batch size, and the memory it takes
     for w in helmet atrium; do for f in 1 8 64 128; do
