@@ -278,6 +278,8 @@ def cpu_baseline_and_parity(scene, w, W, H, F, cpu_seconds, make_gpu_tracer, gpu
     import parity_util as pu
     import oracle_lib
     from vk_gltf_renderer_amd import pathtracer as ptmod
+    if oracle_lib._lib is None:
+        oracle_lib.use_native()  # the timed baseline: -O3 -march=native, built on this box
     setup = pu.Setup(scene.path, W, H, hdr_path=os.path.join(ROOT, "assets", "std_env.hdr") if w["hdr"] else None, max_depth=w["depth"])
     O = oracle_lib.lib()
     o = C.c_void_p()
@@ -310,7 +312,7 @@ def cpu_baseline_and_parity(scene, w, W, H, F, cpu_seconds, make_gpu_tracer, gpu
             cpu_imgs[f + 1] = np.ctypeslib.as_array(O.oracle_pt_accum(o), shape=(H, W, 4))[mask].copy()
     t_cpu = time.perf_counter() - t_cpu0
     O.oracle_pt_destroy(o)
-    cpu = {"value": round(timed[0] * px_owned / timed[1] / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+    cpu = {"value": round(timed[0] * px_owned / timed[1] / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port", "flags": oracle_lib.FLAGS,
            "sample": f"the first {timed[0]} frame(s) x {len(owned)}/{tiles_total} tiles (every {part}th 64x64 tile) of the same workload, {timed[1]:.1f} s "
                      f"(the parity leg went on to {spp} frames: {t_cpu:.1f} s)"}
     # parity at the FULL configuration: the same frames on the GPU, compared on the tiles the oracle rendered

@@ -16,10 +16,26 @@ def build():
     subprocess.run(["make", "-C", ORACLE_DIR, "-s"], check=True)
 
 
+FLAGS = "-O3"  # of the library lib() loaded ("-O3 -march=native" after use_native())
+
+
+def use_native():
+    """Before the first lib(): build oracle/_native/liboracle_pt.so (-O3 -march=native) on THIS host and load that one -- for the timed
+    CPU baseline of bench.py.  Falls back to the portable build when it cannot be built here.  Returns the flags in use."""
+    global _native, FLAGS
+    r = subprocess.run(["make", "-C", ORACLE_DIR, "-s", "native"], capture_output=True, text=True)
+    _native = r.returncode == 0 and os.path.exists(os.path.join(ORACLE_DIR, "_native", "liboracle_pt.so"))
+    FLAGS = "-O3 -march=native" if _native else "-O3"
+    return FLAGS
+
+
+_native = False
+
+
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(ORACLE_DIR, "liboracle_pt.so")
+        path = os.path.join(ORACLE_DIR, "_native", "liboracle_pt.so") if _native else os.path.join(ORACLE_DIR, "liboracle_pt.so")
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)

@@ -458,6 +458,35 @@ def test_shadow_stage_on_a_second_stream_changes_no_bit(built, assets, tmp_path)
             assert a["stats"][k] == b["stats"][k], k
 
 
+def test_paths_alive_at_the_end_of_the_bounce_loop_keep_their_state(built, assets, tmp_path):
+    """The host's bounce loop has an iteration bound (volume random walks: maxDepth * 66 + 512).  A path it cuts must keep the radiance it has
+    gathered and its current seed (the next sample of a multi-sample frame starts from it) -- with the path state travelling in the queue
+    entry those records are written by slot only when a path ENDS, so a pass after the loop (k_flush_survivors) hands the survivors' over.
+    MI_PT_DIAG_MAX_ITERS=N cuts every loop after N iterations: the state-in-queue frames must equal the state-by-slot frames of rounds 1-3
+    (MI_PT_STATE_BY_SLOT=1), where the records always lived by slot, bit for bit -- single- and multi-sample frames, batches, two streams."""
+    hdr = os.path.join(assets, "std_env.hdr")
+    glass = scenegen.scene_glass_class(str(tmp_path / "glass.glb"), seed=9, tess=16)
+    atrium = scenegen.scene_atrium_class(str(tmp_path / "atrium.glb"), seed=5, detail=0.12, tex_size=64)
+    cases = [(pu.Setup(glass, 128, 80, max_depth=10, hdr_path=hdr, spp_per_frame=3), 3, 1, "3"), (pu.Setup(glass, 128, 80, max_depth=10, hdr_path=hdr), 4, 4, "5"),
+             (pu.Setup(atrium, 160, 96, max_depth=8, spp_per_frame=2), 4, 2, "2")]
+    for setup, frames, in_flight, iters in cases:
+        out = {}
+        for by_slot in (False, True):
+            env = {"MI_PT_DIAG_MAX_ITERS": iters, "MI_PT_OVERLAP_MIN_TRIS": "0"}
+            if by_slot:
+                env["MI_PT_STATE_BY_SLOT"] = "1"
+            os.environ.update(env)
+            try:
+                out[by_slot] = pu.render_gpu(setup, frames, in_flight=in_flight)
+            finally:
+                for k in env:
+                    del os.environ[k]
+        full = pu.render_gpu(setup, frames, in_flight=in_flight)
+        assert (out[False]["accum"] == out[True]["accum"]).all(), (iters, in_flight)
+        assert out[False]["stats"]["segments"] == out[True]["stats"]["segments"] < full["stats"]["segments"]  # (the loop was really cut)
+        assert np.isfinite(out[False]["accum"]).all() and out[False]["accum"][..., :3].max() > 0
+
+
 def test_furnace_on_gpu(built, tmp_path):
     """The analytic furnace KAT on the device itself: white Lambert sphere in a uniform environment is invisible."""
     path = scenegen.scene_sphere(str(tmp_path / "s.glb"), scenegen.lambert_material((1, 1, 1)), 48, 24)

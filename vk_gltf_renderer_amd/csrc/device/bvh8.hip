@@ -65,18 +65,6 @@ static_assert(sizeof(Node8) == 80, "Node8 must be 80 bytes");
 // SAH-optimal collapse by default: against the greedy one (MI_PT_COLLAPSE=greedy) 40 % fewer, fuller nodes (atrium 68.8 k -> 44 k),
 // node visits per secondary ray 19.74 -> 19.27 (atrium), 28.66 -> 27.55 (street), 8.01 -> 7.91 (helmet), and
 // atrium 482 -> 490, street 512 -> 518, helmet 3799 -> 3878, glass 537 -> 551 Msamples/s (round 3)
-constexpr bool COLLAPSE_SAH_DEFAULT = true;
-constexpr int MAX_LEAF_TRIS_DEFAULT = 2;
-
-static int maxLeafTris()
-{
-  static const int v = [] {
-    const char* e = getenv("MI_PT_LEAF_TRIS");
-    const int   n = e ? atoi(e) : MAX_LEAF_TRIS_DEFAULT;
-    return n < 1 ? 1 : (n > 2 ? 2 : n);
-  }();
-  return v;
-}
 
 struct Cand
 {
@@ -494,7 +482,7 @@ __global__ void k_collapse_emit(int numItems, const int* items, const float4* no
 
 }  // namespace
 
-bool buildBvh8(const BvhBuildOutput& b2, Bvh8Output& out, hipStream_t stream, std::string& err)
+bool buildBvh8(const BvhBuildOutput& b2, Bvh8Output& out, hipStream_t stream, std::string& err, const Bvh8Options& opt)
 {
   out                = Bvh8Output();
   const uint32_t n   = b2.numTris;
@@ -509,7 +497,8 @@ bool buildBvh8(const BvhBuildOutput& b2, Bvh8Output& out, hipStream_t stream, st
     return true;
   };
   const uint32_t numInner = b2.numNodes;
-  static const bool hostCollapse = getenv("MI_PT_HOST_COLLAPSE") != nullptr;
+  const bool hostCollapse = opt.hostCollapse;
+  const int  leafTrisOpt  = opt.maxLeafTris < 1 ? 1 : (opt.maxLeafTris > 2 ? 2 : opt.maxLeafTris);
   if(numInner > 0 && !hostCollapse)
   {
     // ---- device collapse, one level at a time (see the header comment) -------------------------------------------------------
@@ -539,16 +528,9 @@ bool buildBvh8(const BvhBuildOutput& b2, Bvh8Output& out, hipStream_t stream, st
       const int root = b2.root;
       if(!(ok = check(hipMemcpyAsync(itemsA, &root, sizeof(int), hipMemcpyHostToDevice, stream), "seed level 0"))) break;
       uint32_t levelStart = 0, levelCount = 1;
-      uint32_t maxLeaf = uint32_t(maxLeafTris());
-      // MI_PT_COLLAPSE = sah | greedy: which BVH2 subtrees become the children of an 8-wide node (the images do not depend on it)
-      const char* modeEnv = getenv("MI_PT_COLLAPSE");
-      if(modeEnv && strcmp(modeEnv, "sah") != 0 && strcmp(modeEnv, "greedy") != 0)
-      {
-        fprintf(stderr, "mi_pt: MI_PT_COLLAPSE=%s is neither \"sah\" nor \"greedy\"\n", modeEnv);  // (a typo must not silently select the other collapse)
-        ok = false;
-        break;
-      }
-      const bool  sahDp   = modeEnv ? strcmp(modeEnv, "sah") == 0 : COLLAPSE_SAH_DEFAULT;
+      uint32_t   maxLeaf = uint32_t(leafTrisOpt);
+      // which BVH2 subtrees become the children of an 8-wide node (Bvh8Options; the images do not depend on it)
+      const bool sahDp   = opt.sahCollapse;
       if(sahDp)
       {
         maxLeaf = std::min(maxLeaf, 3u);
@@ -730,7 +712,7 @@ bool buildBvh8(const BvhBuildOutput& b2, Bvh8Output& out, hipStream_t stream, st
     const std::vector<Cand> cands0 = std::move(queue[qi].cands);
     std::vector<Cand>       cands;
     const uint32_t          self = queue[qi].node8;
-    uint32_t                MAX_LEAF_TRIS = uint32_t(maxLeafTris());
+    uint32_t                MAX_LEAF_TRIS = uint32_t(leafTrisOpt);
     for(;;)
     {
       cands = cands0;

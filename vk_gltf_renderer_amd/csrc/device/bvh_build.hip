@@ -435,8 +435,10 @@ __global__ void k_re_refit(Bvh2Tree T, unsigned int* arrive)
     reinsertRefit(T, arrive, leaf);
 }
 
+// A failed call records the error and LEAVES THE ENCLOSING LOOP: the macro is a plain block (no do { } while(0) of its own, whose `break` would
+// only leave the macro), so its `break` belongs to the loop it is written in -- the do { } while(0) around a builder's body, or a pass / round
+// loop inside it, whose conditions test `ok` and which are followed by `if(!ok) break;` where more steps come after them.
 #define BUILD_CHECK(x)                                                                                                  \
-  do                                                                                                                    \
   {                                                                                                                     \
     hipError_t e_ = (x);                                                                                                \
     if(e_ != hipSuccess)                                                                                                \
@@ -445,8 +447,7 @@ __global__ void k_re_refit(Bvh2Tree T, unsigned int* arrive)
       ok  = false;                                                                                                      \
       break;                                                                                                            \
     }                                                                                                                   \
-  } while(0)
-// NB: BUILD_CHECK `break`s out of the single do { } while(0) that wraps buildBvh's body.
+  }
 
 }  // namespace
 

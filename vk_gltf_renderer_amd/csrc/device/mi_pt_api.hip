@@ -101,6 +101,12 @@ struct RunSwitches
                                    //                        atrium 604 -> 633, street 623 -> 680 Msamples/s; both switches: 682 / 727 (profiles/r05_staged_ab.txt)
   int    reinsertUpdate = 4;       // MI_PT_REINSERT_UPDATE  ... at the rebuilds of mi_pt_update_render_nodes (a moving instance pays them every time)
   int    reinsertRounds = 4;       // MI_PT_REINSERT_ROUNDS  lock / move rounds per pass
+  bool   collapseGreedy = false;   // MI_PT_COLLAPSE=sah|greedy  how BVH2 subtrees become children of an 8-wide node (anything else: mi_pt_create fails)
+  bool   collapseBad    = false;
+  int    leafTris       = 2;       // MI_PT_LEAF_TRIS=1|2    triangles per leaf child of the 8-wide BVH
+  bool   hostCollapse   = false;   // MI_PT_HOST_COLLAPSE    collapse on the host (the greedy reference of the device collapse)
+  int    maxItersDiag   = 0;       // MI_PT_DIAG_MAX_ITERS=N test hook: the bounce loop stops after N iterations whatever is still alive (the truncation a
+                                   //                        volume-scatter scene meets at maxDepth * 66 + 512)
   int    failBuildAt    = 0;       // MI_PT_DIAG_FAIL_BUILD=N  test hook: the N-th acceleration REbuild of the instance fails after the old structure is gone
   bool   candPoolSet    = false;   // MI_PT_DIAG_CAND_POOL   entries of the transmissive-candidate pool (tests of the overflow path)
   size_t candPool       = 0;
@@ -128,6 +134,14 @@ struct RunSwitches
     reinsert       = std::max(0, num("MI_PT_REINSERT", 16));
     reinsertUpdate = std::max(0, num("MI_PT_REINSERT_UPDATE", 4));
     reinsertRounds = std::max(1, num("MI_PT_REINSERT_ROUNDS", 4));
+    if(const char* e = getenv("MI_PT_COLLAPSE"))
+    {
+      collapseGreedy = strcmp(e, "greedy") == 0;
+      collapseBad    = !collapseGreedy && strcmp(e, "sah") != 0;  // (a typo must not silently select the other collapse)
+    }
+    leafTris       = std::min(2, std::max(1, num("MI_PT_LEAF_TRIS", 2)));
+    hostCollapse   = flag("MI_PT_HOST_COLLAPSE");
+    maxItersDiag   = num("MI_PT_DIAG_MAX_ITERS", 0);
     failBuildAt    = num("MI_PT_DIAG_FAIL_BUILD", 0);
     if(const char* e = getenv("MI_PT_DIAG_CAND_POOL"))
     {
@@ -493,7 +507,9 @@ int buildAccelerationUnguarded(MiPt* pt)
     if(pt->wide && bo.numTris > 0)
     {
       pt::Bvh8Output b8;
-      if(!pt::buildBvh8(bo, b8, nullptr, err))
+      pt::Bvh8Options b8opt;
+      b8opt.sahCollapse = !pt->sw.collapseGreedy; b8opt.maxLeafTris = pt->sw.leafTris; b8opt.hostCollapse = pt->sw.hostCollapse;
+      if(!pt::buildBvh8(bo, b8, nullptr, err, b8opt))
       {
         if(b8.nodes)
           (void)hipFree(b8.nodes);
@@ -615,6 +631,8 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
 
   std::unique_ptr<MiPt> pt(new MiPt());
   pt->sw.read();
+  if(pt->sw.collapseBad)
+    return fail(MI_PT_ERR_ARGUMENT, std::string("MI_PT_COLLAPSE=") + getenv("MI_PT_COLLAPSE") + " is neither \"sah\" nor \"greedy\"");
   pt->device          = device;
   pt->numCUs          = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   pt->collectCounters = options && options->collectCounters;
@@ -1132,6 +1150,20 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
               && hipEventCreateWithFlags(&pt->evShadowed, hipEventDisableTiming) == hipSuccess;
   pt::LaunchCtx cSide = c;
   cSide.stream        = pt->sideStream;
+  // Any early return below (a failed queue poll, a launch error) must not leave shadow-stage work queued on the side stream behind the caller's
+  // back: a caller that synchronises its own stream and then resizes or updates would race with kernels still adding into the radiance records.
+  // On every exit taken while a shadow stage is outstanding the side stream is drained (error paths only: the ordinary path joins it by event).
+  struct SideJoin
+  {
+    hipStream_t side        = nullptr;
+    bool        outstanding = false;
+    ~SideJoin()
+    {
+      if(outstanding && side)
+        (void)hipStreamSynchronize(side);
+    }
+  } sideJoin;
+  sideJoin.side = overlap ? pt->sideStream : nullptr;
   for(int s = 0; s < params->numSamples; ++s)
   {
     pt::launchResetCounters(c.queues, launchStream);
@@ -1155,6 +1187,8 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
       maxIters = 2 * params->maxDepth + 2;
     if(pt->hasVolumeScatter)
       maxIters = params->maxDepth * 66 + 512;
+    if(pt->sw.maxItersDiag > 0)
+      maxIters = std::min(maxIters, pt->sw.maxItersDiag);
     for(int it = 0; it < maxIters; ++it)
     {
       if(pt->hasVolumeScatter && it >= params->maxDepth && (it % 8) == 0)
@@ -1217,6 +1251,7 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
           (void)hipStreamWaitEvent(pt->sideStream, pt->evShaded, 0);
           timedOn(pt->sideStream, TK_SHADOW, [&] { pt::launchTraceShadow(cSide, cur ^ 1); });
           (void)hipEventRecord(pt->evShadowed, pt->sideStream);
+          sideJoin.outstanding = true;
         }
         else
           timed(TK_SHADOW, [&] { pt::launchTraceShadow(c, cur ^ 1); });
@@ -1225,7 +1260,13 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
       cur ^= 1;
     }
     if(overlap && iterations > 0)
+    {
       (void)hipStreamWaitEvent(stream, pt->evShadowed, 0);  // the last bounce's shadow terms, before the sample is folded
+      sideJoin.outstanding = false;                         // (joined: the caller's stream now orders everything after the side stream's work)
+    }
+    // paths the loop left alive (its iteration bound cut them: volume random walks) hand their radiance and seed over by slot
+    if(c.fc.stateInQueue && (pt->hasVolumeScatter || pt->sw.maxItersDiag > 0))
+      pt::launchFlushSurvivors(c, cur);
     timed(TK_ACCUM, [&] {
       pt::launchFinishSample(c, s, pt->accum, pt->depthImg(), guides ? pt->albedoImg() : nullptr, guides ? pt->normalImg() : nullptr);
     });

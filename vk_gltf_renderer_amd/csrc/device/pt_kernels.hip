@@ -2638,6 +2638,29 @@ __global__ void __launch_bounds__(256) k_shadow_resolve(const DevScene* __restri
 }
 
 //================================================================================================================================
+// k_flush_survivors: paths still alive when the host's bounce loop stops (volume-scatter scenes: the loop is cut at maxDepth * 66 + 512
+// iterations, mi_pt_api.hip) carry their radiance and seed in their queue entry (FrameConsts::stateInQueue) -- the records
+// k_finish_sample and the next sample of a multi-sample frame read BY SLOT are written only when a path ends inside the loop.  This
+// pass writes them for the survivors, so that a truncated path keeps its partial radiance and its current seed as it did while the
+// state lived by slot.  Normally the queue is empty and the launch costs a few microseconds per sample.
+//================================================================================================================================
+__global__ void __launch_bounds__(256) k_flush_survivors(PathSoA P, Queues Q, int cur)
+{
+  __shared__ uint32_t s_prefix[NSUB + 1];
+  queuePrefix(&Q.counters[cur ? QC_PAIR1 : QC_PAIR0], s_prefix);
+  const uint32_t count = s_prefix[NSUB];
+  for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
+  {
+    const uint32_t qpos = queuePos(Q.subCap, s_prefix, i);
+    const uint32_t slot = Q.active[cur].slot[qpos];
+    if(slot == QUEUE_DEAD)
+      continue;
+    P.radiance[slot] = Q.active[cur].rad[qpos];
+    P.misc[slot]     = Q.active[cur].misc[qpos];
+  }
+}
+
+//================================================================================================================================
 // k_finish_sample: firefly clamp + per-frame mean + running-mean accumulation + NDC depth
 // (gltf_pathtrace.slang:531-538, 596, 604-630)
 //================================================================================================================================
@@ -3004,6 +3027,10 @@ void launchTraceShadow(const LaunchCtx& c, int nxt)
     launchTraceShadowT<true>(c, nxt);
   else
     launchTraceShadowT<false>(c, nxt);
+}
+void launchFlushSurvivors(const LaunchCtx& c, int cur)
+{
+  hipLaunchKernelGGL(k_flush_survivors, dim3(c.persistentBlocks), dim3(256), 0, c.stream, c.paths, c.queues, cur);
 }
 void launchFinishSample(const LaunchCtx& c, int sampleIndex, float4* accum, float* depth, float4* albedo, float4* normal)
 {

@@ -741,6 +741,11 @@ bool GltfScene::decompressMeshopt()
 {
   const Value& views   = m_doc["bufferViews"];
   const Value& buffers = m_doc["buffers"];
+  // bytes that came WITH the file, counted once before any fallback buffer is materialised: the bound on those buffers is a multiple
+  // of this figure, and it must not grow with every fallback already filled (k empty fallbacks would compound to 80^k)
+  double loaded = 0.0, fallbackTotal = 0.0;
+  for(const std::vector<uint8_t>& b : m_buffers)
+    loaded += double(b.size());
   for(size_t i = 0; i < views.size(); ++i)
   {
     const Value* e = &ext(views[i], "KHR_meshopt_compression");
@@ -768,12 +773,11 @@ bool GltfScene::decompressMeshopt()
       // a fallback buffer without data: give it its declared length (bounded: what the views into it can address)
       // ... and by what the streams of this file can possibly expand to: the densest vertex stream spends 4 header bytes on a plane of 256 zero
       // differences (64 : 1), an index stream at least one byte per 12-byte triangle
+      // (`loaded`: the file's own bytes; the bound holds for ALL fallback buffers together)
       const double declared = buffers[size_t(dstBuffer)]["byteLength"].number(0.0);
-      double       loaded   = 0.0;
-      for(const std::vector<uint8_t>& b : m_buffers)
-        loaded += double(b.size());
-      if(!(declared >= 0 && declared <= 80.0 * loaded + 4096.0))
+      if(!(declared >= 0 && fallbackTotal + declared <= 80.0 * loaded + 4096.0))
         return bad("fallback buffer length out of proportion to the file");
+      fallbackTotal += declared;
       dst.assign(size_t(declared), 0);
     }
     if(!(dstOffset + dstLength <= double(dst.size())))
