@@ -418,6 +418,7 @@ def secondary_line(name, args, device, width=0, height=0, steps=5, parity=True, 
                        "denoise": ("variance-guided a-trous (mi_pt_denoise_svgf, 5 iterations) once per step, inside the timed region" if denoise else None)},
             "timed_region_s": round(elapsed, 3),
             "device_memory_GB": {"scene": round(mem["sceneBytes"] / 1e9, 3), "path_state_queues_images": round(mem["rendererBytes"] / 1e9, 3)},
+            "bytes_per_path_slot": round(mem["pathStateBytes"] / max(1, mem["pathSlots"]), 1),
             "roofline": roofline_of(kernels, pmc), "kernels": kernels, "streams": streams,
             "per_frame": {k: round(per_frame[k], 1) for k in keys},
             "node_visits_per_secondary_ray": round(per_frame["nodesClosest"] / max(1.0, per_frame["segments"] - per_frame["cameraPaths"]), 2),
@@ -481,6 +482,8 @@ def compact_line(result):
                 out["also"][name] = {"error": ln["error"][:160]}
                 continue
             e = {"value": ln["value"], "ms_per_frame": ln["ms_per_frame"], "resolution": ln["config"]["resolution"], "roofline": compact_roofline(ln.get("roofline"), full=False)}
+            if "bytes_per_path_slot" in ln:
+                e["bytes_per_path_slot"], e["path_state_GB"] = ln["bytes_per_path_slot"], ln["device_memory_GB"]["path_state_queues_images"]
             if ln.get("cpu_baseline") and "error" not in ln["cpu_baseline"]:
                 e["cpu_baseline"] = ln["cpu_baseline"]["value"]
             if ln.get("parity") and "error" not in ln["parity"]:
@@ -755,6 +758,7 @@ def main():
             "per_frame_bounce0": {k: round(first[k], 1) for k in keys},
             "frame_ms_device": round(timing["totalMs"] / frames_timed, 4),
             "device_memory_GB": {"scene": round(mem["sceneBytes"] / 1e9, 3), "path_state_queues_images": round(mem["rendererBytes"] / 1e9, 3)},
+            "bytes_per_path_slot": round(mem["pathStateBytes"] / max(1, mem["pathSlots"]), 1),
             "node_visits_per_secondary_ray": round(per_frame["nodesClosest"] / max(1.0, per_frame["segments"] - per_frame["cameraPaths"]), 2),
             "triangle_tests_per_secondary_ray": round(per_frame["trisClosest"] / max(1.0, per_frame["segments"] - per_frame["cameraPaths"]), 2),
         }

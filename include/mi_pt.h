@@ -278,6 +278,8 @@ typedef struct MiPtMemory
   uint64_t rendererBytes;
   uint64_t deviceUsedBytes;  /* whole device, all processes: total - free as the driver reports it */
   uint64_t deviceTotalBytes;
+  uint64_t pathStateBytes;   /* the part of rendererBytes that grows with the frames in flight: by-slot path records + the three ray queues (+ candidate pool) */
+  uint64_t pathSlots;        /* owned pixel slots x frames in flight the arrays are sized for: pathStateBytes / pathSlots = bytes per path slot */
 } MiPtMemory;
 MI_PT_API int mi_pt_get_memory(MiPt* pt, MiPtMemory* memory);
 

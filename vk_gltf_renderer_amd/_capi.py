@@ -121,7 +121,7 @@ class MiPtStats(C.Structure):
 
 
 class MiPtMemory(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("sceneBytes", "rendererBytes", "deviceUsedBytes", "deviceTotalBytes")]
+    _fields_ = [(n, C.c_uint64) for n in ("sceneBytes", "rendererBytes", "deviceUsedBytes", "deviceTotalBytes", "pathStateBytes", "pathSlots")]
 
 
 class MiPtFrameTiming(C.Structure):

@@ -210,7 +210,13 @@ struct MiPt
   DevBuf<uint32_t>        ownedTiles;
   int                     numSlots = 0, tilesX = 0, tilesY = 0;
   int                     framesCap = 1;  // frames in flight the path/queue arrays are sized for
-  DevBuf<float4>          pathArrays;  // one allocation, sliced into PathSoA
+  size_t                  queueCap  = 0;  // positions of one queue (NSUB x subCap)
+  DevBuf<float4>          pathArrays;  // PathSoA::radiance: the one by-slot record every batch needs
+  // ... and the by-slot records only some batches need, allocated the first time one does (ensureOptionalPathArrays): `optMisc` + `optPixelSum`
+  // multi-sample frames, `optThroughput` (+ optMisc) frames whose state lives by slot (shadow-catcher plane, MI_PT_STATE_BY_SLOT), `optMedium` scenes with
+  // volume materials (the generic shade kernel), `optGuides` batches that capture the denoiser guides, `optShadowAux2` shadow-catcher frames
+  DevBuf<float4>          optThroughput, optMisc, optMedium, optPixelSum, optGuides, optShadowAux2;
+  DevBuf<float4>          firstHit;    // PathSoA::firstHit: per PIXEL slot (frame 0 of a first-frame batch only)
   pt::PathSoA             paths{};
   DevBuf<uint32_t>        queueMem;
   DevBuf<float4>          queuePayload;
@@ -296,12 +302,15 @@ int allocPathResources(MiPt* pt, int frames)
     return fail(MI_PT_ERR_ARGUMENT, "too many path slots: reduce the frames in flight or the resolution");
   pt->framesCap          = frames;
   const size_t n         = std::max(size_t(pt->numSlots) * size_t(frames), size_t(1));
-  const int    numArrays = 8;
-  HIP_TRY(pt->pathArrays.alloc(n * numArrays));
-  float4*      base = pt->pathArrays.ptr;
-  pt::PathSoA& P    = pt->paths;
-  P.throughput = base + n * 0; P.radiance = base + n * 1; P.misc = base + n * 2; P.medium = reinterpret_cast<uint4*>(base + n * 3);
-  P.firstHit = base + n * 4; P.pixelSum = base + n * 5; P.guideAlbedo = base + n * 6; P.guideNormal = base + n * 7;
+  // By slot: the radiance record alone (what k_finish_sample folds; a path's other state travels in its queue entry).  The optional
+  // records of the previous size are dropped and come back on demand.
+  HIP_TRY(pt->pathArrays.alloc(n));
+  HIP_TRY(pt->firstHit.alloc(std::max(size_t(pt->numSlots), size_t(1))));
+  pt->optThroughput.release(); pt->optMisc.release(); pt->optMedium.release(); pt->optPixelSum.release(); pt->optGuides.release(); pt->optShadowAux2.release();
+  pt::PathSoA& P = pt->paths;
+  P              = pt::PathSoA{};
+  P.radiance     = pt->pathArrays.ptr;
+  P.firstHit     = pt->firstHit.ptr;
   // sub-queue capacity: ceil(numChunks / NSUB) chunks (+1 of slack), see pt_scene.h
   const size_t numChunks = (n + pt::QCHUNK - 1) / pt::QCHUNK;
   const size_t subCap    = ((numChunks + pt::NSUB - 1) / pt::NSUB + 1) * pt::QCHUNK;
@@ -312,23 +321,29 @@ int allocPathResources(MiPt* pt, int frames)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_render_frames: " + std::to_string(frames) + " frames in flight x " + std::to_string(pt->numSlots)
                                         + " pixel slots exceed 2^31 path slots");
   HIP_TRY(pt->queueMem.alloc(qsize * 3 + pt::QC_COUNT));
-  HIP_TRY(pt->queuePayload.alloc(qsize * 16));
+  // 14 records of 16 bytes per queue position: the two active queues' ray + state (org, dir, aux2, misc, rad), ONE hit record shared by both (the
+  // closest-hit walk writes it, the shade launch of the same bounce reads it, and the next walk -- of the other queue -- starts after that launch:
+  // the two queues' hit records are never alive together), the shadow queue's ray + contribution (org, dir, aux).  The shadow queue's aux2 exists
+  // on shadow-catcher frames only (optShadowAux2).
+  HIP_TRY(pt->queuePayload.alloc(qsize * 14));
+  pt->queueCap = qsize;
   pt::RayQueue* qs[3] = {&pt->queues.active[0], &pt->queues.active[1], &pt->queues.shadow};
   for(int i = 0; i < 3; ++i)
-  {
     qs[i]->slot = pt->queueMem.ptr + qsize * size_t(i);
-    qs[i]->org  = pt->queuePayload.ptr + qsize * size_t(3 * i + 0);
-    qs[i]->dir  = pt->queuePayload.ptr + qsize * size_t(3 * i + 1);
-    qs[i]->aux  = pt->queuePayload.ptr + qsize * size_t(3 * i + 2);
-  }
-  pt->queues.shadow.aux2    = pt->queuePayload.ptr + qsize * 9;
-  pt->queues.shadow.misc = pt->queues.shadow.rad = nullptr;
-  for(int i = 0; i < 2; ++i)  // the living paths' state, in queue order (pt_scene.h: RayQueue, FrameConsts::stateInQueue)
+  for(int i = 0; i < 2; ++i)  // the living paths' ray and state, in queue order (pt_scene.h: RayQueue, FrameConsts::stateInQueue)
   {
-    qs[i]->aux2 = pt->queuePayload.ptr + qsize * size_t(10 + 3 * i + 0);
-    qs[i]->misc = pt->queuePayload.ptr + qsize * size_t(10 + 3 * i + 1);
-    qs[i]->rad  = pt->queuePayload.ptr + qsize * size_t(10 + 3 * i + 2);
+    qs[i]->org  = pt->queuePayload.ptr + qsize * size_t(5 * i + 0);
+    qs[i]->dir  = pt->queuePayload.ptr + qsize * size_t(5 * i + 1);
+    qs[i]->aux2 = pt->queuePayload.ptr + qsize * size_t(5 * i + 2);
+    qs[i]->misc = pt->queuePayload.ptr + qsize * size_t(5 * i + 3);
+    qs[i]->rad  = pt->queuePayload.ptr + qsize * size_t(5 * i + 4);
+    qs[i]->aux  = pt->queuePayload.ptr + qsize * 10;
   }
+  pt->queues.shadow.org  = pt->queuePayload.ptr + qsize * 11;
+  pt->queues.shadow.dir  = pt->queuePayload.ptr + qsize * 12;
+  pt->queues.shadow.aux  = pt->queuePayload.ptr + qsize * 13;
+  pt->queues.shadow.aux2 = nullptr;
+  pt->queues.shadow.misc = pt->queues.shadow.rad = nullptr;
   pt->queues.counters = pt->queueMem.ptr + 3 * qsize;
   pt->queues.subCap   = uint32_t(subCap);
   // recorded transmissive shadow candidates (pt_scene.h): two pool entries per shadow-queue entry, and an overflow list as long as
@@ -349,6 +364,54 @@ int allocPathResources(MiPt* pt, int frames)
     pt->queues.candCap  = uint32_t(candCap);
   }
   HIP_TRY(hipMemset(pt->queues.counters, 0, sizeof(uint32_t) * pt::QC_COUNT));
+  return MI_PT_OK;
+}
+
+// The by-slot / by-position records only some batches need (MiPt::opt*): allocated the first time a batch needs them, at the size of the
+// current path resources, and kept until those are reallocated.  An allocation here synchronises the device once.
+int ensureOptionalPathArrays(MiPt* pt, bool stateBySlot, bool multiSample, bool guides, bool catcher)
+{
+  const size_t n = std::max(size_t(pt->numSlots) * size_t(pt->framesCap), size_t(1));
+  auto need = [&](DevBuf<float4>& b, size_t count) -> int {
+    if(b.ptr)
+      return MI_PT_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(b.alloc(count));
+    HIP_TRY(hipMemset(b.ptr, 0, count * sizeof(float4)));
+    return MI_PT_OK;
+  };
+  pt::PathSoA& P = pt->paths;
+  if(stateBySlot || multiSample)
+  {
+    if(int rc = need(pt->optMisc, n)) return rc;
+    P.misc = pt->optMisc.ptr;
+  }
+  if(stateBySlot)
+  {
+    if(int rc = need(pt->optThroughput, n)) return rc;
+    P.throughput = pt->optThroughput.ptr;
+  }
+  if(multiSample)
+  {
+    if(int rc = need(pt->optPixelSum, n)) return rc;
+    P.pixelSum = pt->optPixelSum.ptr;
+  }
+  if(!pt->simpleMaterials || pt->sw.genericShade)  // the generic shade kernel keeps the medium a path is inside of
+  {
+    if(int rc = need(pt->optMedium, n)) return rc;
+    P.medium = reinterpret_cast<uint4*>(pt->optMedium.ptr);
+  }
+  if(guides)
+  {
+    if(int rc = need(pt->optGuides, 2 * n)) return rc;
+    P.guideAlbedo = pt->optGuides.ptr;
+    P.guideNormal = pt->optGuides.ptr + n;
+  }
+  if(catcher)
+  {
+    if(int rc = need(pt->optShadowAux2, pt->queueCap)) return rc;
+    pt->queues.shadow.aux2 = pt->optShadowAux2.ptr;
+  }
   return MI_PT_OK;
 }
 
@@ -1027,9 +1090,11 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   pt::divideMagic(uint32_t(std::max(numFrames, 2)), c.fc.framesMagic, c.fc.framesShift);
   c.fc.slotLayout = (numFrames % 64 == 0 && !pt->sw.microtileSlots) ? 1 : 0;  // (A/B switch: micro-tile major at any batch size)
   c.fc.stateInQueue = (!pt->sw.stateBySlot && !(pt->frameInfo.flags & MI_SCENE_INFINITE_PLANE_SHADOW_CATCHER)) ? 1 : 0;
+  const bool guides = (params->flags & MI_PT_USE_OPTIX_DENOISER) != 0;
+  if(int rc = ensureOptionalPathArrays(pt, c.fc.stateInQueue == 0, params->numSamples > 1, guides, (pt->frameInfo.flags & MI_SCENE_INFINITE_PLANE_SHADOW_CATCHER) != 0))
+    return rc;
   c.paths        = pt->paths;
   pt->accumFrames   = float(params->totalSamples) / float(params->numSamples) + float(numFrames);
-  const bool guides = (params->flags & MI_PT_USE_OPTIX_DENOISER) != 0;
   // the second moment covers the accumulation only if every batch since its start carried the guides
   if(guides && (params->totalSamples == 0 || pt->momentFrames == pt->accumFrames - float(numFrames)))
     pt->momentFrames = pt->accumFrames;
@@ -1519,7 +1584,9 @@ int mi_pt_get_memory(MiPt* pt, MiPtMemory* out)
                    + bytes(pt->shadeTris) + bytes(pt->texRefs) + bytes(pt->bvh8Planes);
   // the acceleration structure is raw allocations: 64-B BVH2 nodes or 80-B BVH8 nodes + 48-B triangle records
   scene += uint64_t(pt->staticStats.bvhNodeCount) * pt->staticStats.bvhNodeBytes + uint64_t(sc.numTris) * sizeof(pt::DevTri);
-  const uint64_t renderer = bytes(pt->pathArrays) + bytes(pt->queueMem) + bytes(pt->queuePayload) + bytes(pt->candPool) + bytes(pt->candLists) + bytes(pt->accumOwn)
+  const uint64_t pathState = bytes(pt->pathArrays) + bytes(pt->optThroughput) + bytes(pt->optMisc) + bytes(pt->optMedium) + bytes(pt->optPixelSum) + bytes(pt->optGuides)
+                             + bytes(pt->optShadowAux2) + bytes(pt->queueMem) + bytes(pt->queuePayload) + bytes(pt->candPool) + bytes(pt->candLists);
+  const uint64_t renderer = pathState + bytes(pt->firstHit) + bytes(pt->accumOwn)
                             + bytes(pt->albedo) + bytes(pt->normal) + bytes(pt->denoiseA) + bytes(pt->denoiseB) + bytes(pt->tonemapped) + bytes(pt->depth)
                             + bytes(pt->selection) + bytes(pt->ownedTiles) + bytes(pt->sceneDev) + bytes(pt->fcRing) + bytes(pt->stats);
   size_t freeB = 0, totalB = 0;
@@ -1528,6 +1595,8 @@ int mi_pt_get_memory(MiPt* pt, MiPtMemory* out)
   out->rendererBytes    = renderer;
   out->deviceUsedBytes  = uint64_t(totalB - freeB);
   out->deviceTotalBytes = uint64_t(totalB);
+  out->pathStateBytes   = pathState;
+  out->pathSlots        = uint64_t(std::max(pt->numSlots, 0)) * uint64_t(std::max(pt->framesCap, 1));
   return MI_PT_OK;
 }
 

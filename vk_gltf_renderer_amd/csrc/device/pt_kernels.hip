@@ -377,7 +377,8 @@ __global__ void __launch_bounds__(256) k_generate(DevScene sc, FrameConsts fc, P
     cp = generateCameraPath(fc, P, ownedTiles, slot, sampleIndex);
   if(cp.valid)
   {
-    P.misc[slot] = make_float4(0.0f, __uint_as_float(PF_ALIVE), __uint_as_float(cp.seed), 0.0f);  // cone.width = 0
+    if(P.misc)
+      P.misc[slot] = make_float4(0.0f, __uint_as_float(PF_ALIVE), __uint_as_float(cp.seed), 0.0f);  // cone.width = 0
     if(stats)
       atomicAdd(&stats->cameraPaths, 1ull);
   }
@@ -1405,9 +1406,10 @@ __global__ void __launch_bounds__(256, INTERVAL ? PRIMARY_INTERVAL_MIN_WAVES : P
   if(active && !toShade)
   {
     if(hasFlag(fc.pc.flags, MI_PT_FIRST_FRAME) && cp.frame == 0u)  // NDC depth input of a first frame (k_finish_sample)
-      P.firstHit[slot] = make_float4(cp.direction.x, cp.direction.y, cp.direction.z, 0.0f);
+      P.firstHit[pathSlotPixel(fc, slot)] = make_float4(cp.direction.x, cp.direction.y, cp.direction.z, 0.0f);
     P.radiance[slot] = make_float4(cp.direction.x, cp.direction.y, cp.direction.z, __uint_as_float(RADW_PRIMARY_MISS));
-    P.misc[slot]     = make_float4(0.0f, __uint_as_float(PF_NOT_SOLID | PF_PRIMARY_MISS), __uint_as_float(cp.seed), 0.0f);  // depth 0, not alive
+    if(P.misc)  // (multi-sample frames: the next sample's seed)
+      P.misc[slot] = make_float4(0.0f, __uint_as_float(PF_NOT_SOLID | PF_PRIMARY_MISS), __uint_as_float(cp.seed), 0.0f);  // depth 0, not alive
   }
   if(COUNT)
   {
@@ -1727,7 +1729,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
         {
           solid             = false;
           if(needFirstHit)
-            P.firstHit[slot] = make_float4(rayDir.x, rayDir.y, rayDir.z, 0.0f);
+            P.firstHit[pathSlotPixel(fc, slot)] = make_float4(rayDir.x, rayDir.y, rayDir.z, 0.0f);
           backplate = primaryMissBackplate(sc, fc, rayDir, radiance);
         }
         if(!backplate)
@@ -1765,7 +1767,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
             catcherPlane = true;
             coneWidth    = worldFoot;
             if(FIRST && needFirstHit)  // the reference leaves SampleResult::hitPosition at its 1e34 default on this path
-              P.firstHit[slot] = make_float4(1e34f, 1e34f, 1e34f, 0.0f);
+              P.firstHit[pathSlotPixel(fc, slot)] = make_float4(1e34f, 1e34f, 1e34f, 0.0f);
             DirectLight dl;
             sampleLights(sc, fc, hit.pos, seed, dl);
             const bool traceIt = dot(dl.direction, hit.nrm) > 0.0f && dl.pdf != 0.0f;
@@ -1820,7 +1822,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
           if(firstRay)  // gltf_pathtrace.slang:228-264
           {
             if(needFirstHit)
-              P.firstHit[slot] = make_float4(hit.pos.x, hit.pos.y, hit.pos.z, 0.0f);
+              P.firstHit[pathSlotPixel(fc, slot)] = make_float4(hit.pos.x, hit.pos.y, hit.pos.z, 0.0f);
             if(P.guideAlbedo)
             {
               float4 ga = P.guideAlbedo[slot], gn = P.guideNormal[slot];
@@ -1985,7 +1987,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
       if(!stateInQueue || !alive)
       {
         P.radiance[slot] = nextRad;
-        P.misc[slot]     = nextMisc;
+        if(P.misc)  // (null unless the frame has several samples or its state lives by slot: PathSoA)
+          P.misc[slot] = nextMisc;
       }
       if(alive)
       {
@@ -2656,7 +2659,8 @@ __global__ void __launch_bounds__(256) k_flush_survivors(PathSoA P, Queues Q, in
     if(slot == QUEUE_DEAD)
       continue;
     P.radiance[slot] = Q.active[cur].rad[qpos];
-    P.misc[slot]     = Q.active[cur].misc[qpos];
+    if(P.misc)
+      P.misc[slot] = Q.active[cur].misc[qpos];
   }
 }
 
@@ -2751,7 +2755,7 @@ __global__ void __launch_bounds__(256) k_finish_sample(FrameConsts fc, const Dev
       float      ndcDepth    = 1.0f;
       if(hasSolidHit)
       {
-        float4 fh   = P.firstHit[slot];
+        float4 fh   = P.firstHit[pslot];  // (per pixel slot: f == 0 here)
         f4     clip = mulFull(fc.frameInfo.viewProjMatrix, mk4(fh.x, fh.y, fh.z, 1.0f));
         ndcDepth    = clip.z / clip.w;
       }

@@ -266,6 +266,14 @@ __device__ __forceinline__ uint32_t pathSlotFrame(const FrameConsts& fc, uint32_
   const uint32_t w = fc.slotLayout == 1 ? slot : (slot >> 6), q = __umulhi(w, fc.framesMagic) >> fc.framesShift;
   return w - q * uint32_t(fc.numFrames);
 }
+// the pixel slot of a path slot (the inverse of pathSlot in its first argument): index of the per-pixel records (PathSoA::firstHit)
+__device__ __forceinline__ uint32_t pathSlotPixel(const FrameConsts& fc, uint32_t slot)
+{
+  if(fc.numFrames <= 1)
+    return slot;
+  const uint32_t w = fc.slotLayout == 1 ? slot : (slot >> 6), q = __umulhi(w, fc.framesMagic) >> fc.framesShift;
+  return fc.slotLayout == 1 ? q : (q * 64u + (slot & 63u));
+}
 #endif
 
 // ---- per-path state, structure of arrays indexed by slot -----------------------------------------------------------------
@@ -285,15 +293,20 @@ enum : uint32_t
 constexpr uint32_t RADW_NOT_SOLID    = 0x80000000u;  // sign bit of maxRoughness.x (which is >= 0)
 constexpr uint32_t RADW_PRIMARY_MISS = 0xffc00001u;  // a NaN no arithmetic produces (maxRoughness.x of such a path is 0 and never read)
 
+// `radiance` is the one record every batch has by slot (396 B per path slot went to slot-indexed state and queue entries until round 4; 252 now).
+// The others exist only for the batches that need them (mi_pt_api.hip: ensureOptionalPathArrays) and are NULL otherwise -- a kernel that writes one
+// outside the feature that needs it tests the pointer first.
 struct PathSoA
 {
-  float4*   throughput;   // rgb, lastSamplePdf
   float4*   radiance;     // rgb, maxRoughness.x (>= 0) with the sign bit = !solid (RADW_NOT_SOLID); RADW_PRIMARY_MISS: rgb = the camera
-                          // ray's direction (k_trace_primary) -- k_finish_sample reads this record alone
-  float4*   misc;         // maxRoughness.y, flags (uint bits), seed (uint bits), cone.width
-  uint4*    medium;       // VolumeMedium as 7 halves packed
-  float4*   firstHit;     // firstHitPos.xyz, unused
-  float4*   pixelSum;     // sum over the frame's samples of the clamped radiance rgba
+                          // ray's direction (k_trace_primary) -- k_finish_sample reads this record alone.  Written when a path ENDS (its
+                          // queue entry carries it while it lives), or at every bounce when the state lives by slot
+  float4*   firstHit;     // firstHitPos.xyz, unused.  Per PIXEL slot (pathSlotPixel): only frame 0 of a first-frame batch has one (NDC depth)
+  float4*   misc;         // maxRoughness.y, flags (uint bits), seed (uint bits), cone.width.  Multi-sample frames (the next sample starts from the
+                          // seed) and state-by-slot frames; else null
+  float4*   throughput;   // rgb, lastSamplePdf.  State-by-slot frames (shadow-catcher plane, MI_PT_STATE_BY_SLOT); else null
+  uint4*    medium;       // VolumeMedium as 7 halves packed.  Scenes that run the generic shade kernel (volume materials); else null
+  float4*   pixelSum;     // sum over the frame's samples of the clamped radiance rgba.  Multi-sample frames; else null
   float4*   guideAlbedo;  // optional (denoiser guides): sum over samples
   float4*   guideNormal;
 };
