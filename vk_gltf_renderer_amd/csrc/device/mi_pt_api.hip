@@ -180,7 +180,7 @@ struct MiPt
   pt::DevTri*                 bvhTris   = nullptr;
   bool                        wide      = true;
   pt::DevScene                scene{};
-  bool                        hasAlpha = false, hasVolumeScatter = false, simpleMaterials = true, hasTransmissive = false;
+  bool                        hasAlpha = false, hasAlphaTest = false, hasVolumeScatter = false, simpleMaterials = true, hasTransmissive = false;
   // device-resident descriptor copies (see k_shade): the scene struct, re-uploaded when the environment changes, and a ring
   // of per-batch frame constants fed from pinned host memory
   static constexpr int        FC_RING = 32;
@@ -197,7 +197,7 @@ struct MiPt
   // host copies of what the acceleration structure is built from, kept so that mi_pt_update_render_nodes can rebuild it
   std::vector<MiGltfRenderNode> hostNodes;
   std::vector<uint8_t>          hostVisible;    // empty = all visible
-  std::vector<uint8_t>          matInstFlags;   // per material: INST_FORCE_OPAQUE | INST_CULL_DISABLE | INST_TRANSMISSIVE
+  std::vector<uint8_t>          matInstFlags;   // per material: INST_FORCE_OPAQUE | INST_CULL_DISABLE | INST_TRANSMISSIVE | INST_ALPHA_PASSES
   std::vector<uint8_t>          matFeatures;    // per material: bit0 volume scatter, bit1 needs the generic shade kernel
   std::vector<uint32_t>         primTriangles;  // per render primitive: triangle count, 0 when it has no usable geometry
   int                           bvhBuilder = 0;
@@ -500,7 +500,7 @@ int buildAccelerationUnguarded(MiPt* pt)
   std::vector<int32_t>  entryNode;
   uint64_t              totalTris = 0;
   triOffset.push_back(0);
-  pt->hasAlpha = pt->hasTransmissive = pt->hasVolumeScatter = false;
+  pt->hasAlpha = pt->hasAlphaTest = pt->hasTransmissive = pt->hasVolumeScatter = false;
   pt->simpleMaterials = true;
   for(int n = 0; n < numNodes; ++n)
   {
@@ -509,6 +509,8 @@ int buildAccelerationUnguarded(MiPt* pt)
     uint32_t                f  = pt->matInstFlags[size_t(m)];
     if(!(f & pt::INST_FORCE_OPAQUE))
       pt->hasAlpha = true;
+    if(!(f & (pt::INST_FORCE_OPAQUE | pt::INST_ALPHA_PASSES)))
+      pt->hasAlphaTest = true;  // some candidate's alpha test has an open outcome (MASK / BLEND materials)
     if(f & pt::INST_TRANSMISSIVE)
       pt->hasTransmissive = true;
     if(pt->matFeatures[size_t(m)] & 1u)
@@ -782,6 +784,8 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
       f |= pt::INST_CULL_DISABLE;
     if(mat.transmissionFactor > 0.01f)  // MIN_TRANSMISSION, shaders/pathtrace_functions.h.slang:36,256
       f |= pt::INST_TRANSMISSIVE;
+    if(!(f & pt::INST_FORCE_OPAQUE) && mat.alphaMode == MI_ALPHA_OPAQUE)  // getOpacity == 1: the alpha draw always commits (pt_scene.h)
+      f |= pt::INST_ALPHA_PASSES;
     pt->matInstFlags[size_t(m)] = uint8_t(f);
     uint32_t g = 0;
     if(mat.multiscatterColorFactor[0] > 0.0f || mat.multiscatterColorFactor[1] > 0.0f || mat.multiscatterColorFactor[2] > 0.0f)
@@ -1111,6 +1115,9 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   c.stream           = stream;
   c.persistentBlocks = unsigned(pt->numCUs) * 8u;
   c.hasAlpha         = pt->hasAlpha && !pt->sw.ignoreAlpha;  // diagnostics: what the alpha tests cost (wrong image)
+  // the closest-hit walks run their alpha machinery only where some alpha test has an open outcome: a scene whose non-opaque instances all have
+  // alphaMode OPAQUE (transmissive glass) takes the plain kernels -- every candidate commits (INST_ALPHA_PASSES)
+  c.hasAlphaClosest  = c.hasAlpha && pt->hasAlphaTest;
   c.hasTransmissive  = pt->hasTransmissive;
   c.simpleMaterials  = pt->simpleMaterials && !pt->sw.genericShade;
   c.wide             = pt->wide;

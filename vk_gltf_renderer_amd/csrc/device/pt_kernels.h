@@ -19,6 +19,7 @@ struct LaunchCtx
   hipStream_t     stream;
   unsigned        persistentBlocks;
   bool            hasAlpha;
+  bool            hasAlphaClosest;  // hasAlpha and some instance needs a real alpha test (not INST_ALPHA_PASSES): the closest-hit walks carry the alpha machinery
   bool            hasTransmissive;  // some instance carries INST_TRANSMISSIVE (ordered shadow transmission needed)
   bool            simpleMaterials;  // no material needs the transmission / clearcoat / sheen / iridescence / anisotropy paths
   bool            wide;  // traverse the 8-wide compressed BVH (scene.bvh8Nodes) instead of the BVH2

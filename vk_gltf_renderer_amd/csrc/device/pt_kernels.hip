@@ -496,7 +496,7 @@ PT_DEV void closestTestLoaded(const DevScene& sc, const RaySetup& r, const DevTr
   // RAY_FLAG_CULL_BACK_FACING_TRIANGLES unless TRIANGLE_FACING_CULL_DISABLE; facing is decided in object space
   const bool front = h.front != ((flags & INST_FLIP_FACING) != 0u);
   better           = better && (front || (flags & INST_CULL_DISABLE));
-  if(HAS_ALPHA && better && !(flags & INST_FORCE_OPAQUE))
+  if(HAS_ALPHA && better && !(flags & (INST_FORCE_OPAQUE | INST_ALPHA_PASSES)))  // (ALPHA_PASSES: opacity 1, the draw always commits)
   {
     if(!seedLoaded)
     {
@@ -597,6 +597,38 @@ struct CandRec
   uint32_t  cur, end;
 };
 constexpr uint32_t CAND_CHUNK = 256;  // >= 64, the most one alpha round can record
+// Records the transmissive shadow candidates of the lanes with `record` (whole wave; {t, u, v, triangle} of each goes to the device-wide pool, out of
+// the wave's private piece, chained to its ray -- the lane `owner` of this wave -- through the LDS list heads).
+PT_DEV void recordCandidates(CandRec* rec, bool record, uint32_t owner, float t, float u, float v, uint32_t tri)
+{
+  const unsigned long long m = __ballot(record);
+  if(m == 0ull)
+    return;
+  const uint32_t lane = laneId();
+  const uint32_t n    = uint32_t(__popcll(m));
+  if(rec->cur + n > rec->end)
+  {
+    const int first = __ffsll((long long)m) - 1;
+    uint32_t  base  = 0u;
+    if(int(lane) == first)
+      base = atomicAdd(rec->poolCounter, CAND_CHUNK);
+    rec->cur = uint32_t(__builtin_amdgcn_readlane(int(base), first));
+    rec->end = rec->cur + CAND_CHUNK;
+  }
+  const uint32_t idx = rec->cur + laneCountBelow(m);
+  rec->cur += n;
+  if(record)
+  {
+    if(idx < rec->cap)
+    {
+      rec->pool[idx] = make_float4(t, u, v, __uint_as_float(tri));
+      rec->next[idx] = __hip_atomic_exchange(&rec->waveHead[owner], idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    else
+      rec->waveOvf[owner] = 1u;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
 // SHADOW: any-hit semantics (an accepted candidate occludes, draw < opacity); otherwise closest-hit (draw <= opacity).
 // REC (shadow only): candidates on transmissive instances are not decided here -- their effect depends on their order along
 // the ray (Beer segments, raytracer_interface.h.slang:160-178) -- but recorded for k_shadow_resolve.
@@ -624,36 +656,7 @@ PT_DEV void alphaRound(const DevScene& sc, uint32_t seed0, uint4* waveAlpha, uin
     }
   }
   if(REC)
-  {
-    const unsigned long long m = __ballot(record);
-    if(m != 0ull)
-    {
-      // pool entries of all the round's transmissive candidates, out of the wave's private piece
-      const uint32_t n = uint32_t(__popcll(m));
-      if(rec->cur + n > rec->end)
-      {
-        const int first = __ffsll((long long)m) - 1;
-        uint32_t  base  = 0u;
-        if(int(lane) == first)
-          base = atomicAdd(rec->poolCounter, CAND_CHUNK);
-        rec->cur = uint32_t(__builtin_amdgcn_readlane(int(base), first));
-        rec->end = rec->cur + CAND_CHUNK;
-      }
-      const uint32_t idx = rec->cur + laneCountBelow(m);
-      rec->cur += n;
-      if(record)
-      {
-        if(idx < rec->cap)
-        {
-          rec->pool[idx] = make_float4(__uint_as_float(e.y), __uint_as_float(e.z), __uint_as_float(e.w), __uint_as_float(tri));
-          rec->next[idx] = __hip_atomic_exchange(&rec->waveHead[owner], idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        else
-          rec->waveOvf[owner] = 1u;
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
+    recordCandidates(rec, record, owner, __uint_as_float(e.y), __uint_as_float(e.z), __uint_as_float(e.w), tri);
   unsigned long long acc = __ballot(accept);
   while(acc != 0ull)
   {
@@ -711,7 +714,7 @@ PT_DEV void triRoundFinish(const DevScene& sc, const RaySetup& r, ClosestBest& b
       const bool front = h.front != ((flags & INST_FLIP_FACING) != 0u);
       if(front || (flags & INST_CULL_DISABLE))
       {
-        needAlpha = HAS_ALPHA && !(flags & INST_FORCE_OPAQUE);
+        needAlpha = HAS_ALPHA && !(flags & (INST_FORCE_OPAQUE | INST_ALPHA_PASSES));  // (ALPHA_PASSES: opacity 1, the draw always commits)
         tHit      = h.t;
         rt        = needAlpha ? -1.0f : h.t;  // negative tells the owner "deferred"
         ru        = h.u;
@@ -775,7 +778,7 @@ PT_DEV void triRoundFinishShadow(const DevScene& sc, const RaySetup& r, float tM
   const f3       org = mk3(laneRead(r.org.x, src), laneRead(r.org.y, src), laneRead(r.org.z, src));
   const f3       dir = mk3(laneRead(r.dir.x, src), laneRead(r.dir.y, src), laneRead(r.dir.z, src));
   const float    tmaxSrc = laneRead(tMax, src);
-  bool           commits = false, needAlpha = false;
+  bool           commits = false, needAlpha = false, recordNow = false;
   float          hu = 0.0f, hv = 0.0f, ht = 0.0f;
   if(tr.has)
   {
@@ -787,8 +790,12 @@ PT_DEV void triRoundFinishShadow(const DevScene& sc, const RaySetup& r, float tM
       // RAY_FLAG_NONE: no culling; opaque geometry commits.  Non-transmissive alpha material: an accepted candidate multiplies
       // the transmission by getShadowTransmission() == 0 (pathtrace_functions.h.slang:256-261) whatever its position in the
       // order -- the draw is deferred to an alpha round
-      needAlpha = HAS_ALPHA && !(flags & INST_FORCE_OPAQUE);
-      commits   = !needAlpha;
+      // INST_ALPHA_PASSES (alphaMode OPAQUE on a non-opaque instance): the draw is known to commit.  On a transmissive instance the candidate is
+      // recorded here and now (REC) -- an alpha round would do nothing else with it; on any other it occludes like an opaque one
+      const bool passes = (flags & INST_ALPHA_PASSES) != 0u;
+      recordNow = REC && HAS_ALPHA && passes && (flags & INST_TRANSMISSIVE) != 0u;
+      needAlpha = HAS_ALPHA && !recordNow && !(flags & INST_FORCE_OPAQUE) && !(passes && !(REC && (flags & INST_TRANSMISSIVE)));
+      commits   = !needAlpha && !recordNow;
       hu        = h.u;
       hv        = h.v;
       ht        = h.t;
@@ -796,6 +803,8 @@ PT_DEV void triRoundFinishShadow(const DevScene& sc, const RaySetup& r, float tM
   }
   if(COUNT) tris += tr.has ? 1u : 0u;
   const unsigned long long mine = tr.n ? (((tr.n >= 64u ? 0ull : (1ull << tr.n)) - 1ull) << tr.off) : 0ull;  // this owner's items: lanes [off, off + n)
+  if(REC)
+    recordCandidates(rec, recordNow, src, ht, hu, hv, tr.item & 0x3ffffffu);
   if(HAS_ALPHA)
   {
     ClosestBest none{};
@@ -2923,7 +2932,7 @@ template <bool WIDE>
 void launchTraceClosestT(const LaunchCtx& c, int cur)
 {
   dim3 grid(c.persistentBlocks * 256u / TRACE_BLOCK), block(TRACE_BLOCK);
-  if(c.hasAlpha)
+  if(c.hasAlphaClosest)
   {
     if(c.collectCounters)
       hipLaunchKernelGGL((k_trace_closest<WIDE, true, true>), grid, block, 0, c.stream, c.scene, c.paths, c.queues, cur, c.stats);
@@ -2991,7 +3000,7 @@ void launchTracePrimary(const LaunchCtx& c, int sampleIndex)
     else                                                                                                                                          \
       hipLaunchKernelGGL((k_trace_primary<A, C, false>), grid, block, 0, c.stream, c.scene, c.fc, c.sceneDev, c.fcDev, c.paths, c.queues, c.ownedTiles, sampleIndex, batchSlots, c.stats); \
   } while(0)
-  if(c.hasAlpha)
+  if(c.hasAlphaClosest)
   {
     if(c.collectCounters) MI_LAUNCH_PRIMARY(true, true); else MI_LAUNCH_PRIMARY(true, false);
   }

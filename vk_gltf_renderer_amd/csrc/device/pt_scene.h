@@ -65,6 +65,11 @@ enum : uint32_t
   INST_CULL_DISABLE = 2u,
   INST_FLIP_FACING  = 4u,  // det(objectToWorld) < 0: world-space winding is the mirror of object-space winding
   INST_TRANSMISSIVE = 8u,  // material.transmissionFactor > MIN_TRANSMISSION: shadow rays attenuate instead of stopping
+  // A non-opaque instance whose material has alphaMode OPAQUE (it is non-opaque because it transmits: getInstanceFlag): getOpacity returns 1
+  // (pathtrace_functions.h.slang:196-197), the draw `rand <= 1` always commits -- the candidate needs no alpha test, only the treatment of a
+  // non-opaque instance (no FORCE_OPAQUE: shadow rays do not stop at it).  The walks take such a candidate at once instead of deferring a
+  // test whose outcome is known (round 5: every sphere of the glass-class workload).
+  INST_ALPHA_PASSES = 16u,
 };
 
 // World-space triangle, 48 B: {v0, rnode} {e1, prim} {e2, instFlags}
