@@ -25,7 +25,7 @@ Rank 0 prints ONE JSON line.  Besides the driver's fields it carries
                 them).  "valu" kernels (the BVH walks, bound by vector-instruction issue): frac = USEFUL vector-lane operations (slab and
                 triangle tests at 64 lanes, per-kernel instruction counts of the compiled code) per launch / launch time / 78.6 Tlaneop/s, with
                 the measured issue fraction (`issue_frac`: vector instructions x 4 cycles / SIMD cycles, from the committed SQ counter pass)
-                beside it.  DESIGN.md section 4 states both models;
+                beside it.  LABNOTES.md section 4 states both models;
   also          the other configurations of BASELINE.json measured right after the headline on the same GPU, each with its own per-kernel
                 table: "helmet" (configs[1]), "helmet_4k" (the same at 3840x2160), "street" (configs[3], 3840x2160) and "glass_denoise"
                 (configs[4] with its a-trous pass), the ones with a different scene with their own cpu_baseline + parity leg;
@@ -196,7 +196,7 @@ def kernel_table(all_b, first_b, timing, frames, in_flight=0, pmc=None):
 def overlap_note(kernels, ms_per_frame):
     """Sum of the per-kernel device times over the frame time.  ~1 when the launches of a frame run one after the other; clearly above 1 when
     the library runs a bounce's shadow stage on a second stream next to the following closest-hit walk (small batches, and every batch of a
-    volume-scatter scene: DESIGN.md section 2) -- per-kernel times and fractions are then those of kernels that SHARE the device."""
+    volume-scatter scene: LABNOTES.md section 2) -- per-kernel times and fractions are then those of kernels that SHARE the device."""
     ratio = sum(k["ms_per_frame"] for k in kernels.values()) / max(ms_per_frame, 1e-9)
     out = {"kernel_time_sum_over_frame_time": round(ratio, 3)}
     if ratio > 1.1:
@@ -249,7 +249,7 @@ def roofline_of(kernels, pmc):
 
 
 # path slots (frames in flight x pixels) per GPU: ~0.3 KB of path state and queue entries per slot, ~160 GB of the 288 -- enough for 64
-# 4K frames: a multiple of 64 frames in flight lays the path slots out pixel major (a wave = 64 samples of one pixel)
+# 4K frames: a multiple of 64 frames in flight lays the path slots out pixel major (a wave = 64 samples of one pixel, LABNOTES.md section 2)
 SLOT_BUDGET = 5.4e8
 
 

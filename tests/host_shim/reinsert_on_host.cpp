@@ -41,10 +41,6 @@ __attribute__((visibility("default"))) long long dev_reinsert(float* nodes, int 
       int won = 0;
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 256) reduction(+ : won)
       for(int id = 0; id < ids; ++id) won += reinsertApply(T, moves.data(), locks.data(), id) ? 1 : 0;
-#ifdef REINSERT_SOFT_LOCKS
-#pragma omp parallel for num_threads(threads) schedule(dynamic, 256)
-      for(int id = 0; id < ids; ++id) reinsertMark(T, moves.data(), locks.data(), id);
-#endif
 #pragma omp parallel for num_threads(threads) schedule(static)
       for(int id = 0; id < ids; ++id) reinsertUnlock(locks.data(), id);
       done += won;

@@ -13,13 +13,12 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module", params=["", "-DREINSERT_SOFT_LOCKS"], ids=["path-locks", "soft-locks"])
+@pytest.fixture(scope="module")
 def lib(request, tmp_path_factory):
-    """Both lock flavours of bvh_reinsert.h: the product build's (a move carried out keeps its whole path) and the -DREINSERT_SOFT_LOCKS experiment (only the
-    nodes whose links it rewrote; the rest of its chains may be crossed, not rewritten, by later moves of the pass)."""
+    """The phase functions of bvh_reinsert.h compiled for the host (a move carried out keeps its whole path locked until the next search)."""
     out = str(tmp_path_factory.mktemp("host_shim_reinsert") / "libreinsert_on_host.so")
     shim = os.path.join(ROOT, "tests", "host_shim")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-fopenmp", "-fPIC", "-shared", *request.param.split(), "-I" + shim,
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fopenmp", "-fPIC", "-shared", "-I" + shim,
                     "-I" + os.path.join(ROOT, "vk_gltf_renderer_amd", "csrc", "device"), "-o", out, os.path.join(shim, "reinsert_on_host.cpp")], check=True)
     L = C.CDLL(out)
     L.dev_reinsert.restype = C.c_longlong

@@ -404,14 +404,6 @@ def test_frames_in_flight_bit_identical(built, assets, tmp_path):
     path = scenegen.scene_atrium_class(str(tmp_path / "atrium.glb"), seed=5, detail=0.12, tex_size=64)
     s3 = pu.Setup(path, 160, 96, max_depth=8)
     assert (pu.render_gpu(s3, 6, bvh=1)["accum"] == pu.render_gpu(s3, 6, bvh=1, in_flight=4)["accum"]).all()
-    # the optional hipGraph replay of small batches (MI_PT_GRAPH: capture on a private stream, hipGraphExecUpdate, one launch): same frames
-    os.environ["MI_PT_GRAPH"] = "4"
-    try:
-        for f in (1, 3):
-            bat = pu.render_gpu(s, 7, in_flight=f)
-            assert (seq["accum"] == bat["accum"]).all() and (seq["depth"] == bat["depth"]).all() and (seq["selection"] == bat["selection"]).all()
-    finally:
-        del os.environ["MI_PT_GRAPH"]
     # Path slots are micro-tile major, and PIXEL major when the batch is a multiple of 64 frames (a wave = 64 samples of one pixel):
     # both layouts, a ragged image, multi-sample frames and a first-frame batch (depth / selection) against frame-by-frame rendering
     s4 = pu.Setup(path, 101, 67, max_depth=6, spp_per_frame=2)

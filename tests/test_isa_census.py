@@ -1,4 +1,4 @@
-"""Guards what round 3 found in the compiled shade path ("What the compiled code showed"): the descriptors of the
+"""Guards what round 3 found in the compiled shade path (LABNOTES.md section 4, "What the compiled code showed"): the descriptors of the
 non-inlined helpers and of the shade kernels come through the scalar cache, the tables are read as global memory, helper results
 travel in registers.  None of it changes a pixel, so no parity test would notice it coming back -- the generated code does.
 CPU-only: hipcc cross-compiles gfx950 without a GPU (tools/isa_census.py)."""

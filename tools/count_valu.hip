@@ -1,5 +1,5 @@
 // Static vector-instruction counts of the two inner operations of the per-lane BVH walk, for the VALU roofline of bench.py
-// (DESIGN.md §4): one 8-wide node visit (bvh8Visit: decode + 8 slab tests + child ordering) and one triangle test
+// (LABNOTES.md §4): one 8-wide node visit (bvh8Visit: decode + 8 slab tests + child ordering) and one triangle test
 // (intersectTri + closest update).  Build + count: tools/count_valu.sh.  Not part of the product.
 #include <hip/hip_runtime.h>
 #include "pt_bvh8.h"

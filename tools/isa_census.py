@@ -2,7 +2,7 @@
 and per non-inlined device function, what the counters do not show -- flat loads / stores (a generic pointer: counted on both memory
 counters, so every use drains everything in flight), full drains (s_waitcnt vmcnt(0) lgkmcnt(0)), scratch traffic, vector loads
 whose address is an SGPR pair plus an offset (a uniform address read lane by lane when the index register is a constant), scalar
-loads, LDS operations and vector ALU instructions.  DESIGN.md section 4, "What the compiled code showed".
+loads, LDS operations and vector ALU instructions.  LABNOTES.md section 4, "What the compiled code showed".
 
 usage: python tools/isa_census.py [extra hipcc flags ...]      e.g.  python tools/isa_census.py -DSHADE_SIMPLE_WAVES=4
 as a module: census(flags=()) -> {demangled function name: {counter: value}}"""

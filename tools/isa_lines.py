@@ -2,7 +2,7 @@
 """Static vector-instruction count of one kernel of csrc/device/pt_kernels.hip PER SOURCE LINE (no GPU needed): compiles with
 -gline-tables-only (same code, .loc directives added), attributes every instruction of the kernel to the source location the
 compiler names for it, and prints the totals per file and the heaviest lines.  Complements tools/isa_census.py (per function
-totals) when the question is which lines of an inlined loop body the instructions of a node step belong to.
+totals) when the question is which lines of an inlined loop body the instructions of a node step belong to (LABNOTES.md section 4).
 usage: python tools/isa_lines.py <substring of the mangled kernel name> [top N]   e.g.  tools/isa_lines.py k_trace_closestILb1ELb1ELb0E 40"""
 import collections
 import os

@@ -26,7 +26,7 @@ def mean(*v):
 # each -- a gather that stays inside one 64-B line (16-B texel footprints, 48-B vertex / triangle records) is counted exactly (1.00),
 # a wide request (consecutive 16-B words of a wave: queue entries; an 80-B node record that straddles two lines) is a 128-B request
 # counted as 64 (0.50 / 0.52).  A kernel's ratio is the harmonic mix of the two by the share s of its ALGORITHMIC read bytes that
-# come as wide requests (bench.py's byte model):  r = 1 / (s / r_wide + (1 - s) / r_line).
+# come as wide requests (LABNOTES.md section 4: bench.py's byte model):  r = 1 / (s / r_wide + (1 - s) / r_line).
 if calib:
     r_wide, r_line, r_node = calib["fetch_stream16"], mean(calib["fetch_gather16"], calib["fetch_gather48"]), calib["fetch_gather80"]
 

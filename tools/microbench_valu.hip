@@ -3,7 +3,7 @@
 // Prints shader cycles per wave64 instruction per SIMD (s_memtime ticks of the longest wave x SIMDs / instructions issued) --
 // 2.0 = the SIMD-32 full rate of MI355X_MICROARCH.md, 4.0 = half rate -- and the effective clock (s_memtime against wall time).
 // build: hipcc --offload-arch=gfx950 -O3 tools/microbench_valu.hip -o gpurun_out/mb_valu ; run: gpurun_out/mb_valu
-// Not part of the product: it tells bench.py's "issue_frac" which cycle count a vector instruction stands for.
+// Not part of the product: it tells bench.py's "issue_frac" which cycle count a vector instruction stands for (LABNOTES.md section 4).
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>

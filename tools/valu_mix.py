@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Static mix of vector-ALU instruction classes per kernel of csrc/device/pt_kernels.hip (no GPU needed), for the issue model of
-bench.py's `issue_frac` (tools/make_pmc_latest.py).  On the SIMD-32 of gfx950 a wave64 instruction of the
+bench.py's `issue_frac` (tools/make_pmc_latest.py, LABNOTES.md section 4).  On the SIMD-32 of gfx950 a wave64 instruction of the
 FULL-rate class -- f32 fma / mul / add / sub, and / or / xor, 32-bit integer add / sub, mov -- issues over 2 cycles (MI355X_MICROARCH.md;
 tools/microbench_valu.hip measures that class at 1.9-2.1 cycles per instruction and SIMD against 2.9-3.1 for everything else: min / max /
 med3, conversions, shifts, bit-field ops, selects, compares, 24-bit and 32-bit multiplies, lane permutes in DPP form, packed f32 ops,

@@ -118,7 +118,7 @@ __device__ __forceinline__ float d_area(const DCand& c)
 // node; split[n][0]: the left share of the inner node's eight.  Filled bottom-up (second arrival at a node solves it, like k_fit),
 // read top-down by the level kernels instead of the greedy opening.
 #ifndef MI_PT_DP_C_TRI
-#define MI_PT_DP_C_TRI (56.0f / 235.0f)  // a triangle test against a node visit, in vector instructions (round 3's counts; see DESIGN.md section 3 for the round-4 sweep)
+#define MI_PT_DP_C_TRI (56.0f / 235.0f)  // a triangle test against a node visit, in vector instructions (round 3's counts; see LABNOTES.md section 3 for the round-4 sweep)
 #endif
 constexpr float DP_C_TRI = MI_PT_DP_C_TRI;
 struct DpTables

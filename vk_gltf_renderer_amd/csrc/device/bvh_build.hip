@@ -414,14 +414,6 @@ __global__ void k_re_apply(Bvh2Tree T, int ids, ReinsertMove* moves, unsigned lo
   if(id < ids && reinsertApply(T, moves, locks, id))
     atomicAdd(carriedOut, 1u);
 }
-#ifdef REINSERT_SOFT_LOCKS
-__global__ void k_re_mark(Bvh2Tree T, int ids, ReinsertMove* moves, unsigned long long* locks)
-{
-  const int id = blockIdx.x * blockDim.x + threadIdx.x;
-  if(id < ids)
-    reinsertMark(T, moves, locks, id);
-}
-#endif
 __global__ void k_re_unlock(int ids, unsigned long long* locks)
 {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -489,9 +481,6 @@ static bool reinsertBvh2(float4* nodes, int numInner, int root, int passes, int 
       {
         hipLaunchKernelGGL(k_re_lock, gI, dim3(B), 0, stream, T, ids, moves, locks);
         hipLaunchKernelGGL(k_re_apply, gI, dim3(B), 0, stream, T, ids, moves, locks, carried);
-#ifdef REINSERT_SOFT_LOCKS
-        hipLaunchKernelGGL(k_re_mark, gI, dim3(B), 0, stream, T, ids, moves, locks);  // (variant build: bvh_reinsert.h)
-#endif
         hipLaunchKernelGGL(k_re_unlock, gI, dim3(B), 0, stream, ids, locks);
       }
       hipLaunchKernelGGL(k_re_parents, gN, dim3(B), 0, stream, T);

@@ -224,20 +224,12 @@ PT_DEV bool r2Wanted(const ReinsertMove& m) { return m.lca >= 0 && m.gain > 0.0f
 // Several lock rounds per search: a move that loses a record to a better one gives way for this round only -- unless the better one is then
 // carried out (its records stay TAKEN until the next search), it tries again in the next round, so that one long path through the upper
 // tree does not cost a pass to everything it crosses.
-// -DREINSERT_SOFT_LOCKS (experiment: CPU tests and laboratory only so far -- 8 passes x 12 rounds reach what 24 x 4 reach with whole-path locks, atrium
-// area cost 61.98 against 61.75 -- one more kernel per round, k_re_mark; VARIANT_SRC=bvh_build tools/build_variant.sh soft -DREINSERT_SOFT_LOCKS): of a move carried out only the nodes whose LINKS it rewrote stay TAKEN; the other nodes
-// of its chains are CROSSED -- their boxes are stale, their links are not -- and a later move of the same pass may cross them with its own chains, but
-// not rewrite them: a target inside a moved subtree still has that subtree's root, TAKEN or CROSSED, among the nodes it would have to rewrite or cross.
 constexpr unsigned long long REINSERT_TAKEN   = ~0ull;
 constexpr unsigned long long REINSERT_CROSSED = ~0ull - 1ull;
 PT_DEV bool r2Blocked(unsigned long long lock, bool topo)
 {
-#ifdef REINSERT_SOFT_LOCKS
-  return lock == REINSERT_TAKEN || (topo && lock == REINSERT_CROSSED);
-#else
   (void)topo;
   return lock == REINSERT_TAKEN;
-#endif
 }
 PT_DEV void reinsertLock(const Bvh2Tree& T, ReinsertMove* moves, unsigned long long* locks, int id)
 {
@@ -254,26 +246,6 @@ PT_DEV void reinsertLock(const Bvh2Tree& T, ReinsertMove* moves, unsigned long l
   const unsigned long long key = r2Key(m, id);
   r2ForEachLocked(T, id, m, [&](int n, bool) { atomicMax(&locks[n], key); });  // (a CROSSED node keeps its mark: no key is that large)
 }
-#ifdef REINSERT_SOFT_LOCKS
-// one thread per node and leaf, after reinsertApply and before reinsertUnlock: the moves this round carried out mark their paths
-PT_DEV void reinsertMark(const Bvh2Tree& T, ReinsertMove* moves, unsigned long long* locks, int id)
-{
-  const ReinsertMove m = moves[id];
-  if(!(m.lca >= 0 && m.gain == -1.0f))
-    return;
-  moves[id].lca = -1;
-  // (the chains are read from the parent links of the searched tree, like everywhere in a pass; two moves of one round may both write CROSSED to a node
-  //  they both cross, a TAKEN node is its move's alone)
-  r2ForEachLocked(T, id, m, [&](int n, bool topo) {
-    if(topo)
-      locks[n] = REINSERT_TAKEN;
-  });
-  r2ForEachLocked(T, id, m, [&](int n, bool topo) {
-    if(!topo && locks[n] != REINSERT_TAKEN)
-      locks[n] = REINSERT_CROSSED;
-  });
-}
-#endif
 PT_DEV void reinsertUnlock(unsigned long long* locks, int id)
 {
   if(locks[id] < REINSERT_CROSSED)
@@ -287,11 +259,7 @@ PT_DEV bool reinsertApply(const Bvh2Tree& T, ReinsertMove* moves, unsigned long 
     return false;
   const unsigned long long key = r2Key(m, id);
   bool                     all = true;
-#ifdef REINSERT_SOFT_LOCKS
-  r2ForEachLocked(T, id, m, [&](int n, bool topo) { all = all && (locks[n] == key || (!topo && locks[n] == REINSERT_CROSSED)); });
-#else
   r2ForEachLocked(T, id, m, [&](int n, bool) { all = all && locks[n] == key; });
-#endif
   if(!all)
     return false;
   moves[id].lca = -1;
@@ -310,12 +278,7 @@ PT_DEV bool reinsertApply(const Bvh2Tree& T, ReinsertMove* moves, unsigned long 
   r2SetChildRef(T.nodes, q, qs, p);
   r2SetChildBox(T.nodes, q, qs, r2Union(yb, xb));
   // (the parent links stay those of the searched tree until the pass ends: the chains of the moves still waiting are read from them)
-#ifdef REINSERT_SOFT_LOCKS
-  moves[id].lca  = m.lca;    // (kept for reinsertMark: the marks of this round must not be seen by the checks of this round -- whether a neighbour's
-  moves[id].gain = -1.0f;    //  chain node already reads CROSSED would depend on which thread came first)
-#else
   r2ForEachLocked(T, id, m, [&](int n, bool) { locks[n] = REINSERT_TAKEN; });
-#endif
   return true;
 }
 

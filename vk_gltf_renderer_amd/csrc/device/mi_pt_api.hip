@@ -75,22 +75,16 @@ enum TimedKernel { TK_GENERATE, TK_TRACE, TK_SORT, TK_SHADE, TK_SHADOW, TK_ACCUM
 struct RunSwitches
 {
   int    packetInterval = 1;       // MI_PT_PACKET_INTERVAL  0: per-ray node test in every camera-ray packet
-  bool   microtileSlots = false;   // MI_PT_MICROTILE_SLOTS  micro-tile-major path slots at any batch size
-  bool   ignoreAlpha    = false;   // MI_PT_DIAG_IGNORE_ALPHA  (wrong image: what the alpha tests cost)
-  bool   genericShade   = false;   // MI_PT_GENERIC_SHADE    the generic shade kernel for every scene
   int    sortMode       = 2;       // MI_PT_SORT             window sort of the generic shade kernel: 0 | 1 | 2
   int    sortModeSimple = 0;       // MI_PT_SORT_SIMPLE      ... of the SIMPLE kernel's later bounces: 0 | 1 | 3
   bool   noPacket       = false;   // MI_PT_NO_PACKET        k_generate + per-lane walk instead of k_trace_primary
   bool   stateBySlot    = false;   // MI_PT_STATE_BY_SLOT    path state gathered by slot in every launch (rounds 1-3) instead of travelling in the queue entry
   bool   traceSpans     = false;   // MI_PT_TRACE_SPANS      synchronising diagnostics
-  int    graphUpTo      = 0;       // MI_PT_GRAPH            batches up to this many frames replay a hipGraph
   int    overlapUpTo    = 32;      // MI_PT_OVERLAP          batches up to this many frames run a bounce's shadow stage on a second stream, next to the
                                    //                        following bounce's closest-hit walk (0 = one stream, as in rounds 1-3); same image
   int    overlapMinTris = 200000;  // MI_PT_OVERLAP_MIN_TRIS ... in scenes of at least this many (flattened) triangles
   bool   noPlanes       = false;   // MI_PT_DIAG_NO_PLANES   no float planes for the packet walk
   bool   noOpaqueTris   = false;   // MI_PT_DIAG_NO_OPAQUE_TRIS  alpha-test the OPAQUE class of the alpha cut too
-  bool   allOpaqueTris  = false;   // MI_PT_DIAG_ALL_OPAQUE_TRIS (wrong image) every triangle of an alpha-tested primitive in the OPAQUE class: the alpha
-                                   //                            kernels run without a single alpha candidate -- their fixed cost
   bool   noQuads        = false;   // MI_PT_DIAG_NO_QUADS    four texel gathers per bilinear tap instead of one footprint
   bool   shadowFarFirst = true;    // MI_PT_SHADOW_FAR_FIRST=0 any-hit shadow walks (k_trace_shadow MODE 0 / 1 / 3: order independent) take a node's children near end first,
                                    //                        as in rounds 1-4.  Default since round 5: from the ray's FAR end -- a ray that starts on a surface wades through the
@@ -103,7 +97,6 @@ struct RunSwitches
   int    reinsertRounds = 4;       // MI_PT_REINSERT_ROUNDS  lock / move rounds per pass
   bool   collapseGreedy = false;   // MI_PT_COLLAPSE=sah|greedy  how BVH2 subtrees become children of an 8-wide node (anything else: mi_pt_create fails)
   bool   collapseBad    = false;
-  int    leafTris       = 2;       // MI_PT_LEAF_TRIS=1|2    triangles per leaf child of the 8-wide BVH
   bool   hostCollapse   = false;   // MI_PT_HOST_COLLAPSE    collapse on the host (the greedy reference of the device collapse)
   int    maxItersDiag   = 0;       // MI_PT_DIAG_MAX_ITERS=N test hook: the bounce loop stops after N iterations whatever is still alive (the truncation a
                                    //                        volume-scatter scene meets at maxDepth * 66 + 512)
@@ -115,20 +108,15 @@ struct RunSwitches
     auto flag = [](const char* n) { const char* e = getenv(n); return e != nullptr; };
     auto num  = [](const char* n, int d) { const char* e = getenv(n); return e ? atoi(e) : d; };
     packetInterval = num("MI_PT_PACKET_INTERVAL", 1);
-    microtileSlots = flag("MI_PT_MICROTILE_SLOTS");
-    ignoreAlpha    = flag("MI_PT_DIAG_IGNORE_ALPHA");
-    genericShade   = flag("MI_PT_GENERIC_SHADE");
     sortMode       = num("MI_PT_SORT", 2);
     sortModeSimple = num("MI_PT_SORT_SIMPLE", 0);
     noPacket       = flag("MI_PT_NO_PACKET");
     stateBySlot    = flag("MI_PT_STATE_BY_SLOT");
     traceSpans     = flag("MI_PT_TRACE_SPANS");
-    graphUpTo      = num("MI_PT_GRAPH", 0);
     overlapUpTo    = num("MI_PT_OVERLAP", 32);
     overlapMinTris = num("MI_PT_OVERLAP_MIN_TRIS", 200000);
     noPlanes       = flag("MI_PT_DIAG_NO_PLANES");
     noOpaqueTris   = flag("MI_PT_DIAG_NO_OPAQUE_TRIS");
-    allOpaqueTris  = flag("MI_PT_DIAG_ALL_OPAQUE_TRIS");
     noQuads        = flag("MI_PT_DIAG_NO_QUADS");
     shadowFarFirst = num("MI_PT_SHADOW_FAR_FIRST", 1) != 0;
     reinsert       = std::max(0, num("MI_PT_REINSERT", 16));
@@ -139,7 +127,6 @@ struct RunSwitches
       collapseGreedy = strcmp(e, "greedy") == 0;
       collapseBad    = !collapseGreedy && strcmp(e, "sah") != 0;  // (a typo must not silently select the other collapse)
     }
-    leafTris       = std::min(2, std::max(1, num("MI_PT_LEAF_TRIS", 2)));
     hostCollapse   = flag("MI_PT_HOST_COLLAPSE");
     maxItersDiag   = num("MI_PT_DIAG_MAX_ITERS", 0);
     failBuildAt    = num("MI_PT_DIAG_FAIL_BUILD", 0);
@@ -253,15 +240,8 @@ struct MiPt
   MiPtFrameTiming         accTiming{};
   std::vector<hipEvent_t> eventPool;
   hipStream_t             lastStream = nullptr;
-  // Optional (MI_PT_GRAPH): the launch sequence of a small batch (frame-by-frame use: the reference's interactive loop, ~27 short
-  // launches per frame) captured into a hipGraph and replayed: captured anew every batch on a private stream
-  // (the launch code is the same as without a graph; kernel arguments such as the frame counters are baked in by the capture),
-  // folded into the instantiated graph with hipGraphExecUpdate (same topology: no re-instantiation) and launched on the caller's
-  // stream as ONE submission.
-  hipStream_t             captureStream = nullptr;
   hipStream_t             sideStream = nullptr;                    // the shadow stage of small batches (RunSwitches::overlapUpTo)
   hipEvent_t              evShaded = nullptr, evShadowed = nullptr;  // main -> side after a shade launch, side -> main after the shadow stage
-  hipGraphExec_t          graphExec     = nullptr;
 
   ~MiPt()
   {
@@ -278,10 +258,6 @@ struct MiPt
         (void)hipEventDestroy(e);
     if(fcHost)
       (void)hipHostFree(fcHost);
-    if(graphExec)
-      (void)hipGraphExecDestroy(graphExec);
-    if(captureStream)
-      (void)hipStreamDestroy(captureStream);
     if(sideStream)
       (void)hipStreamDestroy(sideStream);
     if(evShaded)
@@ -396,7 +372,7 @@ int ensureOptionalPathArrays(MiPt* pt, bool stateBySlot, bool multiSample, bool 
     if(int rc = need(pt->optPixelSum, n)) return rc;
     P.pixelSum = pt->optPixelSum.ptr;
   }
-  if(!pt->simpleMaterials || pt->sw.genericShade)  // the generic shade kernel keeps the medium a path is inside of
+  if(!pt->simpleMaterials)  // the generic shade kernel keeps the medium a path is inside of
   {
     if(int rc = need(pt->optMedium, n)) return rc;
     P.medium = reinterpret_cast<uint4*>(pt->optMedium.ptr);
@@ -573,7 +549,7 @@ int buildAccelerationUnguarded(MiPt* pt)
     {
       pt::Bvh8Output b8;
       pt::Bvh8Options b8opt;
-      b8opt.sahCollapse = !pt->sw.collapseGreedy; b8opt.maxLeafTris = pt->sw.leafTris; b8opt.hostCollapse = pt->sw.hostCollapse;
+      b8opt.sahCollapse = !pt->sw.collapseGreedy; b8opt.hostCollapse = pt->sw.hostCollapse;
       if(!pt::buildBvh8(bo, b8, nullptr, err, b8opt))
       {
         if(b8.nodes)
@@ -747,7 +723,7 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
       d.tangents   = reinterpret_cast<const float*>(put(p.tangents, size_t(p.vertexCount) * 16));
       d.texCoords0 = reinterpret_cast<const float*>(put(p.texCoords0, size_t(p.vertexCount) * 8));
       d.texCoords1 = reinterpret_cast<const float*>(put(p.texCoords1, size_t(p.vertexCount) * 8));
-      d.opaqueTriangles = pt->sw.allOpaqueTris ? p.triangleCount : (pt->sw.noOpaqueTris ? 0u : std::min(p.opaqueTriangleCount, p.triangleCount));  // (A/B switch: alpha-test them all)
+      d.opaqueTriangles = pt->sw.noOpaqueTris ? 0u : std::min(p.opaqueTriangleCount, p.triangleCount);  // (test switch: alpha-test them all -- same image)
       d._pad            = 0;
       {
         std::vector<float> iv(size_t(p.vertexCount) * 12, 0.0f);
@@ -885,7 +861,7 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
   S.texRefs = pt->texRefs.ptr; S.alphaTris = nullptr; S.shadeTris = nullptr; S.srgbLut = pt->srgbLut.ptr; S.numMaterials = sd->numMaterials; S.numTextures = sd->numTextures;
   S.numLights = sd->numLights; S.numNodes = sd->numRenderNodes;
   S.envWidth = 0; S.envHeight = 0;
-  S.packetInterval = pt->sw.packetInterval;  // A/B switch: 0 = the per-ray node test in every packet
+  S.packetInterval = pt->sw.packetInterval;  // A/B switch (LABNOTES.md section 2): 0 = the per-ray node test in every packet
   S.shadowOctFlip  = pt->sw.shadowFarFirst ? 7u : 0u;
   if(int rc = buildAcceleration(pt.get()))
     return rc;
@@ -1092,7 +1068,7 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   c.fc.numSlots  = pt->numSlots;
   c.fc.numFrames = numFrames;
   pt::divideMagic(uint32_t(std::max(numFrames, 2)), c.fc.framesMagic, c.fc.framesShift);
-  c.fc.slotLayout = (numFrames % 64 == 0 && !pt->sw.microtileSlots) ? 1 : 0;  // (A/B switch: micro-tile major at any batch size)
+  c.fc.slotLayout = numFrames % 64 == 0 ? 1 : 0;
   c.fc.stateInQueue = (!pt->sw.stateBySlot && !(pt->frameInfo.flags & MI_SCENE_INFINITE_PLANE_SHADOW_CATCHER)) ? 1 : 0;
   const bool guides = (params->flags & MI_PT_USE_OPTIX_DENOISER) != 0;
   if(int rc = ensureOptionalPathArrays(pt, c.fc.stateInQueue == 0, params->numSamples > 1, guides, (pt->frameInfo.flags & MI_SCENE_INFINITE_PLANE_SHADOW_CATCHER) != 0))
@@ -1114,12 +1090,12 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   c.stats            = pt->stats.ptr;
   c.stream           = stream;
   c.persistentBlocks = unsigned(pt->numCUs) * 8u;
-  c.hasAlpha         = pt->hasAlpha && !pt->sw.ignoreAlpha;  // diagnostics: what the alpha tests cost (wrong image)
+  c.hasAlpha         = pt->hasAlpha;
   // the closest-hit walks run their alpha machinery only where some alpha test has an open outcome: a scene whose non-opaque instances all have
   // alphaMode OPAQUE (transmissive glass) takes the plain kernels -- every candidate commits (INST_ALPHA_PASSES)
   c.hasAlphaClosest  = c.hasAlpha && pt->hasAlphaTest;
   c.hasTransmissive  = pt->hasTransmissive;
-  c.simpleMaterials  = pt->simpleMaterials && !pt->sw.genericShade;
+  c.simpleMaterials  = pt->simpleMaterials;
   c.wide             = pt->wide;
   c.collectCounters  = pt->collectCounters;
   {
@@ -1181,32 +1157,11 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   int iterations = 0, traceLaunches = 0, shadeLaunches = 0, shadowLaunches = 0;
   const bool usePacket = !pt->sw.noPacket;
   const bool debugSpans = pt->sw.traceSpans;
-  // hipGraph replay of small batches (MI_PT_GRAPH = largest batch that is captured; default 0 = never).  Not with per-launch timing,
-  // the synchronising diagnostics, or volume-scatter scenes (their loop polls the queue length on the host).  Measured in round 3
-  // (tools/graph_ab.py, 1080p, per-launch timing off): helmet frame by frame 1376 Msamples/s replayed against 1384 launched one by
-  // one, 1894 / 1915 at 2 frames, 2580 / 2592 at 4; atrium 178 / 179 -- the host already queues the ~27 launches of a frame faster
-  // than the device drains them, and what separates consecutive kernels is their dependency (ramp-up and tail of each persistent
-  // grid), which a graph does not remove.  Hence off by default; the images are identical either way.
-  const int   graphUpTo  = pt->sw.graphUpTo;
-  bool        capturing  = numFrames <= graphUpTo && !pt->timingEnabled && !debugSpans && !pt->hasVolumeScatter;
-  if(capturing)
-  {
-    if(!pt->captureStream && hipStreamCreateWithFlags(&pt->captureStream, hipStreamNonBlocking) != hipSuccess)
-      capturing = false;
-    if(capturing && hipStreamBeginCapture(pt->captureStream, hipStreamCaptureModeThreadLocal) != hipSuccess)
-    {
-      (void)hipGetLastError();
-      capturing = false;
-    }
-    if(capturing)
-      c.stream = pt->captureStream;  // every launch helper below records into the capture
-  }
-  hipStream_t const launchStream = capturing ? pt->captureStream : stream;
   // Small batches: a bounce's shadow stage (any-hit walk + resolve) on a second stream, next to the NEXT bounce's closest-hit walk.  The two
   // are independent -- the walk reads the continuation rays the shade launch wrote, the shadow stage adds into radiance records that only
   // the next SHADE launch reads (which therefore waits for it) -- and with few frames in flight neither fills the 256 CUs: most
   // workgroups of a persistent grid find no work and leave, so the other kernel's find room.  Needs the state in the queue entry (on
-  // catcher frames the resolve pass may end a path the walk is about to trace) and no capture.
+  // catcher frames the resolve pass may end a path the walk is about to trace).
   // ... and launches long enough to be worth two cross-stream hand-overs per bounce: measured (round 4, frames in flight 1 / 4 / 8 / 16 / 32 / 64 / 128)
   // atrium-class (406 k triangles, depth 12) +15 / +8 / +6 / +3.5 / +1.7 / +1.0 / +0.3 %, street-class 4K +8 % at 1, +1.6 % at 8, +0.3 % from 32;
   // helmet-class (74 k, 60 % of the camera paths leave at bounce 0) -6.5 / -0.4 / -0.8 / -0.6 %: scenes below 2e5 triangles keep one stream.
@@ -1216,7 +1171,7 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   // batch, three dependent launches each, and taking the shadow stage off that chain measured +31 % for a single frame, +8.7 % at 32 and +2.2 % at 256
   // frames in flight on the glass-class workload (the host's poll of the queue length every eighth iteration only waits for the main stream).
   bool overlap = pt->sw.overlapUpTo > 0 && ((numFrames <= pt->sw.overlapUpTo && pt->scene.numTris >= pt->sw.overlapMinTris) || pt->hasVolumeScatter)
-                 && c.fc.stateInQueue != 0 && !capturing && !debugSpans;
+                 && c.fc.stateInQueue != 0 && !debugSpans;
   if(overlap && !pt->sideStream)
     overlap = hipStreamCreateWithFlags(&pt->sideStream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&pt->evShaded, hipEventDisableTiming) == hipSuccess
               && hipEventCreateWithFlags(&pt->evShadowed, hipEventDisableTiming) == hipSuccess;
@@ -1238,7 +1193,7 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   sideJoin.side = overlap ? pt->sideStream : nullptr;
   for(int s = 0; s < params->numSamples; ++s)
   {
-    pt::launchResetCounters(c.queues, launchStream);
+    pt::launchResetCounters(c.queues, stream);
     // 8-wide BVH: ONE kernel generates the camera rays, walks them as packets, finishes the paths that leave the scene and queues
     // the hits (k_trace_primary); BVH2 / MI_PT_NO_PACKET: k_generate writes the rays and the per-lane kernel walks them
     const bool fusedPrimary = c.wide && usePacket && !debugSpans;
@@ -1345,46 +1300,6 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   }
   if(params->flags & MI_PT_FIRST_FRAME)
     pt::launchSelection(c, pt->selection.ptr);
-  if(capturing)
-  {
-    // Any failure from here on (end of capture, instantiation, launch) must not leave the instance out of step with its accumulator:
-    // nothing of this batch has run yet (it was only recorded), so the graph objects are dropped, the capture stream -- which a failed
-    // capture leaves invalidated -- is recreated on demand, graphs are switched off for this instance, and the batch is issued
-    // again the ordinary way.  (What this function advanced before the capture -- accumFrames, momentFrames, the ring slot of the frame
-    // constants -- is a function of `params` alone or harmless to take twice.)
-    hipGraph_t graph  = nullptr;
-    bool       failed = hipStreamEndCapture(pt->captureStream, &graph) != hipSuccess || graph == nullptr;
-    bool       ready  = false;
-    if(!failed && pt->graphExec)
-    {
-      hipGraphNode_t           errorNode = nullptr;
-      hipGraphExecUpdateResult result    = hipGraphExecUpdateSuccess;
-      ready = hipGraphExecUpdate(pt->graphExec, graph, &errorNode, &result) == hipSuccess && result == hipGraphExecUpdateSuccess;
-      if(!ready)
-      {
-        (void)hipGetLastError();  // another launch sequence (first frame, other depth, other kernels): instantiate afresh
-        (void)hipGraphExecDestroy(pt->graphExec);
-        pt->graphExec = nullptr;
-      }
-    }
-    if(!failed && !ready)
-      failed = hipGraphInstantiate(&pt->graphExec, graph, nullptr, nullptr, 0) != hipSuccess;
-    if(!failed)
-      failed = hipGraphLaunch(pt->graphExec, stream) != hipSuccess;
-    if(graph)
-      (void)hipGraphDestroy(graph);
-    if(failed)
-    {
-      (void)hipGetLastError();
-      if(pt->graphExec)
-        (void)hipGraphExecDestroy(pt->graphExec);
-      pt->graphExec = nullptr;
-      (void)hipStreamDestroy(pt->captureStream);
-      pt->captureStream = nullptr;
-      pt->sw.graphUpTo  = 0;
-      return mi_pt_render_frames(pt, params, numFrames, hipStream);
-    }
-  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(pt->fcDone[fcSlot], stream));
   if(pt->timingEnabled)

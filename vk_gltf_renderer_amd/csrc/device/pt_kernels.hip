@@ -1549,7 +1549,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
   // evaluation of the paths that left the scene each ran in a third of the lanes (PMC: 28 of 64 lanes per vector instruction
   // on the atrium).  sortMode 3 keys the window by exactly that: escaped | surface hit x technique; the coin is the first draw
   // of sampleLights and a function of the path's seed alone, so it is known before anything is shaded.  Paths are independent:
-  // the processing order changes no result.  Measured (round 3, three times): fewer instructions, fuller waves, and
+  // the processing order changes no result.  Measured (round 3, three times, LABNOTES.md section 2): fewer instructions, fuller waves, and
   // 10-15 % slower -- the key costs a dependent gather and the window two barriers -- so the host leaves it off by default.
   constexpr uint32_t ROUNDS = CAN_SORT ? SORT_ROUNDS : 1u;
   constexpr uint32_t WINDOW = ROUNDS * SHADE_BLOCK;

@@ -234,9 +234,6 @@ __device__ __forceinline__ const T& gat(const T* table, I i)
 template <class T>
 __device__ __forceinline__ const T& uniformConst(const T& r)
 {
-#ifdef MI_PT_DIAG_NO_UNIFORM_CONST  // diagnostics build: the descriptors through vector loads again
-  return r;
-#endif
   const unsigned long long p = reinterpret_cast<unsigned long long>(&r);
   // (the builtin returns int: widen through uint32_t, or a low half with bit 31 set sign-extends into the high half)
   const uint32_t           lo = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(p)))), hi = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(p >> 32))));
@@ -282,7 +279,7 @@ __device__ __forceinline__ uint32_t pathSlotPixel(const FrameConsts& fc, uint32_
 #endif
 
 // ---- per-path state, structure of arrays indexed by slot -----------------------------------------------------------------
-// Per-segment traffic (read + write) is accounted in DESIGN.md §5; keep records 16-byte sized for dwordx4 access.
+// Per-segment traffic (read + write) is accounted in DESIGN.md §4; keep records 16-byte sized for dwordx4 access.
 enum : uint32_t
 {
   PF_INSIDE     = 1u << 0,   // pt.isInside

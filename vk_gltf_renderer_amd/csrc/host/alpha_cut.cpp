@@ -1,6 +1,6 @@
 // "Alpha cut": a load-time bake for alpha-MASK geometry -- this renderer's counterpart of the reference's opacity micro-map bake
 // (src/gltf_scene_omm.cpp: classify micro-triangles of alpha-tested triangles once, so that the traversal does not have to run
-// the alpha test on them).  There is no micro-map hardware here and a software look-up in the walk did not pay;
+// the alpha test on them).  There is no micro-map hardware here and a software look-up in the walk did not pay (LABNOTES.md section 4);
 // what does is removing the work instead of classifying it at run time: every alpha-MASK triangle is cut, adaptively, along an
 // N x N barycentric grid, and the pieces on which the alpha test CANNOT pass -- no texel that a fetch inside the piece may touch
 // reaches the cutoff -- are dropped from the geometry; pieces that survive whole are merged back into their parent.  A ray through the empty part of a leaf card then meets no candidate at all: no
