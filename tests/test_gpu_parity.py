@@ -20,8 +20,10 @@ pytestmark = pytest.mark.gpu
 COUNTERS = ("cameraPaths", "segments", "surfaceHits", "shadowRays", "textureTaps")
 
 
-def _check(o, g, rel_l2=2e-3, within_1e2=0.99, within_1e4=0.97, counters=True, counter_rel=2e-3, depth_tol=2e-6, alpha_tol=5e-4):
+def _check(o, g, rel_l2=1e-3, within_1e2=0.99, within_1e4=0.97, counters=True, counter_rel=2e-3, depth_tol=2e-6, alpha_tol=5e-4):
     m = pu.compare_images(o["accum"], g["accum"])
+    import inspect
+    print("PARITY", inspect.stack()[1].function, "rel_l2 %.3e (bound %.1e) within_1e-2 %.5f within_1e-4 %.5f (bound %.2f)" % (m["rel_l2"], rel_l2, m["frac_within_1e-2"], m["frac_within_1e-4"], within_1e4))
     assert np.isfinite(g["accum"]).all()
     assert m["rel_l2"] <= rel_l2, m
     assert m["frac_within_1e-2"] >= within_1e2, m
@@ -80,7 +82,7 @@ def test_shadow_catcher_plane(built, assets):
         # (sky case: the image is dark and the sun is a 1e9 radiance source -- ONE path out of 8 x 27 k whose sun-cone test
         #  flips on an ulp moves the relative L2 by 6e-3 all by itself, so the bound leaves room for a couple of them; the
         #  per-pixel fractions below stay as tight as everywhere else)
-        _check(o, g, rel_l2=1.5e-2 if not kw else 2e-3)
+        _check(o, g, rel_l2=1e-2 if not kw else 1e-3)  # (measured 6.1e-3 with the sun disc in play under the sky, 7.5e-7 under the HDR map)
         assert (g["accum"] == pu.render_gpu(s, 8, in_flight=4, bvh=1)["accum"]).all()
     # the catcher is not a no-op: with the sun up, the box's shadow darkens the plane relative to the sky behind it
     s0 = pu.Setup(os.path.join(assets, "Box.glb"), 192, 144, max_depth=4)
@@ -150,14 +152,14 @@ def test_atrium_class_alpha_lights(built, tmp_path):
     """Alpha-MASK foliage (stochastic-alpha path in both traversals), double-sided drapes, directional light + sky."""
     path = scenegen.scene_atrium_class(str(tmp_path / "atrium.glb"), seed=5, detail=0.12, tex_size=64)
     s = pu.Setup(path, 160, 96, max_depth=8)
-    _check(pu.render_oracle(s, 3), pu.render_gpu(s, 3), rel_l2=5e-3)
+    _check(pu.render_oracle(s, 3), pu.render_gpu(s, 3), rel_l2=1e-3)  # (measured 6.1e-5)
 
 
 def test_glass_class_transmission_volume(built, tmp_path):
     """Transmission, IOR, volume absorption, dispersion, volume scatter, transmissive shadows, sphere light."""
     path = scenegen.scene_glass_class(str(tmp_path / "glass.glb"), seed=3, tess=24)
     s = pu.Setup(path, 160, 96, max_depth=12, hdr_path=os.path.join(os.path.dirname(os.path.dirname(__file__)), "assets", "std_env.hdr"))
-    _check(pu.render_oracle(s, 3), pu.render_gpu(s, 3), rel_l2=1e-2, within_1e4=0.95)
+    _check(pu.render_oracle(s, 3), pu.render_gpu(s, 3), rel_l2=1e-3, within_1e4=0.99)  # (measured 9.4e-6 / 0.9992)
 
 
 def test_transmissive_shadow_paths_agree_bit_for_bit(built, tmp_path):
@@ -181,6 +183,30 @@ def test_transmissive_shadow_paths_agree_bit_for_bit(built, tmp_path):
         assert r.returncode == 0, r.stdout + r.stderr
         traced = int(r.stdout.strip().splitlines()[-1])  # (rays whose candidates overflowed the pool are walked, and counted, twice)
         assert traced == ref["stats"]["shadowRays"] if pool == "0" else traced > ref["stats"]["shadowRays"], (pool, traced)
+        assert np.array_equal(np.load(out), ref["accum"]), pool
+
+
+def test_every_kind_of_non_opaque_instance_side_by_side(built, tmp_path):
+    """INST_ALPHA_PASSES (round 5): a candidate on a non-opaque instance whose material has alphaMode OPAQUE -- clear glass, a diffuse-transmission
+    sphere -- commits without an alpha test (getOpacity == 1, pathtrace_functions.h.slang:196-197) and, on a transmissive instance, is recorded by the
+    shadow walk in the triangle round; BLEND glass and MASK / BLEND cards next to them still take the deferred test.  Against the oracle, and bit for
+    bit across the three shadow implementations (recording walk, ordered search, overflow mix) and the two structures."""
+    import subprocess
+    import sys
+    path = scenegen.scene_mixed_alpha_glass(str(tmp_path / "mixed.glb"))
+    hdr = os.path.join(os.path.dirname(os.path.dirname(__file__)), "assets", "std_env.hdr")
+    s = pu.Setup(path, 160, 100, max_depth=10, hdr_path=hdr)
+    ref = pu.render_gpu(s, 3)
+    _check(pu.render_oracle(s, 3), ref, rel_l2=1e-3, within_1e4=0.99)  # (measured 1.7e-6 / 0.9996)
+    assert ref["stats"]["shadowRays"] > 10000
+    assert (pu.render_gpu(s, 3, bvh=1)["accum"] == ref["accum"]).all()  # (BVH2: the ordered-search kernel walks every shadow ray)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import parity_util as pu; s = pu.Setup(%r, 160, 100, max_depth=10, hdr_path=%r); "
+            "g = pu.render_gpu(s, 3); np.save(sys.argv[1], g['accum'])") % (
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), path, hdr)
+    for pool in ("0", "150"):
+        out = str(tmp_path / f"pool{pool}.npy")
+        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, MI_PT_DIAG_CAND_POOL=pool), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
         assert np.array_equal(np.load(out), ref["accum"]), pool
 
 
@@ -272,7 +298,7 @@ def test_street_class_instancing(built, tmp_path):
     path = scenegen.scene_street_class(str(tmp_path / "street.glb"), seed=11, detail=0.14, tex_size=32)
     s = pu.Setup(path, 160, 90, max_depth=6)
     # NDC depth: hits up to 240 units away through rotated + scaled instance matrices (fma contraction differs by an ulp of t)
-    _check(pu.render_oracle(s, 3), pu.render_gpu(s, 3), rel_l2=5e-3, depth_tol=5e-6)
+    _check(pu.render_oracle(s, 3), pu.render_gpu(s, 3), rel_l2=1e-3, depth_tol=5e-6)  # (measured 1.8e-5)
 
 
 def test_coincident_geometry_tie_break(built, tmp_path):

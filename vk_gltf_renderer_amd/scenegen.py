@@ -640,6 +640,50 @@ def scene_glass_class(path, seed=99, tess=48):
     return b.save(path)
 
 
+def scene_mixed_alpha_glass(path, seed=17, tess=20, tex_size=64):
+    """Every kind of non-opaque instance side by side, for the walks' candidate handling: clear glass (transmissive, alphaMode OPAQUE: the alpha
+    draw always commits), BLEND glass (transmissive AND a real alpha test), a diffuse-transmission sphere (non-opaque, alphaMode OPAQUE, not
+    transmissive for shadow rays), alpha-MASK and alpha-BLEND textured cards, opaque spheres; floor, point light."""
+    rng = np.random.default_rng(seed)
+    b = GlbBuilder()
+    floor = b.material(lambert_material((0.6, 0.6, 0.6)))
+    pos, nrm, uv, idx = grid(6, 6, (10, 10), "y")
+    b.node(mesh=b.mesh([b.primitive(pos, idx, nrm, uv, material=floor)]))
+    sp = uv_sphere(tess, tess // 2, 0.42)
+    a = value_noise(rng, tex_size, 4, 1)[..., 0]
+    rgba = np.concatenate([np.clip(value_noise(rng, tex_size, 3, 3), 0, 1), (a > 0.5).astype(np.float64)[..., None]], -1)
+    mask_tex = b.texture(b.image((rgba * 255 + 0.5).astype(np.uint8)), b.sampler())
+    rgba[..., 3] = np.clip(a * 1.4, 0, 1)
+    blend_tex = b.texture(b.image((rgba * 255 + 0.5).astype(np.uint8)), b.sampler())
+
+    def pbr(color, rough=0.2, **extra):
+        m = {"pbrMetallicRoughness": {"baseColorFactor": [*[float(c) for c in color], 1.0], "metallicFactor": 0.0, "roughnessFactor": float(rough)}}
+        m.update(extra)
+        return m
+    mats = [
+        pbr((0.95, 0.97, 1.0), 0.0, extensions={"KHR_materials_transmission": {"transmissionFactor": 1.0}, "KHR_materials_ior": {"ior": 1.5}}),
+        pbr((0.9, 0.6, 0.5), 0.1, extensions={"KHR_materials_transmission": {"transmissionFactor": 0.7}, "KHR_materials_volume": {
+            "thicknessFactor": 0.8, "attenuationDistance": 0.7, "attenuationColor": [0.8, 0.4, 0.3]}}),
+        {**pbr((0.7, 0.9, 0.8), 0.05, extensions={"KHR_materials_transmission": {"transmissionFactor": 0.9}}), "alphaMode": "BLEND",
+         "pbrMetallicRoughness": {"baseColorFactor": [0.7, 0.9, 0.8, 0.6], "metallicFactor": 0.0, "roughnessFactor": 0.05}},
+        pbr((0.8, 0.7, 0.3), 0.5, extensions={"KHR_materials_diffuse_transmission": {"diffuseTransmissionFactor": 0.6, "diffuseTransmissionColorFactor": [0.9, 0.8, 0.5]}}),
+        pbr((0.7, 0.2, 0.2), 0.6), pbr((0.2, 0.3, 0.8), 0.3),
+    ]
+    for k, m in enumerate(mats):
+        b.node(mesh=b.mesh([b.primitive(sp[0], sp[3], sp[1], sp[2], material=b.material(m))]), translation=[-2.5 + 1.0 * k, 0.43, 0.4 * ((k % 2) * 2 - 1)])
+    # cards between the spheres and the light: MASK and BLEND alpha from a texture, double sided
+    cp, cn, cuv, cidx = grid(3, 3, (1.6, 1.1), "z")
+    mask = b.material({"pbrMetallicRoughness": {"baseColorTexture": {"index": mask_tex}, "metallicFactor": 0.0, "roughnessFactor": 0.8}, "alphaMode": "MASK", "alphaCutoff": 0.5,
+                       "doubleSided": True})
+    blend = b.material({"pbrMetallicRoughness": {"baseColorTexture": {"index": blend_tex}, "metallicFactor": 0.0, "roughnessFactor": 0.8}, "alphaMode": "BLEND", "doubleSided": True})
+    b.node(mesh=b.mesh([b.primitive(cp, cidx, cn, cuv, material=mask)]), translation=[-1.3, 1.5, 0.9], rotation=_quat((1, 0, 0), -0.9))
+    b.node(mesh=b.mesh([b.primitive(cp, cidx, cn, cuv, material=blend)]), translation=[1.3, 1.5, 0.9], rotation=_quat((1, 0, 0), -0.9))
+    li = b.light({"type": "point", "intensity": 220.0, "color": [1, 1, 1], "extras": {"radius": 0.2}})
+    b.node(extensions={"KHR_lights_punctual": {"light": li}}, translation=[0.0, 4.0, 2.5])
+    b.camera_node((0.0, 2.6, 5.0), (0, 0.4, 0), yfov=0.7)
+    return b.save(path)
+
+
 # ---- material zoo: one small scene per glTF material extension / renderer feature (parity tests of every BSDF lobe) -------------
 def _sphere_tangents(pos):
     d = pos / np.maximum(np.linalg.norm(pos, axis=1, keepdims=True), 1e-12)
