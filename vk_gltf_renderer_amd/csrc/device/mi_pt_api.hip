@@ -76,7 +76,6 @@ struct RunSwitches
 {
   int    packetInterval = 1;       // MI_PT_PACKET_INTERVAL  0: per-ray node test in every camera-ray packet
   int    sortMode       = 2;       // MI_PT_SORT             window sort of the generic shade kernel: 0 | 1 | 2
-  int    sortModeSimple = 0;       // MI_PT_SORT_SIMPLE      ... of the SIMPLE kernel's later bounces: 0 | 1 | 3
   bool   noPacket       = false;   // MI_PT_NO_PACKET        k_generate + per-lane walk instead of k_trace_primary
   bool   stateBySlot    = false;   // MI_PT_STATE_BY_SLOT    path state gathered by slot in every launch (rounds 1-3) instead of travelling in the queue entry
   bool   traceSpans     = false;   // MI_PT_TRACE_SPANS      synchronising diagnostics
@@ -109,7 +108,6 @@ struct RunSwitches
     auto num  = [](const char* n, int d) { const char* e = getenv(n); return e ? atoi(e) : d; };
     packetInterval = num("MI_PT_PACKET_INTERVAL", 1);
     sortMode       = num("MI_PT_SORT", 2);
-    sortModeSimple = num("MI_PT_SORT_SIMPLE", 0);
     noPacket       = flag("MI_PT_NO_PACKET");
     stateBySlot    = flag("MI_PT_STATE_BY_SLOT");
     traceSpans     = flag("MI_PT_TRACE_SPANS");
@@ -1104,13 +1102,6 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
     // kernel, which therefore has no sort at all) it only cost (helmet +4 %, atrium +12 %, street +4 % of the shade kernel).
     // MI_PT_SORT = 0 | 1 | 2 is the A/B switch of the generic kernel.
     c.sortMode = pt->sw.sortMode;
-    // The SIMPLE kernel's later bounces (MI_PT_SORT_SIMPLE = 0 | 1 | 3, default 0 = the queue as it is).  Mode 3 keys the window by
-    // next-event technique -- the coin sampleLights() flips between the punctual lights and the environment -- and does what it was
-    // built for: on the atrium the later-bounce shade kernel executes 15 % fewer vector instructions and 32.8 instead of 27.3 of 64
-    // lanes per instruction (PMC, round 3).  It is still 10 % SLOWER (1.30 against 1.18 ms per frame; street 3.79 against 3.57): the
-    // kernel waits on its dependent gathers, not on instruction issue, and the window's three extra gathers + two barriers add to
-    // exactly that.  Mode 1 (hits / misses) is within noise on the atrium and costs the helmet's later bounces 11 %.
-    c.sortModeSimple = pt->sw.sortModeSimple;  // (read at mi_pt_create: the GPU test that flips it creates an instance per setting)
   }
   // descriptor copies for the kernels that read them through a pointer
   if(pt->sceneDevDirty)

@@ -25,7 +25,6 @@ struct LaunchCtx
   bool            wide;  // traverse the 8-wide compressed BVH (scene.bvh8Nodes) instead of the BVH2
   bool            collectCounters;
   int             sortMode;  // per-bounce sort of the generic shade kernel: 0 off, 1 surface hits / others / dead, 2 hits grouped by material too
-  int             sortModeSimple;  // ... of the SIMPLE kernel's later bounces: 0 off, 1 as above, 3 surface hits grouped by next-event technique
 };
 
 void launchBuildShadeRecords(const DevScene& scene, uint32_t numTris, DevShadeTri* out, hipStream_t s);

@@ -1522,9 +1522,11 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
   __shared__ uint32_t s_prefix[NSUB + 1];
   __shared__ uint32_t s_push[4];
   __shared__ float    s_srgb[256];  // sRGB decode table next to the ALU: 3 lookups per texel, up to 8 texels per tap
-  // The window sort exists in the generic kernel (key: material) and in the later bounces of the SIMPLE kernel (key: next-event
-  // technique); the bounce-0 launch of the SIMPLE kernel gets its hits packed by k_trace_primary and walks the queue as it is.
-  constexpr bool CAN_SORT = !SIMPLE || !FIRST;  // (compiling the sort out of the SIMPLE kernel's later bounces measured neutral: round 3)
+  // The window sort exists in the generic kernel only (key: material).  Where every material runs the same code (SIMPLE) grouping by material buys
+  // nothing, and a window keyed by next-event technique (rounds 3-4: fewer instructions, fuller waves, 6-15 % SLOWER -- the key costs a dependent gather
+  // and the window two barriers, and this kernel waits on gather depth, not on issue) was removed in round 5 together with its registers: the
+  // later-bounce SIMPLE kernel spilled 16 VGPRs for a feature that was off (LABNOTES.md).
+  constexpr bool CAN_SORT = !SIMPLE;
   __shared__ uint32_t s_order[CAN_SORT ? SORT_WINDOW : 1];                   // queue positions of the window's live entries, sorted by bin
   __shared__ uint16_t s_segCount[CAN_SORT ? SORT_SEGMENTS : 1][SORT_BINS];   // entries of a bin in one (round, wave) segment -> exclusive prefix inside the bin
   __shared__ uint32_t s_binBase[SORT_BINS + 1];                 // first sorted index of each bin; [SORT_BINS] = live entries of the window
@@ -1542,15 +1544,6 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
   queuePrefix(&Q.counters[cur ? QC_PAIR1 : QC_PAIR0], s_prefix);
   const uint32_t count      = s_prefix[NSUB];
   const int      nxt        = cur ^ 1;
-  // Where every material runs the same code (SIMPLE) grouping the hits by MATERIAL buys nothing (measured: +9 % on the helmet
-  // workload's bounce-0 launch for the window bookkeeping, +13 % / +5 % on the later bounces of atrium / street).  What diverges
-  // there is the next-event technique -- sampleLights() flips a coin between the punctual lights and the environment
-  // (pathtrace_functions.h.slang:357-464), so the light sampler, the sky sampler + evaluation and, next to them, the sky
-  // evaluation of the paths that left the scene each ran in a third of the lanes (PMC: 28 of 64 lanes per vector instruction
-  // on the atrium).  sortMode 3 keys the window by exactly that: escaped | surface hit x technique; the coin is the first draw
-  // of sampleLights and a function of the path's seed alone, so it is known before anything is shaded.  Paths are independent:
-  // the processing order changes no result.  Measured (round 3, three times, LABNOTES.md section 2): fewer instructions, fuller waves, and
-  // 10-15 % slower -- the key costs a dependent gather and the window two barriers -- so the host leaves it off by default.
   constexpr uint32_t ROUNDS = CAN_SORT ? SORT_ROUNDS : 1u;
   constexpr uint32_t WINDOW = ROUNDS * SHADE_BLOCK;
   const uint32_t     numWindows = (count + WINDOW - 1) / WINDOW;
@@ -1570,9 +1563,6 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
     uint32_t live = min(WINDOW, count - win * WINDOW);  // no sort: the window as it is, dead entries and all
     if(CAN_SORT && sortMode != 0)
     {
-    float lightWeight = 0.0f, envWeight = 0.0f;
-    if(sortMode == 3)
-      getDirectLightingTechniqueProbabilities(sc, fc, lightWeight, envWeight);
     uint32_t myPos[SORT_ROUNDS], myBin[SORT_ROUNDS], myRank[SORT_ROUNDS];
     for(uint32_t t = threadIdx.x; t < SORT_SEGMENTS * SORT_BINS; t += SHADE_BLOCK)
       (&s_segCount[0][0])[t] = 0;
@@ -1590,15 +1580,9 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
         if(slot != QUEUE_DEAD)
         {
           const int tri = __float_as_int(Q.active[cur].aux[myPos[k]].y);
-          // sortMode 1: surface hits / the rest / dead; 2: surface hits grouped by material as well; 3: surface hits grouped by the
-          // next-event technique their path is about to draw (sampleLights: `rnd(seed) < lightWeight`, the path's next draw)
+          // sortMode 1: surface hits / the rest / dead; 2: surface hits grouped by material as well
           if(tri < 0)
             bin = SORT_BIN_MISS;
-          else if(sortMode == 3)
-          {
-            uint32_t seedPeek = __float_as_uint((fc.stateInQueue ? Q.active[cur].misc[myPos[k]] : P.misc[slot]).z);
-            bin               = rnd(seedPeek) < lightWeight ? 0u : 1u;
-          }
           else
             bin = sortMode >= 2 ? uint32_t(sc.shadeTris[tri].materialID) % SORT_BIN_MISS : 0u;
         }
@@ -3021,7 +3005,7 @@ void launchShade(const LaunchCtx& c, int cur, bool first)
 {
   dim3 grid(c.persistentBlocks), block(SHADE_BLOCK);
 #define MI_LAUNCH_SHADE(C, S, F) \
-  hipLaunchKernelGGL((k_shade<C, S, F>), grid, block, 0, c.stream, c.sceneDev, c.fcDev, c.paths, c.queues, cur, (S ? (F ? 0 : c.sortModeSimple) : c.sortMode), c.stats)
+  hipLaunchKernelGGL((k_shade<C, S, F>), grid, block, 0, c.stream, c.sceneDev, c.fcDev, c.paths, c.queues, cur, (S ? 0 : c.sortMode), c.stats)
 #define MI_LAUNCH_SHADE_F(C, S) do { if(first) MI_LAUNCH_SHADE(C, S, true); else MI_LAUNCH_SHADE(C, S, false); } while(0)
   if(c.simpleMaterials)
   {
