@@ -92,7 +92,10 @@ struct RunSwitches
   int    reinsert       = 16;      // MI_PT_REINSERT         reinsertion passes over the BVH2 before the 8-wide collapse at scene build (bvh_reinsert.h); 0 = the tree as clustered.
                                    //                        Same image bit for bit (test_reinsertion_changes_the_tree_not_the_image), a tenth fewer node visits per ray:
                                    //                        atrium 604 -> 633, street 623 -> 680 Msamples/s; both switches: 682 / 727 (profiles/r05_staged_ab.txt)
-  int    reinsertUpdate = 4;       // MI_PT_REINSERT_UPDATE  ... at the rebuilds of mi_pt_update_render_nodes (a moving instance pays them every time)
+  int    reinsertUpdate = 0;       // MI_PT_REINSERT_UPDATE  ... at the rebuilds of mi_pt_update_render_nodes: 0, because a moving instance pays them every time and a pass costs
+                                   //                        what the rest of a rebuild costs (2.8 M triangles: rebuild 42 ms, + 27 ms per pass -- the bottom-up refit's
+                                   //                        device-scope fences; profiles/r05_build_times.txt).  A posed scene that is then accumulated for many frames
+                                   //                        can ask for them
   int    reinsertRounds = 4;       // MI_PT_REINSERT_ROUNDS  lock / move rounds per pass
   bool   collapseGreedy = false;   // MI_PT_COLLAPSE=sah|greedy  how BVH2 subtrees become children of an 8-wide node (anything else: mi_pt_create fails)
   bool   collapseBad    = false;
@@ -118,7 +121,7 @@ struct RunSwitches
     noQuads        = flag("MI_PT_DIAG_NO_QUADS");
     shadowFarFirst = num("MI_PT_SHADOW_FAR_FIRST", 1) != 0;
     reinsert       = std::max(0, num("MI_PT_REINSERT", 16));
-    reinsertUpdate = std::max(0, num("MI_PT_REINSERT_UPDATE", 4));
+    reinsertUpdate = std::max(0, num("MI_PT_REINSERT_UPDATE", 0));
     reinsertRounds = std::max(1, num("MI_PT_REINSERT_ROUNDS", 4));
     if(const char* e = getenv("MI_PT_COLLAPSE"))
     {
