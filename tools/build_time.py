@@ -18,7 +18,7 @@ for k in range(2):  # the second create runs with a warm HIP context
     print(f"{name}: mi_pt_create #{k} {1e3 * (time.perf_counter() - t0):.1f} ms, {scene.num_triangles} triangles, collapse = {'host' if os.environ.get('MI_PT_HOST_COLLAPSE') else 'device'}")
     if k == 1:  # what a moving instance pays: mi_pt_update_render_nodes = a rebuild over the resident geometry (same table again)
         d = scene.desc.contents
-        for _ in range(3):
+        for _ in range(8):
             t1 = time.perf_counter()
             t.update_render_nodes(d.renderNodes, d.numRenderNodes, d.renderNodeVisible)
             t.synchronize()

@@ -165,8 +165,16 @@ __device__ void d_dpSolve(const float4* nodes2, DpTables dp, int nd, uint32_t ma
     }
   }
   const float area = d_boxArea(lo, hi);
-  auto get = [&](int k, int i) { return ref[k] < 0 ? leafCost[k] : dp.cost[size_t(ref[k]) * 8 + size_t(min(i, 7))]; };
-  float*  c = dp.cost + size_t(nd) * 8;
+  // The cost tables are what one thread of this kernel writes and another (the solver of the parent, possibly on another XCD) reads: they go through
+  // agent-scope relaxed atomic loads and stores (coherent past the per-XCD L2s), ordered against the ticket in k_dp_solve by the stores'
+  // acknowledgement -- not through plain stores between two device-scope fences, which cost an L2 write-back + invalidate per thread and level
+  // (round 5: the same change as the reinsertion refit, bvh_reinsert.h).  The split tables are read by later kernels only.
+  float childCost[2][8];
+  for(int k = 0; k < 2; ++k)
+    for(int i = 1; i < 8; ++i)
+      childCost[k][i] = ref[k] < 0 ? leafCost[k] : __hip_atomic_load(dp.cost + size_t(ref[k]) * 8 + size_t(i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  auto get = [&](int k, int i) { return childCost[k][min(i, 7)]; };
+  float   c[8];
   int8_t* s = dp.split + size_t(nd) * 8;
   for(int i = 2; i <= 7; ++i)
   {
@@ -208,6 +216,8 @@ __device__ void d_dpSolve(const float4* nodes2, DpTables dp, int nd, uint32_t ma
       c[i] = c[1];
       s[i] = -1;
     }
+  for(int i = 0; i < 8; ++i)
+    __hip_atomic_store(dp.cost + size_t(nd) * 8 + size_t(i), c[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __global__ void k_dp_solve(int numLeaves, const float4* nodes2, const int* parent, const int* leafParent, unsigned* arrive, DpTables dp, uint32_t maxLeaf)
 {
@@ -217,10 +227,10 @@ __global__ void k_dp_solve(int numLeaves, const float4* nodes2, const int* paren
   int cur = leafParent[leaf];
   while(cur >= 0)
   {
-    __threadfence();  // release: tables written below this node are visible before the ticket
-    if(atomicAdd(&arrive[cur], 1u) == 0u)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt: this thread's write-through stores (d_dpSolve) have been acknowledged
+    if(__hip_atomic_fetch_add(&arrive[cur], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
       return;  // first arrival: the sibling subtree finishes this node
-    __threadfence();  // acquire
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // (nothing below moves above the ticket)
     d_dpSolve(nodes2, dp, cur, maxLeaf);
     cur = parent[cur];
   }

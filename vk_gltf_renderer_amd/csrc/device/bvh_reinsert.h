@@ -284,20 +284,60 @@ PT_DEV bool reinsertApply(const Bvh2Tree& T, ReinsertMove* moves, unsigned long 
 
 // ---- phase 5: boxes and triangle counts, bottom-up -----------------------------------------------------------------------------------
 // (parent links rebuilt by phase 1 after the moves; `arrive` zeroed)
+// The words one thread of the refit writes and another reads -- a node's triangle count, the child boxes in its parent's record -- go through
+// AGENT-SCOPE relaxed atomic loads and stores (global_load / global_store with sc1: coherent at the device's memory side, past the per-XCD L2s),
+// ordered against the ticket by waiting for the stores' acknowledgement.  Round 4 wrote them as plain stores between two __threadfence() -- on a
+// device with eight non-coherent L2s that is an L2 write-back + invalidate per thread and tree level, and the refit was 80 % of a reinsertion pass
+// (2.6 ms at 0.26 M triangles, 27 ms at 2.8 M: profiles/r05_build_times.txt).  Same values, same order of operations: the records stay bit-identical
+// to the host run of this function (tools/test_reinsert_gpu.hip).
+#if defined(__HIP_DEVICE_COMPILE__)
+PT_DEV float r2CohLoad(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+PT_DEV int   r2CohLoad(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+PT_DEV void  r2CohStore(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+PT_DEV void  r2CohStore(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+PT_DEV unsigned int r2Ticket(unsigned int* p)
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt: this thread's write-through stores have been acknowledged
+  const unsigned int t = __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // (nothing below moves above the ticket)
+  return t;
+}
+#else  // the host build of the CPU test tier (tests/host_shim): one coherent memory
+PT_DEV float r2CohLoad(const float* p) { const int i = __atomic_load_n(reinterpret_cast<const int*>(p), __ATOMIC_SEQ_CST); float v; __builtin_memcpy(&v, &i, 4); return v; }
+PT_DEV int   r2CohLoad(const int* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
+PT_DEV void  r2CohStore(float* p, float v) { int i; __builtin_memcpy(&i, &v, 4); __atomic_store_n(reinterpret_cast<int*>(p), i, __ATOMIC_SEQ_CST); }
+PT_DEV void  r2CohStore(int* p, int v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
+PT_DEV unsigned int r2Ticket(unsigned int* p) { return __atomic_fetch_add(p, 1u, __ATOMIC_SEQ_CST); }
+#endif
+PT_DEV RBox r2CohChildBox(float4* nodes, int node, int k)
+{
+  const float* f = reinterpret_cast<const float*>(nodes + size_t(node) * 4);
+  RBox         b;
+  b.lo[0] = r2CohLoad(f + 4 * k + 0); b.hi[0] = r2CohLoad(f + 4 * k + 1); b.lo[1] = r2CohLoad(f + 4 * k + 2); b.hi[1] = r2CohLoad(f + 4 * k + 3);
+  b.lo[2] = r2CohLoad(f + 8 + 2 * k); b.hi[2] = r2CohLoad(f + 9 + 2 * k);
+  return b;
+}
 PT_DEV void reinsertRefit(const Bvh2Tree& T, unsigned int* arrive, int leaf)
 {
   int cur = T.leafParent[leaf];
   while(cur >= 0)
   {
-    __threadfence();  // release: what this thread wrote below is visible before its ticket
-    if(atomicAdd(&arrive[cur], 1u) == 0u)
-      return;         // first arrival: the other subtree's thread finishes this node
-    __threadfence();  // acquire
-    const int c0 = r2ChildRef(T.nodes, cur, 0), c1 = r2ChildRef(T.nodes, cur, 1);
-    reinterpret_cast<int*>(T.nodes + size_t(cur) * 4)[14] = r2Count(T.nodes, c0) + r2Count(T.nodes, c1);
+    if(r2Ticket(&arrive[cur]) == 0u)
+      return;  // first arrival: the other subtree's thread finishes this node
+    int* const w  = reinterpret_cast<int*>(T.nodes + size_t(cur) * 4);
+    const int  c0 = w[12], c1 = w[13];  // (child links: nobody writes them in this phase)
+    const int  n0 = c0 >= 0 ? r2CohLoad(reinterpret_cast<const int*>(T.nodes + size_t(c0) * 4) + 14) : 1;
+    const int  n1 = c1 >= 0 ? r2CohLoad(reinterpret_cast<const int*>(T.nodes + size_t(c1) * 4) + 14) : 1;
+    r2CohStore(w + 14, n0 + n1);
     const int up = T.parent[cur];
     if(up >= 0)
-      r2SetChildBox(T.nodes, up, r2SlotOf(T, up, cur), r2Union(r2ChildBox(T.nodes, cur, 0), r2ChildBox(T.nodes, cur, 1)));
+    {
+      const RBox   u = r2Union(r2CohChildBox(T.nodes, cur, 0), r2CohChildBox(T.nodes, cur, 1));
+      const int    k = r2SlotOf(T, up, cur);
+      float* const f = reinterpret_cast<float*>(T.nodes + size_t(up) * 4);
+      r2CohStore(f + 4 * k + 0, u.lo[0]); r2CohStore(f + 4 * k + 1, u.hi[0]); r2CohStore(f + 4 * k + 2, u.lo[1]); r2CohStore(f + 4 * k + 3, u.hi[1]);
+      r2CohStore(f + 8 + 2 * k, u.lo[2]); r2CohStore(f + 9 + 2 * k, u.hi[2]);
+    }
     cur = up;
   }
 }
