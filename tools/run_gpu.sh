@@ -55,14 +55,14 @@ PY
     ;;
   sweep)  # frames in flight 1 / 8 / 64 / 128 at 1080p and 4K: what a maintainer gets per onRender batch size, and the memory it takes
     for w in helmet atrium; do for f in 1 8 64 128; do
-      timeout 200 python bench.py --workload $w --in-flight $f --frames-per-step $((f * 2)) --steps 4 --warmup 1 $N > $O/r04_sweep_${w}_f$f.json 2> /dev/null
+      timeout 200 python bench.py --workload $w --in-flight $f --frames-per-step $((f * 2)) --steps 4 --warmup 1 $N > $O/r05_sweep_${w}_f$f.json 2> /dev/null
       python3 -c "
-import json; j=json.loads(open('$O/r04_sweep_${w}_f$f.json').read().strip().splitlines()[-1]); print('SWEEP ${w} 1080p in_flight', j['config']['frames_in_flight'], j['value'], j['device_memory_GB'])"
+import json; j=json.loads(open('$O/r05_sweep_${w}_f$f.json').read().strip().splitlines()[-1]); print('SWEEP ${w} 1080p in_flight', j['config']['frames_in_flight'], j['value'], j['device_memory_GB'])"
     done; done
     for f in 1 8 64; do
-      timeout 200 python bench.py --workload helmet --width 3840 --height 2160 --in-flight $f --frames-per-step $((f * 2)) --steps 4 --warmup 1 $N > $O/r04_sweep_helmet4k_f$f.json 2> /dev/null
+      timeout 200 python bench.py --workload helmet --width 3840 --height 2160 --in-flight $f --frames-per-step $((f * 2)) --steps 4 --warmup 1 $N > $O/r05_sweep_helmet4k_f$f.json 2> /dev/null
       python3 -c "
-import json; j=json.loads(open('$O/r04_sweep_helmet4k_f$f.json').read().strip().splitlines()[-1]); print('SWEEP helmet 4K in_flight', j['config']['frames_in_flight'], j['value'], j['device_memory_GB'])"
+import json; j=json.loads(open('$O/r05_sweep_helmet4k_f$f.json').read().strip().splitlines()[-1]); print('SWEEP helmet 4K in_flight', j['config']['frames_in_flight'], j['value'], j['device_memory_GB'])"
     done ;;
   overlap)  # MI_PT_OVERLAP: the shadow stage of small batches on a second stream -- on (default 16 frames) against off, 1 / 4 / 8 / 16 frames in flight
     for w in ${OVERLAP_WORKLOADS:-helmet atrium}; do for f in ${OVERLAP_FRAMES:-1 4 8 16}; do for o in 0 1024; do

@@ -93,8 +93,8 @@ struct RunSwitches
                                    //                        Same image bit for bit (test_reinsertion_changes_the_tree_not_the_image), a tenth fewer node visits per ray:
                                    //                        atrium 604 -> 633, street 623 -> 680 Msamples/s; both switches: 682 / 727 (profiles/r05_staged_ab.txt)
   int    reinsertUpdate = 0;       // MI_PT_REINSERT_UPDATE  ... at the rebuilds of mi_pt_update_render_nodes: 0, because a moving instance pays them every time and a pass costs
-                                   //                        what the rest of a rebuild costs (2.8 M triangles: rebuild 42 ms, + 27 ms per pass -- the bottom-up refit's
-                                   //                        device-scope fences; profiles/r05_build_times.txt).  A posed scene that is then accumulated for many frames
+                                   //                        more than half of what the rest of a rebuild costs (2.8 M triangles: rebuild 15.7 ms, + 10 ms per pass;
+                                   //                        profiles/r05_sweep_and_rebuild.txt).  A posed scene that is then accumulated for many frames
                                    //                        can ask for them
   int    reinsertRounds = 4;       // MI_PT_REINSERT_ROUNDS  lock / move rounds per pass
   bool   collapseGreedy = false;   // MI_PT_COLLAPSE=sah|greedy  how BVH2 subtrees become children of an 8-wide node (anything else: mi_pt_create fails)
