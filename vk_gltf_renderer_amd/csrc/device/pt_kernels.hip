@@ -439,9 +439,8 @@ constexpr int TRI_PHASE_EXIT_LANES = 10;
 #ifndef TRI_ROUND_LANES
 #define TRI_ROUND_LANES 20
 #endif
-#ifndef TRI_ROUND_BLOCKED
-#define TRI_ROUND_BLOCKED 4  // ... or this many lanes have both of their park records in use
-#endif
+// (Until round 5 a round also started once 4 lanes had both of their park records in use.  On the reinserted trees that trigger only cut rounds short:
+//  never firing it measured atrium 684.6 -> 691.1, street 728.5 -> 739.4 Msamples/s -- profiles/r05_threshold_retune.txt -- and it is gone.)
 #ifndef TRI_ROUND_LANE_CAP_N
 #define TRI_ROUND_LANE_CAP_N 4  // (7 until round 4.  The publish loop runs as many passes as the busiest lane hands in: 2 / 3 / 4 / 5 / 6 / 7 measured
                                 //  576 / 590 / 607 / 606 / 603 / 600 Msamples/s on the atrium, 593 / 609 / 627 / 626 / 624 / 624 on the street)
@@ -947,7 +946,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
         if(pend != 0ull)
         {
           const bool drain = lastVisiting < TRI_PHASE_LANES;  // few lanes left walking: nothing to wait for
-          round            = drain || __popcll(pend) >= TRI_ROUND_LANES || __popcll(__ballot(active && leafPending(qMask))) >= TRI_ROUND_BLOCKED;
+          round            = drain || __popcll(pend) >= TRI_ROUND_LANES;
           if(round)
           {
             PROF_CNT(2, 1);
@@ -2351,7 +2350,7 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
           {
             const int  visiting = __popcll(__ballot(visited));
             const bool drain    = visiting < TRI_PHASE_LANES;
-            if(drain || __popcll(pend) >= TRI_ROUND_LANES || __popcll(__ballot(active && leafPending(qMask))) >= TRI_ROUND_BLOCKED)
+            if(drain || __popcll(pend) >= TRI_ROUND_LANES)
             {
               do
               {
