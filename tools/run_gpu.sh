@@ -25,10 +25,10 @@ ab() { # ab <tag> <workloads...>: every lib/var_* build next to the product buil
 }
 case "$1" in
   line)  # the full default line (headline + every other configuration with CPU legs), as the driver runs it
-    timeout 1500 python bench.py --steps 20 --warmup 5 > $O/r04_bench_default_a.json 2> $O/r04_bench_default_a.err; echo "bench rc $?"; tail -c 600 $O/r04_bench_default_a.err
+    timeout 1500 python bench.py --steps 20 --warmup 5 > $O/r05_bench_default_a.json 2> $O/r05_bench_default_a.err; echo "bench rc $?"; tail -c 600 $O/r05_bench_default_a.err
     python3 - <<'PY'
 import json
-j=json.loads(open('gpurun_out/r04_bench_default_a.json').read().strip().splitlines()[-1])
+j=json.loads(open('gpurun_out/r05_bench_default_a.json').read().strip().splitlines()[-1])
 print('atrium', j['value'], j.get('parity',{}).get('by_spp'), j.get('cpu_baseline'))
 for n,a in j.get('also',{}).items(): print(n, a['value'], a.get('parity',{}).get('by_spp'), a.get('cpu_baseline',{}).get('value'))
 PY
