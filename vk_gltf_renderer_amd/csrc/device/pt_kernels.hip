@@ -255,7 +255,9 @@ PT_DEV CameraPath generateCameraPath(const FrameConsts& fc, const PathSoA& P, co
     float r     = sqrtf(-2.0f * logf(fmaxf(1e-38f, u1)));
     float theta = 2.0f * K_PI * u2;
     jitter      = mk2(0.5f + ANTIALIASING_STANDARD_DEVIATION * (r * cosf(theta)), 0.5f + ANTIALIASING_STANDARD_DEVIATION * (r * sinf(theta)));
-    if(P.guideAlbedo)
+    // (single-sample frames: the guide records are WRITTEN by the path's first shade -- or zeroed where a path has none -- instead of zeroed here and
+    //  read, added to and written back there: 64 B per path less)
+    if(P.guideAlbedo && fc.pc.numSamples > 1)
     {
       P.guideAlbedo[slot] = make_float4(0, 0, 0, 0);
       P.guideNormal[slot] = make_float4(0, 0, 0, 0);
@@ -1416,6 +1418,11 @@ __global__ void __launch_bounds__(256, INTERVAL ? PRIMARY_INTERVAL_MIN_WAVES : P
     if(hasFlag(fc.pc.flags, MI_PT_FIRST_FRAME) && cp.frame == 0u)  // NDC depth input of a first frame (k_finish_sample)
       P.firstHit[pathSlotPixel(fc, slot)] = make_float4(cp.direction.x, cp.direction.y, cp.direction.z, 0.0f);
     P.radiance[slot] = make_float4(cp.direction.x, cp.direction.y, cp.direction.z, __uint_as_float(RADW_PRIMARY_MISS));
+    if(P.guideAlbedo && fc.pc.numSamples == 1)  // (single-sample frames: nobody zeroed the guide records; this path has no first hit)
+    {
+      P.guideAlbedo[slot] = make_float4(0, 0, 0, 0);
+      P.guideNormal[slot] = make_float4(0, 0, 0, 0);
+    }
     if(P.misc)  // (multi-sample frames: the next sample's seed)
       P.misc[slot] = make_float4(0.0f, __uint_as_float(PF_NOT_SOLID | PF_PRIMARY_MISS), __uint_as_float(cp.seed), 0.0f);  // depth 0, not alive
   }
@@ -1663,6 +1670,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
       int      scatterBounces = int((flags >> PF_SCATTER_SHIFT) & 0xffu);
       bool     isInside = !SIMPLE && (flags & PF_INSIDE) != 0u, solid = !(flags & PF_NOT_SOLID);
       const bool firstRay = (surfaceDepth == 0);
+      bool       guideWritten = false;
       const int  maxDepth = fc.pc.maxDepth;
       // the first-hit position only feeds the NDC depth of a first frame (k_finish_sample), i.e. frame 0 of the batch
       const bool needFirstHit = hasFlag(fc.pc.flags, MI_PT_FIRST_FRAME) && pathSlotFrame(fc, slot) == 0u;
@@ -1817,7 +1825,13 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
               P.firstHit[pathSlotPixel(fc, slot)] = make_float4(hit.pos.x, hit.pos.y, hit.pos.z, 0.0f);
             if(P.guideAlbedo)
             {
-              float4 ga = P.guideAlbedo[slot], gn = P.guideNormal[slot];
+              float4 ga = make_float4(0, 0, 0, 0), gn = ga;
+              if(fc.pc.numSamples > 1)  // (the sum over the frame's samples, zeroed by sample 0: generateCameraPath)
+              {
+                ga = P.guideAlbedo[slot];
+                gn = P.guideNormal[slot];
+              }
+              guideWritten        = true;
               P.guideAlbedo[slot] = make_float4(ga.x + pbrMat.baseColor.x, ga.y + pbrMat.baseColor.y, ga.z + pbrMat.baseColor.z, ga.w + 1.0f);
               P.guideNormal[slot] = make_float4(gn.x + pbrMat.N.x, gn.y + pbrMat.N.y, gn.z + pbrMat.N.z, 0.0f);
             }
@@ -1968,6 +1982,11 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
         (void)earlyContinue;
       }
 
+      if(FIRST && P.guideAlbedo && !guideWritten && fc.pc.numSamples == 1)  // a path without a first surface hit (miss, catcher plane): empty guides
+      {
+        P.guideAlbedo[slot] = make_float4(0, 0, 0, 0);
+        P.guideNormal[slot] = make_float4(0, 0, 0, 0);
+      }
       alive = !done && surfaceDepth < maxDepth;
       flags = (isInside ? PF_INSIDE : 0u) | (solid ? 0u : PF_NOT_SOLID) | (alive ? PF_ALIVE : 0u) | (uint32_t(min(surfaceDepth, 255)) << PF_DEPTH_SHIFT)
               | (uint32_t(scatterBounces) << PF_SCATTER_SHIFT);
@@ -2611,8 +2630,9 @@ __global__ void __launch_bounds__(256) k_shadow_resolve(const DevScene* __restri
         const uint32_t rnode = __float_as_uint(gat(sc.tris, tri).a.w), prim = __float_as_uint(gat(sc.tris, tri).b.w);
         haveLast = true; lastT = bC.x; lastRnode = rnode; lastPrim = prim;
         const f3    bary    = mk3(1.0f - bC.y - bC.z, bC.y, bC.z);
-        const float opacity = getOpacityFast(sc, int(tri), bary);
-        if(candidateRand(seed0, int(rnode), int(prim)) < opacity)
+        // (INST_ALPHA_PASSES: opacity 1, the draw always commits -- no fetch of the alpha record, no draw)
+        const bool  passes  = (__float_as_uint(gat(sc.tris, tri).c.w) & INST_ALPHA_PASSES) != 0u;
+        if(passes || candidateRand(seed0, int(rnode), int(prim)) < getOpacityFast(sc, int(tri), bary))
         {
           const float segment = fmaxf(0.0f, bC.x - prevHitT);
           const f3    curT    = getShadowTransmission(sc, int(rnode), int(prim), bary, segment, dir, isInside);
