@@ -2635,7 +2635,7 @@ __global__ void __launch_bounds__(256) k_shadow_resolve(const DevScene* __restri
         if(passes || candidateRand(seed0, int(rnode), int(prim)) < getOpacityFast(sc, int(tri), bary))
         {
           const float segment = fmaxf(0.0f, bC.x - prevHitT);
-          const f3    curT    = getShadowTransmission(sc, int(rnode), int(prim), bary, segment, dir, isInside);
+          const f3    curT    = getShadowTransmissionTri(sc, int(rnode), int(prim), int(tri), bary, segment, dir, isInside);
           prevHitT            = bC.x;
           total *= curT;
           if(maxComp(total) <= MIN_TRANSMISSION)

@@ -667,11 +667,11 @@ PT_DEV DevAlphaTri makeAlphaRecord(const DevScene& sc, const DevTri& T)
 }
 
 // getShadowTransmission, :244-343
-PT_DEV f3 getShadowTransmissionBody(const DevScene& sc, int rnode, int triangleID, f3 bary, float hitT, f3 rayDir, bool& isInside);
+PT_DEV f3 getShadowTransmissionBody(const DevScene& sc, int rnode, int triangleID, f3 bary, float hitT, f3 rayDir, bool& isInside, int shadeTri);
 // .xyz = transmission, .w != 0: inside after the surface (by value, like sampleLightsCall)
 __device__ __noinline__ f4 getShadowTransmissionCall(const DevScene& scIn, int rnode, int triangleID, f3 bary, float hitT, f3 rayDir, bool isInside)
 {
-  const f3 T = getShadowTransmissionBody(uniformConst(scIn), rnode, triangleID, bary, hitT, rayDir, isInside);
+  const f3 T = getShadowTransmissionBody(uniformConst(scIn), rnode, triangleID, bary, hitT, rayDir, isInside, -1);
   return mk4(T.x, T.y, T.z, isInside ? 1.0f : 0.0f);
 }
 PT_DEV f3 getShadowTransmission(const DevScene& sc, int rnode, int triangleID, f3 bary, float hitT, f3 rayDir, bool& isInside)
@@ -680,16 +680,46 @@ PT_DEV f3 getShadowTransmission(const DevScene& sc, int rnode, int triangleID, f
   isInside   = r.w != 0.0f;
   return xyz(r);
 }
-PT_DEV f3 getShadowTransmissionBody(const DevScene& sc, int rnode, int triangleID, f3 bary, float hitT, f3 rayDir, bool& isInside)
+// the same through the triangle's shade record (`tri`: index in the active structure)
+__device__ __noinline__ f4 getShadowTransmissionTriCall(const DevScene& scIn, int rnode, int triangleID, int tri, f3 bary, float hitT, f3 rayDir, bool isInside)
+{
+  const f3 T = getShadowTransmissionBody(uniformConst(scIn), rnode, triangleID, bary, hitT, rayDir, isInside, tri);
+  return mk4(T.x, T.y, T.z, isInside ? 1.0f : 0.0f);
+}
+PT_DEV f3 getShadowTransmissionTri(const DevScene& sc, int rnode, int triangleID, int tri, f3 bary, float hitT, f3 rayDir, bool& isInside)
+{
+  const f4 r = getShadowTransmissionTriCall(sc, rnode, triangleID, tri, bary, hitT, rayDir, isInside);
+  isInside   = r.w != 0.0f;
+  return xyz(r);
+}
+// SHADE_REC: `shadeTri` >= 0 is the triangle's index in the active structure -- its shade record names the material, the render node and the three
+// interleaved vertices (whose first float4 holds the same object-space position as the primitive's position stream), so the chain is record ->
+// {material, node, vertices} instead of node -> {material, primitive} -> indices -> positions.  Same values, same arithmetic: the same result bit for bit
+// (k_shadow_resolve, round 5); the primitive's pointer table is fetched only for a metallic-roughness TEXTURE.
+PT_DEV f3 getShadowTransmissionBody(const DevScene& sc, int rnode, int triangleID, f3 bary, float hitT, f3 rayDir, bool& isInside, int shadeTri)
 {
   const MiGltfRenderNode&    rn  = gat(sc.nodes, rnode);
-  const MiGltfShadeMaterial& mat = gat(sc.materials, max(0, rn.materialID));
+  DevShadeTri                sr{};
+  if(shadeTri >= 0)
+    sr = gat(sc.shadeTris, shadeTri);
+  const MiGltfShadeMaterial& mat = gat(sc.materials, shadeTri >= 0 ? sr.materialID : max(0, rn.materialID));
   float                      tFactor = mat.transmissionFactor;
   if(tFactor <= MIN_TRANSMISSION)
     return mk3(0.0f);
-  const DevPrim rp = gat(sc.prims, rn.renderPrimID);
-  u3            ti = getTriangleIndices(rp, triangleID);
-  f3 v0 = getVertexPosition(rp, ti.x), v1 = getVertexPosition(rp, ti.y), v2 = getVertexPosition(rp, ti.z);
+  DevPrim rp{};
+  u3      ti{0u, 0u, 0u};
+  f3      v0, v1, v2;
+  if(shadeTri >= 0)
+  {
+    const float4 a = gat(sc.geomPool, sr.v0), b = gat(sc.geomPool, sr.v1), c = gat(sc.geomPool, sr.v2);
+    v0 = mk3(a.x, a.y, a.z); v1 = mk3(b.x, b.y, b.z); v2 = mk3(c.x, c.y, c.z);
+  }
+  else
+  {
+    rp = gat(sc.prims, rn.renderPrimID);
+    ti = getTriangleIndices(rp, triangleID);
+    v0 = getVertexPosition(rp, ti.x); v1 = getVertexPosition(rp, ti.y); v2 = getVertexPosition(rp, ti.z);
+  }
   f3 normal = normalize(cross(v1 - v0, v2 - v0));
   normal    = normalize(mulTransposed(rn.worldToObject, normal));
   float cosTheta = fabsf(dot(rayDir, normal));
@@ -713,6 +743,11 @@ PT_DEV f3 getShadowTransmissionBody(const DevScene& sc, int rnode, int triangleI
   float roughness = mat.pbrRoughnessFactor, metallic = mat.pbrMetallicFactor;
   if(isTexturePresent(mat.pbrMetallicRoughnessTexture))
   {
+    if(shadeTri >= 0)
+    {
+      rp = gat(sc.prims, rn.renderPrimID);
+      ti = getTriangleIndices(rp, triangleID);
+    }
     const MiGltfTextureInfo info = gat(sc.texInfos, mat.pbrMetallicRoughnessTexture);
     f2                      uv   = getInterpolatedVertexTexCoord(rp, info.texCoord, ti, bary);
     f4                      mr   = sampleTexture(sc, info.index, uv, false, mk2(0, 0), mk2(0, 0));
