@@ -430,6 +430,8 @@ __device__ unsigned long long g_shadowProf[16];  // the same for k_trace_shadow 
 #ifndef REFILL_IDLE_LANES
 #define REFILL_IDLE_LANES 16
 #endif
+// (The any-hit walks' rays are short since they start at the far end, and the refill is a third of their wave time (round-5 profile) -- but their own
+//  threshold at 8 / 24 / 32 / 44 measured within +-0.3 % of 16 on every workload: fewer refills serve fewer busy lanes.  One threshold for both.)
 // Dense triangle phase of the 8-wide walk: start once this many lanes have parked triangles, leave below the exit count.
 #ifndef TRI_PHASE_LANES_N
 #define TRI_PHASE_LANES_N 24
