@@ -227,10 +227,10 @@ __global__ void k_dp_solve(int numLeaves, const float4* nodes2, const int* paren
   int cur = leafParent[leaf];
   while(cur >= 0)
   {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt: this thread's write-through stores (d_dpSolve) have been acknowledged
+    __builtin_amdgcn_s_waitcnt(0);  // this thread's write-through stores (d_dpSolve) have been ACKNOWLEDGED before its ticket is taken (bvh_reinsert.h: r2Ticket)
     if(__hip_atomic_fetch_add(&arrive[cur], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
       return;  // first arrival: the sibling subtree finishes this node
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // (nothing below moves above the ticket)
+    __builtin_amdgcn_s_waitcnt(0);  // (the ticket has returned before the tables below it are read)
     d_dpSolve(nodes2, dp, cur, maxLeaf);
     cur = parent[cur];
   }

@@ -297,9 +297,16 @@ PT_DEV void  r2CohStore(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_R
 PT_DEV void  r2CohStore(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 PT_DEV unsigned int r2Ticket(unsigned int* p)
 {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt: this thread's write-through stores have been acknowledged
+  // the write-through stores above must have been ACKNOWLEDGED before the ticket is taken (a workgroup-scope fence compiles to nothing here, and the
+  // memory system may otherwise perform the atomic first): an explicit s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0).  REINSERT_RELEASE_FENCE selects the
+  // memory model's own agent-scope release fence instead (adds an L2 write-back request; same records, measured in profiles/r05_refit_ordering.txt)
+#ifdef REINSERT_RELEASE_FENCE
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#else
+  __builtin_amdgcn_s_waitcnt(0);
+#endif
   const unsigned int t = __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // (nothing below moves above the ticket)
+  __builtin_amdgcn_s_waitcnt(0);  // (the ticket has returned before anything below is issued)
   return t;
 }
 #else  // the host build of the CPU test tier (tests/host_shim): one coherent memory
