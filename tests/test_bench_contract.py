@@ -124,6 +124,26 @@ def test_emit_prints_the_compact_line_last(tmp_path, capfd):
     assert json.loads(open(tmp_path / "full.json").read()) == full and json.loads(err.strip().splitlines()[-1]) == full
 
 
+def test_committed_round5_record_obeys_the_contract():
+    """The full record of the round's last default run (what bench_full.json held): every kernel fraction inside (0, 1], every configuration with its counter
+    passes, parity within the tolerance at the configuration's own sample count, the footprint and the walk figures the round-4 review set as targets."""
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_default.json")).read().strip().splitlines()[-1])
+    assert line["unit"] == "Msamples/s" and line["n_gpus"] == 1 and line["config"]["workload"].startswith("configs[2]") and line["north_star"]["value"] == line["value"]
+    assert set(line["also"]) == set(bench.ALSO_DEFAULT.split(","))
+    for name, ln in {"headline": line, **line["also"]}.items():
+        assert ln["roofline"]["traffic"] is not None, name
+        for k, r in ln["kernels"].items():
+            assert r["frac"] is not None and 0.0 < r["frac"] <= 1.0, (name, k, r["frac"])
+        if name != "helmet_4k":
+            assert ln["parity"]["rel_l2"] <= 1e-3 and ln["parity"]["within_tolerance"], name
+            assert ln["cpu_baseline"]["kind"] == "port" and "-march=native" in ln["cpu_baseline"]["flags"]
+    assert line["value"] >= 640.0 and line["also"]["street"]["value"] >= 670.0 and line["also"]["glass_denoise"]["value"] >= 800.0  # (the review's thresholds)
+    assert line["node_visits_per_secondary_ray"] <= 17.5 and line["also"]["street"]["node_visits_per_secondary_ray"] <= 25.0
+    assert line["bytes_per_path_slot"] <= 256 and line["device_memory_GB"]["path_state_queues_images"] <= 70.0
+    walks = line["kernels"]["trace_closest"]["ms_per_frame"] + line["kernels"]["trace_shadow"]["ms_per_frame"]
+    assert walks <= 1.80, walks
+
+
 def test_more_ranks_than_devices_is_refused_before_anything_runs():
     """`python bench.py --gpus N` starts its own ranks -- and on a box with fewer devices (here: none) it must exit non-zero without a JSON line."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "BENCH_SHARE_GPU")}
