@@ -11,8 +11,10 @@ one after the other; --in-flight 1 gives exactly that).  Metric = the reference'
 W*H*spp / wall_s / 1e6 with spp = all samples of the timed region, inputs resident in HBM before the timed region.
 
 N > 1: the image is split into interleaved 32x32 tiles (--tile; tile % N == rank), every rank renders its tiles with no data-path
-collective, and ONE RCCL reduce(sum) of the RGBA32F accumulator over xGMI closes every step (inside the timed region).  A rank
-owns 1/N of every frame, so a step renders frames_per_step * N frames: the work per GPU is fixed as N grows -> "weak" scaling.
+collective, and ONE RCCL reduce(sum) of the RGBA32F accumulator over xGMI closes every step (inside the timed region).
+--scaling strong (default): a step is the configuration's own sample count whatever N is (256 frames for configs[2]; the frames of a
+step are in flight together, a GPU holds 1/N of their path slots) -- total work fixed, the north star's 1 -> 8 claim.
+--scaling weak: a step renders frames_per_step * N frames, in_flight * N in flight -- work per GPU fixed (step_shape()).
 `python bench.py --gpus N` without a launcher starts its own N ranks (torch.distributed.run on 127.0.0.1) and refuses to run when
 fewer than N devices are visible.
 
@@ -59,8 +61,18 @@ WORKLOADS = {
                    kw=dict(seed=4321, detail=0.8, tex_size=512), width=1920, height=1080, depth=12, hdr=False, spp=256),
     "street": dict(config="configs[3]: BistroExterior-class (instanced street, ~2.8 M triangles, ~1000 render nodes, 130 materials), 3840x2160, 64 spp, depth 8",
                    gen="scene_street_class", kw=dict(seed=777, detail=1.27, tex_size=256), width=3840, height=2160, depth=8, hdr=False, spp=64),
-    "glass": dict(config="configs[4]: TransmissionTest-class, 1920x1080, 512 spp, depth 24", gen="scene_glass_class",
-                  kw=dict(seed=99, tess=96), width=1920, height=1080, depth=24, hdr=True, in_flight=256, frames_per_step=512, spp=512),
+    "glass": dict(config="configs[4]: TransmissionTest-class sphere grid + textured glass slabs + DragonDispersion-class blob (869 k triangles, dispersion + volume), "
+                         "1920x1080, 512 spp, depth 24", gen="scene_glass_class",
+                  kw=dict(seed=99, tess=96, dragon=932), width=1920, height=1080, depth=24, hdr=True, in_flight=256, frames_per_step=512, spp=512),
+    # the sphere grid alone (rounds 1-5's configs[4] stand-in, 166 k triangles, no texture): the unit-test size, kept for comparison
+    "glass_grid": dict(config="configs[4] (sphere grid only): TransmissionTest-class, 1920x1080, 512 spp, depth 24", gen="scene_glass_class",
+                       kw=dict(seed=99, tess=96), width=1920, height=1080, depth=24, hdr=True, in_flight=256, frames_per_step=512, spp=512),
+    # SURVEY 8(d) "triangle sizes log-uniform": the same hall / street with hall-sized wall triangles, 16:1 strips, long thin beams and cables next to
+    # finely tessellated detail (scenegen sliver=True) -- what a BVH builder meets on the real assets
+    "atrium_sliver": dict(config="configs[2] with log-uniform triangle sizes (edges 2 mm .. 38 m, long thin beams): Sponza-class, 1920x1080, 256 spp, depth 12, NEE+MIS",
+                          gen="scene_atrium_class", kw=dict(seed=4321, detail=0.8, tex_size=512, sliver=True), width=1920, height=1080, depth=12, hdr=False, spp=256),
+    "street_sliver": dict(config="configs[3] with 16:1 facade strips, 240-m road strips and overhead cables: BistroExterior-class, 3840x2160, 64 spp, depth 8",
+                          gen="scene_street_class", kw=dict(seed=777, detail=1.27, tex_size=256, sliver=True), width=3840, height=2160, depth=8, hdr=False, spp=64),
     "box": dict(config="configs[0]: resources/Box.glb, 256x256, 16 spp, depth 4", gen=None, kw={}, width=256, height=256, depth=4, hdr=True, spp=16),
 }
 # lines of the default run's "also": name -> (workload, width, height, denoise, parity leg)
@@ -71,8 +83,13 @@ ALSO_LINES = {
     "street": ("street", 0, 0, False, True),
     "glass": ("glass", 0, 0, False, True),
     "glass_denoise": ("glass", 0, 0, True, True),
+    "glass_grid": ("glass_grid", 0, 0, False, False),
+    "glass_grid_denoise": ("glass_grid", 0, 0, True, False),
+    "atrium_sliver": ("atrium_sliver", 0, 0, False, True),
+    "street_sliver": ("street_sliver", 0, 0, False, False),  # (parity leg on request: --also street_sliver_parity)
+    "street_sliver_parity": ("street_sliver", 0, 0, False, True),
 }
-ALSO_DEFAULT = "helmet,helmet_4k,street,glass_denoise"
+ALSO_DEFAULT = "helmet,helmet_4k,street,glass_denoise,atrium_sliver,street_sliver"
 NORTH_STAR = {"workload": "atrium", "target": ">= 2 Gsamples/s on Sponza 1080p at 8 x MI355X (BASELINE.json north_star)", "needs_per_gpu_Msamples_s": 250.0}
 # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy); 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T
 # vector-lane operations per second (x2 flops per fma = the 157.3 TFLOP/s fp32 vector peak)
@@ -102,6 +119,11 @@ def scene_path(name, rank):
         getattr(scenegen, w["gen"])(tmp, **w["kw"])
         os.replace(tmp, path)
     return path
+
+
+# configurations of the default run whose counter passes (profiles/pmc_latest_<workload>.json) have not been collected yet for the current kernels / scenes: their
+# lines print `traffic: null`.  tests/test_bench_contract.py lets exactly these pass without a file.
+PMC_PENDING = {"glass", "atrium_sliver", "street_sliver"}
 
 
 def load_pmc(workload, F, W, H):
@@ -259,6 +281,24 @@ def frames_in_flight(wanted, width, height, world=1):
     return f - f % 64 if f >= 64 else f
 
 
+def step_shape(scaling, world, in_flight, frames_per_step, W, H, exact=False):
+    """(frames in flight, frames per step) of an N-rank run.  Every rank owns 1/world of the pixels of each frame, so F frames in flight are
+    F * W * H / world path slots on each GPU.
+    weak:   frames per step and frames in flight grow with the world size -- path slots per GPU constant (frames_per_step * world, in_flight * world).
+    strong: a step stays the configuration's own frames_per_step (256 spp for configs[2]) whatever the world size; its frames are in flight together up
+            to in_flight * world, so at N = 8 a GPU holds 256 x W*H/8 = 32 W*H path slots -- the per-GPU rate is the one of a 32-frame batch
+            (DESIGN section 5 quotes it), which is what a fixed total job costs.  At world = 1 both modes are the same run."""
+    if scaling == "strong":
+        frames_step = max(1, frames_per_step)
+        F = min(1024, max(1, in_flight) * world, frames_step)
+    else:
+        frames_step = max(1, frames_per_step) * world
+        F = min(1024, max(1, in_flight) * world)
+    # ... within the budget of path slots per GPU (SLOT_BUDGET): 4K frames run 64 in flight
+    F = frames_in_flight(F, W, H, world) if not exact else max(1, min(F, int(SLOT_BUDGET * world // (W * H))))
+    return F, frames_step
+
+
 def alpha_cut_note(subdivisions, triangles_loaded, dropped):
     if subdivisions <= 0:
         return None
@@ -280,7 +320,7 @@ def cpu_baseline_and_parity(scene, w, W, H, F, cpu_seconds, make_gpu_tracer, gpu
     from vk_gltf_renderer_amd import pathtracer as ptmod
     if oracle_lib._lib is None:
         oracle_lib.use_native()  # the timed baseline: -O3 -march=native, built on this box
-    setup = pu.Setup(scene.path, W, H, hdr_path=os.path.join(ROOT, "assets", "std_env.hdr") if w["hdr"] else None, max_depth=w["depth"])
+    setup = pu.Setup(scene.path, W, H, hdr_path=w.get("hdr_path", os.path.join(ROOT, "assets", "std_env.hdr")) if w["hdr"] else None, max_depth=w["depth"])
     O = oracle_lib.lib()
     o = C.c_void_p()
     O.oracle_pt_create(setup.scene.desc, C.byref(o))
@@ -330,6 +370,33 @@ def cpu_baseline_and_parity(scene, w, W, H, F, cpu_seconds, make_gpu_tracer, gpu
                    "within_tolerance": bool(parity["rel_l2"] <= 1e-3),
                    "reference": "CPU oracle (oracle/oracle_pt.cpp), same scene bytes (as loaded: no alpha cut), seeds and frame indices"})
     return cpu, parity
+
+
+def uncut_value(args, w, W, H, F, frames_step, device, hdr, frame_info, params, steps):
+    """Msamples/s of the headline configuration on the scene as loaded (alpha cut off): one warm-up batch, `steps` timed steps."""
+    import torch
+    from vk_gltf_renderer_amd import pathtracer as ptmod
+    scene = ptmod.Scene(args.scenefile or scene_path(args.workload, 0))
+    t = ptmod.PathTracer(scene, device=device, collect_counters=False, bvh=args.bvh)
+    if hdr is not None:
+        t.set_environment(hdr)
+    t.resize(W, H)
+    t.set_frame_info(frame_info)
+    t.set_sky(ptmod.default_sky())
+    r = ptmod.HeadlessRenderer(t, params)
+    r.render(F, in_flight=F)
+    t.synchronize()
+    r.reset_frame()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r.render(frames_step, in_flight=F)
+    t.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t.close()
+    return {"value": round(float(W) * H * steps * frames_step / elapsed / 1e6, 3), "unit": "Msamples/s", "scene_triangles": scene.num_triangles, "steps": steps,
+            "note": "the same timed region on the geometry as loaded (--alpha-cut 0)"}
 
 
 def secondary_line(name, args, device, width=0, height=0, steps=5, parity=True, denoise=False):
@@ -451,7 +518,7 @@ def compact_line(result):
     (src/benchmarking.cpp:281-303).  Kernel tables, per-frame counters and every prose field stay in the full record (bench_full.json, stderr)."""
     c = result["config"]
     out = {k: result[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
-    out["config"] = {k: c[k] for k in ("workload", "resolution", "spp_per_step", "frames_in_flight", "max_depth", "tile", "parallelism", "world_size_reported_by_backend",
+    out["config"] = {k: c[k] for k in ("workload", "resolution", "spp_per_step", "frames_in_flight", "path_slots_per_gpu_in_frames", "max_depth", "tile", "parallelism", "world_size_reported_by_backend",
                                          "devices_visible", "reduce", "denoise", "library") if c.get(k) is not None}
     out["ms_per_frame"] = result["ms_per_frame"]
     out["roofline"] = compact_roofline(result.get("roofline"))
@@ -471,6 +538,8 @@ def compact_line(result):
     for k in ("node_visits_per_secondary_ray", "bytes_per_path_slot"):
         if k in result:
             out[k] = result[k]
+    if isinstance(result.get("value_uncut_geometry"), dict):
+        out["value_uncut_geometry"] = result["value_uncut_geometry"].get("value", result["value_uncut_geometry"].get("error", "")[:80])
     if "device_memory_GB" in result:
         out["device_memory_GB"] = result["device_memory_GB"]
     if "north_star" in result:
@@ -559,6 +628,17 @@ def main():
     ap.add_argument("--alpha-cut", type=int, default=ALPHA_CUT_DEFAULT,
                     help="load-time bake for alpha-MASK geometry (mi_scene_cut_alpha: the counterpart of the reference's opacity micro-map bake): "
                          "subdivisions per triangle edge, 0 = off.  The parity leg renders the UNCUT scene with the CPU oracle")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N > 1.  strong (default): a step is the configuration's OWN sample count (frames_per_step frames, 256 for configs[2]) whatever N is -- every rank "
+                         "renders its 1/N of the pixels of those frames, all of them in flight up to in_flight * N (N = 8: 256 frames x W*H/8 = 32 W*H path slots per GPU): total "
+                         "work fixed, the north star's '>= 6x 1 -> 8 on Sponza 1080p'.  weak: frames_per_step * N frames per step, in_flight * N in flight -- path slots per GPU "
+                         "constant.  At N = 1 the two are the same run")
+    ap.add_argument("--scenefile", default=None,
+                    help="a .gltf / .glb of your own (e.g. the real Sponza) instead of the seeded stand-in of --workload: same timed region, counter passes, CPU baseline and "
+                         "parity leg; resolution / depth / spp default to those of --workload (override: --width --height --depth --parity-spp); the scene's first camera")
+    ap.add_argument("--hdrfile", default=None, help="Radiance .hdr environment for --scenefile (default: std_env.hdr if --workload uses one, else the physical sky)")
+    ap.add_argument("--depth", type=int, default=0, help="maxDepth override (default: the workload's)")
+    ap.add_argument("--no-uncut", action="store_true", help="skip the second timed run on the geometry AS LOADED (no alpha cut) that the default single-GPU run reports as `value_uncut_geometry`")
     ap.add_argument("--exact-in-flight", action="store_true", help="do not round the frames in flight down to a multiple of 64 (A/B of the slot layouts)")
     ap.add_argument("--frames-per-step", type=int, default=0,
                     help="frames (1 spp each) per GPU and step (default 256); a step renders frames_per_step * n_gpus frames")
@@ -599,14 +679,20 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
         assert dist.get_world_size() == world
 
-    w = WORKLOADS[args.workload]
+    w = dict(WORKLOADS[args.workload])
+    if args.scenefile:  # a supplied asset through the same legs: the workload entry only lends its resolution / depth / spp defaults
+        w.update(config=f"--scenefile {os.path.basename(args.scenefile)} ({w['config'].split(':')[0]} settings)", gen="file", hdr=bool(args.hdrfile) or w["hdr"])
+    if args.depth > 0:
+        w["depth"] = args.depth
     args.in_flight = args.in_flight or w.get("in_flight", IN_FLIGHT_DEFAULT)
     args.frames_per_step = args.frames_per_step or w.get("frames_per_step", FRAMES_PER_STEP_DEFAULT)
     W, H = args.width or w["width"], args.height or w["height"]
-    scene = ptmod.Scene(scene_path(args.workload, rank))
+    hdr_path = args.hdrfile or os.path.join(ROOT, "assets", "std_env.hdr")
+    w["hdr_path"] = hdr_path
+    scene = ptmod.Scene(args.scenefile or scene_path(args.workload, rank))
     triangles_loaded = scene.num_triangles
     alpha_cut_dropped = scene.cut_alpha(args.alpha_cut) if args.alpha_cut > 0 else 0
-    hdr = ptmod.HdrEnvironment(path=os.path.join(ROOT, "assets", "std_env.hdr")) if w["hdr"] else None
+    hdr = ptmod.HdrEnvironment(path=hdr_path) if w["hdr"] else None
     cam = scene.camera(0)
     frame_info, pixel_angle, focal = ptmod.camera_frame_info(cam, W, H)
     if hdr is not None:
@@ -659,14 +745,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Every rank owns 1/world of the tiles of each frame, so the frames per step and the frames in flight grow with the world size
-    # to keep the rays in flight per GPU constant (weak scaling).
-    F = min(1024, max(1, args.in_flight) * world)
-    # ... within the budget of path slots per GPU (SLOT_BUDGET): 4K frames run 64 in flight
-    F = frames_in_flight(F, W, H, world) if not args.exact_in_flight else max(1, min(F, int(SLOT_BUDGET * world // (W * H))))
+    F, frames_step = step_shape(args.scaling, world, args.in_flight, args.frames_per_step, W, H, args.exact_in_flight)
     # (a rank owns numSlots = its tiles' pixels, ~W*H/world: F frames in flight are F*W*H/world path slots on this GPU)
     assert F * float(W) * float(H) / world <= SLOT_BUDGET * 1.02, "path slots per GPU beyond the budget"
-    frames_step = max(1, args.frames_per_step) * world
 
     def step():
         runner.render(frames_step, stream.cuda_stream, in_flight=F)
@@ -739,11 +820,11 @@ def main():
         result = {
             "metric": "Msamples/s (and ms/frame @ fixed spp) 1080p & 4K, 1/2/4/8 MI355X", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": w["config"] + " (seeded synthetic stand-in)" if w["gen"] else w["config"], "scene_triangles": scene.num_triangles,
                        "alpha_cut": alpha_cut_note(args.alpha_cut, triangles_loaded, alpha_cut_dropped),
                        "bvh_reinsertion_passes": int(os.environ.get("MI_PT_REINSERT", "16") or 0),  # (read by the library at mi_pt_create; 0 = the builder's tree as clustered)
-                       "resolution": [W, H], "spp_per_step": frames_step, "frames_in_flight": F, "max_depth": w["depth"], "tile": args.tile,
+                       "resolution": [W, H], "spp_per_step": frames_step, "frames_in_flight": F, "path_slots_per_gpu_in_frames": round(F / world, 2), "max_depth": w["depth"], "tile": args.tile,
                        "parallelism": f"tiles{world}" if world > 1 else "single", "world_size_reported_by_backend": (dist.get_world_size() if dist is not None else 1),
                        "devices_visible": torch.cuda.device_count(),
                        "reduce": ((f"one RCCL reduce(sum) of {frame_buf.numel() * 4 / 1e6:.1f} MB (RGBA32F accumulator" + (" + albedo / normal guides + depth" if args.denoise else "") + ") per step") if dist is not None else None),
@@ -765,6 +846,14 @@ def main():
         if args.workload == NORTH_STAR["workload"] and not (args.width or args.height):
             result["north_star"] = dict(NORTH_STAR, workload=result["config"]["workload"], value=result["value"], unit="Msamples/s", n_gpus=world,
                                         value_per_gpu=round(value / world, 3), frac_of_needed_per_gpu=round(value / world / NORTH_STAR["needs_per_gpu_Msamples_s"], 3))
+        if world == 1 and args.alpha_cut > 0 and alpha_cut_dropped > 0 and not args.no_uncut:
+            # The same timed region on the geometry AS LOADED (no load-time alpha cut: a preprocessing step the reference does not perform on an asset without
+            # opacity micro-maps) -- reported next to `value`, which is measured on the cut geometry
+            tracer.close()
+            try:
+                result["value_uncut_geometry"] = uncut_value(args, w, W, H, F, frames_step, local_rank, hdr, frame_info, params, min(args.steps, 5))
+            except Exception as e:  # noqa: BLE001
+                result["value_uncut_geometry"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline and world == 1:
             tracer.close()  # (its path state is not needed any more; the parity leg's tracer may want as much again)
             try:

@@ -291,6 +291,12 @@ MI_PT_API int mi_pt_get_frame_timing(MiPt* pt, MiPtFrameTiming* timing);
 /* Human-readable description of the last failure on this thread ("" if none). */
 MI_PT_API const char* mi_pt_last_error(void);
 MI_PT_API const char* mi_pt_version(void);
+/* Layout version of the public structs of this header.  It is bumped whenever a struct a caller allocates (MiPtMemory, MiPtStats, MiPtFrameTiming,
+ * MiPathtraceParams, ...) grows or changes: the library writes every field of the struct it was compiled with, so a caller built against an older
+ * header must refuse to run -- `if(mi_pt_abi_version() != MI_PT_ABI_VERSION) fail` right after loading the library.
+ * 6: MiPtMemory grew pathStateBytes / pathSlots (round 5); mi_pt_render_frames refuses maxDepth 0. */
+#define MI_PT_ABI_VERSION 6
+MI_PT_API int mi_pt_abi_version(void);
 
 #ifdef __cplusplus
 }

@@ -70,18 +70,25 @@ def test_two_ranks_of_the_hip_renderer_reduce_to_the_single_rank_frame(built, tm
     assert img.shape == (136, 200, 4) and np.isfinite(img).all() and img[..., :3].max() > 0
 
 
-def test_bench_two_ranks_on_one_gpu(built):
+@pytest.mark.parametrize("scaling", ["strong", "weak", None])
+def test_bench_two_ranks_on_one_gpu(built, scaling):
     """bench.py's N = 2 code path, started the way the driver may start it -- plain `python bench.py --gpus 2`, no launcher: bench.py
-    spawns its own ranks (functional check; the numbers of a shared GPU mean nothing)."""
+    spawns its own ranks (functional check; the numbers of a shared GPU mean nothing).  Strong scaling (the default): a step stays the
+    configuration's 8 frames, all of them in flight (4 x 2 ranks); weak: 8 x 2 frames per step."""
     env = dict(os.environ, BENCH_SHARE_GPU="1", BENCH_DIST_BACKEND="gloo")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "box", "--frames-per-step", "8", "--in-flight", "4"]
+    if scaling:
+        cmd += ["--scaling", scaling]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     j = json.loads(line)
-    assert j["n_gpus"] == 2 and j["config"]["world_size_reported_by_backend"] == 2 and j["config"]["spp_per_step"] == 16 and j["value"] > 0
+    assert j["n_gpus"] == 2 and j["config"]["world_size_reported_by_backend"] == 2 and j["value"] > 0
+    assert j["scaling"] == (scaling or "strong")
+    assert j["config"]["spp_per_step"] == (16 if scaling == "weak" else 8) and j["config"]["frames_in_flight"] == 8
+    assert j["config"]["path_slots_per_gpu_in_frames"] == 4.0
     assert j["config"]["reduce"].startswith("one RCCL reduce")
 
 
@@ -105,8 +112,9 @@ def test_bench_denoise_two_ranks_equals_one_rank(built, tmp_path):
         port = _free_port()
         out = tmp_path / f"dump{world}.npz"
         env = dict(os.environ, BENCH_SHARE_GPU="1", BENCH_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BENCH_DUMP=str(out))
+        # (weak: 4 frames x 2 ranks per step; the strong-mode default renders the same 8 frames from `--frames-per-step 8` at either world size)
         args = [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0", "--workload", "box", "--frames-per-step", str(8 // world),
-                "--in-flight", str(4 // world), "--denoise", "--no-cpu-baseline"]
+                "--in-flight", str(4 // world), "--denoise", "--no-cpu-baseline", "--scaling", "weak"]
         cmd = [sys.executable] + args if world == 1 else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                                                           "--master-port", str(port)] + args
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
@@ -117,3 +125,23 @@ def test_bench_denoise_two_ranks_equals_one_rank(built, tmp_path):
     assert np.array_equal(outs[0]["accum"], outs[1]["accum"])
     assert np.array_equal(outs[0]["denoised"], outs[1]["denoised"])
     assert np.abs(outs[0]["denoised"][..., :3] - outs[0]["accum"][..., :3]).max() > 0
+
+
+def test_bench_strong_scaling_two_ranks_equals_one_rank(built, tmp_path):
+    """--scaling strong: the SAME 8 frames whether one rank renders them or two ranks render half the tiles each -- the reduced accumulator is the single-rank
+    one bit for bit (tiles are disjoint, seeds are a function of pixel and frame), and the step's sample count does not grow with the world size."""
+    outs = []
+    for world in (1, 2):
+        port = _free_port()
+        out = tmp_path / f"strong{world}.npz"
+        env = dict(os.environ, BENCH_SHARE_GPU="1", BENCH_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BENCH_DUMP=str(out))
+        args = [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0", "--workload", "box", "--frames-per-step", "8", "--in-flight", "4",
+                "--no-cpu-baseline", "--scaling", "strong"]
+        cmd = [sys.executable] + args if world == 1 else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                                          "--master-port", str(port)] + args
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert j["scaling"] == "strong" and j["config"]["spp_per_step"] == 8 and j["config"]["frames_in_flight"] == 4 * world
+        outs.append(np.load(out))
+    assert np.array_equal(outs[0]["accum"], outs[1]["accum"])

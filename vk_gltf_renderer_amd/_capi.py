@@ -142,6 +142,7 @@ assert C.sizeof(MiGltfTextureInfo) == 32
 assert C.sizeof(MiGltfShadeMaterial) == 288
 assert C.sizeof(MiSceneFrameInfo) == 396
 
+MI_PT_ABI_VERSION = 6  # include/mi_pt.h
 MI_PT_USE_DLSS, MI_PT_USE_OPTIX_DENOISER, MI_PT_FIRST_FRAME = 1, 2, 4
 MI_SCENE_IS_ORTHOGRAPHIC, MI_SCENE_USE_SOLID_BACKGROUND, MI_SCENE_USE_HDR_ENVIRONMENT = 1, 2, 4
 MI_SCENE_USE_INFINITE_PLANE, MI_SCENE_INFINITE_PLANE_SHADOW_CATCHER = 8, 16
@@ -206,6 +207,7 @@ PT_SYMBOLS = {
     "mi_pt_get_frame_timing": (i32, [VP, P(MiPtFrameTiming)]),
     "mi_pt_last_error": (C.c_char_p, []),
     "mi_pt_version": (C.c_char_p, []),
+    "mi_pt_abi_version": (i32, []),
     "mi_pt_update_render_nodes": (i32, [VP, P(MiGltfRenderNode), i32, P(C.c_uint8)]),
     "mi_pt_update_lights": (i32, [VP, P(MiGltfLight), i32]),
 }
@@ -243,6 +245,8 @@ def pt_lib():
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: the HIP extension was not built; the product path has no fallback")
         _pt = _bind(C.CDLL(path), PT_SYMBOLS)
+        if _pt.mi_pt_abi_version() != MI_PT_ABI_VERSION:  # the structs of this module mirror ONE layout version of include/mi_pt.h
+            raise RuntimeError(f"{path}: ABI version {_pt.mi_pt_abi_version()}, this binding was written for {MI_PT_ABI_VERSION}")
     return _pt
 
 

@@ -38,6 +38,7 @@
 #include <vector>
 
 #include "pt_build.h"
+#include "pt_ticket.h"
 #include "pt_bvh.h"
 
 namespace pt {
@@ -59,7 +60,7 @@ struct Node8  // 80 bytes, see header
 };
 static_assert(sizeof(Node8) == 80, "Node8 must be 80 bytes");
 
-// Largest leaf child: 2 (MI_PT_LEAF_TRIS=1 selects one; the images do not depend on it).  Two bits of the node's 16-bit valid mask belong to
+// Largest leaf child: 2 triangles.  Two bits of the node's 16-bit valid mask belong to
 // a slot, so a leaf child holds one or two triangles -- which is also what measured best when the mask had room for three and four
 // (round 2: 2 beats 1, 3 and 4 on the helmet, atrium and street workloads, +0.4 .. +2.5 % over 3).
 // SAH-optimal collapse by default: against the greedy one (MI_PT_COLLAPSE=greedy) 40 % fewer, fuller nodes (atrium 68.8 k -> 44 k),
@@ -227,10 +228,9 @@ __global__ void k_dp_solve(int numLeaves, const float4* nodes2, const int* paren
   int cur = leafParent[leaf];
   while(cur >= 0)
   {
-    __builtin_amdgcn_s_waitcnt(0);  // this thread's write-through stores (d_dpSolve) have been ACKNOWLEDGED before its ticket is taken (bvh_reinsert.h: r2Ticket)
-    if(__hip_atomic_fetch_add(&arrive[cur], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+    // (this thread's write-through stores of d_dpSolve are acknowledged before its ticket, the ticket has returned before the tables are read: pt_ticket.h)
+    if(pt::ticketArrive(&arrive[cur]) == 0u)
       return;  // first arrival: the sibling subtree finishes this node
-    __builtin_amdgcn_s_waitcnt(0);  // (the ticket has returned before the tables below it are read)
     d_dpSolve(nodes2, dp, cur, maxLeaf);
     cur = parent[cur];
   }
@@ -508,7 +508,7 @@ bool buildBvh8(const BvhBuildOutput& b2, Bvh8Output& out, hipStream_t stream, st
   };
   const uint32_t numInner = b2.numNodes;
   const bool hostCollapse = opt.hostCollapse;
-  const int  leafTrisOpt  = opt.maxLeafTris < 1 ? 1 : (opt.maxLeafTris > 2 ? 2 : opt.maxLeafTris);
+  const int  leafTrisOpt  = 2;  // (see the note above Cand)
   if(numInner > 0 && !hostCollapse)
   {
     // ---- device collapse, one level at a time (see the header comment) -------------------------------------------------------

@@ -21,6 +21,7 @@
 // its parent's record (the root's nowhere: it is never needed).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "pt_ticket.h"
 
 #include <cstdint>
 
@@ -295,20 +296,8 @@ PT_DEV float r2CohLoad(const float* p) { return __hip_atomic_load(p, __ATOMIC_RE
 PT_DEV int   r2CohLoad(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 PT_DEV void  r2CohStore(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 PT_DEV void  r2CohStore(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-PT_DEV unsigned int r2Ticket(unsigned int* p)
-{
-  // the write-through stores above must have been ACKNOWLEDGED before the ticket is taken (a workgroup-scope fence compiles to nothing here, and the
-  // memory system may otherwise perform the atomic first): an explicit s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0).  REINSERT_RELEASE_FENCE selects the
-  // memory model's own agent-scope release fence instead (adds an L2 write-back request; same records, measured in profiles/r05_refit_ordering.txt)
-#ifdef REINSERT_RELEASE_FENCE
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-#else
-  __builtin_amdgcn_s_waitcnt(0);
-#endif
-  const unsigned int t = __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __builtin_amdgcn_s_waitcnt(0);  // (the ticket has returned before anything below is issued)
-  return t;
-}
+// (how the data words are ordered against the ticket, and on which targets: pt_ticket.h)
+PT_DEV unsigned int r2Ticket(unsigned int* p) { return ticketArrive(p); }
 #else  // the host build of the CPU test tier (tests/host_shim): one coherent memory
 PT_DEV float r2CohLoad(const float* p) { const int i = __atomic_load_n(reinterpret_cast<const int*>(p), __ATOMIC_SEQ_CST); float v; __builtin_memcpy(&v, &i, 4); return v; }
 PT_DEV int   r2CohLoad(const int* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }

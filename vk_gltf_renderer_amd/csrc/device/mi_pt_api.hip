@@ -1028,8 +1028,10 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_render_frames: 1 <= numFrames <= 1024 required");
   if(pt->width <= 0 || !pt->haveFrameInfo)
     return fail(MI_PT_ERR_STATE, "mi_pt_render_frame: call mi_pt_resize and mi_pt_set_frame_info first");
-  if(params->numSamples < 1 || params->maxDepth < 0 || params->maxDepth > 255)
-    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_render_frame: numSamples >= 1 and 0 <= maxDepth <= 255 required");
+  // (maxDepth 0: the reference's loop `for(depth = 0; depth < maxDepth; ...)` never runs and the image is black; here no shade launch would run and
+  //  the queued camera hits would keep the radiance and guide records of an earlier batch -- refused instead of special-cased)
+  if(params->numSamples < 1 || params->maxDepth < 1 || params->maxDepth > 255)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_render_frame: numSamples >= 1 and 1 <= maxDepth <= 255 required");
   if((pt->frameInfo.flags & MI_SCENE_USE_HDR_ENVIRONMENT) && !pt->scene.envPixels)
     return fail(MI_PT_ERR_STATE, "mi_pt_render_frame: HDR environment requested but none was set");
   HIP_TRY(hipSetDevice(pt->device));
@@ -1075,6 +1077,17 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
   if(int rc = ensureOptionalPathArrays(pt, c.fc.stateInQueue == 0, params->numSamples > 1, guides, (pt->frameInfo.flags & MI_SCENE_INFINITE_PLANE_SHADOW_CATCHER) != 0))
     return rc;
   c.paths        = pt->paths;
+  {
+    // optional records stay allocated (MiPt::opt*) once a batch needed them; THIS batch sees only the ones it needs itself -- a later
+    // single-sample batch must not keep paying the by-slot writes of an earlier multi-sample or catcher batch
+    const bool stateBySlot = c.fc.stateInQueue == 0, multiSample = params->numSamples > 1;
+    if(!(stateBySlot || multiSample))
+      c.paths.misc = nullptr;
+    if(!stateBySlot)
+      c.paths.throughput = nullptr;
+    if(!multiSample)
+      c.paths.pixelSum = nullptr;
+  }
   pt->accumFrames   = float(params->totalSamples) / float(params->numSamples) + float(numFrames);
   // the second moment covers the accumulation only if every batch since its start carried the guides
   if(guides && (params->totalSamples == 0 || pt->momentFrames == pt->accumFrames - float(numFrames)))
@@ -1087,6 +1100,8 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
     c.paths.guideNormal = nullptr;
   }
   c.queues           = pt->queues;
+  if(!(pt->frameInfo.flags & MI_SCENE_INFINITE_PLANE_SHADOW_CATCHER))
+    c.queues.shadow.aux2 = nullptr;
   c.ownedTiles       = pt->ownedTiles.ptr;
   c.stats            = pt->stats.ptr;
   c.stream           = stream;

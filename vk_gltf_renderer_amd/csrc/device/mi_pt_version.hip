@@ -14,3 +14,5 @@ extern "C" const char* mi_pt_version(void)
   // src = sha1 of the device sources + public headers this binary was compiled from (csrc/Makefile), git = HEAD at build time
   return "mi_pt 0.3 (gfx950 wavefront path tracer) src=" MI_PT_SRC_ID " git=" MI_PT_GIT_ID;
 }
+
+extern "C" int mi_pt_abi_version(void) { return MI_PT_ABI_VERSION; }

@@ -39,10 +39,9 @@ struct Bvh8Output
   DevTri*  tris     = nullptr;  // device, node order (triangles of a node's leaf children are contiguous)
   uint32_t numNodes = 0, numTris = 0;
 };
-struct Bvh8Options  // (MI_PT_COLLAPSE / MI_PT_LEAF_TRIS / MI_PT_HOST_COLLAPSE, read and validated once in mi_pt_create: RunSwitches)
+struct Bvh8Options  // (MI_PT_COLLAPSE / MI_PT_HOST_COLLAPSE, read and validated once in mi_pt_create: RunSwitches)
 {
   bool sahCollapse  = true;   // SAH-optimal dynamic programme (default) | greedy by surface area
-  int  maxLeafTris  = 2;      // triangles per leaf child: 1 | 2
   bool hostCollapse = false;  // the greedy host collapse (A/B reference of the device one)
 };
 bool buildBvh8(const BvhBuildOutput& b2, Bvh8Output& out, hipStream_t stream, std::string& err, const Bvh8Options& opt = Bvh8Options());

@@ -361,9 +361,29 @@ def scene_helmet_class(path, seed=1234, tess=272, tex_size=1024):
     return b.save(path)
 
 
-def scene_atrium_class(path, seed=4321, detail=1.0, tex_size=512):
+def _beam(p0, p1, width, up=(0.0, 1.0, 0.0)):
+    """A thin box (12 triangles, each as long as the beam) from p0 to p1 with a square cross-section of edge `width`."""
+    p0, p1 = np.asarray(p0, np.float64), np.asarray(p1, np.float64)
+    ax = p1 - p0
+    ln = np.linalg.norm(ax)
+    ax /= ln
+    u = np.cross(ax, np.asarray(up, np.float64))
+    if np.linalg.norm(u) < 1e-6:
+        u = np.cross(ax, np.array([1.0, 0.0, 0.0]))
+    u /= np.linalg.norm(u)
+    v = np.cross(ax, u)
+    pos, nrm, uv, idx = box((ln, width, width))
+    R = np.stack([ax, u, v], 1)  # box x -> beam axis
+    return (pos.astype(np.float64) @ R.T + (p0 + p1) / 2).astype(np.float32), (nrm.astype(np.float64) @ R.T).astype(np.float32), uv * np.array([ln, 1.0], np.float32), idx
+
+
+def scene_atrium_class(path, seed=4321, detail=1.0, tex_size=512, sliver=False):
     """Sponza-class interior: a long two-storey hall with columns, arches, drapes and alpha-MASK foliage, ~25 materials in
-    ~100 primitives, one directional light + sky.  detail=1.0 gives ~262k triangles."""
+    ~100 primitives, one directional light + sky.  detail=1.0 gives ~262k triangles.
+    sliver=True: the triangle-size distribution SURVEY 8(d) asks for ("triangle sizes log-uniform") and what makes the real asset hard for a BVH:
+    every wall / floor / ceiling is a handful of long strips or two hall-sized triangles, long thin beams, rails and diagonal ropes run between
+    finely tessellated columns, and half of the clutter is four times finer than the rest -- triangle edges from ~5 mm to 36 m (3.9 decades) at the
+    same triangle count (+-2 %) and the same materials, light and camera."""
     rng = np.random.default_rng(seed)
     b = GlbBuilder()
     smp = b.sampler()
@@ -407,8 +427,35 @@ def scene_atrium_class(path, seed=4321, detail=1.0, tex_size=512):
         return pos, idx, nrm, uv * np.array([size[0] / 4, size[1] / 4], np.float32)
 
     # shell: floor, ceiling (with a skylight slot), walls
-    add(quad_grid(g * 3, g, (L, Wd), "y"), mats[0])
-    for s in (-1, 1):
+    if sliver:
+        # hall-long strips and two-triangle walls (the shell loses ~10 k triangles; the finer half of the clutter below takes them)
+        add(quad_grid(1, g, (L, Wd), "y"), mats[0])
+        for s in (-1, 1):
+            add(quad_grid(1, 3, (L, Wd * 0.32), "y", flip=True), mats[1], translation=[0, Hh, s * Wd * 0.34])
+            add(quad_grid(1, 1, (L, Hh), "z", flip=(s > 0)), mats[2], translation=[0, Hh / 2, s * Wd / 2])
+            add(quad_grid(1, 1, (Wd, Hh), "x", flip=(s > 0)), mats[3], translation=[s * L / 2, Hh / 2, 0])
+            add(quad_grid(1, 2, (L, 2.6), "y"), mats[4], translation=[0, Hh * 0.5, s * (Wd / 2 - 1.3)])
+        # beams between the columns, hand rails along the galleries, ropes across the hall: long thin boxes, most of them not axis aligned
+        beams = []
+        for s in (-1, 1):
+            z = s * (Wd / 2 - 2.6)
+            for i in range(9):
+                x0, x1 = -L / 2 + (i + 0.5) * L / 10, -L / 2 + (i + 1.5) * L / 10
+                for y in (Hh * 0.47, Hh * 0.97):
+                    beams.append(_beam((x0, y, z), (x1, y, z), 0.22))
+                beams.append(_beam((x0, Hh * 0.5, z), (x1, Hh * 0.97, z), 0.05))  # diagonal brace
+            for y in (Hh * 0.5 + 0.9, Hh * 0.5 + 0.5):
+                beams.append(_beam((-L / 2, y, s * (Wd / 2 - 2.55)), (L / 2, y, s * (Wd / 2 - 2.55)), 0.04))  # 36-m rails
+        for k in range(120):
+            a = np.array([rng.uniform(-L / 2 + 1, L / 2 - 1), rng.uniform(Hh * 0.55, Hh * 0.98), -(Wd / 2 - 2.6)])
+            c = np.array([a[0] + rng.uniform(-6, 6), rng.uniform(Hh * 0.55, Hh * 0.98), Wd / 2 - 2.6])
+            beams.append(_beam(a, c, float(np.exp(rng.uniform(np.log(0.005), np.log(0.03))))))
+        bp = np.concatenate([bm[0] for bm in beams]); bn = np.concatenate([bm[1] for bm in beams]); bu = np.concatenate([bm[2] for bm in beams])
+        bi = np.concatenate([bm[3] + 24 * k for k, bm in enumerate(beams)]).astype(np.uint32)
+        add((bp, bi, bn, bu), mats[9])
+    else:
+      add(quad_grid(g * 3, g, (L, Wd), "y"), mats[0])
+      for s in (-1, 1):
         add(quad_grid(g * 3, g // 2, (L, Wd * 0.32), "y", flip=True), mats[1], translation=[0, Hh, s * Wd * 0.34])
         add(quad_grid(g * 3, g, (L, Hh), "z", flip=(s > 0)), mats[2], translation=[0, Hh / 2, s * Wd / 2])
         add(quad_grid(g, g, (Wd, Hh), "x", flip=(s > 0)), mats[3], translation=[s * L / 2, Hh / 2, 0])
@@ -462,8 +509,11 @@ def scene_atrium_class(path, seed=4321, detail=1.0, tex_size=512):
         def displace(d, amp=amp, fr=fr):
             return 1.0 + amp * np.sin(d @ fr.T).sum(1) / 3.0
 
-        pos, nrm, uv, idx = uv_sphere(max(8, int(96 * detail)), max(6, int(48 * detail)), rng.uniform(0.5, 1.1), displace)
-        add((pos, idx, nrm, uv), mats[11 + k % 11], translation=[float(rng.uniform(-L / 2 + 2, L / 2 - 2)), float(rng.uniform(0.6, 1.2)),
+        radius = rng.uniform(0.5, 1.1)
+        fine = sliver and k % 2 == 1  # every other blob: a third of the size at 1.3 x the tessellation (edges ~4 mm .. 3 cm instead of 3 .. 9 cm)
+        pos, nrm, uv, idx = uv_sphere(max(8, int(96 * detail * (1.3 if fine else 0.72 if sliver else 1.0))),
+                                      max(6, int(48 * detail * (1.3 if fine else 0.72 if sliver else 1.0))), radius * (0.3 if fine else 1.0), displace)
+        add((pos, idx, nrm, uv), mats[11 + k % 11], translation=[float(rng.uniform(-L / 2 + 2, L / 2 - 2)), float(rng.uniform(0.6, 1.2)) * (0.3 if fine else 1.0),
                                                                 float(rng.uniform(-Wd / 2 + 3.4, Wd / 2 - 3.4))])
     li = b.light({"type": "directional", "intensity": 12.0, "color": [1.0, 0.96, 0.9]})
     # light direction = -Z of the node: tilt so it shines through the skylight slot
@@ -473,10 +523,12 @@ def scene_atrium_class(path, seed=4321, detail=1.0, tex_size=512):
     return b.save(path)
 
 
-def scene_street_class(path, seed=777, detail=1.0, tex_size=256):
+def scene_street_class(path, seed=777, detail=1.0, tex_size=256, sliver=False):
     """BistroExterior-class street: two rows of buildings along a street, every building an instance of
     one of 24 facade meshes (EXT_mesh_gpu_instancing: ~1000 render nodes from ~40 glTF nodes), street furniture and trees with
-    alpha-MASK foliage, ~130 materials over 24 textures, sun + sky.  detail=1.27 gives ~2.8 M triangles."""
+    alpha-MASK foliage, ~130 materials over 24 textures, sun + sky.  detail=1.27 gives ~2.8 M triangles.
+    sliver=True: the same street with the triangle shapes of a modelled one -- the road is 240-m strips, every facade is tessellated 16 : 1 along one
+    direction (ledges and pilasters: triangles 10 m long and centimetres wide), overhead cables sag across the street; same triangle count (-3 %)."""
     rng = np.random.default_rng(seed)
     b = GlbBuilder()
     b.ext_used.add("EXT_mesh_gpu_instancing")
@@ -522,8 +574,21 @@ def scene_street_class(path, seed=777, detail=1.0, tex_size=256):
 
     L, Wd = 240.0, 18.0
     g = max(2, int(40 * detail))
-    pos, nrm, uv, idx = grid(g * 4, g, (L, Wd * 3), "y")
+    pos, nrm, uv, idx = grid(1 if sliver else g * 4, g, (L, Wd * 3), "y")
     b.node(mesh=b.mesh([b.primitive(pos, idx, nrm, uv * np.array([L / 4, Wd], np.float32), material=m_road)]))
+    if sliver:  # overhead cables: chains of 12-m beams a centimetre or two thick, sagging, most of them diagonal across the street
+        beams = []
+        for k in range(60):
+            x0, x1 = sorted(rng.uniform(-L / 2, L / 2, 2))
+            x1 = min(x1, x0 + 60.0)
+            z0, z1 = rng.choice([-1, 1]) * Wd / 2, rng.choice([-1, 1]) * Wd / 2
+            y, w, n = rng.uniform(6.0, 9.0), float(np.exp(rng.uniform(np.log(0.008), np.log(0.03)))), 5
+            t = np.linspace(0, 1, n + 1)
+            pts = np.stack([x0 + (x1 - x0) * t, y - 1.2 * np.sin(np.pi * t), z0 + (z1 - z0) * t], 1)
+            beams += [_beam(pts[i], pts[i + 1], w) for i in range(n)]
+        bp = np.concatenate([bm[0] for bm in beams]); bn = np.concatenate([bm[1] for bm in beams]); bu = np.concatenate([bm[2] for bm in beams])
+        bi = np.concatenate([bm[3] + 24 * k for k, bm in enumerate(beams)]).astype(np.uint32)
+        b.node(mesh=b.mesh([b.primitive(bp, bi, bn, bu, material=mats[7])]))
     # 24 building types: a displaced facade slab with window bays (4 primitives of different materials each)
     fx, fy = max(4, int(28 * detail)), max(4, int(40 * detail))
     building_meshes = []
@@ -532,7 +597,10 @@ def scene_street_class(path, seed=777, detail=1.0, tex_size=256):
         w, h, d = rng.uniform(8, 14), rng.uniform(10, 26), rng.uniform(8, 12)
         for face, (sz, axis, off, flip) in enumerate((((w, h), "z", (0, h / 2, d / 2), False), ((w, h), "z", (0, h / 2, -d / 2), True),
                                                       ((d, h), "x", (w / 2, h / 2, 0), False), ((d, h), "x", (-w / 2, h / 2, 0), True))):
-            pos, nrm, uv, idx = grid(fx, fy, sz, axis)
+            if sliver:  # 16 : 1 strips, alternately horizontal (ledges) and vertical (pilasters)
+                pos, nrm, uv, idx = grid(fx * 4, max(1, fy // 4), sz, axis) if (t + face) % 2 == 0 else grid(max(1, fx // 4), fy * 4, sz, axis)
+            else:
+                pos, nrm, uv, idx = grid(fx, fy, sz, axis)
             bays = np.sin(uv[:, 0] * np.pi * rng.integers(3, 7)) * np.sin(uv[:, 1] * np.pi * rng.integers(4, 10))
             relief = (0.12 * np.clip(bays, 0, 1) + 0.03 * np.sin(uv[:, 1] * 90.0)).astype(np.float32)
             pos = pos + nrm * relief[:, None]
@@ -608,9 +676,13 @@ def scene_street_class(path, seed=777, detail=1.0, tex_size=256):
     return b.save(path)
 
 
-def scene_glass_class(path, seed=99, tess=48):
+def scene_glass_class(path, seed=99, tess=48, dragon=0, tex_size=512):
     """TransmissionTest-class: a grid of spheres sweeping transmission / roughness / IOR / attenuation / dispersion /
-    volume scatter, plus opaque reference spheres, on a diffuse floor with one point light."""
+    volume scatter, plus opaque reference spheres, on a diffuse floor with one point light.
+    dragon > 0 adds the DragonDispersion half of BASELINE configs[4]: ONE high-poly dispersive glass blob of
+    2 * dragon * (dragon // 2) triangles (dragon = 932: 868 624) with KHR_materials_dispersion + a coloured volume behind the grid, and four
+    TEXTURED glass slabs (base-colour, metallic-roughness, transmission and thickness maps) standing around it; the sphere grid alone stays the
+    unit-test size."""
     rng = np.random.default_rng(seed)
     b = GlbBuilder()
     floor = b.material(lambert_material((0.55, 0.55, 0.55)))
@@ -634,6 +706,45 @@ def scene_glass_class(path, seed=99, tess=48):
                                                      "roughnessFactor": float([0.0, 0.15, 0.4][iy])}, "extensions": ext})
             b.node(mesh=b.mesh([b.primitive(sp[0], sp[3], sp[1], sp[2], material=m)]), translation=[-3.0 + 1.2 * ix, 0.46, -1.2 + 1.2 * iy])
             k += 1
+    if dragon > 0:
+        bumps = rng.normal(size=(40, 3))
+        bumps /= np.linalg.norm(bumps, axis=1, keepdims=True)
+        amp, sharp = rng.uniform(0.05, 0.22, 40), rng.uniform(6.0, 40.0, 40)
+        fr = rng.normal(size=(8, 3)) * 9.0
+
+        def displace(d):
+            sc = np.ones(d.shape[0])
+            for k in range(40):
+                sc += amp[k] * np.exp(-((1 - d @ bumps[k]) * sharp[k]))
+            return sc + 0.012 * np.sin(d @ fr.T).sum(1)  # scales
+
+        pos, nrm, uv, idx = uv_sphere(dragon, dragon // 2, 0.95, displace)
+        m = b.material({"pbrMetallicRoughness": {"baseColorFactor": [0.95, 0.98, 0.96, 1.0], "metallicFactor": 0.0, "roughnessFactor": 0.02},
+                        "extensions": {"KHR_materials_transmission": {"transmissionFactor": 1.0}, "KHR_materials_ior": {"ior": 1.55},
+                                       "KHR_materials_dispersion": {"dispersion": 12.0},
+                                       "KHR_materials_volume": {"thicknessFactor": 1.0, "attenuationDistance": 1.4, "attenuationColor": [0.55, 0.9, 0.7]}}})
+        b.node(mesh=b.mesh([b.primitive(pos, idx, nrm, uv, material=m)]), translation=[0.0, 1.25, -3.1])
+        smp = b.sampler()
+
+        def tex(img):
+            return b.texture(b.image((np.clip(img, 0, 1) * 255 + 0.5).astype(np.uint8)), smp)
+
+        for k in range(4):
+            n3, n1 = value_noise(rng, tex_size, 5, 3), value_noise(rng, tex_size, 4, 1)[..., 0]
+            hue = rng.uniform(0.6, 1.0, 3)
+            one = np.ones_like(n1)
+            t_base = tex(np.concatenate([np.clip(hue * (0.6 + 0.4 * n3), 0, 1), one[..., None]], -1))
+            t_mr = tex(np.stack([one, np.clip(0.02 + 0.5 * n1 * n1, 0, 1), np.zeros_like(n1), one], -1))  # g: roughness, b: metallic
+            t_tr = tex(np.stack([np.clip(0.35 + 0.65 * value_noise(rng, tex_size, 3, 1)[..., 0], 0, 1), 0.5 + 0.5 * n1, one, one], -1))  # r: transmission, g: thickness
+            ext = {"KHR_materials_transmission": {"transmissionFactor": 1.0, "transmissionTexture": {"index": t_tr}}, "KHR_materials_ior": {"ior": float(1.3 + 0.1 * k)},
+                   "KHR_materials_volume": {"thicknessFactor": 0.25, "thicknessTexture": {"index": t_tr}, "attenuationDistance": float(0.5 + 0.5 * k),
+                                            "attenuationColor": [float(v) for v in rng.uniform(0.4, 1.0, 3)]}}
+            m = b.material({"pbrMetallicRoughness": {"baseColorTexture": {"index": t_base}, "metallicRoughnessTexture": {"index": t_mr}, "metallicFactor": 1.0,
+                                                     "roughnessFactor": 1.0}, "extensions": ext})
+            sp_ = box((1.6, 2.2, 0.12))
+            ang = [0.5, -0.5, 0.25, -0.25][k]
+            b.node(mesh=b.mesh([b.primitive(sp_[0], sp_[3], sp_[1], sp_[2], material=m)]), translation=[[-3.6, 3.6, -2.0, 2.0][k], 1.11, [-1.6, -1.6, -3.6, -3.6][k]],
+                   rotation=[0.0, float(np.sin(ang / 2)), 0.0, float(np.cos(ang / 2))])
     li = b.light({"type": "point", "intensity": 300.0, "color": [1, 1, 1], "extras": {"radius": 0.25}})
     b.node(extensions={"KHR_lights_punctual": {"light": li}}, translation=[0.0, 5.0, 2.0])
     b.camera_node((0.0, 3.2, 5.2), (0, 0.3, 0), yfov=0.75)
