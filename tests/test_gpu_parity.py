@@ -354,6 +354,54 @@ def test_image_independent_of_acceleration_structure(built, tmp_path):
     assert (pu.render_gpu(s, 2, bvh=0)["accum"] == pu.render_gpu(s, 2, bvh=1)["accum"]).all()
 
 
+def test_pre_splitting_changes_the_tree_not_the_image(built, tmp_path):
+    """MI_PT_SPLIT=F (bvh_split.h: a triangle whose box exceeds F x the mean box area is filed under several references, each with the box of one part
+    of it): on the sliver stand-in (hall-sized wall triangles, 36-m rails, diagonal ropes next to fine detail) the references change the tree and cut the
+    triangle tests per ray -- and not one bit of the image, the selection ids, the depth or the path counters, on either walk (8-wide and BVH2), with
+    and without reinsertion; the mixed alpha / glass scene (transmissive instances are never split, alpha-tested ones are) agrees as well."""
+    path = scenegen.scene_atrium_class(str(tmp_path / "sliver.glb"), seed=5, detail=0.12, tex_size=64, sliver=True)
+    s = pu.Setup(path, 160, 96, max_depth=8)
+
+    def render(factor, bvh=0, setup=s, frames=2, **env):
+        env = dict({"MI_PT_SPLIT_MIN_SHARE": "0"}, **env, MI_PT_SPLIT=str(factor))  # (the share rule off: every variant really splits)
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            return pu.render_gpu(setup, frames, bvh=bvh)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+
+    plain = render(0)
+    assert plain["stats"]["bvhTriangleCount"] == s.scene.num_triangles
+    seen = []
+    for factor, bvh, env in ((16, 0, {}), (4, 0, {}), (1, 0, {"MI_PT_SPLIT_DEPTH": "10"}), (16, 1, {}), (16, 0, {"MI_PT_REINSERT": "0"})):
+        r = render(factor, bvh, **env)
+        assert r["stats"]["bvhTriangleCount"] > s.scene.num_triangles, (factor, bvh)  # references, not triangles
+        assert r["stats"]["bvhTriangleCount"] <= 1.5 * s.scene.num_triangles + 4096  # ... within the builder's budget
+        assert (r["accum"] == plain["accum"]).all(), (factor, bvh, env)
+        assert (r["selection"] == plain["selection"]).all() and (r["depth"] == plain["depth"]).all()
+        for k in ("segments", "shadowRays", "textureTaps", "surfaceHits"):
+            assert r["stats"][k] == plain["stats"][k], k
+        seen.append((factor, bvh, r["stats"]["bvhTriangleCount"], r["stats"]["trisClosest"], r["stats"]["trisShadow"]))
+    print("sliver scene: triangles", s.scene.num_triangles, "tests closest / shadow unsplit", plain["stats"]["trisClosest"], plain["stats"]["trisShadow"], "split:", seen)
+    assert min(v[3] for v in seen) < 0.95 * plain["stats"]["trisClosest"]  # the point of it (at this toy size a few per cent; the bench-size scene: 30.5 -> 9.5 per ray)
+    # the default rule (factor 4 where the large triangles hold >= 10 % of the box area) engages on this scene by itself
+    assert pu.render_gpu(s, 1)["stats"]["bvhTriangleCount"] > s.scene.num_triangles
+    o = pu.render_oracle(s, 2)
+    m = pu.compare_images(o["accum"], render(16)["accum"])
+    assert m["rel_l2"] < 6e-3 and m["frac_within_1e-2"] > 0.99, m
+    # every kind of non-opaque instance: transmissive ones keep one reference (the recording shadow walk counts candidates), alpha-tested ones are split
+    mixed = scenegen.scene_mixed_alpha_glass(str(tmp_path / "mixed.glb"))
+    sm = pu.Setup(mixed, 128, 80, max_depth=10)
+    a, b = render(0, setup=sm), render(0.25, setup=sm, MI_PT_SPLIT_DEPTH="6")
+    assert b["stats"]["bvhTriangleCount"] > a["stats"]["bvhTriangleCount"]
+    assert (a["accum"] == b["accum"]).all()
+
+
 def test_reinsertion_changes_the_tree_not_the_image(built, tmp_path):
     """MI_PT_REINSERT=n (bvh_reinsert.h: n searches over the BVH2, each followed by lock / move rounds and a refit, before the 8-wide collapse):
     another tree, the same image bit for bit, fewer node visits.  On by default since round 5 (16 passes): MI_PT_REINSERT=0 is the tree as clustered."""

@@ -730,6 +730,9 @@ int main(int argc, char** argv)
   // references (optionally pre-split: a triangle whose box area exceeds split x mean is cut along its box's longest axis, recursively)
   std::vector<int> refTri; std::vector<Box> refBox;
   const float splitF = std::stof(get("split", "0"));
+  const bool  splitGrid = get("splitmode", "mid") == "grid";
+  const int   splitDepth = std::stoi(get("splitdepth", "6"));
+  Box sceneB; for(int i = 0; i < n; ++i) { sceneB.grow(tris[i].p0); sceneB.grow(tris[i].p1); sceneB.grow(tris[i].p2); }
   {
     double meanA = 0;
     std::vector<Box> tb(n);
@@ -741,10 +744,29 @@ int main(int argc, char** argv)
       // clip polygon against box halves recursively
       std::function<void(std::vector<V3>, int)> rec = [&](std::vector<V3> poly, int depth) {
         Box b; for(V3 p : poly) b.grow(p);
-        if(depth >= 6 || b.area() <= splitF * meanA) { refTri.push_back(i); refBox.push_back(b); return; }
+        if(depth >= splitDepth || b.area() <= splitF * meanA) { refTri.push_back(i); refBox.push_back(b); return; }
         int ax = 0; float ext = 0;
         for(int a = 0; a < 3; ++a) if(b.hi[a] - b.lo[a] > ext) { ext = b.hi[a] - b.lo[a]; ax = a; }
         float mid = 0.5f * (b.lo[ax] + b.hi[ax]);
+        if(splitGrid)  // the coarsest plane of the scene's recursive bisection that crosses the box (Karras & Aila 2013): splits of neighbouring triangles coincide
+        {
+          const float o = sceneB.lo[ax], w = sceneB.hi[ax] - sceneB.lo[ax];
+          double lo = (b.lo[ax] - o) / w, hi = (b.hi[ax] - o) / w;
+          for(int lvl = 1; lvl <= 24; ++lvl)
+          {
+            const double cell = std::ldexp(1.0, -lvl);
+            const double k = std::ceil(lo / cell);
+            if(k * cell < hi && k * cell > lo)
+            {
+              // several planes of this level may cross: take the one nearest the middle
+              const double km = std::round(0.5 * (lo + hi) / cell);
+              const double kk = (km * cell > lo && km * cell < hi) ? km : k;
+              mid = float(o + kk * cell * w);
+              break;
+            }
+          }
+          if(!(mid > b.lo[ax] && mid < b.hi[ax])) mid = 0.5f * (b.lo[ax] + b.hi[ax]);
+        }
         std::vector<V3> L, R;
         for(size_t k = 0; k < poly.size(); ++k)
         {

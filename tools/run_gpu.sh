@@ -23,7 +23,16 @@ ab() { # ab <tag> <workloads...>: every lib/var_* build next to the product buil
   done
   unset MI_PT_LIB
 }
+envab() { # envab <tag> <VAR> "<values...>" <workloads...>: the product build with VAR set to each value (run-time switches), --steps 3
+  tag=$1; var=$2; values=$3; shift 3
+  for v in $values; do
+    for w in "$@"; do
+      env $var=$v timeout 200 python bench.py --workload $w --steps 3 --warmup 1 $N > $O/${tag}_${w}_$v.json 2> $O/${tag}_${w}_$v.err && val $O/${tag}_${w}_$v.json ${w}_${var}=$v || { echo "FAILED ${w}_$v"; tail -3 $O/${tag}_${w}_$v.err; }
+    done
+  done
+}
 case "$1" in
+  envab) shift; envab "$@" ;;
   line)  # the full default line (headline + every other configuration with CPU legs), as the driver runs it
     timeout 1500 python bench.py --steps 20 --warmup 5 > $O/r05_bench_default_a.json 2> $O/r05_bench_default_a.err; echo "bench rc $?"; tail -c 600 $O/r05_bench_default_a.err
     python3 - <<'PY'

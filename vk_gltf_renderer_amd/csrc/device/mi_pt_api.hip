@@ -97,6 +97,14 @@ struct RunSwitches
                                    //                        profiles/r05_sweep_and_rebuild.txt).  A posed scene that is then accumulated for many frames
                                    //                        can ask for them
   int    reinsertRounds = 4;       // MI_PT_REINSERT_ROUNDS  lock / move rounds per pass
+  bool   missPass       = true;    // MI_PT_MISS_PASS=0      later-bounce paths that leave the scene end inside k_shade (rounds 1-5) instead of in the dense pass k_shade_miss
+  float  splitFactor    = 4.0f;    // MI_PT_SPLIT            triangle pre-splitting (bvh_split.h): a triangle whose box area exceeds this x the scene's mean gets one
+                                   //                        reference per part of a recursive bisection of its box; 0 = one reference per triangle (rounds 1-5).  Same image
+                                   //                        bit for bit; sliver stand-in of the atrium 30.5 -> 9.5 triangle tests per secondary ray, 419 -> 594 Msamples/s
+                                   //                        (0 / 64 / 16 / 4 / 1: 419 / 533 / 590 / 594 / 614; street sliver 679 / 703 / 719 / 723 / 696: profiles/r06_split_ab.txt)
+  int    splitMaxDepth  = 8;       // MI_PT_SPLIT_DEPTH      ... at most 2^this references per triangle
+  float  splitMinShare  = 0.1f;    // MI_PT_SPLIT_MIN_SHARE  ... only in scenes where triangles above 64 x the mean hold this share of the summed box area (0 = always):
+                                   //                        the evenly tessellated stand-ins (share 0 / 0.05) keep their round-5 trees -- splitting perturbs them by -1 %
   bool   collapseGreedy = false;   // MI_PT_COLLAPSE=sah|greedy  how BVH2 subtrees become children of an 8-wide node (anything else: mi_pt_create fails)
   bool   collapseBad    = false;
   bool   hostCollapse   = false;   // MI_PT_HOST_COLLAPSE    collapse on the host (the greedy reference of the device collapse)
@@ -123,6 +131,12 @@ struct RunSwitches
     reinsert       = std::max(0, num("MI_PT_REINSERT", 16));
     reinsertUpdate = std::max(0, num("MI_PT_REINSERT_UPDATE", 0));
     reinsertRounds = std::max(1, num("MI_PT_REINSERT_ROUNDS", 4));
+    missPass       = num("MI_PT_MISS_PASS", 1) != 0;
+    if(const char* e = getenv("MI_PT_SPLIT"))
+      splitFactor = std::max(0.0f, float(atof(e)));
+    if(const char* e = getenv("MI_PT_SPLIT_MIN_SHARE"))
+      splitMinShare = std::max(0.0f, float(atof(e)));
+    splitMaxDepth  = std::min(std::max(0, num("MI_PT_SPLIT_DEPTH", 8)), 10);  // (bvh_split.h: SPLIT_MAX_DEPTH)
     if(const char* e = getenv("MI_PT_COLLAPSE"))
     {
       collapseGreedy = strcmp(e, "greedy") == 0;
@@ -529,6 +543,9 @@ int buildAccelerationUnguarded(MiPt* pt)
     in.karrasTopology = (pt->bvhBuilder & 2) != 0;
     in.reinsertPasses = pt->accelBuilds == 1 ? pt->sw.reinsert : pt->sw.reinsertUpdate;  // (accelBuilds counts this build already)
     in.reinsertRounds = pt->sw.reinsertRounds;
+    in.splitFactor    = pt->sw.splitFactor;
+    in.splitMaxDepth  = pt->sw.splitMaxDepth;
+    in.splitMinShare  = pt->sw.splitMinShare;
     pt::BvhBuildOutput bo;
     std::string        err;
     if(!pt::buildBvh(in, bo, nullptr, err))
@@ -1263,7 +1280,7 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
         const pt::StatCounters s0 = segs();
         double   tTrace = span([&] { pt::launchTraceClosest(c, cur); });
         const pt::StatCounters s1 = segs();
-        double   tShade = span([&] { pt::launchShade(c, cur, it == 0); });
+        double   tShade = span([&] { pt::launchShade(c, cur, it == 0, pt->sw.missPass); });
         uint32_t nSh    = count((cur ? pt::QC_PAIR0 : pt::QC_PAIR1) + 1);
         double   tShadow = span([&] { pt::launchTraceShadow(c, cur ^ 1); });
         const pt::StatCounters s2 = segs();
@@ -1278,7 +1295,7 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
           timed(TK_TRACE, [&] { pt::launchTraceClosest(c, cur); });
         if(overlap && it > 0)
           (void)hipStreamWaitEvent(stream, pt->evShadowed, 0);  // the previous bounce's shadow terms are in before this shade launch reads them
-        timed(it == 0 ? TK_SHADE_FIRST : TK_SHADE, [&] { pt::launchShade(c, cur, it == 0); });
+        timed(it == 0 ? TK_SHADE_FIRST : TK_SHADE, [&] { pt::launchShade(c, cur, it == 0, pt->sw.missPass); });
         if(it == 0 && pt->timingEnabled)
           ++pt->accTiming.shadeFirstLaunches;
         if(overlap)

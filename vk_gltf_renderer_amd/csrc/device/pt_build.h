@@ -20,12 +20,16 @@ struct BvhBuildInput
   bool                    karrasTopology = false;  // true: plain LBVH (Morton-prefix hierarchy); false: PLOC clustering
   int                     reinsertPasses = 0;      // parallel reinsertion over the finished BVH2 (bvh_reinsert.h): searches ...
   int                     reinsertRounds = 4;      // ... and lock / move rounds per search
+  float                   splitFactor    = 0.0f;   // triangle pre-splitting (bvh_split.h): references for parts whose box area exceeds this x the mean; 0 = off
+  int                     splitMaxDepth  = 8;      // ... at most 2^this references per triangle
+  float                   splitMinShare  = 0.1f;   // ... and only in scenes where triangles above 64 x the mean hold at least this share of the summed box area (0 = always)
 };
 struct BvhBuildOutput
 {
   float4*  nodes    = nullptr;  // device, 4 float4 per node
   DevTri*  tris     = nullptr;  // device, Morton order (leaf reference ~i = triangle i of this array)
-  uint32_t numNodes = 0, numTris = 0;
+  uint32_t numNodes = 0, numTris = 0;   // numTris = REFERENCES: a pre-split triangle appears once per reference (each a full copy of its record)
+  uint32_t sceneTris = 0;               // triangles the references were made from
   int      root     = 0;
   uint32_t reinsertMoves = 0;   // subtrees the reinsertion passes moved
   float    centroidLo[3] = {0, 0, 0}, centroidHi[3] = {0, 0, 0};

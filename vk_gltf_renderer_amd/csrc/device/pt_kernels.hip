@@ -1516,7 +1516,10 @@ __global__ void __launch_bounds__(SEL_BLOCK) k_selection(DevScene sc, FrameConst
 // k_shade: everything of pathTraceOneBounce / pathTrace between the two Trace calls (gltf_pathtrace.slang:104-430, 441-494)
 //================================================================================================================================
 // FIRST: the launch shades bounce 0 (every queued path still has its initial state, see k_generate).
-template <bool COUNT, bool SIMPLE, bool FIRST>
+// MISS: the launch also ends the paths whose ray left the scene.  false: k_shade_miss has done that (later bounces of a frame without the infinite
+// plane): such entries are dead to this launch, and the environment branch -- ~1 000 vector instructions that nearly every wave of a later bounce ran
+// for the two or three of its 64 lanes that missed -- is not in the kernel at all.
+template <bool COUNT, bool SIMPLE, bool FIRST, bool MISS = true>
 __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) k_shade(const DevScene* __restrict__ scp, const FrameConsts* __restrict__ fcp, PathSoA P, Queues Q, int cur, int sortMode, StatCounters* stats)
 {
   // The scene / frame descriptors reach the non-inlined helpers (getTexture, sampleLights, the sky) by reference.  As
@@ -1655,9 +1658,13 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
     float4         nextRad = make_float4(0, 0, 0, 0), nextMisc = make_float4(0, 0, 0, 0), nextThr = make_float4(0, 0, 0, 0);  // state of a path that goes on
     float4         shOrg = make_float4(0, 0, 0, 0), shDir = make_float4(0, 0, 0, 0), shCon = make_float4(0, 0, 0, 0), shCon2 = make_float4(0, 0, 0, 0);
     bool           catcher = false;
+    // (MISS == false: an entry without a surface hit was finished by k_shade_miss; the launch has no infinite plane to test it against)
+    const float4 hit4 = (inRange && slot != QUEUE_DEAD) ? Q.active[cur].aux[inPos] : make_float4(0, 0, 0, 0);
+    if(!MISS && __float_as_int(hit4.y) < 0)
+      slot = QUEUE_DEAD;
     if(inRange && slot != QUEUE_DEAD)
     {
-      const float4 hit4 = Q.active[cur].aux[inPos], o4 = Q.active[cur].org[inPos], d4 = Q.active[cur].dir[inPos];
+      const float4 o4 = Q.active[cur].org[inPos], d4 = Q.active[cur].dir[inPos];
       // the path's state: records of its queue entry (unit stride, like the ray), or -- catcher frames / MI_PT_STATE_BY_SLOT -- gathered by slot
       const float4 misc4 = stateInQueue ? Q.active[cur].misc[inPos] : P.misc[slot];
       const float4 tp4   = FIRST ? make_float4(1.0f, 1.0f, 1.0f, DIRAC) : (stateInQueue ? Q.active[cur].aux2[inPos] : P.throughput[slot]);
@@ -1724,7 +1731,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
         }
       }
 
-      if(hitT == INFINITE_F)  // gltf_pathtrace.slang:129-156
+      if(MISS && hitT == INFINITE_F)  // gltf_pathtrace.slang:129-156
       {
         bool backplate = false;
         if(firstRay)  // tryPrimaryMissBackplate, pathtrace_functions.h.slang:944-971
@@ -2043,6 +2050,87 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
    }  // rounds of the window
    if(CAN_SORT)
      __syncthreads();  // s_order / s_segCount are rebuilt for the next window
+  }
+}
+
+//================================================================================================================================
+// k_shade_miss: the miss branch of pathTraceOneBounce (gltf_pathtrace.slang:129-156) for the later bounces, as a pass of its own.
+// By the later bounces 5 % (atrium) to 18 % (street) of a queue's rays leave the scene, spread evenly over the waves: inside k_shade the
+// environment evaluation (physical sky + sun disc, or the HDR lookup, and the MIS weight against next-event estimation) ran in nearly every
+// wave for a handful of lanes.  Here a workgroup scans its part of the queue for entries without a hit (one 4-byte read per entry), packs
+// their positions into LDS and finishes 256 of them at a time with every lane busy; k_shade<..., MISS = false> treats them as dead.
+// Only launched where a miss ends the path whatever else is set: bounce iterations >= 1 of frames without the infinite plane (a first
+// ray's miss may show the backplate; a plane may still catch a ray that missed the geometry).  Same arithmetic through the same
+// non-inlined missEnvironmentCall as k_shade, k_trace_primary and k_finish_sample.
+//================================================================================================================================
+constexpr int MISS_BLOCK = 256;
+constexpr int MISS_SCAN  = 8;  // entries scanned per thread between two dense rounds (a round needs >= 1 miss in 2048 entries to be non-empty)
+__global__ void __launch_bounds__(MISS_BLOCK) k_shade_miss(const DevScene* __restrict__ scp, const FrameConsts* __restrict__ fcp, PathSoA P, Queues Q, int cur, int simple)
+{
+  const DevScene&    sc = uniformConst(*scp);
+  const FrameConsts& fc = uniformConst(*fcp);
+  const bool         stateInQueue = fc.stateInQueue != 0;
+  __shared__ uint32_t s_prefix[NSUB + 1];
+  __shared__ uint32_t s_list[MISS_BLOCK * MISS_SCAN];
+  __shared__ uint32_t s_count;
+  queuePrefix(&Q.counters[cur ? QC_PAIR1 : QC_PAIR0], s_prefix);
+  const uint32_t count = s_prefix[NSUB];
+  constexpr uint32_t WINDOW = MISS_BLOCK * MISS_SCAN;
+  const uint32_t numWindows = (count + WINDOW - 1) / WINDOW;
+  for(uint32_t win = blockIdx.x; win < numWindows; win += gridDim.x)
+  {
+    if(threadIdx.x == 0)
+      s_count = 0;
+    __syncthreads();
+#pragma unroll
+    for(int k = 0; k < MISS_SCAN; ++k)
+    {
+      const uint32_t i = win * WINDOW + uint32_t(k) * MISS_BLOCK + threadIdx.x;
+      bool           miss = false;
+      uint32_t       pos  = 0;
+      if(i < count)
+      {
+        pos  = queuePos(Q.subCap, s_prefix, i);
+        miss = Q.active[cur].slot[pos] != QUEUE_DEAD && __float_as_int(Q.active[cur].aux[pos].y) < 0;
+      }
+      const unsigned long long m = __ballot(miss);
+      if(m != 0ull)
+      {
+        uint32_t base = 0;
+        if(laneId() == uint32_t(__ffsll((long long)m) - 1))
+          base = atomicAdd(&s_count, uint32_t(__popcll(m)));
+        base = uint32_t(__builtin_amdgcn_readlane(int(base), __ffsll((long long)m) - 1));
+        if(miss)
+          s_list[base + laneCountBelow(m)] = pos;
+      }
+    }
+    __syncthreads();
+    const uint32_t n = s_count;
+    for(uint32_t e = threadIdx.x; e < n; e += MISS_BLOCK)
+    {
+      const uint32_t pos  = s_list[e];
+      const uint32_t slot = Q.active[cur].slot[pos];
+      const float4   d4   = Q.active[cur].dir[pos];
+      const float4   misc4 = stateInQueue ? Q.active[cur].misc[pos] : P.misc[slot];
+      const float4   tp4   = stateInQueue ? Q.active[cur].aux2[pos] : P.throughput[slot];
+      const float4   rad4  = stateInQueue ? Q.active[cur].rad[pos] : P.radiance[slot];
+      const f3       rayDir = xyz(d4), throughput = xyz(tp4);
+      f3             radiance = xyz(rad4);
+      f3             envColor;
+      float          mis;
+      missEnvironment(sc, fc, rayDir, tp4.w, envColor, mis);
+      radiance += throughput * mis * envColor;
+      // the record an ended path leaves behind, as k_shade writes it: radiance + maxRoughness.x | !solid; flags without ALIVE (and, from the
+      // SIMPLE kernel, without INSIDE: it does not track media), seed, cone width
+      uint32_t flags = __float_as_uint(misc4.y) & (PF_INSIDE | PF_NOT_SOLID | (0xffu << PF_DEPTH_SHIFT) | (0xffu << PF_SCATTER_SHIFT));
+      if(simple)
+        flags &= ~PF_INSIDE;
+      const bool solid = !(flags & PF_NOT_SOLID);
+      P.radiance[slot] = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(__float_as_uint(fmaxf(fabsf(rad4.w), 0.0f)) | (solid ? 0u : RADW_NOT_SOLID)));
+      if(P.misc)
+        P.misc[slot] = make_float4(misc4.x, __uint_as_float(flags), misc4.z, misc4.w);
+    }
+    __syncthreads();
   }
 }
 
@@ -3022,11 +3110,16 @@ void launchTraceClosest(const LaunchCtx& c, int cur)
   else
     launchTraceClosestT<false>(c, cur);
 }
-void launchShade(const LaunchCtx& c, int cur, bool first)
+void launchShade(const LaunchCtx& c, int cur, bool first, bool missPass)
 {
   dim3 grid(c.persistentBlocks), block(SHADE_BLOCK);
+  // later bounces of a frame without the infinite plane: the paths that left the scene end in a dense pass of their own (k_shade_miss)
+  const bool split = missPass && !first && (c.fc.frameInfo.flags & MI_SCENE_USE_INFINITE_PLANE) == 0;
+  if(split)
+    hipLaunchKernelGGL(k_shade_miss, grid, dim3(MISS_BLOCK), 0, c.stream, c.sceneDev, c.fcDev, c.paths, c.queues, cur, c.simpleMaterials ? 1 : 0);
 #define MI_LAUNCH_SHADE(C, S, F) \
-  hipLaunchKernelGGL((k_shade<C, S, F>), grid, block, 0, c.stream, c.sceneDev, c.fcDev, c.paths, c.queues, cur, (S ? 0 : c.sortMode), c.stats)
+  do { if(!F && split) hipLaunchKernelGGL((k_shade<C, S, false, false>), grid, block, 0, c.stream, c.sceneDev, c.fcDev, c.paths, c.queues, cur, (S ? 0 : c.sortMode), c.stats); \
+       else hipLaunchKernelGGL((k_shade<C, S, F>), grid, block, 0, c.stream, c.sceneDev, c.fcDev, c.paths, c.queues, cur, (S ? 0 : c.sortMode), c.stats); } while(0)
 #define MI_LAUNCH_SHADE_F(C, S) do { if(first) MI_LAUNCH_SHADE(C, S, true); else MI_LAUNCH_SHADE(C, S, false); } while(0)
   if(c.simpleMaterials)
   {
