@@ -227,6 +227,15 @@ MI_PT_API int mi_pt_render_frame(MiPt* pt, const MiPathtraceParams* params, void
  * arrays grow (one synchronising reallocation) the first time a larger batch is requested: ~0.3 KB per pixel per frame. */
 MI_PT_API int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames, void* hipStream);
 
+/* The same batching for a caller that keeps the reference's one-call-per-frame shape (GltfRenderer::onRender -> PathTracer::onRender once per app
+ * frame, src/renderer.cpp:713-717, :1939-1977): with depth > 1, mi_pt_render_frame only RECORDS the frame; consecutive frames (frameCount + 1,
+ * totalSamples + numSamples, everything else equal, same stream) are held back and issued as one mi_pt_render_frames batch when `depth` of them are
+ * pending -- or as soon as any other entry point of this header is called on the instance (mi_pt_synchronize, every read / bind / set / update /
+ * denoise / tonemap / statistics call): whatever a caller can observe is what depth 1 would have produced, bit for bit, only later in time.
+ * A frame that does not continue the pending run (a reset: MI_PT_FIRST_FRAME, changed parameters) flushes the run and starts a new one.
+ * depth 1 (the default) = every call launches its frame at once, as in the reference.  1 <= depth <= 1024. */
+MI_PT_API int mi_pt_set_frame_queue(MiPt* pt, int depth);
+
 /* Block until everything enqueued by this instance has finished. */
 MI_PT_API int mi_pt_synchronize(MiPt* pt);
 
@@ -294,7 +303,7 @@ MI_PT_API const char* mi_pt_version(void);
 /* Layout version of the public structs of this header.  It is bumped whenever a struct a caller allocates (MiPtMemory, MiPtStats, MiPtFrameTiming,
  * MiPathtraceParams, ...) grows or changes: the library writes every field of the struct it was compiled with, so a caller built against an older
  * header must refuse to run -- `if(mi_pt_abi_version() != MI_PT_ABI_VERSION) fail` right after loading the library.
- * 6: MiPtMemory grew pathStateBytes / pathSlots (round 5); mi_pt_render_frames refuses maxDepth 0. */
+ * 6: MiPtMemory grew pathStateBytes / pathSlots (round 5); mi_pt_render_frames refuses maxDepth 0; mi_pt_set_frame_queue. */
 #define MI_PT_ABI_VERSION 6
 MI_PT_API int mi_pt_abi_version(void);
 

@@ -13,6 +13,7 @@ import pytest
 
 import parity_util as pu
 from vk_gltf_renderer_amd import _capi as capi
+from vk_gltf_renderer_amd import pathtracer as ptmod
 from vk_gltf_renderer_amd import scenegen
 
 pytestmark = pytest.mark.gpu
@@ -389,8 +390,11 @@ def test_pre_splitting_changes_the_tree_not_the_image(built, tmp_path):
         seen.append((factor, bvh, r["stats"]["bvhTriangleCount"], r["stats"]["trisClosest"], r["stats"]["trisShadow"]))
     print("sliver scene: triangles", s.scene.num_triangles, "tests closest / shadow unsplit", plain["stats"]["trisClosest"], plain["stats"]["trisShadow"], "split:", seen)
     assert min(v[3] for v in seen) < 0.95 * plain["stats"]["trisClosest"]  # the point of it (at this toy size a few per cent; the bench-size scene: 30.5 -> 9.5 per ray)
-    # the default rule (factor 4 where the large triangles hold >= 10 % of the box area) engages on this scene by itself
-    assert pu.render_gpu(s, 1)["stats"]["bvhTriangleCount"] > s.scene.num_triangles
+    # the default rule (factor 4 where triangles above 64 x the mean hold >= 10 % of the box area) engages on the bench-size sliver scene by itself and leaves
+    # the evenly tessellated one alone
+    for sliver, engaged in ((True, True), (False, False)):
+        big = pu.Setup(scenegen.scene_atrium_class(str(tmp_path / f"big{int(sliver)}.glb"), seed=4321, detail=0.8, tex_size=32, sliver=sliver), 64, 36, max_depth=2)
+        assert (pu.render_gpu(big, 1)["stats"]["bvhTriangleCount"] > big.scene.num_triangles) == engaged, sliver
     o = pu.render_oracle(s, 2)
     m = pu.compare_images(o["accum"], render(16)["accum"])
     assert m["rel_l2"] < 6e-3 and m["frac_within_1e-2"] > 0.99, m
@@ -400,6 +404,52 @@ def test_pre_splitting_changes_the_tree_not_the_image(built, tmp_path):
     a, b = render(0, setup=sm), render(0.25, setup=sm, MI_PT_SPLIT_DEPTH="6")
     assert b["stats"]["bvhTriangleCount"] > a["stats"]["bvhTriangleCount"]
     assert (a["accum"] == b["accum"]).all()
+
+
+def test_frame_queue_is_invisible(built, tmp_path):
+    """mi_pt_set_frame_queue(depth): mi_pt_render_frame calls are held back and issued `depth` at a time as one batch -- whatever the caller can observe
+    (accumulator, depth, selection, counters) is what frame-by-frame rendering produces, bit for bit: reads flush, a reset flushes and starts over,
+    a change of parameters in the middle of a run flushes, frames that do not fill a batch are rendered by the next synchronising call."""
+    path = scenegen.scene_material_zoo(str(tmp_path / "zoo.glb"), "specular")
+    s = pu.Setup(path, 96, 64, max_depth=5, hdr_path=os.path.join(os.path.dirname(os.path.dirname(__file__)), "assets", "std_env.hdr"))
+
+    def run(depth):
+        t = ptmod.PathTracer(s.scene, collect_counters=True)
+        t.set_environment(s.hdr)
+        t.resize(s.width, s.height)
+        t.set_frame_info(s.frame_info)
+        t.set_sky(s.sky)
+        t.set_frame_queue(depth)
+        outs = []
+        total = 0
+        for f in range(11):  # 11 frames: two full batches of 4 and a rest of 3 at depth 4
+            t.render_frame(s.frame_params(f, total))
+            total += 1
+            if f == 5:
+                outs.append(t.read_accum())  # a read in the middle of a batch
+        outs.append(t.read_accum())
+        outs.append(t.read_depth())
+        outs.append(t.read_selection())
+        # a reset (frame 0 again) right after frames that were never read, then a parameter change in the middle of a run
+        total = 0
+        for f in range(6):
+            p = s.frame_params(f, total)
+            if f >= 3:
+                p.maxDepth = 3
+            t.render_frame(p)
+            total += 1
+        t.synchronize()
+        outs.append(t.read_accum())
+        st = t.stats()
+        t.close()
+        return outs, st
+
+    base, st1 = run(1)
+    for depth in (4, 64):
+        got, st = run(depth)
+        for a, b in zip(base, got):
+            assert np.array_equal(a, b), depth
+        assert st["segments"] == st1["segments"] and st["cameraPaths"] == st1["cameraPaths"]
 
 
 def test_reinsertion_changes_the_tree_not_the_image(built, tmp_path):

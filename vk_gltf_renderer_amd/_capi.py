@@ -193,6 +193,7 @@ PT_SYMBOLS = {
     "mi_pt_read_guides": (i32, [VP, P(f32), P(f32)]),
     "mi_pt_read_selection": (i32, [VP, P(u32)]),
     "mi_pt_read_depth": (i32, [VP, P(f32)]),
+    "mi_pt_set_frame_queue": (i32, [VP, i32]),
     "mi_pt_accum_device_ptr": (VP, [VP]),
     "mi_pt_denoise": (i32, [VP, i32, f32, f32, f32, P(f32), VP]),
     "mi_pt_denoise_svgf": (i32, [VP, i32, f32, f32, f32, P(f32), VP]),

@@ -159,6 +159,11 @@ struct MiPt
   int numCUs = 256;
   RunSwitches sw;
   int accelBuilds = 0;  // acceleration-structure builds of this instance so far (0 while the first one runs)
+  // mi_pt_set_frame_queue: consecutive mi_pt_render_frame calls held back and issued together (flushPending)
+  int               frameQueueDepth = 1;
+  int               pendingFrames   = 0;
+  MiPathtraceParams pendingFirst{};
+  void*             pendingStream   = nullptr;
   // scene
   DevBuf<MiGltfShadeMaterial> materials;
   DevBuf<MiGltfTextureInfo>   texInfos;
@@ -627,6 +632,23 @@ const char* mi_pt_last_error(void)
 {
   return g_lastError.c_str();
 }
+// Issues the frames mi_pt_render_frame has been holding back (mi_pt_set_frame_queue) as ONE mi_pt_render_frames batch.  Every entry point that
+// reads or changes what those frames depend on calls this first, so a caller never observes the deferral except through time.
+static int flushPending(MiPt* pt)
+{
+  if(!pt || pt->pendingFrames == 0)
+    return MI_PT_OK;
+  const int n       = pt->pendingFrames;
+  pt->pendingFrames = 0;
+  return mi_pt_render_frames(pt, &pt->pendingFirst, n, pt->pendingStream);
+}
+#define FLUSH_PENDING(pt)              \
+  do                                   \
+  {                                    \
+    if(int rcFlush_ = flushPending(pt)) \
+      return rcFlush_;                 \
+  } while(0)
+
 int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt** out)
 {
   if(!sd || !out)
@@ -899,6 +921,7 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
 
 int mi_pt_update_render_nodes(MiPt* pt, const MiGltfRenderNode* renderNodes, int numRenderNodes, const uint8_t* renderNodeVisible)
 {
+  FLUSH_PENDING(pt);
   if(!pt || !renderNodes || numRenderNodes != int(pt->hostNodes.size()))
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_update_render_nodes: the render-node count must be the one the instance was created with");
   for(int n = 0; n < numRenderNodes; ++n)
@@ -916,6 +939,7 @@ int mi_pt_update_render_nodes(MiPt* pt, const MiGltfRenderNode* renderNodes, int
 
 int mi_pt_update_lights(MiPt* pt, const MiGltfLight* lights, int numLights)
 {
+  FLUSH_PENDING(pt);
   if(!pt || numLights != pt->scene.numLights || (numLights > 0 && !lights))
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_update_lights: the light count must be the one the instance was created with");
   if(numLights == 0)
@@ -928,6 +952,8 @@ int mi_pt_update_lights(MiPt* pt, const MiGltfLight* lights, int numLights)
 
 int mi_pt_destroy(MiPt* pt)
 {
+  if(pt)
+    pt->pendingFrames = 0;  // (frames still held back are dropped with the instance)
   if(!pt)
     return MI_PT_OK;
   (void)hipSetDevice(pt->device);
@@ -939,6 +965,7 @@ int mi_pt_destroy(MiPt* pt)
 
 int mi_pt_set_environment(MiPt* pt, const MiPtEnvironment* env)
 {
+  FLUSH_PENDING(pt);
   if(!pt)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_set_environment: null instance");
   HIP_TRY(hipSetDevice(pt->device));
@@ -966,6 +993,7 @@ int mi_pt_set_environment(MiPt* pt, const MiPtEnvironment* env)
 
 int mi_pt_resize(MiPt* pt, int width, int height)
 {
+  FLUSH_PENDING(pt);
   if(!pt || width <= 0 || height <= 0 || width > 32768 || height > 32768)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_resize: need 0 < width, height <= 32768");
   HIP_TRY(hipSetDevice(pt->device));
@@ -980,6 +1008,7 @@ int mi_pt_resize(MiPt* pt, int width, int height)
 
 int mi_pt_set_frame_info(MiPt* pt, const MiSceneFrameInfo* info)
 {
+  FLUSH_PENDING(pt);
   if(!pt || !info)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_set_frame_info: null argument");
   pt->frameInfo     = *info;
@@ -988,6 +1017,7 @@ int mi_pt_set_frame_info(MiPt* pt, const MiSceneFrameInfo* info)
 }
 int mi_pt_set_sky(MiPt* pt, const MiSkyPhysicalParameters* sky)
 {
+  FLUSH_PENDING(pt);
   if(!pt || !sky)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_set_sky: null argument");
   pt->sky = *sky;
@@ -996,6 +1026,7 @@ int mi_pt_set_sky(MiPt* pt, const MiSkyPhysicalParameters* sky)
 
 int mi_pt_set_tile_partition(MiPt* pt, int rank, int world, int tileSize)
 {
+  FLUSH_PENDING(pt);
   if(!pt || world < 1 || rank < 0 || rank >= world || tileSize < 16 || tileSize > 4096 || (tileSize & (tileSize - 1)) != 0)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_set_tile_partition: need 0 <= rank < world and tileSize a power of two in [16, 4096]");
   pt->tileRank  = rank;
@@ -1016,6 +1047,7 @@ int mi_pt_set_tile_partition(MiPt* pt, int rank, int world, int tileSize)
 
 int mi_pt_bind_accum(MiPt* pt, void* deviceRGBA32F)
 {
+  FLUSH_PENDING(pt);
   if(!pt)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_bind_accum: null instance");
   pt->accum = deviceRGBA32F ? reinterpret_cast<float4*>(deviceRGBA32F) : pt->accumOwn.ptr;
@@ -1024,6 +1056,7 @@ int mi_pt_bind_accum(MiPt* pt, void* deviceRGBA32F)
 
 int mi_pt_bind_guides(MiPt* pt, void* albedoRGBA32F, void* normalRGBA32F, void* depthR32F)
 {
+  FLUSH_PENDING(pt);
   if(!pt)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_bind_guides: null instance");
   pt->albedoBound = reinterpret_cast<float4*>(albedoRGBA32F);
@@ -1032,13 +1065,54 @@ int mi_pt_bind_guides(MiPt* pt, void* albedoRGBA32F, void* normalRGBA32F, void* 
   return MI_PT_OK;
 }
 
+int mi_pt_set_frame_queue(MiPt* pt, int depth)
+{
+  if(!pt || depth < 1 || depth > 1024)
+    return fail(MI_PT_ERR_ARGUMENT, "mi_pt_set_frame_queue: 1 <= depth <= 1024 required");
+  FLUSH_PENDING(pt);
+  pt->frameQueueDepth = depth;
+  return MI_PT_OK;
+}
+
 int mi_pt_render_frame(MiPt* pt, const MiPathtraceParams* params, void* hipStream)
 {
+  if(pt && params && pt->frameQueueDepth > 1)
+  {
+    // frame k of a batch is the first frame's parameters with frameCount + k and totalSamples + k * numSamples (mi_pt_render_frames): a call joins
+    // the pending batch when it is exactly that, on the same stream, and does not start a new accumulation
+    if(pt->pendingFrames > 0)
+    {
+      MiPathtraceParams expect = pt->pendingFirst;
+      expect.frameCount += pt->pendingFrames;
+      expect.totalSamples += pt->pendingFrames * expect.numSamples;
+      expect.flags &= ~MI_PT_FIRST_FRAME;
+      expect.mouseCoord[0] = params->mouseCoord[0];
+      expect.mouseCoord[1] = params->mouseCoord[1];
+      if(hipStream == pt->pendingStream && memcmp(&expect, params, sizeof(expect)) == 0)
+      {
+        if(++pt->pendingFrames >= pt->frameQueueDepth)
+          return flushPending(pt);
+        return MI_PT_OK;
+      }
+      FLUSH_PENDING(pt);
+    }
+    // argument errors are reported by THIS call, not by a later flush
+    if(params->numSamples < 1 || params->maxDepth < 1 || params->maxDepth > 255)
+      return fail(MI_PT_ERR_ARGUMENT, "mi_pt_render_frame: numSamples >= 1 and 1 <= maxDepth <= 255 required");
+    if(pt->width <= 0 || !pt->haveFrameInfo)
+      return fail(MI_PT_ERR_STATE, "mi_pt_render_frame: call mi_pt_resize and mi_pt_set_frame_info first");
+    pt->pendingFirst  = *params;
+    pt->pendingStream = hipStream;
+    pt->pendingFrames = 1;
+    return MI_PT_OK;
+  }
+
   return mi_pt_render_frames(pt, params, 1, hipStream);
 }
 
 int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames, void* hipStream)
 {
+  FLUSH_PENDING(pt);
   if(!pt || !params)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_render_frame: null argument");
   if(numFrames < 1 || numFrames > 1024)
@@ -1342,6 +1416,7 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
 
 int mi_pt_synchronize(MiPt* pt)
 {
+  FLUSH_PENDING(pt);
   if(!pt)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_synchronize: null instance");
   HIP_TRY(hipSetDevice(pt->device));
@@ -1351,6 +1426,7 @@ int mi_pt_synchronize(MiPt* pt)
 
 int mi_pt_read_accum(MiPt* pt, float* host)
 {
+  FLUSH_PENDING(pt);
   if(!pt || !host || pt->width <= 0)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_read_accum: bad arguments");
   HIP_TRY(hipSetDevice(pt->device));
@@ -1360,6 +1436,7 @@ int mi_pt_read_accum(MiPt* pt, float* host)
 }
 int mi_pt_write_accum(MiPt* pt, const float* host)
 {
+  FLUSH_PENDING(pt);
   if(!pt || !host || pt->width <= 0)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_write_accum: bad arguments");
   HIP_TRY(hipSetDevice(pt->device));
@@ -1371,6 +1448,7 @@ int mi_pt_write_accum(MiPt* pt, const float* host)
 }
 int mi_pt_read_guides(MiPt* pt, float* albedo, float* normal)
 {
+  FLUSH_PENDING(pt);
   if(!pt || pt->width <= 0)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_read_guides: bad arguments");
   HIP_TRY(hipSetDevice(pt->device));
@@ -1384,6 +1462,7 @@ int mi_pt_read_guides(MiPt* pt, float* albedo, float* normal)
 }
 int mi_pt_read_selection(MiPt* pt, uint32_t* host)
 {
+  FLUSH_PENDING(pt);
   if(!pt || !host || pt->width <= 0)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_read_selection: bad arguments");
   HIP_TRY(hipSetDevice(pt->device));
@@ -1393,6 +1472,7 @@ int mi_pt_read_selection(MiPt* pt, uint32_t* host)
 }
 int mi_pt_read_depth(MiPt* pt, float* host)
 {
+  FLUSH_PENDING(pt);
   if(!pt || !host || pt->width <= 0)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_read_depth: bad arguments");
   HIP_TRY(hipSetDevice(pt->device));
@@ -1402,11 +1482,13 @@ int mi_pt_read_depth(MiPt* pt, float* host)
 }
 void* mi_pt_accum_device_ptr(MiPt* pt)
 {
+  (void)flushPending(pt);
   return pt ? pt->accum : nullptr;
 }
 
 int mi_pt_denoise(MiPt* pt, int iterations, float sigmaColor, float sigmaNormal, float sigmaAlbedo, float* host, void* hipStream)
 {
+  FLUSH_PENDING(pt);
   if(!pt || pt->width <= 0 || iterations < 1 || iterations > 8)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_denoise: bad arguments");
   HIP_TRY(hipSetDevice(pt->device));
@@ -1435,6 +1517,7 @@ int mi_pt_denoise(MiPt* pt, int iterations, float sigmaColor, float sigmaNormal,
 
 int mi_pt_denoise_svgf(MiPt* pt, int iterations, float sigmaLuminance, float sigmaNormal, float sigmaDepth, float* host, void* hipStream)
 {
+  FLUSH_PENDING(pt);
   if(!pt || pt->width <= 0 || iterations < 1 || iterations > 8 || !(sigmaLuminance > 0.0f) || !(sigmaDepth > 0.0f) || !(sigmaNormal >= 0.0f))
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_denoise_svgf: bad arguments");
   if(!(pt->accumFrames >= 1.0f))
@@ -1482,6 +1565,7 @@ void mi_pt_default_tonemapper(MiTonemapperData* tm, int autoExposure)
 
 int mi_pt_tonemap(MiPt* pt, const MiTonemapperData* tm, int source, float dtSeconds, uint8_t* host, void* hipStream)
 {
+  FLUSH_PENDING(pt);
   if(!pt || !tm || pt->width <= 0 || source < 0 || source > 1)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_tonemap: bad arguments");
   if(tm->method < MI_TONEMAP_FILMIC || tm->method > MI_TONEMAP_KHRONOS_PBR || !(tm->brightness > 0.0f) || !(tm->evMaxValue > tm->evMinValue))
@@ -1550,6 +1634,7 @@ int mi_pt_get_memory(MiPt* pt, MiPtMemory* out)
 
 int mi_pt_get_stats(MiPt* pt, MiPtStats* out)
 {
+  FLUSH_PENDING(pt);
   if(!pt || !out)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_get_stats: null argument");
   HIP_TRY(hipSetDevice(pt->device));
@@ -1572,6 +1657,7 @@ int mi_pt_get_stats(MiPt* pt, MiPtStats* out)
 }
 int mi_pt_reset_stats(MiPt* pt)
 {
+  FLUSH_PENDING(pt);
   if(!pt)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_reset_stats: null instance");
   HIP_TRY(hipSetDevice(pt->device));
@@ -1581,6 +1667,7 @@ int mi_pt_reset_stats(MiPt* pt)
 }
 int mi_pt_enable_timing(MiPt* pt, int enable)
 {
+  FLUSH_PENDING(pt);
   if(!pt)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_enable_timing: null instance");
   pt->timingEnabled = enable != 0;
@@ -1594,6 +1681,7 @@ int mi_pt_enable_timing(MiPt* pt, int enable)
 }
 int mi_pt_get_frame_timing(MiPt* pt, MiPtFrameTiming* out)
 {
+  FLUSH_PENDING(pt);
   if(!pt || !out)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_get_frame_timing: null argument");
   // Totals since mi_pt_enable_timing(1): resolves the recorded events (one device synchronisation, here, not per frame).

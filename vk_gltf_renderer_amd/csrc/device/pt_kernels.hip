@@ -130,6 +130,61 @@ PT_DEV PushPos queuePushBlock2(bool predNext, bool predShadow, uint32_t subCap, 
 }
 
 
+#ifdef SHADE_CLASS_PARTITION
+// A/B variant (tools/build_variant.sh classes -DSHADE_CLASS_PARTITION): the continuation entries of a block's round are laid out in FOUR runs by the class
+// the shade launch of the NEXT bounce will find them in -- next-event technique (light / environment: the first draw of sampleLights, known from the seed the
+// entry carries) x "the lobe draw of bsdfSample is small" (the GGX lobes of a dielectric are picked by xi.z < Fresnel weight) -- inside the block's one
+// reservation: same atomics, same positions overall, entries of one class contiguous, so that a consuming wave runs one technique and mostly one lobe.
+// The software form of the reference's ReorderThread (raytracer_interface.h.slang:199-204).  Paths are independent: the order cannot change a result.
+PT_DEV PushPos queuePushBlock2Classes(bool predNext, uint32_t cls, bool predShadow, uint32_t subCap, uint32_t* pair, uint32_t sub, uint32_t* s_tmp /* 12 words */)
+{
+  if(threadIdx.x < 6)
+    s_tmp[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t           lane  = laneId();
+  const unsigned long long maskS = __ballot(predShadow);
+  unsigned long long       maskC[4];
+  uint32_t                 wbase[4], wbaseS = 0;
+#pragma unroll
+  for(uint32_t c = 0; c < 4; ++c)
+    maskC[c] = __ballot(predNext && cls == c);
+  if(lane == 0)
+  {
+#pragma unroll
+    for(uint32_t c = 0; c < 4; ++c)
+      wbase[c] = maskC[c] ? atomicAdd(&s_tmp[c], uint32_t(__popcll(maskC[c]))) : 0u;
+    if(maskS != 0ull)
+      wbaseS = atomicAdd(&s_tmp[4], uint32_t(__popcll(maskS)));
+  }
+#pragma unroll
+  for(uint32_t c = 0; c < 4; ++c)
+    wbase[c] = uint32_t(__shfl(int(wbase[c]), 0));
+  wbaseS = uint32_t(__shfl(int(wbaseS), 0));
+  __syncthreads();
+  if(threadIdx.x == 0)
+  {
+    const uint32_t     n0 = s_tmp[0], n1 = s_tmp[1], n2 = s_tmp[2], n3 = s_tmp[3], nS = s_tmp[4];
+    const uint32_t     nN = n0 + n1 + n2 + n3;
+    unsigned long long base = 0ull;
+    if((nN | nS) != 0u)
+      base = atomicAdd(reinterpret_cast<unsigned long long*>(pair), (static_cast<unsigned long long>(nS) << 32) | nN);
+    s_tmp[6]  = uint32_t(base);
+    s_tmp[7]  = uint32_t(base) + n0;
+    s_tmp[8]  = uint32_t(base) + n0 + n1;
+    s_tmp[9]  = uint32_t(base) + n0 + n1 + n2;
+    s_tmp[10] = uint32_t(base >> 32);
+  }
+  __syncthreads();
+  const unsigned long long below = (1ull << lane) - 1ull;
+  PushPos                  p;
+  const uint32_t           c = cls & 3u;
+  p.next   = sub * subCap + s_tmp[6 + c] + (c == 0 ? wbase[0] : c == 1 ? wbase[1] : c == 2 ? wbase[2] : wbase[3])
+           + uint32_t(__popcll((c == 0 ? maskC[0] : c == 1 ? maskC[1] : c == 2 ? maskC[2] : maskC[3]) & below));
+  p.shadow = sub * subCap + s_tmp[10] + wbaseS + uint32_t(__popcll(maskS & below));
+  return p;
+}
+#endif
+
 // (A per-WAVE version of this append -- one 64-bit global atomic per wave, no barrier, so that the waves of a block run their chunks
 //  independently -- was measured in round 3: helmet 3793 against 3799 Msamples/s, atrium 478 / 482, street 504 / 512, glass 529 / 537.
 //  The three barriers per chunk are not what the shade kernel waits for; four times the device-scope atomics are.)
@@ -1531,7 +1586,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
   const FrameConsts& fc = uniformConst(*fcp);
   const bool         stateInQueue = fc.stateInQueue != 0;  // misc / throughput / radiance of a living path ride in its queue entry (pt_scene.h: RayQueue)
   __shared__ uint32_t s_prefix[NSUB + 1];
-  __shared__ uint32_t s_push[4];
+  __shared__ uint32_t s_push[12];
   __shared__ float    s_srgb[256];  // sRGB decode table next to the ALU: 3 lookups per texel, up to 8 texels per tap
   // The window sort exists in the generic kernel only (key: material).  Where every material runs the same code (SIMPLE) grouping by material buys
   // nothing, and a window keyed by next-event technique (rounds 3-4: fewer instructions, fuller waves, 6-15 % SLOWER -- the key costs a dependent gather
@@ -2023,7 +2078,25 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
       if(COUNT && (meshHit || hitInfinitePlane))
         atomicAdd(&stats->surfaceHits, 1ull);
     }
+#ifdef SHADE_CLASS_PARTITION
+    uint32_t cls = 0;
+    if(SIMPLE && alive)
+    {
+      // what the next bounce's shade launch will draw from this entry's seed (gltf_pathtrace.slang:319-361): technique, then the light / sky / HDR
+      // sample (3 / 2 / 3 draws), the three of bsdfEvaluate (if the next event is valid: assumed), the three of bsdfSample -- the last of those picks the lobe
+      float lightWeight, envWeight;
+      getDirectLightingTechniqueProbabilities(sc, fc, lightWeight, envWeight);
+      uint32_t   st    = __float_as_uint(nextMisc.z);
+      const bool light = rnd(st) < lightWeight;
+      const int  skip  = (light || hasFlag(fc.frameInfo.flags, MI_SCENE_USE_HDR_ENVIRONMENT)) ? 3 + 5 : 2 + 5;
+      for(int k = 0; k < skip; ++k)
+        (void)pcg(st);
+      cls = (light ? 0u : 1u) | (rnd(st) < 0.2f ? 2u : 0u);
+    }
+    const PushPos  pp      = queuePushBlock2Classes(alive, cls, pushShadow, Q.subCap, &Q.counters[(nxt ? QC_PAIR1 : QC_PAIR0) + 2 * (chunk % NSUB)], chunk % NSUB, s_push);
+#else
     const PushPos  pp      = queuePushBlock2(alive, pushShadow, Q.subCap, &Q.counters[(nxt ? QC_PAIR1 : QC_PAIR0) + 2 * (chunk % NSUB)], chunk % NSUB, s_push);
+#endif
     const uint32_t posNext = pp.next, posShadow = pp.shadow;
     if(alive)
     {

@@ -200,6 +200,10 @@ class PathTracer:
         """Denoiser guide / depth images in caller-owned device memory (0 = the internal image)."""
         _check_pt(self._l.mi_pt_bind_guides(self._p, C.c_void_p(albedo_ptr or None), C.c_void_p(normal_ptr or None), C.c_void_p(depth_ptr or None)))
 
+    def set_frame_queue(self, depth):
+        """render_frame calls are held back and issued `depth` at a time as one batch (mi_pt_set_frame_queue); 1 = at once."""
+        _check_pt(self._l.mi_pt_set_frame_queue(self._p, int(depth)))
+
     def render_frame(self, params, stream=None):
         _check_pt(self._l.mi_pt_render_frame(self._p, C.byref(params), C.c_void_p(stream or 0)))
 
