@@ -397,7 +397,7 @@ def test_pre_splitting_changes_the_tree_not_the_image(built, tmp_path):
         assert (pu.render_gpu(big, 1)["stats"]["bvhTriangleCount"] > big.scene.num_triangles) == engaged, sliver
     o = pu.render_oracle(s, 2)
     m = pu.compare_images(o["accum"], render(16)["accum"])
-    assert m["rel_l2"] < 6e-3 and m["frac_within_1e-2"] > 0.99, m
+    assert m["rel_l2"] < 1e-2 and m["frac_within_1e-2"] > 0.99, m  # (2 spp with the sun disc in play, like test_atrium_class_alpha_lights)
     # every kind of non-opaque instance: transmissive ones keep one reference (the recording shadow walk counts candidates), alpha-tested ones are split
     mixed = scenegen.scene_mixed_alpha_glass(str(tmp_path / "mixed.glb"))
     sm = pu.Setup(mixed, 128, 80, max_depth=10)

@@ -97,7 +97,6 @@ struct RunSwitches
                                    //                        profiles/r05_sweep_and_rebuild.txt).  A posed scene that is then accumulated for many frames
                                    //                        can ask for them
   int    reinsertRounds = 4;       // MI_PT_REINSERT_ROUNDS  lock / move rounds per pass
-  bool   missPass       = true;    // MI_PT_MISS_PASS=0      later-bounce paths that leave the scene end inside k_shade (rounds 1-5) instead of in the dense pass k_shade_miss
   float  splitFactor    = 4.0f;    // MI_PT_SPLIT            triangle pre-splitting (bvh_split.h): a triangle whose box area exceeds this x the scene's mean gets one
                                    //                        reference per part of a recursive bisection of its box; 0 = one reference per triangle (rounds 1-5).  Same image
                                    //                        bit for bit; sliver stand-in of the atrium 30.5 -> 9.5 triangle tests per secondary ray, 419 -> 594 Msamples/s
@@ -131,7 +130,6 @@ struct RunSwitches
     reinsert       = std::max(0, num("MI_PT_REINSERT", 16));
     reinsertUpdate = std::max(0, num("MI_PT_REINSERT_UPDATE", 0));
     reinsertRounds = std::max(1, num("MI_PT_REINSERT_ROUNDS", 4));
-    missPass       = num("MI_PT_MISS_PASS", 1) != 0;
     if(const char* e = getenv("MI_PT_SPLIT"))
       splitFactor = std::max(0.0f, float(atof(e)));
     if(const char* e = getenv("MI_PT_SPLIT_MIN_SHARE"))
@@ -1354,7 +1352,7 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
         const pt::StatCounters s0 = segs();
         double   tTrace = span([&] { pt::launchTraceClosest(c, cur); });
         const pt::StatCounters s1 = segs();
-        double   tShade = span([&] { pt::launchShade(c, cur, it == 0, pt->sw.missPass); });
+        double   tShade = span([&] { pt::launchShade(c, cur, it == 0); });
         uint32_t nSh    = count((cur ? pt::QC_PAIR0 : pt::QC_PAIR1) + 1);
         double   tShadow = span([&] { pt::launchTraceShadow(c, cur ^ 1); });
         const pt::StatCounters s2 = segs();
@@ -1369,7 +1367,7 @@ int mi_pt_render_frames(MiPt* pt, const MiPathtraceParams* params, int numFrames
           timed(TK_TRACE, [&] { pt::launchTraceClosest(c, cur); });
         if(overlap && it > 0)
           (void)hipStreamWaitEvent(stream, pt->evShadowed, 0);  // the previous bounce's shadow terms are in before this shade launch reads them
-        timed(it == 0 ? TK_SHADE_FIRST : TK_SHADE, [&] { pt::launchShade(c, cur, it == 0, pt->sw.missPass); });
+        timed(it == 0 ? TK_SHADE_FIRST : TK_SHADE, [&] { pt::launchShade(c, cur, it == 0); });
         if(it == 0 && pt->timingEnabled)
           ++pt->accTiming.shadeFirstLaunches;
         if(overlap)

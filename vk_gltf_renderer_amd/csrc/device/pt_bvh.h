@@ -34,7 +34,7 @@ PT_DEV bool intersectTri(f3 v0, f3 e1, f3 e2, f3 org, f3 dir, TriHit& h)
   float det  = dotFma(e1, pvec);
   if(det == 0.0f)
     return false;
-  float inv  = 1.0f / det;
+  float inv  = divExact(1.0f, det);  // (IEEE whatever the compile options: hit records agree with the oracle bit for bit, pt_math.h)
   f3    tvec = org - v0;
   float u    = dotFma(tvec, pvec) * inv;
   if(u < 0.0f || u > 1.0f)
@@ -60,9 +60,9 @@ PT_DEV RaySetup makeRaySetup(f3 org, f3 dir)
   const float eps = 1e-30f;
   r.org           = org;
   r.dir           = dir;
-  r.idir.x        = 1.0f / (fabsf(dir.x) < eps ? copysignf(eps, dir.x) : dir.x);
-  r.idir.y        = 1.0f / (fabsf(dir.y) < eps ? copysignf(eps, dir.y) : dir.y);
-  r.idir.z        = 1.0f / (fabsf(dir.z) < eps ? copysignf(eps, dir.z) : dir.z);
+  r.idir.x        = divExact(1.0f, fabsf(dir.x) < eps ? copysignf(eps, dir.x) : dir.x);
+  r.idir.y        = divExact(1.0f, fabsf(dir.y) < eps ? copysignf(eps, dir.y) : dir.y);
+  r.idir.z        = divExact(1.0f, fabsf(dir.z) < eps ? copysignf(eps, dir.z) : dir.z);
   r.ood           = org * r.idir;
   return r;
 }

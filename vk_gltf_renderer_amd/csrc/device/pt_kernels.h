@@ -37,7 +37,7 @@ void launchSkyPrecomp(const MiSkyPhysicalParameters& sky, SkyPrecomp* out, hipSt
 void launchGenerate(const LaunchCtx& c, int sampleIndex);
 void launchTraceClosest(const LaunchCtx& c, int cur);
 void launchTracePrimary(const LaunchCtx& c, int sampleIndex);  // bounce 0 of an 8-wide-BVH scene: camera rays generated, packet-walked, misses finished, hits into queue 0
-void launchShade(const LaunchCtx& c, int cur, bool first, bool missPass);  // first: bounce 0 (paths still carry k_generate's initial state); missPass: k_shade_miss ends the paths that left the scene
+void launchShade(const LaunchCtx& c, int cur, bool first);  // first: bounce 0 (paths still carry k_generate's initial state)
 void launchTraceShadow(const LaunchCtx& c, int nxt);  // nxt: active queue the preceding shade launch appended to
 void launchFlushSurvivors(const LaunchCtx& c, int cur);  // cur: the active queue the last shade launch appended to (paths alive when the bounce loop stopped)
 void launchFinishSample(const LaunchCtx& c, int sampleIndex, float4* accum, float* depth, float4* albedo, float4* normal);

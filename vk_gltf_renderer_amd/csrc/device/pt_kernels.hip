@@ -130,61 +130,6 @@ PT_DEV PushPos queuePushBlock2(bool predNext, bool predShadow, uint32_t subCap, 
 }
 
 
-#ifdef SHADE_CLASS_PARTITION
-// A/B variant (tools/build_variant.sh classes -DSHADE_CLASS_PARTITION): the continuation entries of a block's round are laid out in FOUR runs by the class
-// the shade launch of the NEXT bounce will find them in -- next-event technique (light / environment: the first draw of sampleLights, known from the seed the
-// entry carries) x "the lobe draw of bsdfSample is small" (the GGX lobes of a dielectric are picked by xi.z < Fresnel weight) -- inside the block's one
-// reservation: same atomics, same positions overall, entries of one class contiguous, so that a consuming wave runs one technique and mostly one lobe.
-// The software form of the reference's ReorderThread (raytracer_interface.h.slang:199-204).  Paths are independent: the order cannot change a result.
-PT_DEV PushPos queuePushBlock2Classes(bool predNext, uint32_t cls, bool predShadow, uint32_t subCap, uint32_t* pair, uint32_t sub, uint32_t* s_tmp /* 12 words */)
-{
-  if(threadIdx.x < 6)
-    s_tmp[threadIdx.x] = 0;
-  __syncthreads();
-  const uint32_t           lane  = laneId();
-  const unsigned long long maskS = __ballot(predShadow);
-  unsigned long long       maskC[4];
-  uint32_t                 wbase[4], wbaseS = 0;
-#pragma unroll
-  for(uint32_t c = 0; c < 4; ++c)
-    maskC[c] = __ballot(predNext && cls == c);
-  if(lane == 0)
-  {
-#pragma unroll
-    for(uint32_t c = 0; c < 4; ++c)
-      wbase[c] = maskC[c] ? atomicAdd(&s_tmp[c], uint32_t(__popcll(maskC[c]))) : 0u;
-    if(maskS != 0ull)
-      wbaseS = atomicAdd(&s_tmp[4], uint32_t(__popcll(maskS)));
-  }
-#pragma unroll
-  for(uint32_t c = 0; c < 4; ++c)
-    wbase[c] = uint32_t(__shfl(int(wbase[c]), 0));
-  wbaseS = uint32_t(__shfl(int(wbaseS), 0));
-  __syncthreads();
-  if(threadIdx.x == 0)
-  {
-    const uint32_t     n0 = s_tmp[0], n1 = s_tmp[1], n2 = s_tmp[2], n3 = s_tmp[3], nS = s_tmp[4];
-    const uint32_t     nN = n0 + n1 + n2 + n3;
-    unsigned long long base = 0ull;
-    if((nN | nS) != 0u)
-      base = atomicAdd(reinterpret_cast<unsigned long long*>(pair), (static_cast<unsigned long long>(nS) << 32) | nN);
-    s_tmp[6]  = uint32_t(base);
-    s_tmp[7]  = uint32_t(base) + n0;
-    s_tmp[8]  = uint32_t(base) + n0 + n1;
-    s_tmp[9]  = uint32_t(base) + n0 + n1 + n2;
-    s_tmp[10] = uint32_t(base >> 32);
-  }
-  __syncthreads();
-  const unsigned long long below = (1ull << lane) - 1ull;
-  PushPos                  p;
-  const uint32_t           c = cls & 3u;
-  p.next   = sub * subCap + s_tmp[6 + c] + (c == 0 ? wbase[0] : c == 1 ? wbase[1] : c == 2 ? wbase[2] : wbase[3])
-           + uint32_t(__popcll((c == 0 ? maskC[0] : c == 1 ? maskC[1] : c == 2 ? maskC[2] : maskC[3]) & below));
-  p.shadow = sub * subCap + s_tmp[10] + wbaseS + uint32_t(__popcll(maskS & below));
-  return p;
-}
-#endif
-
 // (A per-WAVE version of this append -- one 64-bit global atomic per wave, no barrier, so that the waves of a block run their chunks
 //  independently -- was measured in round 3: helmet 3793 against 3799 Msamples/s, atrium 478 / 482, street 504 / 512, glass 529 / 537.
 //  The three barriers per chunk are not what the shade kernel waits for; four times the device-scope atomics are.)
@@ -207,18 +152,19 @@ PT_DEV bool slotToPixel(const FrameConsts& fc, const uint32_t* ownedTiles, uint3
 PT_DEV void getRay(const FrameConsts& fc, f2 samplePos, f2 offset, f3& origin, f3& direction)
 {
   const MiSceneFrameInfo& fi = fc.frameInfo;
-  f2 clip = mk2((samplePos.x + offset.x) / float(fc.width) * 2.0f - 1.0f, (samplePos.y + offset.y) / float(fc.height) * 2.0f - 1.0f);
+  // (IEEE division / square root whatever the compile options -- divExact, normalizeExact: camera rays agree with the oracle bit for bit)
+  f2 clip = mk2(divExact(samplePos.x + offset.x, float(fc.width)) * 2.0f - 1.0f, divExact(samplePos.y + offset.y, float(fc.height)) * 2.0f - 1.0f);
   f4 view = mulFull(fi.projInv, mk4(clip.x, clip.y, -1.0f, 1.0f));
-  view    = view / view.w;
+  view    = mk4(divExact(view.x, view.w), divExact(view.y, view.w), divExact(view.z, view.w), divExact(view.w, view.w));
   if(hasFlag(fi.flags, MI_SCENE_IS_ORTHOGRAPHIC))
   {
     origin    = xyz(mulFull(fi.viewInv, view));
-    direction = normalize(xyz(mulFull(fi.viewInv, mk4(0, 0, -1, 0))));
+    direction = normalizeExact(xyz(mulFull(fi.viewInv, mk4(0, 0, -1, 0))));
   }
   else
   {
     origin    = mk3(fi.viewInv[12], fi.viewInv[13], fi.viewInv[14]);
-    direction = normalize(xyz(mulFull(fi.viewInv, view)) - origin);
+    direction = normalizeExact(xyz(mulFull(fi.viewInv, view)) - origin);
   }
 }
 
@@ -307,7 +253,7 @@ PT_DEV CameraPath generateCameraPath(const FrameConsts& fc, const PathSoA& P, co
     seed     = xxhash32(uint32_t(px), uint32_t(py), uint32_t(fc.pc.frameCount) + frame);
     float u1 = rnd(seed), u2 = rnd(seed);
     // sampleGaussian (Box-Muller), pathtrace_functions.h.slang:784-789
-    float r     = sqrtf(-2.0f * logf(fmaxf(1e-38f, u1)));
+    float r     = sqrtExact(-2.0f * logf(fmaxf(1e-38f, u1)));
     float theta = 2.0f * K_PI * u2;
     jitter      = mk2(0.5f + ANTIALIASING_STANDARD_DEVIATION * (r * cosf(theta)), 0.5f + ANTIALIASING_STANDARD_DEVIATION * (r * sinf(theta)));
     // (single-sample frames: the guide records are WRITTEN by the path's first shade -- or zeroed where a path has none -- instead of zeroed here and
@@ -326,19 +272,19 @@ PT_DEV CameraPath generateCameraPath(const FrameConsts& fc, const PathSoA& P, co
   }
   // getRay (pathtrace_functions.h.slang:791-811)
   const MiSceneFrameInfo& fi = fc.frameInfo;
-  const f2 clip = mk2((float(px) + jitter.x) / float(fc.width) * 2.0f - 1.0f, (float(py) + jitter.y) / float(fc.height) * 2.0f - 1.0f);
+  const f2 clip = mk2(divExact(float(px) + jitter.x, float(fc.width)) * 2.0f - 1.0f, divExact(float(py) + jitter.y, float(fc.height)) * 2.0f - 1.0f);
   f4       view = mulFull(fi.projInv, mk4(clip.x, clip.y, -1.0f, 1.0f));
-  view          = view / view.w;
+  view          = mk4(divExact(view.x, view.w), divExact(view.y, view.w), divExact(view.z, view.w), divExact(view.w, view.w));
   f3 origin, direction;
   if(hasFlag(fi.flags, MI_SCENE_IS_ORTHOGRAPHIC))
   {
     origin    = xyz(mulFull(fi.viewInv, view));
-    direction = normalize(xyz(mulFull(fi.viewInv, mk4(0, 0, -1, 0))));
+    direction = normalizeExact(xyz(mulFull(fi.viewInv, mk4(0, 0, -1, 0))));
   }
   else
   {
     origin    = mk3(fi.viewInv[12], fi.viewInv[13], fi.viewInv[14]);
-    direction = normalize(xyz(mulFull(fi.viewInv, view)) - origin);
+    direction = normalizeExact(xyz(mulFull(fi.viewInv, view)) - origin);
     // thin lens (gltf_pathtrace.slang:502-529)
     const float* V          = fi.viewInv;
     f3           focalPoint = direction * fc.pc.focalDistance;
@@ -349,14 +295,14 @@ PT_DEV CameraPath generateCameraPath(const FrameConsts& fc, const PathSoA& P, co
     {
       f3 cam_right = mk3(V[0], V[4], V[8]);  // Slang mul(viewMatrixI, float4(1,0,0,0)) = M^T e0
       f3 cam_up    = mk3(V[1], V[5], V[9]);
-      aperturePos  = (cam_right * cosf(cam_r1) + cam_up * sinf(cam_r1)) * sqrtf(cam_r2);
+      aperturePos  = (cam_right * cosf(cam_r1) + cam_up * sinf(cam_r1)) * sqrtExact(cam_r2);
     }
-    direction = normalize(focalPoint - aperturePos);
+    direction = normalizeExact(focalPoint - aperturePos);
     origin += aperturePos;
   }
   cp.seed      = seed;
   cp.origin    = origin;
-  cp.direction = normalize(direction);  // pathTrace loop head, gltf_pathtrace.slang:447
+  cp.direction = normalizeExact(direction);  // pathTrace loop head, gltf_pathtrace.slang:447
   return cp;
 }
 
@@ -413,7 +359,7 @@ PT_DEV float infinitePlaneT(const FrameConsts& fc, f3 rayOrigin, f3 rayDir, floa
   const float planeHeight = fc.frameInfo.infinitePlaneDistance, Dn = rayDir.y;
   if(rayOrigin.y > planeHeight && fabsf(Dn) > 1e-6f)
   {
-    const float t = (-rayOrigin.y + planeHeight) / Dn;
+    const float t = divExact(-rayOrigin.y + planeHeight, Dn);
     if(t > 0.0f && t < hitT)
       return t;
   }
@@ -1005,6 +951,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) k_trace_closest(
         if(pend != 0ull)
         {
           const bool drain = lastVisiting < TRI_PHASE_LANES;  // few lanes left walking: nothing to wait for
+          // (round 6, review item 4a: a round started on the number of TRIANGLES the wave would hand in -- 32 / 48 / 60 instead of 20 lanes holding some --
+          //  measured atrium closest-hit walk 1.365 -> 1.464 / 1.387 / 1.385 ms per frame, street 5.44 -> 5.82 / 5.51 / 5.50: profiles/r06_shade_walk_ab.txt)
           round            = drain || __popcll(pend) >= TRI_ROUND_LANES;
           if(round)
           {
@@ -1571,10 +1519,10 @@ __global__ void __launch_bounds__(SEL_BLOCK) k_selection(DevScene sc, FrameConst
 // k_shade: everything of pathTraceOneBounce / pathTrace between the two Trace calls (gltf_pathtrace.slang:104-430, 441-494)
 //================================================================================================================================
 // FIRST: the launch shades bounce 0 (every queued path still has its initial state, see k_generate).
-// MISS: the launch also ends the paths whose ray left the scene.  false: k_shade_miss has done that (later bounces of a frame without the infinite
-// plane): such entries are dead to this launch, and the environment branch -- ~1 000 vector instructions that nearly every wave of a later bounce ran
-// for the two or three of its 64 lanes that missed -- is not in the kernel at all.
-template <bool COUNT, bool SIMPLE, bool FIRST, bool MISS = true>
+// (Round 6 measured the reorder family on this kernel -- a dense pass of its own for the paths that leave the scene, continuation entries partitioned by
+//  next-event technique x lobe draw at append -- profiles/r06_ser_ab.txt: lanes per instruction 27.7 -> 30.9, 8 % fewer instructions, no time saved:
+//  the later-bounce launch waits on its gather chain at 3 waves per SIMD.  Removed again.)
+template <bool COUNT, bool SIMPLE, bool FIRST>
 __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) k_shade(const DevScene* __restrict__ scp, const FrameConsts* __restrict__ fcp, PathSoA P, Queues Q, int cur, int sortMode, StatCounters* stats)
 {
   // The scene / frame descriptors reach the non-inlined helpers (getTexture, sampleLights, the sky) by reference.  As
@@ -1586,8 +1534,60 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
   const FrameConsts& fc = uniformConst(*fcp);
   const bool         stateInQueue = fc.stateInQueue != 0;  // misc / throughput / radiance of a living path ride in its queue entry (pt_scene.h: RayQueue)
   __shared__ uint32_t s_prefix[NSUB + 1];
-  __shared__ uint32_t s_push[12];
+  __shared__ uint32_t s_push[4];
   __shared__ float    s_srgb[256];  // sRGB decode table next to the ALU: 3 lookups per texel, up to 8 texels per tap
+#ifndef SHADE_NO_DEFERRED_MISS
+  // Later bounces: the paths that left the scene are not finished where they are found -- by then 5 % (atrium) to 18 % (street) of a queue's rays miss,
+  // spread evenly, and nearly every wave ran the environment evaluation (physical sky + sun disc or the HDR lookup, and the MIS weight: ~900 vector
+  // instructions) for two or three of its lanes -- but listed in LDS and finished by the whole block, 256 at a time with every lane busy, once that many
+  // have gathered (and at the block's end).  A first ray's miss (backplate) and any miss of a frame with the infinite plane stay inline.
+  // (As a pass of its own -- a scan of the whole queue for the misses -- the gain was eaten by the scan: profiles/r06_ser_ab.txt.)
+  constexpr bool DEFER_MISS = !FIRST;
+#else
+  constexpr bool DEFER_MISS = false;
+#endif
+  __shared__ uint32_t s_missPos[DEFER_MISS ? 2 * SHADE_BLOCK : 1];
+  __shared__ uint32_t s_missCount;
+  const bool          deferMiss = DEFER_MISS && !hasFlag(fc.frameInfo.flags, MI_SCENE_USE_INFINITE_PLANE);
+  if(threadIdx.x == 0)
+    s_missCount = 0;  // (the barrier of queuePrefix below orders it)
+  // finishes up to 256 listed misses: exactly what the inline branch does for a ray that is not a first ray (gltf_pathtrace.slang:139-156), through the same
+  // non-inlined missEnvironmentCall.  Whole block; contains barriers.
+  auto finishMisses = [&](bool all) {
+    __syncthreads();
+    const uint32_t n = s_missCount;
+    if(n == 0u || (!all && n < uint32_t(SHADE_BLOCK)))
+      return;
+    const uint32_t take = min(n, uint32_t(SHADE_BLOCK)), base = n - take;
+    uint32_t       pos = 0;
+    if(threadIdx.x < take)
+      pos = s_missPos[base + threadIdx.x];
+    __syncthreads();
+    if(threadIdx.x == 0)
+      s_missCount = base;
+    if(threadIdx.x < take)
+    {
+      const uint32_t slot  = Q.active[cur].slot[pos];
+      const float4   d4    = Q.active[cur].dir[pos];
+      const float4   misc4 = stateInQueue ? Q.active[cur].misc[pos] : P.misc[slot];
+      const float4   tp4   = stateInQueue ? Q.active[cur].aux2[pos] : P.throughput[slot];
+      const float4   rad4  = stateInQueue ? Q.active[cur].rad[pos] : P.radiance[slot];
+      f3             radiance = xyz(rad4);
+      f3             envColor;
+      float          mis;
+      missEnvironment(sc, fc, xyz(d4), tp4.w, envColor, mis);
+      radiance += xyz(tp4) * mis * envColor;
+      // the record an ended path leaves behind (see the end of the round below): flags without ALIVE -- and, from the SIMPLE kernel, without INSIDE
+      uint32_t flags = __float_as_uint(misc4.y) & (PF_INSIDE | PF_NOT_SOLID | (0xffu << PF_DEPTH_SHIFT) | (0xffu << PF_SCATTER_SHIFT));
+      if(SIMPLE)
+        flags &= ~uint32_t(PF_INSIDE);
+      const bool solid = !(flags & PF_NOT_SOLID);
+      P.radiance[slot] = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(__float_as_uint(fmaxf(fabsf(rad4.w), 0.0f)) | (solid ? 0u : RADW_NOT_SOLID)));
+      if(P.misc)
+        P.misc[slot] = make_float4(misc4.x, __uint_as_float(flags), misc4.z, misc4.w);
+    }
+    __syncthreads();
+  };
   // The window sort exists in the generic kernel only (key: material).  Where every material runs the same code (SIMPLE) grouping by material buys
   // nothing, and a window keyed by next-event technique (rounds 3-4: fewer instructions, fuller waves, 6-15 % SLOWER -- the key costs a dependent gather
   // and the window two barriers, and this kernel waits on gather depth, not on issue) was removed in round 5 together with its registers: the
@@ -1713,14 +1713,12 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
     float4         nextRad = make_float4(0, 0, 0, 0), nextMisc = make_float4(0, 0, 0, 0), nextThr = make_float4(0, 0, 0, 0);  // state of a path that goes on
     float4         shOrg = make_float4(0, 0, 0, 0), shDir = make_float4(0, 0, 0, 0), shCon = make_float4(0, 0, 0, 0), shCon2 = make_float4(0, 0, 0, 0);
     bool           catcher = false;
-    // (MISS == false: an entry without a surface hit was finished by k_shade_miss; the launch has no infinite plane to test it against)
-    const float4 hit4 = (inRange && slot != QUEUE_DEAD) ? Q.active[cur].aux[inPos] : make_float4(0, 0, 0, 0);
-    if(!MISS && __float_as_int(hit4.y) < 0)
-      slot = QUEUE_DEAD;
     if(inRange && slot != QUEUE_DEAD)
     {
-      const float4 o4 = Q.active[cur].org[inPos], d4 = Q.active[cur].dir[inPos];
+      const float4 hit4 = Q.active[cur].aux[inPos], o4 = Q.active[cur].org[inPos], d4 = Q.active[cur].dir[inPos];
       // the path's state: records of its queue entry (unit stride, like the ray), or -- catcher frames / MI_PT_STATE_BY_SLOT -- gathered by slot
+      // (round 6: the NEXT round's entry prefetched into registers across the append -- 28 VGPRs spilled at the 168-register budget: atrium 690.7 -> 686.7,
+      //  helmet 5255 -> 5068 Msamples/s; profiles/r06_shade_walk_ab.txt)
       const float4 misc4 = stateInQueue ? Q.active[cur].misc[inPos] : P.misc[slot];
       const float4 tp4   = FIRST ? make_float4(1.0f, 1.0f, 1.0f, DIRAC) : (stateInQueue ? Q.active[cur].aux2[inPos] : P.throughput[slot]);
       const float4 rad4  = FIRST ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : (stateInQueue ? Q.active[cur].rad[inPos] : P.radiance[slot]);
@@ -1742,6 +1740,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
       float hitT   = hit4.x;
       int   triIdx = __float_as_int(hit4.y);
       bool  done   = false;  // eBreak
+      bool  deferred = false;  // a miss handed to finishMisses
       bool  earlyContinue = false;
 
       HitState hit;
@@ -1786,7 +1785,13 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
         }
       }
 
-      if(MISS && hitT == INFINITE_F)  // gltf_pathtrace.slang:129-156
+      if(deferMiss && hitT == INFINITE_F && !firstRay)  // finished by the whole block later (finishMisses): nothing else of this entry is touched
+      {
+        s_missPos[atomicAdd(&s_missCount, 1u)] = inPos;
+        deferred = true;
+        done     = true;
+      }
+      else if(hitT == INFINITE_F)  // gltf_pathtrace.slang:129-156
       {
         bool backplate = false;
         if(firstRay)  // tryPrimaryMissBackplate, pathtrace_functions.h.slang:944-971
@@ -2059,7 +2064,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
       nextMisc = make_float4(maxRoughness.y, __uint_as_float(flags), __uint_as_float(seed), coneWidth);
       // A path that ends here leaves its radiance where k_finish_sample reads it and its seed where the next sample of a multi-sample
       // frame picks it up; one that goes on takes its state along in its queue entry (below, once the entry's position is known).
-      if(!stateInQueue || !alive)
+      if((!stateInQueue || !alive) && !deferred)
       {
         P.radiance[slot] = nextRad;
         if(P.misc)  // (null unless the frame has several samples or its state lives by slot: PathSoA)
@@ -2078,25 +2083,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
       if(COUNT && (meshHit || hitInfinitePlane))
         atomicAdd(&stats->surfaceHits, 1ull);
     }
-#ifdef SHADE_CLASS_PARTITION
-    uint32_t cls = 0;
-    if(SIMPLE && alive)
-    {
-      // what the next bounce's shade launch will draw from this entry's seed (gltf_pathtrace.slang:319-361): technique, then the light / sky / HDR
-      // sample (3 / 2 / 3 draws), the three of bsdfEvaluate (if the next event is valid: assumed), the three of bsdfSample -- the last of those picks the lobe
-      float lightWeight, envWeight;
-      getDirectLightingTechniqueProbabilities(sc, fc, lightWeight, envWeight);
-      uint32_t   st    = __float_as_uint(nextMisc.z);
-      const bool light = rnd(st) < lightWeight;
-      const int  skip  = (light || hasFlag(fc.frameInfo.flags, MI_SCENE_USE_HDR_ENVIRONMENT)) ? 3 + 5 : 2 + 5;
-      for(int k = 0; k < skip; ++k)
-        (void)pcg(st);
-      cls = (light ? 0u : 1u) | (rnd(st) < 0.2f ? 2u : 0u);
-    }
-    const PushPos  pp      = queuePushBlock2Classes(alive, cls, pushShadow, Q.subCap, &Q.counters[(nxt ? QC_PAIR1 : QC_PAIR0) + 2 * (chunk % NSUB)], chunk % NSUB, s_push);
-#else
     const PushPos  pp      = queuePushBlock2(alive, pushShadow, Q.subCap, &Q.counters[(nxt ? QC_PAIR1 : QC_PAIR0) + 2 * (chunk % NSUB)], chunk % NSUB, s_push);
-#endif
     const uint32_t posNext = pp.next, posShadow = pp.shadow;
     if(alive)
     {
@@ -2120,90 +2107,16 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
       if(catcher)
         Q.shadow.aux2[posShadow] = make_float4(shCon2.x, shCon2.y, shCon2.z, __uint_as_float(alive ? posNext : 0xffffffffu));
     }
+    if(DEFER_MISS && deferMiss)
+      finishMisses(false);  // (once 256 have gathered)
    }  // rounds of the window
    if(CAN_SORT)
      __syncthreads();  // s_order / s_segCount are rebuilt for the next window
   }
-}
-
-//================================================================================================================================
-// k_shade_miss: the miss branch of pathTraceOneBounce (gltf_pathtrace.slang:129-156) for the later bounces, as a pass of its own.
-// By the later bounces 5 % (atrium) to 18 % (street) of a queue's rays leave the scene, spread evenly over the waves: inside k_shade the
-// environment evaluation (physical sky + sun disc, or the HDR lookup, and the MIS weight against next-event estimation) ran in nearly every
-// wave for a handful of lanes.  Here a workgroup scans its part of the queue for entries without a hit (one 4-byte read per entry), packs
-// their positions into LDS and finishes 256 of them at a time with every lane busy; k_shade<..., MISS = false> treats them as dead.
-// Only launched where a miss ends the path whatever else is set: bounce iterations >= 1 of frames without the infinite plane (a first
-// ray's miss may show the backplate; a plane may still catch a ray that missed the geometry).  Same arithmetic through the same
-// non-inlined missEnvironmentCall as k_shade, k_trace_primary and k_finish_sample.
-//================================================================================================================================
-constexpr int MISS_BLOCK = 256;
-constexpr int MISS_SCAN  = 8;  // entries scanned per thread between two dense rounds (a round needs >= 1 miss in 2048 entries to be non-empty)
-__global__ void __launch_bounds__(MISS_BLOCK) k_shade_miss(const DevScene* __restrict__ scp, const FrameConsts* __restrict__ fcp, PathSoA P, Queues Q, int cur, int simple)
-{
-  const DevScene&    sc = uniformConst(*scp);
-  const FrameConsts& fc = uniformConst(*fcp);
-  const bool         stateInQueue = fc.stateInQueue != 0;
-  __shared__ uint32_t s_prefix[NSUB + 1];
-  __shared__ uint32_t s_list[MISS_BLOCK * MISS_SCAN];
-  __shared__ uint32_t s_count;
-  queuePrefix(&Q.counters[cur ? QC_PAIR1 : QC_PAIR0], s_prefix);
-  const uint32_t count = s_prefix[NSUB];
-  constexpr uint32_t WINDOW = MISS_BLOCK * MISS_SCAN;
-  const uint32_t numWindows = (count + WINDOW - 1) / WINDOW;
-  for(uint32_t win = blockIdx.x; win < numWindows; win += gridDim.x)
+  if(DEFER_MISS && deferMiss)
   {
-    if(threadIdx.x == 0)
-      s_count = 0;
-    __syncthreads();
-#pragma unroll
-    for(int k = 0; k < MISS_SCAN; ++k)
-    {
-      const uint32_t i = win * WINDOW + uint32_t(k) * MISS_BLOCK + threadIdx.x;
-      bool           miss = false;
-      uint32_t       pos  = 0;
-      if(i < count)
-      {
-        pos  = queuePos(Q.subCap, s_prefix, i);
-        miss = Q.active[cur].slot[pos] != QUEUE_DEAD && __float_as_int(Q.active[cur].aux[pos].y) < 0;
-      }
-      const unsigned long long m = __ballot(miss);
-      if(m != 0ull)
-      {
-        uint32_t base = 0;
-        if(laneId() == uint32_t(__ffsll((long long)m) - 1))
-          base = atomicAdd(&s_count, uint32_t(__popcll(m)));
-        base = uint32_t(__builtin_amdgcn_readlane(int(base), __ffsll((long long)m) - 1));
-        if(miss)
-          s_list[base + laneCountBelow(m)] = pos;
-      }
-    }
-    __syncthreads();
-    const uint32_t n = s_count;
-    for(uint32_t e = threadIdx.x; e < n; e += MISS_BLOCK)
-    {
-      const uint32_t pos  = s_list[e];
-      const uint32_t slot = Q.active[cur].slot[pos];
-      const float4   d4   = Q.active[cur].dir[pos];
-      const float4   misc4 = stateInQueue ? Q.active[cur].misc[pos] : P.misc[slot];
-      const float4   tp4   = stateInQueue ? Q.active[cur].aux2[pos] : P.throughput[slot];
-      const float4   rad4  = stateInQueue ? Q.active[cur].rad[pos] : P.radiance[slot];
-      const f3       rayDir = xyz(d4), throughput = xyz(tp4);
-      f3             radiance = xyz(rad4);
-      f3             envColor;
-      float          mis;
-      missEnvironment(sc, fc, rayDir, tp4.w, envColor, mis);
-      radiance += throughput * mis * envColor;
-      // the record an ended path leaves behind, as k_shade writes it: radiance + maxRoughness.x | !solid; flags without ALIVE (and, from the
-      // SIMPLE kernel, without INSIDE: it does not track media), seed, cone width
-      uint32_t flags = __float_as_uint(misc4.y) & (PF_INSIDE | PF_NOT_SOLID | (0xffu << PF_DEPTH_SHIFT) | (0xffu << PF_SCATTER_SHIFT));
-      if(simple)
-        flags &= ~PF_INSIDE;
-      const bool solid = !(flags & PF_NOT_SOLID);
-      P.radiance[slot] = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(__float_as_uint(fmaxf(fabsf(rad4.w), 0.0f)) | (solid ? 0u : RADW_NOT_SOLID)));
-      if(P.misc)
-        P.misc[slot] = make_float4(misc4.x, __uint_as_float(flags), misc4.z, misc4.w);
-    }
-    __syncthreads();
+    finishMisses(true);
+    finishMisses(true);  // (at most 511 were listed)
   }
 }
 
@@ -2903,7 +2816,7 @@ __global__ void __launch_bounds__(256) k_finish_sample(FrameConsts fc, const Dev
     f4             r     = mk4(rad4.x, rad4.y, rad4.z, solid ? 1.0f : 0.0f);
     float          lum   = dot(xyz(r), mk3(1.0f / 3.0f));
     if(lum > fc.pc.fireflyClampThreshold)
-      r *= fc.pc.fireflyClampThreshold / lum;
+      r *= divExact(fc.pc.fireflyClampThreshold, lum);  // (k_finish_sample keeps IEEE division: the accumulator is the oracle's running mean of the same samples, pt_math.h)
     float4 sum = sampleIndex == 0 ? make_float4(0, 0, 0, 0) : P.pixelSum[slot];
     sum        = make_float4(sum.x + r.x, sum.y + r.y, sum.z + r.z, sum.w + r.w);
     if(!lastSample)
@@ -2911,7 +2824,7 @@ __global__ void __launch_bounds__(256) k_finish_sample(FrameConsts fc, const Dev
       P.pixelSum[slot] = sum;
       continue;
     }
-    const f4    pixel      = mk4(sum.x, sum.y, sum.z, sum.w) / n;
+    const f4    pixel      = mk4(divExact(sum.x, n), divExact(sum.y, n), divExact(sum.z, n), divExact(sum.w, n));
     const bool  firstFrame = f == 0 && hasFlag(fc.pc.flags, MI_PT_FIRST_FRAME);
     const float tot = float(fc.pc.totalSamples + f * fc.pc.numSamples), after = float(fc.pc.totalSamples + (f + 1) * fc.pc.numSamples);
     if(!firstFrame && !loaded)
@@ -2932,22 +2845,22 @@ __global__ void __launch_bounds__(256) k_finish_sample(FrameConsts fc, const Dev
       {
         float4 fh   = P.firstHit[pslot];  // (per pixel slot: f == 0 here)
         f4     clip = mulFull(fc.frameInfo.viewProjMatrix, mk4(fh.x, fh.y, fh.z, 1.0f));
-        ndcDepth    = clip.z / clip.w;
+        ndcDepth    = divExact(clip.z, clip.w);
       }
       depth[idx] = ndcDepth;
       acc        = make_float4(pixel.x, pixel.y, pixel.z, pixel.w);
     }
     else
-      acc = make_float4((acc.x * tot + pixel.x * n) / after, (acc.y * tot + pixel.y * n) / after, (acc.z * tot + pixel.z * n) / after,
-                        (acc.w * tot + pixel.w * n) / after);
+      acc = make_float4(divExact(acc.x * tot + pixel.x * n, after), divExact(acc.y * tot + pixel.y * n, after), divExact(acc.z * tot + pixel.z * n, after),
+                        divExact(acc.w * tot + pixel.w * n, after));
     if(guides)
     {
       const float4 ga = P.guideAlbedo[slot], gn = P.guideNormal[slot];
-      const float4 a  = make_float4(ga.x / n, ga.y / n, ga.z / n, r.w > 0.0f ? 1.0f : 0.0f);
+      const float4 a  = make_float4(divExact(ga.x, n), divExact(ga.y, n), divExact(ga.z, n), r.w > 0.0f ? 1.0f : 0.0f);
       // .w: second moment of this frame's pixel luminance (Rec. 709) -- with luminance(accum) it gives the temporal variance the
       // SVGF pass is guided by (denoise.hip), at no extra image
       const float  lumP = 0.2126f * pixel.x + 0.7152f * pixel.y + 0.0722f * pixel.z;
-      const float4 nn   = make_float4(gn.x / n, gn.y / n, gn.z / n, lumP * lumP);
+      const float4 nn   = make_float4(divExact(gn.x, n), divExact(gn.y, n), divExact(gn.z, n), lumP * lumP);
       if(firstFrame)
       {
         accA = a;
@@ -2955,7 +2868,7 @@ __global__ void __launch_bounds__(256) k_finish_sample(FrameConsts fc, const Dev
       }
       else
       {
-        const float wOld = tot / after, wNew = n / after;
+        const float wOld = divExact(tot, after), wNew = divExact(n, after);
         accA = make_float4(accA.x * wOld + a.x * wNew, accA.y * wOld + a.y * wNew, accA.z * wOld + a.z * wNew, accA.w * wOld + a.w * wNew);
         accN = make_float4(accN.x * wOld + nn.x * wNew, accN.y * wOld + nn.y * wNew, accN.z * wOld + nn.z * wNew, accN.w * wOld + nn.w * wNew);
       }
@@ -3183,16 +3096,11 @@ void launchTraceClosest(const LaunchCtx& c, int cur)
   else
     launchTraceClosestT<false>(c, cur);
 }
-void launchShade(const LaunchCtx& c, int cur, bool first, bool missPass)
+void launchShade(const LaunchCtx& c, int cur, bool first)
 {
   dim3 grid(c.persistentBlocks), block(SHADE_BLOCK);
-  // later bounces of a frame without the infinite plane: the paths that left the scene end in a dense pass of their own (k_shade_miss)
-  const bool split = missPass && !first && (c.fc.frameInfo.flags & MI_SCENE_USE_INFINITE_PLANE) == 0;
-  if(split)
-    hipLaunchKernelGGL(k_shade_miss, grid, dim3(MISS_BLOCK), 0, c.stream, c.sceneDev, c.fcDev, c.paths, c.queues, cur, c.simpleMaterials ? 1 : 0);
 #define MI_LAUNCH_SHADE(C, S, F) \
-  do { if(!F && split) hipLaunchKernelGGL((k_shade<C, S, false, false>), grid, block, 0, c.stream, c.sceneDev, c.fcDev, c.paths, c.queues, cur, (S ? 0 : c.sortMode), c.stats); \
-       else hipLaunchKernelGGL((k_shade<C, S, F>), grid, block, 0, c.stream, c.sceneDev, c.fcDev, c.paths, c.queues, cur, (S ? 0 : c.sortMode), c.stats); } while(0)
+  hipLaunchKernelGGL((k_shade<C, S, F>), grid, block, 0, c.stream, c.sceneDev, c.fcDev, c.paths, c.queues, cur, (S ? 0 : c.sortMode), c.stats)
 #define MI_LAUNCH_SHADE_F(C, S) do { if(first) MI_LAUNCH_SHADE(C, S, true); else MI_LAUNCH_SHADE(C, S, false); } while(0)
   if(c.simpleMaterials)
   {

@@ -58,6 +58,37 @@ PT_DEV f4& operator+=(f4& a, f4 b) { a = a + b; return a; }
 PT_DEV f4& operator*=(f4& a, f4 b) { a = a * b; return a; }
 PT_DEV f4& operator*=(f4& a, float s) { a = a * s; return a; }
 
+// ---- correctly rounded division / square root, whatever the translation unit's floating-point options ----------------------------------
+// pt_kernels.hip is compiled with -fno-hip-fp32-correctly-rounded-divide-sqrt (csrc/Makefile): `a / b` there is the 2.5-ulp division and
+// sqrtf the 1-ulp square root the REFERENCE's own arithmetic has (Vulkan's SPIR-V precision: OpFDiv 2.5 ULP, sqrt / inversesqrt 2 ULP) --
+// a fifth of the shade kernels' vector instructions were the IEEE expansions (profiles/r06_fast_div_ab.txt: atrium +3.3 %, helmet +4 %).
+// What must agree with the CPU oracle BIT FOR BIT keeps IEEE results through these helpers: camera rays (coverage, selection ids, depth),
+// the ray setup and the ray / triangle test (hit records, tie-breaks on coincident geometry), the running mean of k_finish_sample.
+// divExact is the AMDGPU back end's own IEEE expansion (v_div_scale / v_rcp / Newton-Raphson in fma / v_div_fmas / v_div_fixup) written with
+// its builtins; sqrtExact is OCML's correctly rounded sqrt.  tools/test_exact_math.hip checks both against `/` and sqrtf of a translation
+// unit compiled WITHOUT the option, bit for bit, on the device.
+#if defined(__HIP_DEVICE_COMPILE__)
+PT_DEV float divExact(float a, float b)
+{
+  bool        vcc  = false, unused = false;
+  const float den  = __builtin_amdgcn_div_scalef(a, b, false, &unused);
+  const float num  = __builtin_amdgcn_div_scalef(a, b, true, &vcc);
+  const float rcp  = __builtin_amdgcn_rcpf(den);
+  const float e0   = __builtin_fmaf(-den, rcp, 1.0f);
+  const float r1   = __builtin_fmaf(e0, rcp, rcp);
+  const float q0   = num * r1;
+  const float e1   = __builtin_fmaf(-den, q0, num);
+  const float q1   = __builtin_fmaf(e1, r1, q0);
+  const float e2   = __builtin_fmaf(-den, q1, num);
+  const float fmas = __builtin_amdgcn_div_fmasf(e2, r1, q1, vcc);
+  return __builtin_amdgcn_div_fixupf(fmas, b, a);
+}
+PT_DEV float sqrtExact(float x) { return __ocml_sqrt_f32(x); }
+#else  // hipcc's host pass (never runs) and the device headers compiled for the host (tests/host_shim): IEEE by the language
+PT_DEV float divExact(float a, float b) { return a / b; }
+PT_DEV float sqrtExact(float x) { return sqrtf(x); }
+#endif
+
 PT_DEV float dot(f2 a, f2 b) { return a.x * b.x + a.y * b.y; }
 PT_DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 PT_DEV f3 cross(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
@@ -74,6 +105,13 @@ PT_DEV f3 normalize(f3 a)
   return {a.x * r, a.y * r, a.z * r};
 }
 PT_DEV f2 normalize(f2 a) { float l = length(a); return {a.x / l, a.y / l}; }
+// ... with IEEE square root and reciprocal whatever the compile options (camera rays: divExact above)
+PT_DEV f3 normalizeExact(f3 a)
+{
+#pragma clang fp contract(off)
+  const float r = divExact(1.0f, sqrtExact(dot(a, a)));
+  return {a.x * r, a.y * r, a.z * r};
+}
 // sin / cos of an angle given in REVOLUTIONS (angle / 2 pi), |t| <= 256: v_sin_f32 / v_cos_f32 take their argument that way, so
 // phi = 2 pi u needs neither the multiply nor a range reduction.  Max abs error 1.3e-7 on [0, 1) against double precision.
 PT_DEV float sinTurns(float t) { return __builtin_amdgcn_sinf(t); }
