@@ -10,7 +10,7 @@ cd "$(dirname "$0")/../vk_gltf_renderer_amd/csrc"
 make -s -j8
 mkdir -p ../lib/var_$name
 src=${VARIANT_SRC:-pt_kernels}
-fp=""; [ "$src" = pt_kernels ] && fp="-fno-hip-fp32-correctly-rounded-divide-sqrt"  # (csrc/Makefile: PT_KERNELS_FP)
+fp=""; [ "$src" = pt_kernels ] && fp="-fno-hip-fp32-correctly-rounded-divide-sqrt -freciprocal-math -fapprox-func"  # (csrc/Makefile: PT_KERNELS_FP)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -I../../include -Idevice -Wno-unused-function $fp "$@" -c -o build/variant_$name.o device/$src.hip
 objs=$(ls build/*.o | grep -v "build/$src.o" | grep -v "build/variant_")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o ../lib/var_$name/libmi_pt.so build/variant_$name.o $objs

@@ -24,7 +24,7 @@ def census(flags=(), source="pt_kernels.hip"):
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-I" + os.path.join(ROOT, "include"), "-I" + DEVICE,
                "-Wno-unused-function", "--cuda-device-only", "-S", "-o", asm, os.path.join(DEVICE, source), *flags]
         if source == "pt_kernels.hip":
-            cmd.append("-fno-hip-fp32-correctly-rounded-divide-sqrt")  # (csrc/Makefile: PT_KERNELS_FP)
+            cmd += ["-fno-hip-fp32-correctly-rounded-divide-sqrt", "-freciprocal-math", "-fapprox-func"]  # (csrc/Makefile: PT_KERNELS_FP)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(r.stderr[-2000:])

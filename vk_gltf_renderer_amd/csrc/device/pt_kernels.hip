@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
+#define PT_FAST_SHADING_MATH 1  // pt_math.h: hardware reciprocal / reciprocal square root in the vector helpers of THIS translation unit (see csrc/Makefile: PT_KERNELS_FP)
 #include "pt_kernels.h"
 #include "pt_shading.h"
 #include "pt_bvh.h"
@@ -253,9 +254,9 @@ PT_DEV CameraPath generateCameraPath(const FrameConsts& fc, const PathSoA& P, co
     seed     = xxhash32(uint32_t(px), uint32_t(py), uint32_t(fc.pc.frameCount) + frame);
     float u1 = rnd(seed), u2 = rnd(seed);
     // sampleGaussian (Box-Muller), pathtrace_functions.h.slang:784-789
-    float r     = sqrtExact(-2.0f * logf(fmaxf(1e-38f, u1)));
+    float r     = sqrtExact(-2.0f * logExact(fmaxf(1e-38f, u1)));
     float theta = 2.0f * K_PI * u2;
-    jitter      = mk2(0.5f + ANTIALIASING_STANDARD_DEVIATION * (r * cosf(theta)), 0.5f + ANTIALIASING_STANDARD_DEVIATION * (r * sinf(theta)));
+    jitter      = mk2(0.5f + ANTIALIASING_STANDARD_DEVIATION * (r * cosExact(theta)), 0.5f + ANTIALIASING_STANDARD_DEVIATION * (r * sinExact(theta)));
     // (single-sample frames: the guide records are WRITTEN by the path's first shade -- or zeroed where a path has none -- instead of zeroed here and
     //  read, added to and written back there: 64 B per path less)
     if(P.guideAlbedo && fc.pc.numSamples > 1)
@@ -295,7 +296,7 @@ PT_DEV CameraPath generateCameraPath(const FrameConsts& fc, const PathSoA& P, co
     {
       f3 cam_right = mk3(V[0], V[4], V[8]);  // Slang mul(viewMatrixI, float4(1,0,0,0)) = M^T e0
       f3 cam_up    = mk3(V[1], V[5], V[9]);
-      aperturePos  = (cam_right * cosf(cam_r1) + cam_up * sinf(cam_r1)) * sqrtExact(cam_r2);
+      aperturePos  = (cam_right * cosExact(cam_r1) + cam_up * sinExact(cam_r1)) * sqrtExact(cam_r2);
     }
     direction = normalizeExact(focalPoint - aperturePos);
     origin += aperturePos;
@@ -1548,7 +1549,9 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
 #endif
   __shared__ uint32_t s_missPos[DEFER_MISS ? 2 * SHADE_BLOCK : 1];
   __shared__ uint32_t s_missCount;
-  const bool          deferMiss = DEFER_MISS && !hasFlag(fc.frameInfo.flags, MI_SCENE_USE_INFINITE_PLANE);
+  // ... and only where the environment is the physical sky: an HDR lookup is too cheap to be worth the list (helmet 5310 -> 5285, glass 551 -> 549 Msamples/s with it,
+  // atrium 715 -> 727, street 764 -> 771: profiles/r06_deferred_miss_ab.txt)
+  const bool          deferMiss = DEFER_MISS && !hasFlag(fc.frameInfo.flags, MI_SCENE_USE_INFINITE_PLANE) && !hasFlag(fc.frameInfo.flags, MI_SCENE_USE_HDR_ENVIRONMENT);
   if(threadIdx.x == 0)
     s_missCount = 0;  // (the barrier of queuePrefix below orders it)
   // finishes up to 256 listed misses: exactly what the inline branch does for a ray that is not a first ray (gltf_pathtrace.slang:139-156), through the same

@@ -42,7 +42,18 @@ PT_DEV f3 operator-(f3 a) { return {-a.x, -a.y, -a.z}; }
 PT_DEV f3 operator*(f3 a, f3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
 PT_DEV f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 PT_DEV f3 operator*(float s, f3 a) { return {a.x * s, a.y * s, a.z * s}; }
+// (pt_kernels.hip defines PT_FAST_SHADING_MATH: a vector over a scalar is ONE hardware reciprocal (v_rcp_f32, 1 ulp) and three multiplies there -- within the
+//  2.5 ulp the translation unit's divisions have anyway, see divExact below -- instead of three 8-instruction divisions; everything that must stay IEEE says so
+//  explicitly with divExact / normalizeExact.  The builders, the denoiser and the host compile of these headers keep the plain form.)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PT_FAST_SHADING_MATH)
+PT_DEV f3 operator/(f3 a, float s)
+{
+  const float r = __builtin_amdgcn_rcpf(s);
+  return {a.x * r, a.y * r, a.z * r};
+}
+#else
 PT_DEV f3 operator/(f3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+#endif
 PT_DEV f3 operator/(f3 a, f3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
 PT_DEV f3& operator+=(f3& a, f3 b) { a = a + b; return a; }
 PT_DEV f3& operator-=(f3& a, f3 b) { a = a - b; return a; }
@@ -84,9 +95,17 @@ PT_DEV float divExact(float a, float b)
   return __builtin_amdgcn_div_fixupf(fmas, b, a);
 }
 PT_DEV float sqrtExact(float x) { return __ocml_sqrt_f32(x); }
+// libm-grade logarithm / sine / cosine whatever the options (camera jitter and lens: the translation unit may be compiled with -fapprox-func, which turns
+// logf / sinf / cosf CALLS into the hardware's v_log / v_sin / v_cos approximations; OCML's own entry points are not calls the option rewrites)
+PT_DEV float logExact(float x) { return __ocml_log_f32(x); }
+PT_DEV float sinExact(float x) { return __ocml_sin_f32(x); }
+PT_DEV float cosExact(float x) { return __ocml_cos_f32(x); }
 #else  // hipcc's host pass (never runs) and the device headers compiled for the host (tests/host_shim): IEEE by the language
 PT_DEV float divExact(float a, float b) { return a / b; }
 PT_DEV float sqrtExact(float x) { return sqrtf(x); }
+PT_DEV float logExact(float x) { return logf(x); }
+PT_DEV float sinExact(float x) { return sinf(x); }
+PT_DEV float cosExact(float x) { return cosf(x); }
 #endif
 
 PT_DEV float dot(f2 a, f2 b) { return a.x * b.x + a.y * b.y; }
@@ -101,7 +120,11 @@ PT_DEV float length(f2 a) { return sqrtf(dot(a, a)); }
 PT_DEV f3 normalize(f3 a)
 {
 #pragma clang fp contract(off)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PT_FAST_SHADING_MATH)
+  const float r = __builtin_amdgcn_rsqf(dot(a, a));  // v_rsq_f32, 1 ulp (shading directions; camera rays: normalizeExact)
+#else
   const float r = 1.0f / length(a);
+#endif
   return {a.x * r, a.y * r, a.z * r};
 }
 PT_DEV f2 normalize(f2 a) { float l = length(a); return {a.x / l, a.y / l}; }
