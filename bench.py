@@ -51,7 +51,9 @@ import numpy as np  # noqa: E402
 
 # Frames in flight per GPU and frames per step: 64 -> 96 -> 128 frames measured 3809 / 3896 / 3927 Msamples/s on the helmet and 484 / 489 / 492
 # on the atrium (round 3; a batch of 128 1080p frames is 2.65e8 path slots, ~80 GB of the 288)
-IN_FLIGHT_DEFAULT, FRAMES_PER_STEP_DEFAULT = 128, 256
+# Round 6: 64 frames in flight by default (33.8 GB of path state at 1080p instead of 67.5) -- 97.6 % of the 128-frame rate on the atrium (728.6 / 746.4 / 758.5 Msamples/s at
+# 64 / 128 / 256, profiles/r06_in_flight.txt); the 128-frame figure stands beside the headline as also.atrium_f128.  The glass workload keeps 256 (528 / 546 / 563 at 128 / 192 / 256)
+IN_FLIGHT_DEFAULT, FRAMES_PER_STEP_DEFAULT = 64, 256
 ALPHA_CUT_DEFAULT = 4  # measured (adaptive cut): atrium 462 -> 483 / 479 / 494 and street 455 -> 510 / 507 / 490 Msamples/s at 4 / 8 / 16
 WORKLOADS = {
     # name: BASELINE config, generator kwargs, width, height, maxDepth, env, spp = the configuration's OWN sample count (the parity leg's)
@@ -59,6 +61,8 @@ WORKLOADS = {
                    kw=dict(seed=1234, tess=272, tex_size=2048), width=1920, height=1080, depth=8, hdr=True, spp=64),
     "atrium": dict(config="configs[2]: Sponza-class, 1920x1080, 256 spp, depth 12, NEE+MIS (directional light + sky)", gen="scene_atrium_class",
                    kw=dict(seed=4321, detail=0.8, tex_size=512), width=1920, height=1080, depth=12, hdr=False, spp=256),
+    "atrium_f128": dict(config="configs[2] with 128 frames in flight: Sponza-class, 1920x1080, 256 spp, depth 12, NEE+MIS", gen="scene_atrium_class",
+                        kw=dict(seed=4321, detail=0.8, tex_size=512), width=1920, height=1080, depth=12, hdr=False, spp=256, in_flight=128),
     "street": dict(config="configs[3]: BistroExterior-class (instanced street, ~2.8 M triangles, ~1000 render nodes, 130 materials), 3840x2160, 64 spp, depth 8",
                    gen="scene_street_class", kw=dict(seed=777, detail=1.27, tex_size=256), width=3840, height=2160, depth=8, hdr=False, spp=64),
     "glass": dict(config="configs[4]: TransmissionTest-class sphere grid + textured glass slabs + DragonDispersion-class blob (869 k triangles, dispersion + volume), "
@@ -80,6 +84,7 @@ ALSO_LINES = {
     "helmet": ("helmet", 0, 0, False, True),
     "helmet_4k": ("helmet", 3840, 2160, False, False),  # the same scene as "helmet": no second parity leg
     "atrium": ("atrium", 0, 0, False, True),
+    "atrium_f128": ("atrium_f128", 0, 0, False, False),  # the headline configuration with 128 frames in flight (rounds 3-5's default)
     "street": ("street", 0, 0, False, True),
     "glass": ("glass", 0, 0, False, True),
     "glass_denoise": ("glass", 0, 0, True, True),
@@ -89,7 +94,7 @@ ALSO_LINES = {
     "street_sliver": ("street_sliver", 0, 0, False, False),  # (parity leg on request: --also street_sliver_parity)
     "street_sliver_parity": ("street_sliver", 0, 0, False, True),
 }
-ALSO_DEFAULT = "helmet,helmet_4k,street,glass_denoise,atrium_sliver,street_sliver"
+ALSO_DEFAULT = "helmet,helmet_4k,street,glass_denoise,atrium_sliver,street_sliver,atrium_f128"
 NORTH_STAR = {"workload": "atrium", "target": ">= 2 Gsamples/s on Sponza 1080p at 8 x MI355X (BASELINE.json north_star)", "needs_per_gpu_Msamples_s": 250.0}
 # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy); 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T
 # vector-lane operations per second (x2 flops per fma = the 157.3 TFLOP/s fp32 vector peak)
@@ -113,7 +118,7 @@ def scene_path(name, rank):
     d = os.path.join(tempfile.gettempdir(), "mi_pt_scenes")
     os.makedirs(d, exist_ok=True)
     tag = "_".join(f"{k}{v}" for k, v in sorted(w["kw"].items()))
-    path = os.path.join(d, f"{name}_{tag}.glb")
+    path = os.path.join(d, f"{w['gen']}_{tag}.glb")  # (keyed by generator + arguments: workloads that differ only in how they are run share the file)
     if not os.path.exists(path):
         tmp = f"{path}.{os.getpid()}.{rank}.tmp"
         getattr(scenegen, w["gen"])(tmp, **w["kw"])
@@ -123,7 +128,7 @@ def scene_path(name, rank):
 
 # configurations of the default run whose counter passes (profiles/pmc_latest_<workload>.json) have not been collected yet for the current kernels / scenes: their
 # lines print `traffic: null`.  tests/test_bench_contract.py lets exactly these pass without a file.
-PMC_PENDING = {"glass", "atrium_sliver", "street_sliver"}
+PMC_PENDING = {"glass", "atrium_sliver", "street_sliver", "atrium", "helmet", "atrium_f128"}
 
 
 def load_pmc(workload, F, W, H):

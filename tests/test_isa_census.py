@@ -26,8 +26,9 @@ def _one(table, prefix):
 
 
 def test_helpers_read_descriptors_through_the_scalar_cache(table):
-    for name, min_s_loads in (("pt::sampleLightsCall", 20), ("pt::evalPhysicalSky", 20), ("missEnvironmentCall", 10), ("primaryMissBackplateCall", 4),
-                              ("pt::getShadowTransmissionCall", 4)):
+    # (pt::sampleLightsCall: inlined at its call sites since round 6 -- its descriptor reads are then the shade kernels' own, checked below: no vector
+    #  load of a uniform address, and well over a hundred scalar loads in the kernels that carry its body)
+    for name, min_s_loads in (("pt::evalPhysicalSky", 20), ("missEnvironmentCall", 10), ("primaryMissBackplateCall", 4), ("pt::getShadowTransmissionCall", 4)):
         for s in _one(table, name):
             assert s["flat_load"] == 0 and s["flat_store"] == 0 and s["drain"] == 0, (name, s)
             assert s["s_load"] >= min_s_loads, (name, s)
@@ -43,7 +44,10 @@ def test_shade_kernels_have_no_generic_loads_and_no_uniform_vector_loads(table):
     assert len(kernels) == 8
     for name, s in kernels.items():
         assert s["flat_load"] <= 1 and s["flat_store"] == 0 and s["drain"] == 0, (name, s)  # (one: the sRGB table's copy into LDS)
-        assert s["sgpr_base_load"] == 0, (name, s)  # sc. / fc. after a store or a call: scalar, not a vector load of a uniform address
+        # sc. / fc. after a store or a call: scalar, not a vector load of a uniform address.  (The later-bounce kernels have two loads in SGPR-base form that are
+        # real gathers: finishMisses reads the listed entries' slot / ray through a uniform queue base + the per-lane position it took from LDS.)
+        assert s["sgpr_base_load"] <= (2 if name.endswith(", false>") else 0), (name, s)
+        assert s["s_load"] >= 90, (name, s)         # ... and sampleLights' light / sky tables arrive through the scalar cache (its body is inlined here)
     for name in ("k_shade<false, true, true>", "k_shade<true, true, true>"):  # the bounce-0 launch of the common flavour: nothing spilled
         assert kernels[name]["vgpr_spill"] == 0 and kernels[name]["scratch"] == 0, (name, kernels[name])
 

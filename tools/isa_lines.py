@@ -18,7 +18,8 @@ DEVICE = os.path.join(ROOT, "vk_gltf_renderer_amd", "csrc", "device")
 def compile_asm(extra=()):
     out = os.path.join(tempfile.gettempdir(), "pt_kernels_lines.s")
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-I" + os.path.join(ROOT, "include"), "-I" + DEVICE,
-           "-Wno-unused-function", "--cuda-device-only", "-gline-tables-only", "-S", "-o", out, os.path.join(DEVICE, "pt_kernels.hip"), *extra]
+           "-Wno-unused-function", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-freciprocal-math", "-fapprox-func",  # (csrc/Makefile: PT_KERNELS_FP)
+           "--cuda-device-only", "-gline-tables-only", "-S", "-o", out, os.path.join(DEVICE, "pt_kernels.hip"), *extra]
     subprocess.run(cmd, check=True, capture_output=True)
     return out
 

@@ -9,7 +9,7 @@ import json, os, sys
 
 summary, workload, frames = json.load(open(sys.argv[1]))["kernels"], sys.argv[2], int(sys.argv[3])
 try:
-    MIX = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_valu_mix.json")))["kernels"]
+    MIX = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r06_valu_mix.json")))["kernels"]
 except Exception:
     MIX = {}
 calib_path = sys.argv[5] if len(sys.argv) > 5 else None
@@ -73,7 +73,7 @@ for key, match in pick.items():
                                    "avg_us": round(k.get("avg_us", 0.0), 1)}
             # from the SQ / TCC passes of the same command (tools/profile.sh): how much of the launch the 1024 SIMDs spend issuing vector
             # instructions -- instructions x (cycles per wave64 instruction) / (SIMDs x duration x 2.4 GHz).  The cycles come from the kernel's
-            # static class mix (profiles/r04_valu_mix.json, tools/valu_mix.py): 2 for the full-rate class (f32 fma / mul / add, and / or / xor,
+            # static class mix (profiles/r06_valu_mix.json, tools/valu_mix.py): 2 for the full-rate class (f32 fma / mul / add, and / or / xor,
             # integer add, mov), 4 for the rest (min / max, conversions, shifts, selects, compares, packed f32), 8 for transcendentals -- classes
             # timed by tools/microbench_valu.hip.  A model (the dynamic mix of the hot loop may differ); the bounds at 2 and at 4 cycles for every
             # instruction stand beside it -- also the lanes active per vector instruction, and the L2 hit rate

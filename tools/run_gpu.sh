@@ -34,33 +34,33 @@ envab() { # envab <tag> <VAR> "<values...>" <workloads...>: the product build wi
 case "$1" in
   envab) shift; envab "$@" ;;
   line)  # the full default line (headline + every other configuration with CPU legs), as the driver runs it
-    timeout 1500 python bench.py --steps 20 --warmup 5 > $O/r05_bench_default_a.json 2> $O/r05_bench_default_a.err; echo "bench rc $?"; tail -c 600 $O/r05_bench_default_a.err
+    timeout 1500 python bench.py --steps 20 --warmup 5 > $O/r06_bench_default_a.json 2> $O/r06_bench_default_a.err; echo "bench rc $?"; tail -c 600 $O/r06_bench_default_a.err
     python3 - <<'PY'
 import json
-j=json.loads(open('gpurun_out/r05_bench_default_a.json').read().strip().splitlines()[-1])
+j=json.loads(open('gpurun_out/r06_bench_default_a.json').read().strip().splitlines()[-1])
 print('atrium', j['value'], j.get('parity',{}).get('by_spp'), j.get('cpu_baseline'))
 for n,a in j.get('also',{}).items(): print(n, a['value'], a.get('parity',{}).get('by_spp'), a.get('cpu_baseline',{}).get('value'))
 PY
     ;;
-  evidence)  # tools/run_gpu.sh evidence <tag> <bench args...>: kernel-trace stats + counter passes of ONE configuration; leaves
-             # gpurun_out/r04_<tag>_kernel_stats.csv, r04_<tag>_pmc_summary.json and pmc_latest_<tag>.json (to be copied to profiles/)
+  evidence)  # tools/run_gpu.sh evidence <tag> <bench args...>: kernel-trace stats + counter passes of ONE configuration (tag = the pmc file's name:
+             # a workload of bench.py, or helmet_4k); leaves gpurun_out/r06_<tag>_kernel_stats.csv, r06_<tag>_pmc_summary.json and pmc_latest_<tag>.json (copy to profiles/)
     shift; tag=$1; shift
-    tools/profile.sh r05_$tag "$@" --steps 2 --warmup 1 > /dev/null 2>&1
-    python tools/summarize_pmc.py $O/prof_r05_$tag $O/r05_${tag}_pmc_summary.json > /dev/null
-    cp "$(find $O/prof_r05_$tag/stats -name '*kernel_stats.csv' | head -1)" $O/r05_${tag}_kernel_stats.csv
+    tools/profile.sh r06_$tag "$@" --steps 2 --warmup 1 > /dev/null 2>&1
+    python tools/summarize_pmc.py $O/prof_r06_$tag $O/r06_${tag}_pmc_summary.json > /dev/null
+    cp "$(find $O/prof_r06_$tag/stats -name '*kernel_stats.csv' | head -1)" $O/r06_${tag}_kernel_stats.csv
     python3 - $tag <<'PY'
 import json, subprocess, sys
 tag = sys.argv[1]
-line = [l for l in open(f"gpurun_out/prof_r05_{tag}/stats.log") if l.startswith("{")][-1]
+line = [l for l in open(f"gpurun_out/prof_r06_{tag}/stats.log") if l.startswith("{")][-1]
 j = json.loads(line); c = j["config"]
-wl = [w for w in ("helmet", "atrium", "street", "glass", "box") if w in tag][0]
-out = subprocess.run([sys.executable, "tools/make_pmc_latest.py", f"gpurun_out/r05_{tag}_pmc_summary.json", wl, str(c["frames_in_flight"]), "5",
+wl = "helmet" if tag == "helmet_4k" else tag
+out = subprocess.run([sys.executable, "tools/make_pmc_latest.py", f"gpurun_out/r06_{tag}_pmc_summary.json", wl, str(c["frames_in_flight"]), "6",
                       "profiles/r03_fetch_calibration.json", str(c["resolution"][0]), str(c["resolution"][1])], capture_output=True, text=True)
 open(f"gpurun_out/pmc_latest_{tag}.json", "w").write(out.stdout)
 k = json.loads(out.stdout)["kernels"]
 print("EVIDENCE", tag, j["value"], {n: (v.get("issue_frac"), v.get("active_lanes"), round(v["hbm_bytes_per_launch"] / 1e9, 2)) for n, v in k.items()}, out.stderr[-300:])
 PY
-    rm -rf $O/prof_r05_$tag  # (the per-dispatch counter CSVs are tens of MB per configuration; gpurun copies back at most 64 MiB)
+    rm -rf $O/prof_r06_$tag  # (the per-dispatch counter CSVs are tens of MB per configuration; gpurun copies back at most 64 MiB)
     ;;
   sweep)  # frames in flight 1 / 8 / 64 / 128 at 1080p and 4K: what a maintainer gets per onRender batch size, and the memory it takes
     for w in helmet atrium; do for f in 1 8 64 128; do

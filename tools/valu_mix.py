@@ -7,7 +7,7 @@ med3, conversions, shifts, bit-field ops, selects, compares, 24-bit and 32-bit m
 and 5.6 for a reciprocal).  The model charges 2 / 4 / 4 / 8 cycles to full / half / packed / transcendental instructions -- the upper
 end of what was measured -- and a kernel's average follows from the static shares of its compiled code (the dynamic mix of its hot loop
 may differ: a model, stated as such).
-usage: python tools/valu_mix.py > profiles/r04_valu_mix.json"""
+usage: python tools/valu_mix.py > profiles/r06_valu_mix.json"""
 import collections
 import json
 import os

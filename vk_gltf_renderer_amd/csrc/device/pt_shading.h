@@ -793,9 +793,16 @@ __device__ __noinline__ LightSample sampleLightsCall(const DevScene& scIn, const
 }
 PT_DEV void sampleLights(const DevScene& sc, const FrameConsts& fc, f3 pos, uint32_t& seed, DirectLight& dl)  // :379-464
 {
+  // inlined at its call sites since round 6 (a non-inlined copy until then: the call's argument / result moves and the registers saved around it cost more than
+  // the body's second copy once the division expansions were gone -- atrium 748.1 -> 750.9, street 792.3 -> 795.2, helmet 5411 -> 5441 Msamples/s,
+  // profiles/r06_shade_walk_ab.txt).  -DMI_PT_CALL_SAMPLE_LIGHTS restores the call.
+#ifdef MI_PT_CALL_SAMPLE_LIGHTS
   const LightSample r = sampleLightsCall(sc, fc, pos, seed);
   seed = r.seed;
   dl   = r.dl;
+#else
+  sampleLightsBody(uniformConst(sc), uniformConst(fc), pos, seed, dl);
+#endif
 }
 PT_DEV void sampleLightsBody(const DevScene& sc, const FrameConsts& fc, f3 pos, uint32_t& seed, DirectLight& dl)
 {
