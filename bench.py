@@ -128,7 +128,7 @@ def scene_path(name, rank):
 
 # configurations of the default run whose counter passes (profiles/pmc_latest_<workload>.json) have not been collected yet for the current kernels / scenes: their
 # lines print `traffic: null`.  tests/test_bench_contract.py lets exactly these pass without a file.
-PMC_PENDING = {"glass", "atrium_sliver", "street_sliver", "atrium", "helmet", "atrium_f128"}
+PMC_PENDING = set()
 
 
 def load_pmc(workload, F, W, H):
@@ -147,7 +147,7 @@ def load_pmc(workload, F, W, H):
     return None
 
 
-def kernel_table(all_b, first_b, timing, frames, in_flight=0, pmc=None):
+def kernel_table(all_b, first_b, timing, frames, in_flight=0, pmc=None, guides=False):
     """Per-kernel roofline entries.  all_b / first_b: counters PER FRAME of the whole path loop and of bounce 0 alone (a second
     counter pass with maxDepth = 1); timing: MiPtFrameTiming totals over `frames` frames; pmc: load_pmc() of this configuration.
     "hbm" rows: achieved = bytes across the memory interface per launch (pmc) / THIS run's launch time, frac = achieved / 8 TB/s; the
@@ -215,8 +215,10 @@ def kernel_table(all_b, first_b, timing, frames, in_flight=0, pmc=None):
         f"nodesShadow x {VALU_PER_NODE} + trisShadow x {VALU_PER_TRI} lane-ops")
     if timing["accumulateMs"] > 0 and in_flight > 0:
         # k_finish_sample (SURVEY 8(d) "pixel accumulate"): one 16-B path record per pixel and frame, the accumulator once per launch
-        add("finish_sample", timing["accumulateMs"], max(1, round(frames / in_flight)), "hbm", all_b["cameraPaths"] * (16.0 + 32.0 / in_flight),
-            "algorithmic: cameraPaths x (16 B path record + 32 B of accumulator per launch)")
+        # ... and with the denoiser guides captured (--denoise): the path's albedo and normal sums (2 x 16 B) and the two guide images beside the accumulator
+        per_path = (48.0 + 96.0 / in_flight) if guides else (16.0 + 32.0 / in_flight)
+        add("finish_sample", timing["accumulateMs"], max(1, round(frames / in_flight)), "hbm", all_b["cameraPaths"] * per_path,
+            "algorithmic: cameraPaths x (16 B path record + 32 B of accumulator per launch" + (" + 32 B of guide sums + 64 B of guide images per launch)" if guides else ")"))
     return rows
 
 
@@ -475,11 +477,11 @@ def secondary_line(name, args, device, width=0, height=0, steps=5, parity=True, 
     per_frame, first = counter_pass(w["depth"]), counter_pass(1)
     frames = steps * frames_step
     pmc = load_pmc(name, F, W, H)
-    kernels = kernel_table(per_frame, first, timing, frames, F, pmc)
+    kernels = kernel_table(per_frame, first, timing, frames, F, pmc, guides=denoise)
     streams = overlap_note(kernels, elapsed / frames * 1e3)
     if "note" in streams:  # two streams in the timed run: the kernel table from the same frames on one stream
         timing1, frames1 = single_stream_timing(lambda: tracer(False), params(w["depth"], denoise), frames_step, F, denoise=denoise)
-        kernels = kernel_table(per_frame, first, timing1, frames1, F, pmc)
+        kernels = kernel_table(per_frame, first, timing1, frames1, F, pmc, guides=denoise)
         streams["kernel_table"] = f"per-launch times of {frames1} frames of the same configuration on ONE stream (MI_PT_OVERLAP=0); `value` is the two-stream run"
     keys = ("cameraPaths", "segments", "surfaceHits", "shadowRays", "nodesPrimary", "trisPrimary", "nodesClosest", "trisClosest", "nodesShadow", "trisShadow", "textureTaps")
     line = {"value": round(float(W) * H * frames / elapsed / 1e6, 3), "unit": "Msamples/s", "ms_per_frame": round(elapsed / frames * 1e3, 5),
@@ -644,6 +646,9 @@ def main():
     ap.add_argument("--hdrfile", default=None, help="Radiance .hdr environment for --scenefile (default: std_env.hdr if --workload uses one, else the physical sky)")
     ap.add_argument("--depth", type=int, default=0, help="maxDepth override (default: the workload's)")
     ap.add_argument("--no-uncut", action="store_true", help="skip the second timed run on the geometry AS LOADED (no alpha cut) that the default single-GPU run reports as `value_uncut_geometry`")
+    ap.add_argument("--frame-queue", type=int, default=0,
+                    help="issue the frames through mi_pt_render_frame ONE CALL PER FRAME -- the reference's onRender cadence, INTEGRATION.md's stub -- with mi_pt_set_frame_queue(N): the library "
+                         "holds the calls back and issues N frames at a time (N replaces --in-flight; same image).  N = 1: one frame per set of launches, no batching at all")
     ap.add_argument("--exact-in-flight", action="store_true", help="do not round the frames in flight down to a multiple of 64 (A/B of the slot layouts)")
     ap.add_argument("--frames-per-step", type=int, default=0,
                     help="frames (1 spp each) per GPU and step (default 256); a step renders frames_per_step * n_gpus frames")
@@ -689,7 +694,7 @@ def main():
         w.update(config=f"--scenefile {os.path.basename(args.scenefile)} ({w['config'].split(':')[0]} settings)", gen="file", hdr=bool(args.hdrfile) or w["hdr"])
     if args.depth > 0:
         w["depth"] = args.depth
-    args.in_flight = args.in_flight or w.get("in_flight", IN_FLIGHT_DEFAULT)
+    args.in_flight = args.frame_queue or args.in_flight or w.get("in_flight", IN_FLIGHT_DEFAULT)
     args.frames_per_step = args.frames_per_step or w.get("frames_per_step", FRAMES_PER_STEP_DEFAULT)
     W, H = args.width or w["width"], args.height or w["height"]
     hdr_path = args.hdrfile or os.path.join(ROOT, "assets", "std_env.hdr")
@@ -754,8 +759,11 @@ def main():
     # (a rank owns numSlots = its tiles' pixels, ~W*H/world: F frames in flight are F*W*H/world path slots on this GPU)
     assert F * float(W) * float(H) / world <= SLOT_BUDGET * 1.02, "path slots per GPU beyond the budget"
 
+    if args.frame_queue:  # one mi_pt_render_frame call per frame; the library batches them (exact-in-flight: the queue depth is the caller's figure)
+        tracer.set_frame_queue(F)
+
     def step():
-        runner.render(frames_step, stream.cuda_stream, in_flight=F)
+        runner.render(frames_step, stream.cuda_stream, in_flight=1 if args.frame_queue else F)
         if dist is not None:  # one reduce of the accumulator (+ guides) per step: disjoint tiles, so sum == gather
             reduced_buf.copy_(frame_buf)
             dist.reduce(reduced_buf, dst=0, op=dist.ReduceOp.SUM)
@@ -818,7 +826,7 @@ def main():
         first = counter_pass(1) if w["depth"] >= 1 else dict(per_frame)  # bounce 0 alone: paths end after their first shade
         # the timed frames belong to this rank's tiles: timing and counters are both rank 0's
         pmc = load_pmc(args.workload, F, W, H) if world == 1 else None  # (the committed counter passes are single-GPU runs)
-        kernels = kernel_table(per_frame, first, timing, frames_timed, F, pmc)
+        kernels = kernel_table(per_frame, first, timing, frames_timed, F, pmc, guides=args.denoise)
         roof = roofline_of(kernels, pmc)
         keys = ("cameraPaths", "segments", "surfaceHits", "shadowRays", "nodesPrimary", "trisPrimary", "nodesClosest", "trisClosest", "nodesShadow", "trisShadow", "textureTaps")
         assert world == args.gpus
@@ -829,7 +837,7 @@ def main():
             "config": {"workload": w["config"] + " (seeded synthetic stand-in)" if w["gen"] else w["config"], "scene_triangles": scene.num_triangles,
                        "alpha_cut": alpha_cut_note(args.alpha_cut, triangles_loaded, alpha_cut_dropped),
                        "bvh_reinsertion_passes": int(os.environ.get("MI_PT_REINSERT", "16") or 0),  # (read by the library at mi_pt_create; 0 = the builder's tree as clustered)
-                       "resolution": [W, H], "spp_per_step": frames_step, "frames_in_flight": F, "path_slots_per_gpu_in_frames": round(F / world, 2), "max_depth": w["depth"], "tile": args.tile,
+                       "resolution": [W, H], "spp_per_step": frames_step, "frames_in_flight": F, "frame_queue": (F if args.frame_queue else None), "path_slots_per_gpu_in_frames": round(F / world, 2), "max_depth": w["depth"], "tile": args.tile,
                        "parallelism": f"tiles{world}" if world > 1 else "single", "world_size_reported_by_backend": (dist.get_world_size() if dist is not None else 1),
                        "devices_visible": torch.cuda.device_count(),
                        "reduce": ((f"one RCCL reduce(sum) of {frame_buf.numel() * 4 / 1e6:.1f} MB (RGBA32F accumulator" + (" + albedo / normal guides + depth" if args.denoise else "") + ") per step") if dist is not None else None),

@@ -49,6 +49,14 @@ def test_box_sky(built, assets):
     _check(pu.render_oracle(s, 16), pu.render_gpu(s, 16), rel_l2=6e-3)
 
 
+def test_box_sky_at_a_sample_count_where_the_north_star_tolerance_holds(built, assets):
+    """The low-spp tests whose image contains the sun disc carry bounds of 4e-3 .. 1e-2 (one sample that hits or misses the disc on an ulp moves the L2 norm of a
+    16-spp image); the difference falls like Monte-Carlo noise, and at 512 spp the same scene -- sun disc, physical sky, next-event estimation against it -- is
+    inside the north star's 1e-3 with the per-pixel fractions of the strict tests."""
+    s = pu.Setup(os.path.join(assets, "Box.glb"), 128, 128, max_depth=4)
+    _check(pu.render_oracle(s, 512), pu.render_gpu(s, 512, in_flight=64), rel_l2=1e-3)
+
+
 def test_box_hdr(built, assets):
     """BASELINE config 1 with --envSystem 1 (std_env.hdr)."""
     s = pu.Setup(os.path.join(assets, "Box.glb"), 256, 256, max_depth=4, hdr_path=os.path.join(assets, "std_env.hdr"))
@@ -423,6 +431,8 @@ def test_frame_queue_is_invisible(built, tmp_path):
         outs = []
         total = 0
         for f in range(11):  # 11 frames: two full batches of 4 and a rest of 3 at depth 4
+            t.set_frame_info(s.frame_info)  # (the drop-in stub re-sends both in every onRender, like the reference: unchanged values do not flush)
+            t.set_sky(s.sky)
             t.render_frame(s.frame_params(f, total))
             total += 1
             if f == 5:
@@ -450,6 +460,23 @@ def test_frame_queue_is_invisible(built, tmp_path):
         for a, b in zip(base, got):
             assert np.array_equal(a, b), depth
         assert st["segments"] == st1["segments"] and st["cameraPaths"] == st1["cameraPaths"]
+    # ... and the frames really are issued together: with the launch timer on, 8 queued frames are ONE set of bounce launches, not eight
+    def launches(depth):
+        t = ptmod.PathTracer(s.scene)
+        t.set_environment(s.hdr)
+        t.resize(s.width, s.height)
+        t.set_frame_info(s.frame_info)
+        t.set_sky(s.sky)
+        t.set_frame_queue(depth)
+        t.enable_timing(True)
+        for f in range(8):
+            t.set_frame_info(s.frame_info)
+            t.render_frame(s.frame_params(f, f))
+        t.synchronize()
+        n = t.frame_timing()["shadeLaunches"]
+        t.close()
+        return n
+    assert launches(8) * 4 <= launches(1)
 
 
 def test_reinsertion_changes_the_tree_not_the_image(built, tmp_path):

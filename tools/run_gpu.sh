@@ -62,17 +62,22 @@ print("EVIDENCE", tag, j["value"], {n: (v.get("issue_frac"), v.get("active_lanes
 PY
     rm -rf $O/prof_r06_$tag  # (the per-dispatch counter CSVs are tens of MB per configuration; gpurun copies back at most 64 MiB)
     ;;
-  sweep)  # frames in flight 1 / 8 / 64 / 128 at 1080p and 4K: what a maintainer gets per onRender batch size, and the memory it takes
+  sweep)  # frames in flight 1 / 8 / 64 / 128 at 1080p and 4K: what a maintainer gets per onRender batch size, and the memory it takes; then the same
+          # through ONE mi_pt_render_frame CALL PER FRAME with mi_pt_set_frame_queue (bench.py --frame-queue)
+    pr() { python3 -c "
+import json,sys; j=json.loads(open('$1').read().strip().splitlines()[-1]); print('$2', j['config']['frames_in_flight'], j['value'], j['device_memory_GB'])"; }
     for w in helmet atrium; do for f in 1 8 64 128; do
-      timeout 200 python bench.py --workload $w --in-flight $f --frames-per-step $((f * 2)) --steps 4 --warmup 1 $N > $O/r05_sweep_${w}_f$f.json 2> /dev/null
-      python3 -c "
-import json; j=json.loads(open('$O/r05_sweep_${w}_f$f.json').read().strip().splitlines()[-1]); print('SWEEP ${w} 1080p in_flight', j['config']['frames_in_flight'], j['value'], j['device_memory_GB'])"
+      timeout 200 python bench.py --workload $w --in-flight $f --exact-in-flight --frames-per-step $((f * 2)) --steps 4 --warmup 1 --no-uncut $N > $O/r06_sweep_${w}_f$f.json 2> /dev/null
+      pr $O/r06_sweep_${w}_f$f.json "SWEEP ${w} 1080p render_frames in_flight"
     done; done
     for f in 1 8 64; do
-      timeout 200 python bench.py --workload helmet --width 3840 --height 2160 --in-flight $f --frames-per-step $((f * 2)) --steps 4 --warmup 1 $N > $O/r05_sweep_helmet4k_f$f.json 2> /dev/null
-      python3 -c "
-import json; j=json.loads(open('$O/r05_sweep_helmet4k_f$f.json').read().strip().splitlines()[-1]); print('SWEEP helmet 4K in_flight', j['config']['frames_in_flight'], j['value'], j['device_memory_GB'])"
-    done ;;
+      timeout 200 python bench.py --workload helmet --width 3840 --height 2160 --in-flight $f --exact-in-flight --frames-per-step $((f * 2)) --steps 4 --warmup 1 --no-uncut $N > $O/r06_sweep_helmet4k_f$f.json 2> /dev/null
+      pr $O/r06_sweep_helmet4k_f$f.json "SWEEP helmet 4K render_frames in_flight"
+    done
+    for w in helmet atrium; do for f in 1 8 64; do
+      timeout 200 python bench.py --workload $w --frame-queue $f --exact-in-flight --frames-per-step $((f * 2)) --steps 4 --warmup 1 --no-uncut $N > $O/r06_sweepq_${w}_f$f.json 2> /dev/null
+      pr $O/r06_sweepq_${w}_f$f.json "SWEEP ${w} 1080p render_frame x1 + frame_queue"
+    done; done ;;
   overlap)  # MI_PT_OVERLAP: the shadow stage of small batches on a second stream -- on (default 16 frames) against off, 1 / 4 / 8 / 16 frames in flight
     for w in ${OVERLAP_WORKLOADS:-helmet atrium}; do for f in ${OVERLAP_FRAMES:-1 4 8 16}; do for o in 0 1024; do
       MI_PT_OVERLAP=$o timeout 200 python bench.py --workload $w --in-flight $f --frames-per-step $((f * 4 > 256 ? 256 : f * 4)) --steps 4 --warmup 1 $N > $O/r04_overlap_${w}_f${f}_o$o.json 2> /dev/null

@@ -1006,18 +1006,24 @@ int mi_pt_resize(MiPt* pt, int width, int height)
 
 int mi_pt_set_frame_info(MiPt* pt, const MiSceneFrameInfo* info)
 {
-  FLUSH_PENDING(pt);
   if(!pt || !info)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_set_frame_info: null argument");
+  // (the reference updates bFrameInfo / bSkyParams in EVERY onRender, changed or not -- src/renderer.cpp:675-708 -- and so does a drop-in caller: the same values again
+  //  are no reason to issue the frames mi_pt_set_frame_queue is holding back)
+  if(pt->haveFrameInfo && memcmp(&pt->frameInfo, info, sizeof(*info)) == 0)
+    return MI_PT_OK;
+  FLUSH_PENDING(pt);
   pt->frameInfo     = *info;
   pt->haveFrameInfo = true;
   return MI_PT_OK;
 }
 int mi_pt_set_sky(MiPt* pt, const MiSkyPhysicalParameters* sky)
 {
-  FLUSH_PENDING(pt);
   if(!pt || !sky)
     return fail(MI_PT_ERR_ARGUMENT, "mi_pt_set_sky: null argument");
+  if(memcmp(&pt->sky, sky, sizeof(*sky)) == 0)
+    return MI_PT_OK;
+  FLUSH_PENDING(pt);
   pt->sky = *sky;
   return MI_PT_OK;
 }

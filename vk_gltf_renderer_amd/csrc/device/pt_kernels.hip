@@ -2638,96 +2638,154 @@ __global__ void __launch_bounds__(ShadowCfg<MODE>::BLOCK, TRACE_MIN_WAVES) k_tra
 // point and the light) takes them in increasing (t, renderNode, primitive) order by repeated selection over the chain -- no
 // per-thread array, the chain is L2 resident -- and each accepted one multiplies the transmission by getShadowTransmission() over
 // the segment since the previous accepted one, until the product drops to MIN_TRANSMISSION.  Nothing here walks the BVH.
+// One recorded shadow ray: its transmissive candidates in increasing (t, renderNode, primitive) order -> transmission (raytracer_interface.h.slang:160-178),
+// then the deposit.  `code` = head of the ray's candidate chain.
+PT_DEV void resolveChain(const DevScene& sc, const PathSoA& P, const Queues& Q, int nxt, uint32_t qpos, uint32_t slot, float4 d4, float4 c4, uint32_t code, bool catcherRay,
+                         float catcherDarken)
+{
+  f3             total    = mk3(1.0f);
+  bool           occluded = false;
+  const f3       dir      = xyz(d4);
+  const uint32_t seed0    = __float_as_uint(c4.w);
+  bool           isInside = (__float_as_uint(d4.w) & 1u) != 0u, haveLast = false;
+  float          lastT = -1.0f, prevHitT = 0.0f;
+  uint32_t       lastRnode = 0u, lastPrim = 0u;
+  for(;;)
+  {
+    // next candidate in the order: the smallest (t, renderNode, primitive) after the last one taken
+    uint32_t best = CAND_NIL, bRnode = 0u, bPrim = 0u;
+    bool     bIds = false;
+    float4   bC   = make_float4(0, 0, 0, 0);
+    for(uint32_t k = code; k != CAND_NIL; k = Q.candNext[k])
+    {
+      const float4   c   = Q.candPool[k];
+      const uint32_t tri = __float_as_uint(c.w);
+      const bool     tieLast = haveLast && c.x == lastT, tieBest = best != CAND_NIL && c.x == bC.x;
+      uint32_t       rnode = 0u, prim = 0u;
+      if(tieLast || tieBest)  // exact ties only: coincident surfaces
+      {
+        rnode = __float_as_uint(gat(sc.tris, tri).a.w);
+        prim  = __float_as_uint(gat(sc.tris, tri).b.w);
+      }
+      const bool afterLast  = !haveLast || c.x > lastT || (tieLast && (rnode > lastRnode || (rnode == lastRnode && prim > lastPrim)));
+      bool       beforeBest = best == CAND_NIL || c.x < bC.x;
+      if(tieBest)
+      {
+        if(!bIds)  // the best so far was taken without its ids
+        {
+          const uint32_t bt = __float_as_uint(bC.w);
+          bRnode = __float_as_uint(gat(sc.tris, bt).a.w);
+          bPrim  = __float_as_uint(gat(sc.tris, bt).b.w);
+          bIds   = true;
+        }
+        beforeBest = rnode < bRnode || (rnode == bRnode && prim < bPrim);
+      }
+      if(afterLast && beforeBest)
+      {
+        best = k; bC = c; bRnode = rnode; bPrim = prim; bIds = tieLast || tieBest;
+      }
+    }
+    if(best == CAND_NIL)
+      break;
+    const uint32_t tri = __float_as_uint(bC.w);
+    const uint32_t rnode = __float_as_uint(gat(sc.tris, tri).a.w), prim = __float_as_uint(gat(sc.tris, tri).b.w);
+    haveLast = true; lastT = bC.x; lastRnode = rnode; lastPrim = prim;
+    const f3    bary    = mk3(1.0f - bC.y - bC.z, bC.y, bC.z);
+    // (INST_ALPHA_PASSES: opacity 1, the draw always commits -- no fetch of the alpha record, no draw)
+    const bool  passes  = (__float_as_uint(gat(sc.tris, tri).c.w) & INST_ALPHA_PASSES) != 0u;
+    if(passes || candidateRand(seed0, int(rnode), int(prim)) < getOpacityFast(sc, int(tri), bary))
+    {
+      const float segment = fmaxf(0.0f, bC.x - prevHitT);
+      const f3    curT    = getShadowTransmissionTri(sc, int(rnode), int(prim), int(tri), bary, segment, dir, isInside);
+      prevHitT            = bC.x;
+      total *= curT;
+      if(maxComp(total) <= MIN_TRANSMISSION)
+      {
+        occluded = true;
+        break;
+      }
+    }
+  }
+  if(occluded && !catcherRay)
+    return;
+  shadowDeposit(P, Q, nxt, slot, qpos, catcherRay, xyz(c4), total, occluded, catcherDarken);
+}
+
+// REC: the rays that carry a chain of recorded candidates are a minority spread over every wave (glass-class workload: the kernel ran 12.8 of 64 lanes, profiles/
+// r06_glass_pmc_summary.json): they are listed in LDS while the block streams through its entries -- rays without a chain are settled on the spot -- and the block
+// works the list off 256 rays at a time, every lane on a chain (-DRESOLVE_INLINE_CHAINS: rounds 2-5, each ray's chain where the ray is met).
 template <bool REC>
 __global__ void __launch_bounds__(256) k_shadow_resolve(const DevScene* __restrict__ scp, PathSoA P, Queues Q, int nxt, float catcherDarken)
 {
   __shared__ uint32_t s_prefix[NSUB + 1];
+#ifndef RESOLVE_INLINE_CHAINS
+  constexpr bool LIST = REC;
+#else
+  constexpr bool LIST = false;
+#endif
+  __shared__ uint32_t s_chain[LIST ? 512 : 1];
+  __shared__ uint32_t s_chainCount;
+  if(threadIdx.x == 0)
+    s_chainCount = 0;
   queuePrefix(&Q.counters[(nxt ? QC_PAIR1 : QC_PAIR0) + 1], s_prefix);
-  const uint32_t count = s_prefix[NSUB];
-  for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
-  {
-    const uint32_t qpos = queuePos(Q.subCap, s_prefix, i);
-    const uint32_t slot = Q.shadow.slot[qpos];
-    if(slot == QUEUE_DEAD)
-      continue;
-    const float4 d4 = Q.shadow.dir[qpos];
-    if(REC && (__float_as_uint(d4.w) & SHADOW_DIR_OVERFLOW))
-      continue;  // settled by the ordered-search kernel
-    const uint32_t code       = reinterpret_cast<const uint32_t*>(&Q.shadow.org[qpos])[3];
-    const bool     catcherRay = (__float_as_uint(d4.w) & 2u) != 0u;
-    bool         occluded   = code == SHADOW_OCCLUDED;
-    if(occluded && !catcherRay)
-      continue;
-    const float4 c4 = Q.shadow.aux[qpos];
-    f3           total = mk3(1.0f);
-    if(REC && !occluded && code != CAND_NIL)
+  const uint32_t  count = s_prefix[NSUB];
+  const DevScene& sc    = uniformConst(*scp);
+  auto workOff = [&](bool all) {  // whole block; contains barriers
+    __syncthreads();
+    const uint32_t n = s_chainCount;
+    if(n == 0u || (!all && n < 256u))
+      return;
+    const uint32_t take = min(n, 256u), base = n - take;
+    uint32_t       qpos = 0;
+    if(threadIdx.x < take)
+      qpos = s_chain[base + threadIdx.x];
+    __syncthreads();
+    if(threadIdx.x == 0)
+      s_chainCount = base;
+    if(threadIdx.x < take)
     {
-      const DevScene& sc       = uniformConst(*scp);
-      const f3        dir      = xyz(d4);
-      const uint32_t  seed0    = __float_as_uint(c4.w);
-      bool            isInside = (__float_as_uint(d4.w) & 1u) != 0u, haveLast = false;
-      float           lastT = -1.0f, prevHitT = 0.0f;
-      uint32_t        lastRnode = 0u, lastPrim = 0u;
-      for(;;)
+      const float4 d4 = Q.shadow.dir[qpos];
+      resolveChain(sc, P, Q, nxt, qpos, Q.shadow.slot[qpos], d4, Q.shadow.aux[qpos], reinterpret_cast<const uint32_t*>(&Q.shadow.org[qpos])[3], (__float_as_uint(d4.w) & 2u) != 0u,
+                   catcherDarken);
+    }
+    __syncthreads();
+  };
+  const uint32_t rounds = (count + gridDim.x * blockDim.x - 1u) / (gridDim.x * blockDim.x);  // (the same for every thread of the block: workOff has barriers)
+  for(uint32_t it = 0; it < rounds; ++it)
+  {
+    const uint32_t i = it * gridDim.x * blockDim.x + blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < count)
+    {
+      const uint32_t qpos = queuePos(Q.subCap, s_prefix, i);
+      const uint32_t slot = Q.shadow.slot[qpos];
+      const float4   d4   = slot != QUEUE_DEAD ? Q.shadow.dir[qpos] : make_float4(0, 0, 0, 0);
+      // (dead entry; or REC: settled by the ordered-search kernel)
+      if(slot != QUEUE_DEAD && !(REC && (__float_as_uint(d4.w) & SHADOW_DIR_OVERFLOW)))
       {
-        // next candidate in the order: the smallest (t, renderNode, primitive) after the last one taken
-        uint32_t best = CAND_NIL, bRnode = 0u, bPrim = 0u;
-        bool     bIds = false;
-        float4   bC   = make_float4(0, 0, 0, 0);
-        for(uint32_t k = code; k != CAND_NIL; k = Q.candNext[k])
+        const uint32_t code       = reinterpret_cast<const uint32_t*>(&Q.shadow.org[qpos])[3];
+        const bool     catcherRay = (__float_as_uint(d4.w) & 2u) != 0u;
+        const bool     occluded   = code == SHADOW_OCCLUDED;
+        if(!occluded || catcherRay)
         {
-          const float4   c   = Q.candPool[k];
-          const uint32_t tri = __float_as_uint(c.w);
-          const bool     tieLast = haveLast && c.x == lastT, tieBest = best != CAND_NIL && c.x == bC.x;
-          uint32_t       rnode = 0u, prim = 0u;
-          if(tieLast || tieBest)  // exact ties only: coincident surfaces
+          if(REC && !occluded && code != CAND_NIL)
           {
-            rnode = __float_as_uint(gat(sc.tris, tri).a.w);
-            prim  = __float_as_uint(gat(sc.tris, tri).b.w);
+            if(LIST)
+              s_chain[atomicAdd(&s_chainCount, 1u)] = qpos;
+            else
+              resolveChain(sc, P, Q, nxt, qpos, slot, d4, Q.shadow.aux[qpos], code, catcherRay, catcherDarken);
           }
-          const bool afterLast  = !haveLast || c.x > lastT || (tieLast && (rnode > lastRnode || (rnode == lastRnode && prim > lastPrim)));
-          bool       beforeBest = best == CAND_NIL || c.x < bC.x;
-          if(tieBest)
-          {
-            if(!bIds)  // the best so far was taken without its ids
-            {
-              const uint32_t bt = __float_as_uint(bC.w);
-              bRnode = __float_as_uint(gat(sc.tris, bt).a.w);
-              bPrim  = __float_as_uint(gat(sc.tris, bt).b.w);
-              bIds   = true;
-            }
-            beforeBest = rnode < bRnode || (rnode == bRnode && prim < bPrim);
-          }
-          if(afterLast && beforeBest)
-          {
-            best = k; bC = c; bRnode = rnode; bPrim = prim; bIds = tieLast || tieBest;
-          }
-        }
-        if(best == CAND_NIL)
-          break;
-        const uint32_t tri = __float_as_uint(bC.w);
-        const uint32_t rnode = __float_as_uint(gat(sc.tris, tri).a.w), prim = __float_as_uint(gat(sc.tris, tri).b.w);
-        haveLast = true; lastT = bC.x; lastRnode = rnode; lastPrim = prim;
-        const f3    bary    = mk3(1.0f - bC.y - bC.z, bC.y, bC.z);
-        // (INST_ALPHA_PASSES: opacity 1, the draw always commits -- no fetch of the alpha record, no draw)
-        const bool  passes  = (__float_as_uint(gat(sc.tris, tri).c.w) & INST_ALPHA_PASSES) != 0u;
-        if(passes || candidateRand(seed0, int(rnode), int(prim)) < getOpacityFast(sc, int(tri), bary))
-        {
-          const float segment = fmaxf(0.0f, bC.x - prevHitT);
-          const f3    curT    = getShadowTransmissionTri(sc, int(rnode), int(prim), int(tri), bary, segment, dir, isInside);
-          prevHitT            = bC.x;
-          total *= curT;
-          if(maxComp(total) <= MIN_TRANSMISSION)
-          {
-            occluded = true;
-            break;
-          }
+          else
+            shadowDeposit(P, Q, nxt, slot, qpos, catcherRay, xyz(Q.shadow.aux[qpos]), mk3(1.0f), occluded, catcherDarken);
         }
       }
-      if(occluded && !catcherRay)
-        continue;
     }
-    shadowDeposit(P, Q, nxt, slot, qpos, catcherRay, xyz(c4), total, occluded, catcherDarken);
+    if(LIST)
+      workOff(false);
+  }
+  if(LIST)
+  {
+    workOff(true);
+    workOff(true);
   }
 }
 
