@@ -46,8 +46,10 @@ def test_kernel_table_fractions_are_fractions():
     """hbm rows: frac = counter traffic / launch time / 8 TB/s (None without counters), the algorithmic figure stands beside it under its own
     name; valu rows: useful lane-operations against the vector peak, with the per-kernel instruction counts."""
     per_frame, first = _counters(), {k: v * (0.3 if k != "cameraPaths" else 1.0) for k, v in _counters().items()}
-    pmc = bench.load_pmc("atrium", 128, 1920, 1080)
-    rows = bench.kernel_table(per_frame, first, _timing(), frames=128, in_flight=128, pmc=pmc)
+    F = bench.IN_FLIGHT_DEFAULT
+    pmc = bench.load_pmc("atrium", F, 1920, 1080)
+    assert pmc is not None
+    rows = bench.kernel_table(per_frame, first, _timing(), frames=F, in_flight=F, pmc=pmc)
     for name, r in rows.items():
         assert r["frac"] is None or 0.0 <= r["frac"], name
         if r["bound"] == "hbm" and r["traffic"]:
@@ -57,7 +59,7 @@ def test_kernel_table_fractions_are_fractions():
             assert r["peak"] == pytest.approx(78.64, abs=0.01) and 0.0 < r["issue_frac"] <= 1.0
     # the packet walk is charged its interval test (50 instructions of all 64 lanes per node), not the per-ray test's count
     tp = rows["trace_primary"]
-    assert tp["useful_laneops_per_launch"] == round(64 * (per_frame["nodesPrimary"] * bench.VALU_PER_PACKET_NODE + per_frame["trisPrimary"] * bench.VALU_PER_TRI) * 128)
+    assert tp["useful_laneops_per_launch"] == round(64 * (per_frame["nodesPrimary"] * bench.VALU_PER_PACKET_NODE + per_frame["trisPrimary"] * bench.VALU_PER_TRI) * F)
     # no counters (another resolution / batch size): no invented fraction for the memory-bound kernels
     rows = bench.kernel_table(per_frame, first, _timing(), frames=128, in_flight=96, pmc=None)
     assert rows["shade"]["frac"] is None and rows["shade"]["traffic"] is None and rows["shade"]["algorithmic_frac"] > 0

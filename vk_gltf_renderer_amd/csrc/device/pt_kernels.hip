@@ -6,7 +6,9 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
+#ifndef MI_PT_EXACT_FP  // (A/B: tools/build_variant.sh exactfp -DMI_PT_EXACT_FP -fhip-fp32-correctly-rounded-divide-sqrt -fno-reciprocal-math -fno-approx-func = IEEE everywhere)
 #define PT_FAST_SHADING_MATH 1  // pt_math.h: hardware reciprocal / reciprocal square root in the vector helpers of THIS translation unit (see csrc/Makefile: PT_KERNELS_FP)
+#endif
 #include "pt_kernels.h"
 #include "pt_shading.h"
 #include "pt_bvh.h"

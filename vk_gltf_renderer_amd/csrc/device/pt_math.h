@@ -109,6 +109,8 @@ PT_DEV float cosExact(float x) { return cosf(x); }
 #endif
 
 PT_DEV float dot(f2 a, f2 b) { return a.x * b.x + a.y * b.y; }
+PT_DEV float dot(f3 a, f3 b);
+PT_DEV float normalizeScale(f3 a) { return divExact(1.0f, sqrtExact(dot(a, a))); }
 PT_DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 PT_DEV f3 cross(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 PT_DEV float length(f3 a) { return sqrtf(dot(a, a)); }
@@ -120,8 +122,15 @@ PT_DEV float length(f2 a) { return sqrtf(dot(a, a)); }
 PT_DEV f3 normalize(f3 a)
 {
 #pragma clang fp contract(off)
-#if defined(__HIP_DEVICE_COMPILE__) && defined(PT_FAST_SHADING_MATH)
-  const float r = __builtin_amdgcn_rsqf(dot(a, a));  // v_rsq_f32, 1 ulp (shading directions; camera rays: normalizeExact)
+  // DIRECTIONS stay IEEE in every translation unit (normalizeScale: divExact / sqrtExact above), bit for bit the oracle's normalize: a unit vector decides where the
+  // next ray goes, and a 1-2 ulp difference there sends three times as many paths another way as the FMA contractions do -- the full-size parity legs measured
+  // street 3.6e-4 -> 7.5e-4 and sliver atrium 0.93e-3 -> 1.21e-3 with v_rsq_f32 here, and exactly the IEEE build's figures without it, while every other fast
+  // operation of pt_kernels.hip (weights, pdfs, Fresnel, sky: radiometric) changed no digit (profiles/r06_parity_by_arithmetic.txt).  Cost: 1.4 % of the atrium.
+  // -DPT_NORMALIZE_FAST (A/B) = the hardware reciprocal square root.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PT_FAST_SHADING_MATH) && defined(PT_NORMALIZE_FAST)
+  const float r = __builtin_amdgcn_rsqf(dot(a, a));
+#elif defined(__HIP_DEVICE_COMPILE__) && defined(PT_FAST_SHADING_MATH)
+  const float r = normalizeScale(a);
 #else
   const float r = 1.0f / length(a);
 #endif
