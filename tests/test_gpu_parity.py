@@ -57,6 +57,28 @@ def test_box_sky_at_a_sample_count_where_the_north_star_tolerance_holds(built, a
     _check(pu.render_oracle(s, 512), pu.render_gpu(s, 512, in_flight=64), rel_l2=1e-3)
 
 
+def test_a_non_finite_sample_does_not_reach_the_accumulator(built, tmp_path):
+    """Frame 407 of the glass + dragon bench scene at 1920x1080 holds the one path in 1e9 whose radiance is not finite on the device (a division by a denormal pdf in
+    the dispersive blob: an infinity with the hardware reciprocal, a 4.5e5 firefly under IEEE that the clamp cuts to luminance 10).  k_finish_sample drops such a
+    sample -- black, coverage kept -- instead of writing NaN into the running mean for good; every other pixel of the frame is untouched."""
+    import bench
+    w = bench.WORKLOADS["glass"]
+    path = scenegen.scene_glass_class(str(tmp_path / "glass.glb"), **w["kw"])
+    s = pu.Setup(path, w["width"], w["height"], max_depth=w["depth"], hdr_path=os.path.join(os.path.dirname(os.path.dirname(__file__)), "assets", "std_env.hdr"))
+    t = ptmod.PathTracer(s.scene)
+    t.set_environment(s.hdr)
+    t.resize(s.width, s.height)
+    t.set_frame_info(s.frame_info)
+    t.set_sky(s.sky)
+    p = s.frame_params(407, 0)
+    p.flags |= capi.MI_PT_FIRST_FRAME
+    t.render_frames(p, 8)  # frames 407 .. 414
+    img = t.read_accum()
+    t.close()
+    assert np.isfinite(img).all()
+    assert img[558, 1736, 3] > 0.0 and img[..., :3].max() <= 3.0 * 10.0 + 1e-3  # (the firefly clamp's bound: luminance <= 10)
+
+
 def test_box_hdr(built, assets):
     """BASELINE config 1 with --envSystem 1 (std_env.hdr)."""
     s = pu.Setup(os.path.join(assets, "Box.glb"), 256, 256, max_depth=4, hdr_path=os.path.join(assets, "std_env.hdr"))

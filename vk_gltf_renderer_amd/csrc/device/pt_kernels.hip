@@ -2877,6 +2877,12 @@ __global__ void __launch_bounds__(256) k_finish_sample(FrameConsts fc, const Dev
       rad4 = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
     }
     f4             r     = mk4(rad4.x, rad4.y, rad4.z, solid ? 1.0f : 0.0f);
+    // A sample whose radiance is not finite is dropped (black, its coverage kept) instead of poisoning the running mean for good: with the shading arithmetic at
+    // the reference's precision class a division by a denormal pdf is an infinity where IEEE gives ~1e38 -- the glass + dragon workload produced one such path in
+    // 1e9 (frame 407, pixel (1736, 558): the oracle's value there is a 4.5e5 firefly the clamp below cuts to luminance 10; tools/diag_nonfinite.py) -- and the
+    // reference's own OpFDiv is undefined for that divisor as well.
+    if(!(fabsf(r.x) <= 3.0e38f && fabsf(r.y) <= 3.0e38f && fabsf(r.z) <= 3.0e38f))
+      r = mk4(0.0f, 0.0f, 0.0f, r.w);
     float          lum   = dot(xyz(r), mk3(1.0f / 3.0f));
     if(lum > fc.pc.fireflyClampThreshold)
       r *= divExact(fc.pc.fireflyClampThreshold, lum);  // (k_finish_sample keeps IEEE division: the accumulator is the oracle's running mean of the same samples, pt_math.h)
