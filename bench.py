@@ -314,7 +314,7 @@ def alpha_cut_note(subdivisions, triangles_loaded, dropped):
                     "(mi_scene_cut_alpha, the counterpart of the reference's opacity micro-map bake); the parity leg renders the scene AS LOADED (uncut) with the CPU oracle"}
 
 
-def cpu_baseline_and_parity(scene, w, W, H, F, cpu_seconds, make_gpu_tracer, gpu_params, parity_spp=0):
+def cpu_baseline_and_parity(scene, w, W, H, F, cpu_seconds, make_gpu_tracer, gpu_params, parity_spp=0, tile_step=16):
     """The CPU oracle on the host cores over a bounded sample of the workload -- every 16th 64x64 tile of the same frames at 1080p, every
     64th at 4K: about 32 tiles spread over the image (same scene bytes, seeds, depth) -- and the GPU accumulator of exactly those frames compared with the oracle's on exactly those tiles.
     Frames = the configuration's own sample count (`parity_spp`, default WORKLOADS[..]["spp"]: 256 for configs[2]); the difference is
@@ -339,7 +339,9 @@ def cpu_baseline_and_parity(scene, w, W, H, F, cpu_seconds, make_gpu_tracer, gpu
     O.oracle_pt_set_sky(o, C.byref(setup.sky))
     tx, ty = (W + 63) // 64, (H + 63) // 64
     tiles_total = tx * ty
-    part = 16 * max(1, round(tiles_total / 510))  # ~32 tiles whatever the resolution (4K: every 64th tile), so that the leg's CPU time follows spp, not pixels
+    # ~32 tiles whatever the resolution (4K: every 64th tile), so that the leg's CPU time follows spp, not pixels; the `also` lines take every second of those
+    # (tile_step 32: ~16 tiles -- their five CPU legs were two thirds of the default run's wall time)
+    part = tile_step * max(1, round(tiles_total / 510))
     O.oracle_pt_set_tile_partition(o, 0, part, 64)
     owned = [t for t in range(tiles_total) if t % part == 0]
     px_owned = sum(min(64, W - (t % tx) * 64) * min(64, H - (t // tx) * 64) for t in owned)
@@ -498,7 +500,7 @@ def secondary_line(name, args, device, width=0, height=0, steps=5, parity=True, 
             "node_visits_per_secondary_ray": round(per_frame["nodesClosest"] / max(1.0, per_frame["segments"] - per_frame["cameraPaths"]), 2),
             "triangle_tests_per_secondary_ray": round(per_frame["trisClosest"] / max(1.0, per_frame["segments"] - per_frame["cameraPaths"]), 2)}
     if parity:
-        line["cpu_baseline"], line["parity"] = cpu_baseline_and_parity(scene, w, W, H, F, args.cpu_seconds, lambda: tracer(False), params(w["depth"]), args.parity_spp)
+        line["cpu_baseline"], line["parity"] = cpu_baseline_and_parity(scene, w, W, H, F, min(args.cpu_seconds, 8.0), lambda: tracer(False), params(w["depth"]), args.parity_spp, tile_step=32)
     return line
 
 

@@ -145,6 +145,25 @@ def test_committed_round5_record_obeys_the_contract():
             assert ln["cpu_baseline"]["kind"] == "port" and "-march=native" in ln["cpu_baseline"]["flags"]
 
 
+def test_committed_round6_record_obeys_the_contract():
+    """Schema and consistency of the round's last default run (profiles/r06_bench_default.json + the compact line the driver parses): strong scaling at N = 1, the
+    uncut-geometry value beside the headline, every default `also` line present with its counter passes, fractions inside (0, 1], parity legs reported with their tolerance flag."""
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r06_bench_default.json")).read().strip().splitlines()[-1])
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r06_bench_line.json")).read().strip().splitlines()[-1])
+    assert line == bench.compact_line(full)
+    assert full["scaling"] == "strong" and full["n_gpus"] == 1 and full["config"]["frames_in_flight"] == bench.IN_FLIGHT_DEFAULT and full["config"]["spp_per_step"] == 256
+    assert full["value_uncut_geometry"]["value"] > 0 and full["value_uncut_geometry"]["scene_triangles"] < full["config"]["scene_triangles"]
+    assert set(full["also"]) == set(bench.ALSO_DEFAULT.split(","))
+    for name, ln in {"headline": full, **full["also"]}.items():
+        assert "error" not in ln, name
+        assert ln["roofline"]["traffic"] is not None, name
+        for k, r in ln["kernels"].items():
+            assert r["frac"] is not None and 0.0 < r["frac"] <= 1.0, (name, k, r["frac"])
+        if "parity" in ln:
+            assert ln["parity"]["within_tolerance"] == (ln["parity"]["rel_l2"] <= 1e-3) and ln["parity"]["spp"] == bench.WORKLOADS[bench.ALSO_LINES[name][0] if name != "headline" else "atrium"]["spp"]
+    assert full["also"]["glass_denoise"]["config"]["scene_triangles"] > 1000000 and full["also"]["glass_denoise"]["per_frame"]["textureTaps"] > 0  # the dragon + textured slabs
+
+
 def test_more_ranks_than_devices_is_refused_before_anything_runs():
     """`python bench.py --gpus N` starts its own ranks -- and on a box with fewer devices (here: none) it must exit non-zero without a JSON line."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "BENCH_SHARE_GPU")}

@@ -38,8 +38,8 @@ case "$1" in
     python3 - <<'PY'
 import json
 j=json.loads(open('gpurun_out/r06_bench_default_a.json').read().strip().splitlines()[-1])
-print('atrium', j['value'], j.get('parity',{}).get('by_spp'), j.get('cpu_baseline'))
-for n,a in j.get('also',{}).items(): print(n, a['value'], a.get('parity',{}).get('by_spp'), a.get('cpu_baseline',{}).get('value'))
+print('atrium', j['value'], j.get('parity'), j.get('cpu_baseline'))
+for n,a in j.get('also',{}).items(): print(n, a.get('value'), a.get('parity_rel_l2'), a.get('cpu_baseline'))
 PY
     ;;
   evidence)  # tools/run_gpu.sh evidence <tag> <bench args...>: kernel-trace stats + counter passes of ONE configuration (tag = the pmc file's name:
