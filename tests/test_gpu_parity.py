@@ -383,6 +383,12 @@ def test_image_independent_of_acceleration_structure(built, tmp_path):
     path = scenegen.scene_glass_class(str(tmp_path / "glass.glb"), seed=3, tess=24)
     s = pu.Setup(path, 128, 80, max_depth=12, hdr_path=os.path.join(os.path.dirname(os.path.dirname(__file__)), "assets", "std_env.hdr"))
     assert (pu.render_gpu(s, 2, bvh=0)["accum"] == pu.render_gpu(s, 2, bvh=1)["accum"]).all()
+    # ... and on the sliver stand-in (hall-sized wall triangles, long thin beams: the geometry a BVH over triangle boxes finds hard; the builder's default rule
+    # pre-splits it into references -- test_pre_splitting_changes_the_tree_not_the_image has the factor sweep): both structures, the same image, ids and depth
+    path = scenegen.scene_atrium_class(str(tmp_path / "sliver.glb"), seed=5, detail=0.12, tex_size=64, sliver=True)
+    s = pu.Setup(path, 160, 96, max_depth=8)
+    wide, two = pu.render_gpu(s, 2, bvh=0), pu.render_gpu(s, 2, bvh=1)
+    assert (wide["accum"] == two["accum"]).all() and (wide["selection"] == two["selection"]).all() and (wide["depth"] == two["depth"]).all()
 
 
 def test_pre_splitting_changes_the_tree_not_the_image(built, tmp_path):
