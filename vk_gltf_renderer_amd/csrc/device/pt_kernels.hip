@@ -430,6 +430,30 @@ __device__ unsigned long long g_shadowProf[16];  // the same for k_trace_shadow 
 #define PROF_CNT(i, n) (void)0
 #endif
 
+#ifdef SHADE_PROFILE
+// Diagnostics build only (-DSHADE_PROFILE, tools/build_variant.sh): shader-clock ticks per wave and lane-ticks (ticks x lanes of the wave inside the region) of the regions of the
+// LATER-BOUNCE k_shade<., ., FIRST = false>: [2r] ticks, [2r + 1] lane-ticks; r = 0 entry + hit state, 1 material + textures, 2 sampleLights, 3 bsdfEvaluate, 4 bsdfSample,
+// 5 rest of the bounce (ratchet, emissive, shadow origin, roulette, state), 6 miss (inline or deferred list), 7 append + stores, 8 finishMisses, 9 whole round
+__device__ unsigned long long g_shadeProf[20];
+#define SPROF_BEGIN() const unsigned long long sprofT0_ = __builtin_amdgcn_s_memtime(); const int sprofLanes_ = __popcll(__ballot(true))
+#define SPROF_END(r)                                                                                                             \
+  do                                                                                                                             \
+  {                                                                                                                              \
+    if(!FIRST)                                                                                                                   \
+    {                                                                                                                            \
+      const unsigned long long dt_ = __builtin_amdgcn_s_memtime() - sprofT0_;                                                   \
+      if(laneId() == uint32_t(__ffsll((long long)__ballot(true)) - 1))                                                          \
+      {                                                                                                                          \
+        atomicAdd(&g_shadeProf[2 * (r)], dt_);                                                                                   \
+        atomicAdd(&g_shadeProf[2 * (r) + 1], dt_ * (unsigned long long)sprofLanes_);                                             \
+      }                                                                                                                          \
+    }                                                                                                                            \
+  } while(0)
+#else
+#define SPROF_BEGIN() (void)0
+#define SPROF_END(r) (void)0
+#endif
+
 // Refill policy of the persistent trace waves: go back for new rays once this many lanes of the wave are idle.
 #ifndef REFILL_IDLE_LANES
 #define REFILL_IDLE_LANES 16
@@ -1718,8 +1742,12 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
     float4         nextRad = make_float4(0, 0, 0, 0), nextMisc = make_float4(0, 0, 0, 0), nextThr = make_float4(0, 0, 0, 0);  // state of a path that goes on
     float4         shOrg = make_float4(0, 0, 0, 0), shDir = make_float4(0, 0, 0, 0), shCon = make_float4(0, 0, 0, 0), shCon2 = make_float4(0, 0, 0, 0);
     bool           catcher = false;
+#ifdef SHADE_PROFILE
+    const unsigned long long sprofRound0 = __builtin_amdgcn_s_memtime();
+#endif
     if(inRange && slot != QUEUE_DEAD)
     {
+      SPROF_BEGIN();
       const float4 hit4 = Q.active[cur].aux[inPos], o4 = Q.active[cur].org[inPos], d4 = Q.active[cur].dir[inPos];
       // the path's state: records of its queue entry (unit stride, like the ray), or -- catcher frames / MI_PT_STATE_BY_SLOT -- gathered by slot
       // (round 6: the NEXT round's entry prefetched into registers across the append -- 28 VGPRs spilled at the 168-register budget: atrium 690.7 -> 686.7,
@@ -1772,6 +1800,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
       }
       else
         hitT = INFINITE_F;
+      SPROF_END(0);
 
       // checkInfinitePlaneIntersection, pathtrace_functions.h.slang:556-585
       bool hitInfinitePlane = false;
@@ -1792,12 +1821,15 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
 
       if(deferMiss && hitT == INFINITE_F && !firstRay)  // finished by the whole block later (finishMisses): nothing else of this entry is touched
       {
+        SPROF_BEGIN();
         s_missPos[atomicAdd(&s_missCount, 1u)] = inPos;
         deferred = true;
         done     = true;
+        SPROF_END(6);
       }
       else if(hitT == INFINITE_F)  // gltf_pathtrace.slang:129-156
       {
+        SPROF_BEGIN();
         bool backplate = false;
         if(firstRay)  // tryPrimaryMissBackplate, pathtrace_functions.h.slang:944-971
         {
@@ -1814,6 +1846,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
           radiance += throughput * mis * envColor;
         }
         done = true;
+        SPROF_END(6);
       }
 
       if(!done)
@@ -1888,8 +1921,10 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
           mesh.texGrad            = worldFoot * hit.texelDensity * fc.pc.texGradScale;
           mesh.baseColorVertexMul = hit.color;
           mesh.tex                = TexCtx{sc.texRefs, sc.texels, s_srgb, sc.texQuads};
+          SPROF_BEGIN();
           pbrMat                  = evaluateMaterial<SIMPLE>(sc, mat, mesh, taps);
           unlit                   = mat.unlit > 0;
+          SPROF_END(1);
         }
         if(!catcherPlane)
         {
@@ -1988,12 +2023,17 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
 #ifdef MI_PT_DIAG_NO_NEE  // cost-attribution build (tools/attribution.sh): wrong image, no next-event estimation
             dl = DirectLight{};
 #else
-            sampleLights(sc, fc, hit.pos, seed, dl);  // :319-320
+            {
+              SPROF_BEGIN();
+              sampleLights(sc, fc, hit.pos, seed, dl);  // :319-320
+              SPROF_END(2);
+            }
 #endif
             bool nextEventValid = (dot(dl.direction, hit.nrm) > 0.0f || pbrMat.diffuseTransmissionFactor > 0.0f) && dl.pdf != 0.0f;
             f3   contribution   = mk3(0.0f);
             if(nextEventValid)  // :330-351
             {
+              SPROF_BEGIN();
               float    r1 = rnd(seed), r2 = rnd(seed), r3 = rnd(seed);
               BsdfEval ev = bsdfEvaluate(-rayDir, dl.direction, mk3(r1, r2, r3), pbrMat);
               if(ev.pdf > 0.0f)
@@ -2001,8 +2041,10 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
                 float mis    = (dl.pdf == DIRAC) ? 1.0f : dl.pdf / (dl.pdf + ev.pdf);
                 contribution = throughput * dl.radianceOverPdf * mis * ev.bsdf;
               }
+              SPROF_END(3);
             }
             {  // :357-416
+              SPROF_BEGIN();
               float      r1 = rnd(seed), r2 = rnd(seed), r3 = rnd(seed);
 #ifdef MI_PT_DIAG_NO_SAMPLE  // cost-attribution build: mirror direction at half weight instead of the BSDF sample
               BsdfSample sd{};
@@ -2027,6 +2069,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
               }
               else
                 surfaceDepth = maxDepth;
+              SPROF_END(4);
             }
             if(nextEventValid)  // :421-426 + the TraceShadow of pathTrace :462-471, deferred to k_trace_shadow
             {
@@ -2088,6 +2131,9 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
       if(COUNT && (meshHit || hitInfinitePlane))
         atomicAdd(&stats->surfaceHits, 1ull);
     }
+#ifdef SHADE_PROFILE
+    const unsigned long long sprofPush0 = __builtin_amdgcn_s_memtime();
+#endif
     const PushPos  pp      = queuePushBlock2(alive, pushShadow, Q.subCap, &Q.counters[(nxt ? QC_PAIR1 : QC_PAIR0) + 2 * (chunk % NSUB)], chunk % NSUB, s_push);
     const uint32_t posNext = pp.next, posShadow = pp.shadow;
     if(alive)
@@ -2112,8 +2158,26 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
       if(catcher)
         Q.shadow.aux2[posShadow] = make_float4(shCon2.x, shCon2.y, shCon2.z, __uint_as_float(alive ? posNext : 0xffffffffu));
     }
+#ifdef SHADE_PROFILE
+    if(!FIRST && laneId() == 0)
+    {
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();
+      atomicAdd(&g_shadeProf[14], t_ - sprofPush0);
+      atomicAdd(&g_shadeProf[15], (t_ - sprofPush0) * (unsigned long long)__popcll(__ballot(alive || pushShadow)));
+    }
+    const unsigned long long sprofFin0 = __builtin_amdgcn_s_memtime();
+#endif
     if(DEFER_MISS && deferMiss)
       finishMisses(false);  // (once 256 have gathered)
+#ifdef SHADE_PROFILE
+    if(!FIRST && laneId() == 0)
+    {
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();
+      atomicAdd(&g_shadeProf[16], t_ - sprofFin0);
+      atomicAdd(&g_shadeProf[18], t_ - sprofRound0);
+      atomicAdd(&g_shadeProf[19], (t_ - sprofRound0) * (unsigned long long)__popcll(__ballot(inRange && slot != QUEUE_DEAD)));
+    }
+#endif
    }  // rounds of the window
    if(CAN_SORT)
      __syncthreads();  // s_order / s_segCount are rebuilt for the next window
@@ -3000,6 +3064,20 @@ void launchBuildAlphaRecords(const DevScene& scene, uint32_t numTris, DevAlphaTr
 }
 void dumpTraceProfile()
 {
+#ifdef SHADE_PROFILE
+  {
+    unsigned long long h[20] = {};
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_shadeProf), sizeof(h));
+    const double tot = h[18] ? double(h[18]) : 1.0;
+    const char*  names[9] = {"entry + hit state", "material + textures", "sampleLights", "bsdfEvaluate", "bsdfSample", "(unused)", "miss (inline / listed)", "append + stores", "finishMisses"};
+    fprintf(stderr, "[mi_pt shade profile] later-bounce k_shade: round ticks %.4g, lanes with an entry %.1f\n", tot, h[18] ? double(h[19]) / double(h[18]) : 0.0);
+    for(int r = 0; r < 9; ++r)
+      if(h[2 * r])
+        fprintf(stderr, "[mi_pt shade profile]   %-24s %5.1f %% of the round's wave time, %5.1f lanes inside\n", names[r], 100.0 * double(h[2 * r]) / tot,
+                r == 8 ? 0.0 : double(h[2 * r + 1]) / double(h[2 * r]));
+  }
+#endif
 #ifdef TRACE_PROFILE
   unsigned long long h[20] = {};
   (void)hipDeviceSynchronize();
