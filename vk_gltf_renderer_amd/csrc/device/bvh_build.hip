@@ -673,14 +673,25 @@ bool buildBvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream, 
       break;
     if(total > n)
     {
+      // (the reference arrays replace the triangle arrays only once all three exist and are filled; a failure on the way frees what was allocated)
       DevTri* refTris = nullptr;
       float4 *refLo = nullptr, *refHi = nullptr;
-      BUILD_CHECK(hipMalloc(&refTris, sizeof(DevTri) * total));
-      BUILD_CHECK(hipMalloc(&refLo, sizeof(float4) * total));
-      BUILD_CHECK(hipMalloc(&refHi, sizeof(float4) * total));
-      hipLaunchKernelGGL(k_split_refs, dim3(gridT), dim3(B), 0, stream, n, trisTmp, boxLo, boxHi, splitSum, factor, in.splitMaxDepth, splitOffsets, splitCounts, refTris, refLo, refHi);
-      BUILD_CHECK(hipGetLastError());
-      BUILD_CHECK(hipStreamSynchronize(stream));
+      hipError_t e = hipMalloc(&refTris, sizeof(DevTri) * total);
+      if(e == hipSuccess) e = hipMalloc(&refLo, sizeof(float4) * total);
+      if(e == hipSuccess) e = hipMalloc(&refHi, sizeof(float4) * total);
+      if(e == hipSuccess)
+      {
+        hipLaunchKernelGGL(k_split_refs, dim3(gridT), dim3(B), 0, stream, n, trisTmp, boxLo, boxHi, splitSum, factor, in.splitMaxDepth, splitOffsets, splitCounts, refTris, refLo, refHi);
+        e = hipGetLastError();
+      }
+      if(e == hipSuccess) e = hipStreamSynchronize(stream);
+      if(e != hipSuccess)
+      {
+        (void)hipFree(refTris); (void)hipFree(refLo); (void)hipFree(refHi);
+        err = std::string("triangle pre-splitting: ") + hipGetErrorString(e);
+        ok  = false;
+        break;
+      }
       (void)hipFree(trisTmp); (void)hipFree(boxLo); (void)hipFree(boxHi);
       trisTmp = refTris; boxLo = refLo; boxHi = refHi;
       n           = total;
