@@ -4,6 +4,7 @@
 #   line                       the full default bench line
 #   ab <tag> <workloads...>    every vk_gltf_renderer_amd/lib/var_*/libmi_pt.so (tools/build_variant.sh, tools/build_rev_variant.sh) next to the product build
 #   evidence <tag> <args...>   kernel-trace stats + counter passes of one configuration -> pmc_latest_<tag>.json (copy to profiles/)
+#   timeline <tag> <args...>   per-bounce launch durations of one configuration (rocprofv3 --kernel-trace, tools/launch_timeline.py)
 #   sweep                      frames in flight 1 / 8 / 64 / 128 at 1080p and 4K with device memory
 #   mbvalu                     tools/microbench_valu.hip (build it first: hipcc --offload-arch=gfx950 -O3 tools/microbench_valu.hip -o tools/_scratch/mb_valu)
 cd "$(dirname "$0")/.."; ulimit -c 0
@@ -84,6 +85,11 @@ import json,sys; j=json.loads(open('$1').read().strip().splitlines()[-1]); print
       python3 -c "
 import json; j=json.loads(open('$O/r04_overlap_${w}_f${f}_o$o.json').read().strip().splitlines()[-1]); print('OVERLAP ${w} in_flight $f overlap_up_to $o', j['value'])"
     done; done; done ;;
+  timeline)  # tools/run_gpu.sh timeline <tag> <bench args...>: per-dispatch kernel trace of one configuration -> per-bounce launch durations (tools/launch_timeline.py)
+    shift; tag=$1; shift
+    ( cd /tmp && TMPDIR=/tmp timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/tl_$tag -- python $OLDPWD/bench.py "$@" --no-uncut $N > $O/tl_$tag.log 2>&1 )
+    python3 tools/launch_timeline.py $O/tl_$tag ${SHORT_US:-200} | tee $O/r06_timeline_$tag.txt
+    grep -h -o 'k_[a-z_]*<[^>]*>' $O/tl_$tag/*/*kernel_trace.csv | sort | uniq -c | sort -rn | head -12; rm -rf $O/tl_$tag ;;
   mbvalu) timeout 200 tools/_scratch/mb_valu > $O/r04_mb_valu.txt 2>&1; grep "waves/SIMD=4" $O/r04_mb_valu.txt | cut -c1-20,80-160 ;;
   tests) timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ;;
   ab) shift; ab "$@" ;;
