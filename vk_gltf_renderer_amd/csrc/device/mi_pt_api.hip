@@ -107,6 +107,7 @@ struct RunSwitches
   bool   collapseGreedy = false;   // MI_PT_COLLAPSE=sah|greedy  how BVH2 subtrees become children of an 8-wide node (anything else: mi_pt_create fails)
   bool   collapseBad    = false;
   bool   hostCollapse   = false;   // MI_PT_HOST_COLLAPSE    collapse on the host (the greedy reference of the device collapse)
+  bool   coreTex        = true;    // MI_PT_CORE_TEX=0: A/B switch -- the per-material slot records (pt_scene.h: DevCoreTex) send every fetch the general way
   int    maxItersDiag   = 0;       // MI_PT_DIAG_MAX_ITERS=N test hook: the bounce loop stops after N iterations whatever is still alive (the truncation a
                                    //                        volume-scatter scene meets at maxDepth * 66 + 512)
   int    failBuildAt    = 0;       // MI_PT_DIAG_FAIL_BUILD=N  test hook: the N-th acceleration REbuild of the instance fails after the old structure is gone
@@ -142,6 +143,7 @@ struct RunSwitches
     }
     hostCollapse   = flag("MI_PT_HOST_COLLAPSE");
     maxItersDiag   = num("MI_PT_DIAG_MAX_ITERS", 0);
+    coreTex        = num("MI_PT_CORE_TEX", 1) != 0;
     failBuildAt    = num("MI_PT_DIAG_FAIL_BUILD", 0);
     if(const char* e = getenv("MI_PT_DIAG_CAND_POOL"))
     {
@@ -166,6 +168,7 @@ struct MiPt
   DevBuf<MiGltfShadeMaterial> materials;
   DevBuf<MiGltfTextureInfo>   texInfos;
   DevBuf<pt::DevTexRef>       texRefs;
+  DevBuf<pt::DevCoreTex>      coreTex;   // 5 per material (pt_scene.h)
   DevBuf<MiGltfRenderNode>    nodes;
   DevBuf<pt::DevPrim>         prims;
   DevBuf<MiGltfLight>         lights;
@@ -880,6 +883,30 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
       }
     }
     HIP_TRY(pt->texRefs.upload(refs.data(), refs.size()));
+    // the five core map slots per material (pt_scene.h: DevCoreTex), in the order of the material's slot words
+    std::vector<pt::DevCoreTex> core(size_t(std::max(sd->numMaterials, 1)) * 5);
+    memset(core.data(), 0, core.size() * sizeof(pt::DevCoreTex));
+    static const float identityUv[6] = {1.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f};
+    for(int m = 0; m < sd->numMaterials; ++m)
+    {
+      const MiGltfShadeMaterial& M = sd->materials[m];
+      const uint16_t slots[5] = {M.pbrBaseColorTexture, M.normalTexture, M.pbrMetallicRoughnessTexture, M.emissiveTexture, M.occlusionTexture};
+      for(int k = 0; k < 5; ++k)
+      {
+        pt::DevCoreTex& c = core[size_t(m) * 5 + size_t(k)];
+        c.ref = slots[k];
+        if(slots[k] == 0 || int(slots[k]) >= sd->numTextureInfos)
+          continue;
+        const pt::DevTexRef& r = refs[slots[k]];
+        c.level0 = r.level0;
+        c.wh     = uint32_t(r.width) | (uint32_t(r.height) << 16);
+        const bool fast = pt->sw.coreTex && r.width > 0 && r.magFilter == MI_FILTER_LINEAR && r.minFilter == MI_FILTER_LINEAR && r.wrapS != MI_WRAP_MIRRORED_REPEAT && r.wrapT != MI_WRAP_MIRRORED_REPEAT;
+        c.flags  = (fast ? pt::CT_FAST : 0u) | (r.srgb ? pt::CT_SRGB : 0u) | (r.texCoord ? pt::CT_TEXCOORD1 : 0u) | (memcmp(r.uv, identityUv, sizeof(identityUv)) != 0 ? pt::CT_TRANSFORM : 0u)
+                  | (r.mipmapMode == MI_FILTER_LINEAR ? pt::CT_MIP_LINEAR : 0u) | (uint32_t(r.wrapS) << pt::CT_WRAPS_SHIFT) | (uint32_t(r.wrapT) << pt::CT_WRAPT_SHIFT)
+                  | (uint32_t(r.numLevels) << pt::CT_LEVELS_SHIFT);
+      }
+    }
+    HIP_TRY(pt->coreTex.upload(core.data(), core.size()));
   }
   {
     float lut[256];
@@ -896,7 +923,7 @@ int mi_pt_create(const MiPtSceneDesc* sd, const MiPtCreateOptions* options, MiPt
   S.materials = pt->materials.ptr; S.texInfos = pt->texInfos.ptr; S.nodes = pt->nodes.ptr; S.prims = pt->prims.ptr; S.lights = pt->lights.ptr;
   S.textures = pt->textures.ptr; S.texels = pt->texels.ptr; S.texQuads = pt->texQuads.ptr; S.envPixels = nullptr; S.envAccel = nullptr; S.bvhNodes = nullptr; S.bvh8Nodes = nullptr; S.bvh8Planes = nullptr; S.tris = nullptr;
   S.geomPool = reinterpret_cast<const float4*>(pt->geometry.ptr);
-  S.texRefs = pt->texRefs.ptr; S.alphaTris = nullptr; S.shadeTris = nullptr; S.srgbLut = pt->srgbLut.ptr; S.numMaterials = sd->numMaterials; S.numTextures = sd->numTextures;
+  S.texRefs = pt->texRefs.ptr; S.coreTex = reinterpret_cast<const uint4*>(pt->coreTex.ptr); S.alphaTris = nullptr; S.shadeTris = nullptr; S.srgbLut = pt->srgbLut.ptr; S.numMaterials = sd->numMaterials; S.numTextures = sd->numTextures;
   S.numLights = sd->numLights; S.numNodes = sd->numRenderNodes;
   S.envWidth = 0; S.envHeight = 0;
   S.packetInterval = pt->sw.packetInterval;  // A/B switch (LABNOTES.md section 2): 0 = the per-ray node test in every packet
@@ -1617,7 +1644,7 @@ int mi_pt_get_memory(MiPt* pt, MiPtMemory* out)
   const pt::DevScene& sc = pt->scene;
   uint64_t scene = bytes(pt->materials) + bytes(pt->texInfos) + bytes(pt->nodes) + bytes(pt->prims) + bytes(pt->lights) + bytes(pt->textures) + bytes(pt->texels) + bytes(pt->texQuads)
                    + bytes(pt->geometry) + bytes(pt->instFlags) + bytes(pt->srgbLut) + bytes(pt->envPixels) + bytes(pt->envAccel) + bytes(pt->alphaTris)
-                   + bytes(pt->shadeTris) + bytes(pt->texRefs) + bytes(pt->bvh8Planes);
+                   + bytes(pt->shadeTris) + bytes(pt->texRefs) + bytes(pt->coreTex) + bytes(pt->bvh8Planes);
   // the acceleration structure is raw allocations: 64-B BVH2 nodes or 80-B BVH8 nodes + 48-B triangle records
   scene += uint64_t(pt->staticStats.bvhNodeCount) * pt->staticStats.bvhNodeBytes + uint64_t(sc.numTris) * sizeof(pt::DevTri);
   const uint64_t pathState = bytes(pt->pathArrays) + bytes(pt->optThroughput) + bytes(pt->optMisc) + bytes(pt->optMedium) + bytes(pt->optPixelSum) + bytes(pt->optGuides)

@@ -1922,8 +1922,9 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
           mesh.texGrad            = worldFoot * hit.texelDensity * fc.pc.texGradScale;
           mesh.baseColorVertexMul = hit.color;
           mesh.tex                = TexCtx{sc.texRefs, sc.texels, s_srgb, sc.texQuads};
+          mesh.core               = sc.coreTex + 5u * uint32_t(materialID);
           SPROF_BEGIN();
-          pbrMat                  = evaluateMaterial<SIMPLE>(sc, mat, mesh, taps);
+          pbrMat                  = evaluateMaterial<SIMPLE, !FIRST>(sc, mat, mesh, taps);  // (!FIRST: the base colour through its core record, pt_shading.h)
           unlit                   = mat.unlit > 0;
           SPROF_END(1);
         }

@@ -31,6 +31,28 @@ struct DevTexRef  // 44 B
   uint8_t  numLevels, srgb, magFilter, minFilter, mipmapMode, wrapS, wrapT, texCoord;
   uint32_t _pad;
 };
+// The five CORE map slots of a material -- base colour, normal, metallic-roughness, emissive, occlusion, the order of MiGltfShadeMaterial's slot words --
+// as 16-byte records indexed by MATERIAL: coreTex[5 * materialID + k].  Their address depends on the material index alone, so a shade kernel can fetch a
+// slot's record next to the material record instead of behind it (pt_shading.h: coreTexPlan; in use for the base colour).  Slots whose sampler the footprint
+// path does not cover (NEAREST filters, MIRRORED_REPEAT) keep the general fetch through `ref`.
+struct DevCoreTex  // 16 B
+{
+  uint32_t level0;  // texel offset of mip 0
+  uint32_t wh;      // width | height << 16; 0: no valid texture behind the slot (sampling yields 1)
+  uint32_t flags;   // CT_*
+  uint32_t ref;     // the slot's texture-info index (DevTexRef): the general fetch, and the uv transform where CT_TRANSFORM says there is one
+};
+enum : uint32_t
+{
+  CT_FAST         = 1u,       // LINEAR mag and min filter, no MIRRORED_REPEAT: every shape of the fetch is one or two footprint records
+  CT_SRGB         = 1u << 1,
+  CT_TEXCOORD1    = 1u << 2,
+  CT_TRANSFORM    = 1u << 3,  // KHR_texture_transform other than the identity
+  CT_MIP_LINEAR   = 1u << 4,
+  CT_WRAPS_SHIFT  = 8,        // 2 bits
+  CT_WRAPT_SHIFT  = 10,       // 2 bits
+  CT_LEVELS_SHIFT = 16,       // 8 bits
+};
 struct TexCtx  // what a texture fetch needs, passed BY VALUE (registers) into the non-inlined fetch
 {
   const DevTexRef* refs;
@@ -143,6 +165,7 @@ struct DevScene
   const float*               bvh8Planes;  // BVH8: the nodes' quantised planes as floats, 48 per node (pt_bvh8.h: bvh8TestChildrenPlanes); may be null
   const DevTri*              tris;      // triangles in the order of the ACTIVE structure (hit records index this array)
   const DevTexRef*           texRefs;   // numTextureInfos entries
+  const uint4*               coreTex;   // DevCoreTex, 5 per material (see there)
   const DevShadeTri*         shadeTris; // same indexing as tris
   const float4*              geomPool;  // the geometry pool (every DevPrim stream is a 16-byte aligned piece of it)
   const DevAlphaTri*         alphaTris; // same indexing as tris; valid for triangles of non-FORCE_OPAQUE instances

@@ -149,6 +149,7 @@ struct MeshState
   float texGrad;
   f4    baseColorVertexMul;
   TexCtx tex;  // texture tables for the fetches of this hit (the shade kernel stages the sRGB table in LDS)
+  const uint4* core;  // the hit material's five DevCoreTex records (DevScene::coreTex + 5 * materialID)
 };
 PT_DEV bool isTexturePresent(uint16_t t) { return t > 0; }
 // getTexture (gltf_material_eval.h.slang:76-110) on the flattened DevTexRef table: the arithmetic of sampleTexture ->
@@ -160,13 +161,14 @@ PT_DEV f4 fetchTexelRef(const TexCtx& tc, const DevTexRef& R, uint32_t levelOffs
     return mk4(tc.lut[p.x], tc.lut[p.y], tc.lut[p.z], float(p.w) * (1.0f / 255.0f));
   return mk4(float(p.x) * (1.0f / 255.0f), float(p.y) * (1.0f / 255.0f), float(p.z) * (1.0f / 255.0f), float(p.w) * (1.0f / 255.0f));
 }
-PT_DEV f4 decodeTexelRef(const TexCtx& tc, const DevTexRef& R, uint32_t p)  // fetchTexelRef's arithmetic on an already fetched texel
+PT_DEV f4 decodeTexel(const TexCtx& tc, bool srgb, uint32_t p)  // fetchTexelRef's arithmetic on an already fetched texel
 {
   const uint32_t r = p & 0xffu, g = (p >> 8) & 0xffu, b = (p >> 16) & 0xffu, a = p >> 24;
-  if(R.srgb)
+  if(srgb)
     return mk4(tc.lut[r], tc.lut[g], tc.lut[b], float(a) * (1.0f / 255.0f));
   return mk4(float(r) * (1.0f / 255.0f), float(g) * (1.0f / 255.0f), float(b) * (1.0f / 255.0f), float(a) * (1.0f / 255.0f));
 }
+PT_DEV f4 decodeTexelRef(const TexCtx& tc, const DevTexRef& R, uint32_t p) { return decodeTexel(tc, R.srgb != 0, p); }
 // The two blends of a texture fetch with their operation order pinned (one multiply and one fma per weight pair): the fetch
 // exists in several shapes -- footprint records or four texels, levels one after the other or together -- and all of them must
 // return the same bits (test_texture_footprint_layout_is_bit_identical), which free contraction of `a * (1 - t) + b * t` inside
@@ -193,13 +195,14 @@ struct QuadTap
   bool     dupX, dupY;  // CLAMP_TO_EDGE left of / above the image: both coordinates of the pair clamp to texel 0
 };
 PT_DEV bool hasQuadPath(const TexCtx& tc, const DevTexRef& R) { return tc.quads && R.wrapS != MI_WRAP_MIRRORED_REPEAT && R.wrapT != MI_WRAP_MIRRORED_REPEAT; }
-PT_DEV uint32_t levelOffsetRef(const DevTexRef& R, int level)
+PT_DEV uint32_t levelOffsetWH(uint32_t level0, int W, int H, int level)
 {
-  uint32_t off = R.level0;
+  uint32_t off = level0;
   for(int l = 0; l < level; ++l)
-    off += uint32_t(max(1, int(R.width) >> l)) * uint32_t(max(1, int(R.height) >> l));
+    off += uint32_t(max(1, W >> l)) * uint32_t(max(1, H >> l));
   return off;
 }
+PT_DEV uint32_t levelOffsetRef(const DevTexRef& R, int level) { return levelOffsetWH(R.level0, int(R.width), int(R.height), level); }
 // first texel and weights of a bilinear footprint (shared by every shape of the fetch; products and differences stay what they are)
 PT_DEV void bilinearCoords(f2 uv, int w, int h, int& ix, int& iy, float& tx, float& ty)
 {
@@ -213,24 +216,25 @@ PT_DEV void bilinearCoords(f2 uv, int w, int h, int& ix, int& iy, float& tx, flo
   tx = fx - flx;
   ty = fy - fly;
 }
-PT_DEV QuadTap quadTap(const DevTexRef& R, f2 uv, int level, uint32_t off)  // off = levelOffsetRef(R, level)
+PT_DEV QuadTap quadTapWH(int W, int H, int wrapS, int wrapT, f2 uv, int level, uint32_t off)  // off = levelOffsetWH(level0, W, H, level)
 {
-  const int      w = max(1, int(R.width) >> level), h = max(1, int(R.height) >> level);
+  const int      w = max(1, W >> level), h = max(1, H >> level);
   int            ix, iy;
   QuadTap        t;
   bilinearCoords(uv, w, h, ix, iy, t.tx, t.ty);
-  t.index = texelIndex(off, w, wrapCoord(ix, w, R.wrapS), wrapCoord(iy, h, R.wrapT));
-  t.dupX  = R.wrapS == MI_WRAP_CLAMP_TO_EDGE && ix < 0;
-  t.dupY  = R.wrapT == MI_WRAP_CLAMP_TO_EDGE && iy < 0;
+  t.index = texelIndex(off, w, wrapCoord(ix, w, wrapS), wrapCoord(iy, h, wrapT));
+  t.dupX  = wrapS == MI_WRAP_CLAMP_TO_EDGE && ix < 0;
+  t.dupY  = wrapT == MI_WRAP_CLAMP_TO_EDGE && iy < 0;
   return t;
 }
-PT_DEV f4 quadFilter(const TexCtx& tc, const DevTexRef& R, const QuadTap& t, const uint4 q)
+PT_DEV QuadTap quadTap(const DevTexRef& R, f2 uv, int level, uint32_t off) { return quadTapWH(int(R.width), int(R.height), R.wrapS, R.wrapT, uv, level, off); }
+PT_DEV f4 quadFilterS(const TexCtx& tc, bool srgb, float tx, float ty, bool dupX, bool dupY, const uint4 q)
 {
-  const float tx = t.tx, ty = t.ty;
-  const f4    a = decodeTexelRef(tc, R, q.x), b = decodeTexelRef(tc, R, t.dupX ? q.x : q.y);
-  const f4    c = decodeTexelRef(tc, R, t.dupY ? q.x : q.z), d = decodeTexelRef(tc, R, t.dupY ? (t.dupX ? q.x : q.y) : (t.dupX ? q.z : q.w));
+  const f4 a = decodeTexel(tc, srgb, q.x), b = decodeTexel(tc, srgb, dupX ? q.x : q.y);
+  const f4 c = decodeTexel(tc, srgb, dupY ? q.x : q.z), d = decodeTexel(tc, srgb, dupY ? (dupX ? q.x : q.y) : (dupX ? q.z : q.w));
   return bilinearBlend(a, b, c, d, tx, ty);
 }
+PT_DEV f4 quadFilter(const TexCtx& tc, const DevTexRef& R, const QuadTap& t, const uint4 q) { return quadFilterS(tc, R.srgb != 0, t.tx, t.ty, t.dupX, t.dupY, q); }
 PT_DEV f4 sampleLevelRef(const TexCtx& tc, const DevTexRef& R, f2 uv, int level, int filter)
 {
   if(filter != MI_FILTER_NEAREST && hasQuadPath(tc, R))
@@ -258,6 +262,32 @@ PT_DEV f4 sampleLevelRef(const TexCtx& tc, const DevTexRef& R, f2 uv, int level,
   f4    a = decodeTexelRef(tc, R, p00), b = decodeTexelRef(tc, R, p10);
   f4    c = decodeTexelRef(tc, R, p01), d = decodeTexelRef(tc, R, p11);
   return bilinearBlend(a, b, c, d, tx, ty);
+}
+// The texture coordinate and the level of detail of a fetch, with their operation order PINNED (no contraction): the general fetch (getTextureRef) and
+// the batched fetch of the core slots (coreTex*) are separate instantiations and must compute the same bits
+// (test_texture_footprint_layout_is_bit_identical runs one against the other).
+PT_DEV f2 texUv(const float* U, f2 t)
+{
+#pragma clang fp contract(off)
+  return mk2(__fmaf_rn(t.y, U[2], t.x * U[0]) + U[4], __fmaf_rn(t.y, U[3], t.x * U[1]) + U[5]);
+}
+PT_DEV float texLodOf(float rx2, float ry2)
+{
+  // max(sqrt(a), sqrt(b)) as sqrt(max(a, b)): the same bits (the square root is monotone), one square root less
+  const float rho = sqrtf(fmaxf(rx2, ry2));
+  return rho > 0.0f ? log2f(rho) : -126.0f;
+}
+PT_DEV float texLod(const float* U, float texGrad, float W, float H)
+{
+#pragma clang fp contract(off)
+  const float ax = (U[0] * texGrad) * W, bx = (U[1] * texGrad) * H, ay = (U[2] * texGrad) * W, by = (U[3] * texGrad) * H;
+  return texLodOf(__fmaf_rn(bx, bx, ax * ax), __fmaf_rn(by, by, ay * ay));
+}
+PT_DEV float texLodIdentity(float texGrad, float W, float H)  // texLod under the identity transform: the same bits (the cross terms are exact zeros)
+{
+#pragma clang fp contract(off)
+  const float ax = texGrad * W, by = texGrad * H;
+  return texLodOf(ax * ax, by * by);
 }
 // The texture record of a slot in ONE round trip: the compiler would fetch `width` first (the early-out below tests it) and
 // the rest behind the branch -- two dependent loads at the head of every fetch.
@@ -292,19 +322,12 @@ __device__ __noinline__ f4 getTextureRef(TexCtx tc, uint32_t slot, f2 tc0, f2 tc
   const DevTexRef R  = loadTexRef(tc.refs, slot);
   f2              t  = R.texCoord == 0 ? tc0 : tc1;
   const float*    U  = R.uv;
-  f2              uv = mk2(t.x * U[0] + t.y * U[2] + U[4], t.x * U[1] + t.y * U[3] + U[5]);
+  f2              uv = texUv(U, t);
   if(R.width == 0)
     return mk4(1.0f);
   float lod = 0.0f;
   if(texGrad > 0.0f)
-  {
-    f2    ddx = mk2(U[0] * texGrad, U[1] * texGrad), ddy = mk2(U[2] * texGrad, U[3] * texGrad);
-    // max(sqrt(a), sqrt(b)) as sqrt(max(a, b)): the same bits (a correctly rounded square root is monotone), one square root less
-    float rx2 = sqr(ddx.x * float(R.width)) + sqr(ddx.y * float(R.height));
-    float ry2 = sqr(ddy.x * float(R.width)) + sqr(ddy.y * float(R.height));
-    float rho = sqrtf(fmaxf(rx2, ry2));
-    lod       = rho > 0.0f ? log2f(rho) : -126.0f;
-  }
+    lod = texLod(U, texGrad, float(R.width), float(R.height));
   if(lod <= 0.0f)
     return sampleLevelRef(tc, R, uv, 0, R.magFilter);
   float maxLevel = float(int(R.numLevels) - 1);
@@ -328,6 +351,108 @@ __device__ __noinline__ f4 getTextureRef(TexCtx tc, uint32_t slot, f2 tc0, f2 tc
     return a;
   f4 b = sampleLevelRef(tc, R, uv, l1, R.minFilter);
   return levelBlend(a, b, f);
+}
+// ---- a core slot of a material fetched through its per-material record (pt_scene.h: DevCoreTex), in three steps: PLAN (which footprint records, which weights --
+// the arithmetic of getTextureRef for a sampler with LINEAR filters), ISSUE (the records' gathers), FINISH (filter, blend) where evaluateMaterial uses the value.
+// The same functions as the general fetch throughout, so the values are its values bit for bit.  Used for the BASE COLOUR in the later-bounce shade kernels
+// (evaluateMaterial<SIMPLE, CORE>): the slot's record arrives with the material instead of one round trip behind it.
+// Measured (profiles/r06_shade_walk_ab.txt): atrium +1.3 %, street +0.8 %; in the bounce-0 kernel as well: helmet -0.6 % (its code, not its path: the same with every
+// slot sent the general way).  All five slots as ONE batch (ten dependent round trips of a five-map hit down to two) spills the 168-register kernel and is slower
+// everywhere, the helmet included (5247 -> 4932; in two batches 5183); the record handed to a non-inlined fetch gains nothing.
+#ifndef MI_PT_CORE_TEX_BATCH
+#define MI_PT_CORE_TEX_BATCH 1  // (A/B: 0 = every slot through getTextureRef)
+#endif
+struct CoreTap
+{
+  uint32_t i0, i1;  // footprint records (i1: the coarser level of a trilinear fetch)
+  float    tx0, ty0, tx1, ty1, f;
+  uint32_t bits;    // CP_*
+};
+enum : uint32_t { CP_FAST = 1u, CP_TWO = 2u, CP_SRGB = 4u, CP_DUPX0 = 8u, CP_DUPY0 = 16u, CP_DUPX1 = 32u, CP_DUPY1 = 64u, CP_SLOW = 128u };
+PT_DEV CoreTap coreTexPlan(const TexCtx& tc, const uint4 c, f2 tc0, f2 tc1, float texGrad)
+{
+  CoreTap p;
+  p.i0 = p.i1 = 0u;
+  p.tx0 = p.ty0 = p.tx1 = p.ty1 = p.f = 0.0f;
+  p.bits = 0u;
+  const int W = int(c.y & 0xffffu), H = int(c.y >> 16);
+  if(W == 0)
+    return p;  // no valid texture behind the slot: the value is 1
+#ifdef MI_PT_DIAG_NO_TEX
+  p.bits = CP_SLOW;
+  return p;
+#endif
+  if(!(c.z & CT_FAST) || !tc.quads)
+  {
+    p.bits = CP_SLOW;
+    return p;
+  }
+  const f2 t   = (c.z & CT_TEXCOORD1) ? tc1 : tc0;
+  f2       uv  = t;
+  float    lod = 0.0f;
+  if(c.z & CT_TRANSFORM)
+  {
+    const float* U6 = gat(tc.refs, c.w).uv;
+    const float  U[6] = {U6[0], U6[1], U6[2], U6[3], U6[4], U6[5]};
+    uv = texUv(U, t);
+    if(texGrad > 0.0f)
+      lod = texLod(U, texGrad, float(W), float(H));
+  }
+  else if(texGrad > 0.0f)
+    lod = texLodIdentity(texGrad, float(W), float(H));
+  const int wrapS = int((c.z >> CT_WRAPS_SHIFT) & 3u), wrapT = int((c.z >> CT_WRAPT_SHIFT) & 3u), levels = int((c.z >> CT_LEVELS_SHIFT) & 0xffu);
+  int   l0  = 0;
+  bool  two = false;
+  float f   = 0.0f;
+  if(!(lod <= 0.0f))
+  {
+    lod = fminf(lod, float(levels - 1));
+    if(!(c.z & CT_MIP_LINEAR))
+      l0 = min(int(floorf(lod + 0.5f)), levels - 1);
+    else
+    {
+      l0           = int(floorf(lod));
+      const int l1 = min(l0 + 1, levels - 1);
+      f            = lod - float(l0);
+      two          = !(f == 0.0f || l1 == l0);
+    }
+  }
+  const uint32_t off0 = levelOffsetWH(c.x, W, H, l0);
+  const QuadTap  t0   = quadTapWH(W, H, wrapS, wrapT, uv, l0, off0);
+  p.i0 = t0.index; p.tx0 = t0.tx; p.ty0 = t0.ty;
+  p.bits = CP_FAST | ((c.z & CT_SRGB) ? CP_SRGB : 0u) | (t0.dupX ? CP_DUPX0 : 0u) | (t0.dupY ? CP_DUPY0 : 0u);
+  if(two)
+  {
+    // (l1 == l0 + 1 here: the coarser level starts where the finer one ends)
+    const uint32_t off1 = off0 + uint32_t(max(1, W >> l0)) * uint32_t(max(1, H >> l0));
+    const QuadTap  t1   = quadTapWH(W, H, wrapS, wrapT, uv, l0 + 1, off1);
+    p.i1 = t1.index; p.tx1 = t1.tx; p.ty1 = t1.ty; p.f = f;
+    p.bits |= CP_TWO | (t1.dupX ? CP_DUPX1 : 0u) | (t1.dupY ? CP_DUPY1 : 0u);
+  }
+  return p;
+}
+PT_DEV void coreTexIssue(const TexCtx& tc, const CoreTap& p, uint4& q0, uint4& q1)
+{
+  q0 = q1 = make_uint4(0u, 0u, 0u, 0u);
+  if(p.bits & CP_FAST)
+  {
+    q0 = gat(tc.quads, p.i0);
+    if(p.bits & CP_TWO)
+      q1 = gat(tc.quads, p.i1);
+  }
+}
+PT_DEV f4 coreTexFinish(const TexCtx& tc, const CoreTap& p, const uint4& q0, const uint4& q1, uint32_t slot, f2 tc0, f2 tc1, float texGrad)
+{
+  if(p.bits & CP_SLOW)
+    return getTextureRef(tc, slot, tc0, tc1, texGrad);
+  if(!(p.bits & CP_FAST))
+    return mk4(1.0f);
+  const bool srgb = (p.bits & CP_SRGB) != 0u;
+  const f4   a    = quadFilterS(tc, srgb, p.tx0, p.ty0, (p.bits & CP_DUPX0) != 0u, (p.bits & CP_DUPY0) != 0u, q0);
+  if(!(p.bits & CP_TWO))
+    return a;
+  const f4 b = quadFilterS(tc, srgb, p.tx1, p.ty1, (p.bits & CP_DUPX1) != 0u, (p.bits & CP_DUPY1) != 0u, q1);
+  return levelBlend(a, b, p.f);
 }
 PT_DEV f3 multiToSingleScatterAlbedo(f3 rho)  // :125-129
 {
@@ -355,7 +480,7 @@ PT_DEV f3 convertSGToMR(f3 diffuseColor, f3 specularColor, float glossiness, flo
 // retroreflection (isSimpleMaterial below, decided once per scene like the reference's scene-aware shader variants,
 // src/renderer_pathtracer.cpp feature macros): those inputs keep their neutral defaults as compile-time constants and
 // the lobes, volume tracking and texture fetches that depend on them fold away.
-template <bool SIMPLE>
+template <bool SIMPLE, bool CORE = false>
 PT_DEV PbrMaterial evaluateMaterial(const DevScene& sc, const MiGltfShadeMaterial& m, const MeshState& st, unsigned& taps)  // :168-457
 {
 #define TEX(slot) (++taps, getTextureRef(st.tex, slot, st.tc0, st.tc1, st.texGrad))
@@ -368,6 +493,16 @@ PT_DEV PbrMaterial evaluateMaterial(const DevScene& sc, const MiGltfShadeMateria
   const uint32_t  sw0 = slotWords[0], sw1 = slotWords[1], sw2 = slotWords[2];
   const uint16_t  texBaseColor = uint16_t(sw0 & 0xffffu), texNormal = uint16_t(sw0 >> 16), texMetallicRoughness = uint16_t(sw1 & 0xffffu),
                  texEmissive = uint16_t(sw1 >> 16), texOcclusion = uint16_t(sw2 & 0xffffu);
+  // the base colour through its core record (slot 0 of the material's five, pt_scene.h: DevCoreTex): planned and in flight before anything else of the material is read
+  CoreTap cp0{};
+  uint4   cq0 = make_uint4(0u, 0u, 0u, 0u), cq1 = cq0;
+  if(CORE && MI_PT_CORE_TEX_BATCH)
+  {
+    const bool  present = m.pbrModel != MI_PBR_SPECULAR_GLOSSINESS && isTexturePresent(texBaseColor);  // (the specular-glossiness model does not read it)
+    const uint4 c       = gat(st.core, 0);
+    cp0                 = coreTexPlan(st.tex, present ? c : make_uint4(0u, 0u, 0u, 0u), st.tc0, st.tc1, st.texGrad);
+    coreTexIssue(st.tex, cp0, cq0, cq1);
+  }
   if(m.pbrModel == MI_PBR_SPECULAR_GLOSSINESS)
   {
     f4    diffuse    = mk4(m.pbrDiffuseFactor[0], m.pbrDiffuseFactor[1], m.pbrDiffuseFactor[2], m.pbrDiffuseFactor[3]) * st.baseColorVertexMul;
@@ -388,7 +523,7 @@ PT_DEV PbrMaterial evaluateMaterial(const DevScene& sc, const MiGltfShadeMateria
   {
     f4 baseColor = mk4(m.pbrBaseColorFactor[0], m.pbrBaseColorFactor[1], m.pbrBaseColorFactor[2], m.pbrBaseColorFactor[3]) * st.baseColorVertexMul;
     if(isTexturePresent(texBaseColor))
-      baseColor *= TEX(texBaseColor);
+      baseColor *= (CORE && MI_PT_CORE_TEX_BATCH) ? (++taps, coreTexFinish(st.tex, cp0, cq0, cq1, texBaseColor, st.tc0, st.tc1, st.texGrad)) : TEX(texBaseColor);
     p.baseColor     = xyz(baseColor);
     p.opacity       = baseColor.w;
     float roughness = m.pbrRoughnessFactor, metallic = m.pbrMetallicFactor;
