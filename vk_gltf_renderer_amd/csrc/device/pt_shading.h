@@ -311,9 +311,7 @@ PT_DEV DevTexRef loadTexRef(const DevTexRef* refs, uint32_t slot)
   return R;
 #endif
 }
-// (round 6: the five core slots of a material as ONE batch -- 16-byte slot records per material fetched next to the material record, all five fetches planned, every
-//  footprint record in flight at once, ten dependent round trips of a five-map hit down to two -- measured SLOWER on every workload, the five-map helmet included
-//  (bounce-0 shade 0.128 -> 0.150 ms per frame in one batch, 0.131 in two): what the batch holds at once spills the 168-register kernel.  profiles/r06_shade_walk_ab.txt)
+// (a slot whose record is fetched NEXT to the material record instead of here, behind it: coreTexPlan below -- in use for the base colour of the later bounces)
 __device__ __noinline__ f4 getTextureRef(TexCtx tc, uint32_t slot, f2 tc0, f2 tc1, float texGrad)
 {
 #ifdef MI_PT_DIAG_NO_TEX  // cost-attribution build (tools/attribution.sh): wrong image, no texture filtering
