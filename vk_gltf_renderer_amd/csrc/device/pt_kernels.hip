@@ -1778,6 +1778,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
       bool  earlyContinue = false;
 
       HitState hit;
+      uint4    core0 = make_uint4(0u, 0u, 0u, 0u);
       int      rnodeID = -1, primitiveID = -1, materialID = 0;
       (void)primitiveID;
       const bool meshHit = triIdx >= 0;
@@ -1787,6 +1788,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
         rnodeID             = int(S.rnode);
         primitiveID         = int(S.prim);
         materialID          = S.materialID;
+        if(!FIRST)  // (in flight next to the vertices: evaluateMaterial<SIMPLE, CORE> plans the base-colour fetch from it)
+          core0 = gat(sc.coreTex, 5u * uint32_t(materialID));
         const MiGltfRenderNode& rn = gat(sc.nodes, rnodeID);
         // record -> vertices directly; the primitive's stream table only for the attributes that are not interleaved (uv1, colours)
         DevPrim rp{};
@@ -1922,7 +1925,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
           mesh.texGrad            = worldFoot * hit.texelDensity * fc.pc.texGradScale;
           mesh.baseColorVertexMul = hit.color;
           mesh.tex                = TexCtx{sc.texRefs, sc.texels, s_srgb, sc.texQuads};
-          mesh.core               = sc.coreTex + 5u * uint32_t(materialID);
+          mesh.core0              = core0;
           SPROF_BEGIN();
           pbrMat                  = evaluateMaterial<SIMPLE, !FIRST>(sc, mat, mesh, taps);  // (!FIRST: the base colour through its core record, pt_shading.h)
           unlit                   = mat.unlit > 0;

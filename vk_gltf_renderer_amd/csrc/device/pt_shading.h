@@ -149,7 +149,7 @@ struct MeshState
   float texGrad;
   f4    baseColorVertexMul;
   TexCtx tex;  // texture tables for the fetches of this hit (the shade kernel stages the sRGB table in LDS)
-  const uint4* core;  // the hit material's five DevCoreTex records (DevScene::coreTex + 5 * materialID)
+  uint4 core0;  // the hit material's base-colour slot record (DevScene::coreTex[5 * materialID], pt_scene.h: DevCoreTex), loaded by the caller as soon as the material index is known
 };
 PT_DEV bool isTexturePresent(uint16_t t) { return t > 0; }
 // getTexture (gltf_material_eval.h.slang:76-110) on the flattened DevTexRef table: the arithmetic of sampleTexture ->
@@ -497,7 +497,7 @@ PT_DEV PbrMaterial evaluateMaterial(const DevScene& sc, const MiGltfShadeMateria
   if(CORE && MI_PT_CORE_TEX_BATCH)
   {
     const bool  present = m.pbrModel != MI_PBR_SPECULAR_GLOSSINESS && isTexturePresent(texBaseColor);  // (the specular-glossiness model does not read it)
-    const uint4 c       = gat(st.core, 0);
+    const uint4 c       = st.core0;
     cp0                 = coreTexPlan(st.tex, present ? c : make_uint4(0u, 0u, 0u, 0u), st.tc0, st.tc1, st.texGrad);
     coreTexIssue(st.tex, cp0, cq0, cq1);
   }
