@@ -1752,7 +1752,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
       // the path's state: records of its queue entry (unit stride, like the ray), or -- catcher frames / MI_PT_STATE_BY_SLOT -- gathered by slot
       // (round 6: the NEXT round's entry prefetched into registers across the append -- 28 VGPRs spilled at the 168-register budget: atrium 690.7 -> 686.7,
       //  helmet 5255 -> 5068 Msamples/s; and staged through LDS by global_load_lds together with its triangle's shade record (no register held: 37 KB of LDS
-      //  per block, one more barrier, every later wait of the round a full drain): atrium 722.9 -> 717.3, helmet 5216 -> 5099 -- profiles/r06_shade_walk_ab.txt)
+      //  per block, one more barrier, every later wait of the round a full drain): atrium 722.9 -> 717.3, helmet 5216 -> 5099; and only the first TWO levels of the next
+      //  window's chain held -- position, hit triangle, 32-byte shade record, ten registers: later-bounce shade 0.661 -> 0.710 ms, atrium 730.9 -> 717.2 -- profiles/r06_shade_walk_ab.txt)
       const float4 misc4 = stateInQueue ? Q.active[cur].misc[inPos] : P.misc[slot];
       const float4 tp4   = FIRST ? make_float4(1.0f, 1.0f, 1.0f, DIRAC) : (stateInQueue ? Q.active[cur].aux2[inPos] : P.throughput[slot]);
       const float4 rad4  = FIRST ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : (stateInQueue ? Q.active[cur].rad[inPos] : P.radiance[slot]);
