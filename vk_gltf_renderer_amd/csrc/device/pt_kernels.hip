@@ -1793,6 +1793,9 @@ __global__ void __launch_bounds__(SHADE_BLOCK, SIMPLE ? SHADE_SIMPLE_WAVES : 1) 
           core0 = gat(sc.coreTex, 5u * uint32_t(materialID));
         const MiGltfRenderNode& rn = gat(sc.nodes, rnodeID);
         // record -> vertices directly; the primitive's stream table only for the attributes that are not interleaved (uv1, colours)
+        // (round 6: ONE 192-byte record per triangle -- its three vertices copied, the shade record's fields, the base-colour slot record -- so that vertices, material index
+        //  and texel addresses are one round trip behind the queue entry instead of two: GPU suite green, later-bounce shade 0.659 -> 0.664 ms (atrium), 0.653 -> 0.676 (sliver
+        //  atrium), helmet / street unchanged -- de-indexed vertices lose the lines neighbouring hits share.  Removed: profiles/r06_shade_walk_ab.txt)
         DevPrim rp{};
         u3      ti{0u, 0u, 0u};
         if(S.attrs & (SHADE_HAS_UV1 | SHADE_HAS_COLORS))
