@@ -566,6 +566,32 @@ def test_shadow_walk_from_the_far_end_changes_no_bit(built, assets, tmp_path):
               near["stats"]["trisShadow"], "->", far["stats"]["trisShadow"])
 
 
+def test_base_colour_slot_record_changes_no_bit(built, assets, tmp_path):
+    """The later-bounce shade kernels read the base-colour map through the per-material slot record (pt_scene.h: DevCoreTex; planned and in flight before the rest of the
+    material) -- MI_PT_CORE_TEX=0 sends it through the general fetch like every other slot.  Same image, same texture-tap count: plain and mip-mapped maps, five-map
+    materials, KHR_texture_transform with clamp / mirror wraps and the texCoord override (mirror wraps and NEAREST filters take the general fetch inside the new path)."""
+    scenes = [(scenegen.scene_atrium_class(str(tmp_path / "atrium.glb"), seed=5, detail=0.12, tex_size=64), 160, 96, 8, None),
+              (scenegen.scene_helmet_class(str(tmp_path / "helmet.glb"), seed=7, tess=24, tex_size=128), 128, 80, 6, os.path.join(assets, "std_env.hdr")),
+              (scenegen.scene_material_zoo(str(tmp_path / "zoo_tt.glb"), "texture_transform"), 128, 96, 6, None),
+              (scenegen.scene_material_zoo(str(tmp_path / "zoo_spec.glb"), "specular"), 128, 96, 6, None)]
+    for path, w, h, depth, hdr in scenes:
+        s = pu.Setup(path, w, h, max_depth=depth, hdr_path=hdr)
+        rec = pu.render_gpu(s, 4)
+        old = os.environ.get("MI_PT_CORE_TEX")
+        os.environ["MI_PT_CORE_TEX"] = "0"
+        try:
+            gen = pu.render_gpu(s, 4)
+        finally:
+            if old is None:
+                del os.environ["MI_PT_CORE_TEX"]
+            else:
+                os.environ["MI_PT_CORE_TEX"] = old
+        assert (rec["accum"] == gen["accum"]).all() and (rec["selection"] == gen["selection"]).all(), path
+        for k in ("cameraPaths", "segments", "shadowRays", "surfaceHits", "textureTaps"):
+            assert rec["stats"][k] == gen["stats"][k], (path, k)
+        assert rec["stats"]["textureTaps"] > 0, path
+
+
 def test_frames_in_flight_bit_identical(built, assets, tmp_path):
     """mi_pt_render_frames(F) == F successive mi_pt_render_frame calls, bit for bit (accumulator, depth, selection,
     counters): ragged batches, multi-sample frames, a tile partition, an alpha/light scene."""
